@@ -1,0 +1,95 @@
+"""Seeded synthetic ATAC chunk sets (BASELINE.json configs 3-5).
+
+There is no network for real BAMs, so every benchmark / parity workload is generated:
+  * BED-like windows of fixed width on a synthetic genome, spaced so that they do not
+    merge after the +-60 bp slop (gap >= 120 bp, pyatac/chunk.py:116);
+  * paired-end fragments: centres uniform over window +- 126 bp with 5x enrichment in a
+    +-20 bp band every 190 bp (phased nucleosomes); sizes from the mixture
+    0.5 * (30 + Gamma(k=2.5, theta=22))  (+)  0.5 * Normal(185, 18), clipped to [20, 700];
+  * log Tn5-bias track ~ Normal(0, 0.8) (stands in for the PWM score of a random genome).
+Everything is vectorised numpy with `numpy.random.default_rng(seed)`.
+"""
+import numpy as np
+
+from .packing import BIAS_LEFT, BIAS_RIGHT, PackedChunks
+
+
+def synth_sizes(rng, n):
+    nfr = 30.0 + rng.gamma(2.5, 22.0, size=n)
+    nuc = rng.normal(185.0, 18.0, size=n)
+    pick = rng.random(n) < 0.5
+    s = np.where(pick, nfr, nuc)
+    return np.clip(np.rint(s), 20, 700).astype(np.int32)
+
+
+def synth_centres(rng, n, span, period=190, band=20, enrich=5.0):
+    """n centre offsets in [0, span): uniform background + enriched bands (rejection-free)."""
+    nb = int(np.ceil(span / period))
+    w_band = enrich * (2 * band + 1) * nb
+    w_bg = float(span)
+    in_band = rng.random(n) < (w_band / (w_band + w_bg))
+    bg = rng.integers(0, span, size=n)
+    k = rng.integers(0, nb, size=n)
+    off = rng.integers(-band, band + 1, size=n)
+    bc = np.clip(k * period + period // 2 + off, 0, span - 1)
+    return np.where(in_band, bc, bg).astype(np.int64)
+
+
+def make_synthetic_chunks(n_chunks, chunk_len, frags_per_chunk, seed=0, with_bias=True, flank=126,
+                          genome_gap=1000, poisson=False):
+    """PackedChunks with `n_chunks` chunks of length `chunk_len` (length AFTER slop+merge).
+
+    frags_per_chunk fragments are attached to every chunk (Poisson-distributed when
+    poisson=True -- heavy-ish tail for load-balance tests).
+    """
+    rng = np.random.default_rng(seed)
+    nc = int(n_chunks)
+    L = int(chunk_len)
+    if poisson:
+        per = rng.poisson(frags_per_chunk, size=nc).astype(np.int64)
+    else:
+        per = np.full(nc, int(frags_per_chunk), dtype=np.int64)
+    nf = int(per.sum())
+    frag_off = np.zeros(nc + 1, dtype=np.int64)
+    np.cumsum(per, out=frag_off[1:])
+    span = L + 2 * flank
+    n = synth_sizes(rng, nf)
+    c = synth_centres(rng, nf, span) - flank  # centre relative to chunk start
+    lpos = (c - (n.astype(np.int64) - 1) // 2).astype(np.int32)
+    # sort by (chunk, centre): chunk id is implicit in the CSR slices
+    cid = np.repeat(np.arange(nc, dtype=np.int64), per)
+    order = np.lexsort((c, cid))
+    lpos, n = lpos[order], n[order]
+    chunk_start = (np.arange(nc, dtype=np.int64) * (L + genome_gap)) + 10000
+    bias_off = bias_log = None
+    if with_bias:
+        per_b = L + BIAS_LEFT + BIAS_RIGHT
+        bias_off = np.arange(nc + 1, dtype=np.int64) * per_b
+        bias_log = rng.normal(0.0, 0.8, size=nc * per_b)
+    return PackedChunks(chunk_start=chunk_start, chunk_len=np.full(nc, L, np.int32), frag_off=frag_off,
+                        frag_lpos=lpos, frag_ilen=n, bias_off=bias_off, bias_log=bias_log)
+
+
+def synth_size_distribution(upper=251):
+    """analytic insert-size distribution of the generator over [0, upper) (stand-in for
+    FragmentSizes.calculateSizes, pyatac/fragmentsizes.py:22-27), normalised to sum 1."""
+    from scipy import stats
+    x = np.arange(upper)
+    nfr = stats.gamma.pdf(x - 30.0, 2.5, scale=22.0)
+    nuc = stats.norm.pdf(x, 185.0, 18.0)
+    s = 0.5 * nfr + 0.5 * nuc
+    s[:20] = 0
+    return s / s.sum()
+
+
+def synth_occ_distributions(upper=251):
+    """(nuc_probs, nfr_probs) over [0, upper), each normalised, strictly positive -- the shape
+    OccupancyCalcParams expects (nucleoatac/Occupancy.py:95-98) after modelNFR's floors (:59-63)."""
+    from scipy import stats
+    x = np.arange(upper)
+    nfr = stats.gamma.pdf(np.maximum(x - 30.0, 0), 2.5, scale=22.0)
+    nuc = stats.norm.pdf(x, 185.0, 18.0)
+    nfr[nfr <= 0] = nfr[nfr > 0].min() * 0.01
+    nuc[x < 115] = 0
+    nuc[nuc <= 0] = min(nfr.min() * 0.1, nuc[nuc > 0].min() * 0.001)
+    return nuc / nuc.sum(), nfr / nfr.sum()

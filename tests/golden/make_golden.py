@@ -1,0 +1,378 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and the Python-3 scratch copy made
+by oracle/make_scratch_ref.py).  For each case it
+  1. builds seeded synthetic inputs (or takes the reference's own fixtures),
+  2. runs the reference's classes (OccChunk, NucChunk, calculateCov, ...) on them,
+  3. asserts that oracle/natac_oracle.py reproduces every output (the oracle "pin"),
+  4. stores inputs + reference outputs as .npz (data only; no reference source).
+
+usage:  python oracle/make_scratch_ref.py /tmp/natac_scratch_ref
+        python tests/golden/make_golden.py [/tmp/natac_scratch_ref]
+"""
+import os
+import sys
+from copy import copy
+
+import numpy as np
+
+SCRATCH = sys.argv[1] if len(sys.argv) > 1 else "/tmp/natac_scratch_ref"
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(SCRATCH, "stubs"), os.path.join(SCRATCH, "src"), REPO]
+os.environ.setdefault("MPLBACKEND", "agg")
+os.chdir(os.path.join(SCRATCH, "src"))
+
+import pyatac.VMat as V  # noqa: E402
+from nucleoatac import NucleosomeCalling as Nuc  # noqa: E402
+from nucleoatac import Occupancy as Occ  # noqa: E402
+from nucleoatac.multinomial_cov import calculateCov  # noqa: E402
+from pyatac.bias import PWM, InsertionBiasTrack  # noqa: E402
+from pyatac.chunk import Chunk, ChunkList  # noqa: E402
+from pyatac.chunkmat2d import BiasMat2D, FragmentMat2D  # noqa: E402
+from pyatac.fragmentsizes import FragmentSizes  # noqa: E402
+from pyatac.tracks import InsertionTrack  # noqa: E402
+from pyatac.utils import call_peaks  # noqa: E402
+
+from nucleoatac_amd.synth import synth_centres, synth_sizes  # noqa: E402
+from oracle import natac_oracle as O  # noqa: E402
+
+TMP = os.path.join(SCRATCH, "work")
+os.makedirs(TMP, exist_ok=True)
+REPORT = []
+
+
+def check(name, ref, got, rtol=1e-9, atol=1e-12, exact=False):
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    assert ref.shape == got.shape, (name, ref.shape, got.shape)
+    assert np.array_equal(np.isnan(ref), np.isnan(got)), name + ": NaN pattern differs"
+    m = ~np.isnan(ref)
+    if exact:
+        assert np.array_equal(ref[m], got[m]), name + ": not bit-exact"
+        err = 0.0
+    else:
+        d = np.abs(ref[m] - got[m])
+        sc = np.maximum(np.abs(ref[m]), 1e-300)
+        err = float(np.max(d / (atol / rtol + sc))) if d.size else 0.0
+        assert np.all(d <= atol + rtol * np.abs(ref[m])), "%s: max rel err %.3e" % (name, err)
+    REPORT.append("%-44s %s max_rel=%.2e n=%d" % (name, "exact" if exact else "close", err, ref.size))
+
+
+def save(name, **arrs):
+    p = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(p, **arrs)
+    print("wrote %s (%.1f KB)" % (p, os.path.getsize(p) / 1024.0))
+
+
+# ----------------------------------------------------------------------------------------
+# case A: run-level parameters from the reference's own example results
+# ----------------------------------------------------------------------------------------
+def case_params():
+    ex = "example/example_results/"
+    nuc_dist = FragmentSizes.open(ex + "example.nuc_dist.txt")
+    vmat = V.VMat.open("nucleoatac/vplot/standard_vplot.VMat")
+    vmat.trim(105, 251, 60)  # nucleoatac/run_vprocess.py:20-33 with cli defaults
+    vmat.symmetrize()
+    vmat.norm_y(nuc_dist)
+    vmat.smooth(sd=0.75)
+    vmat.norm()
+    gold = V.VMat.open(ex + "example.VMat")
+    check("vprocess == example_results/example.VMat", gold.mat, vmat.mat, rtol=1e-9, atol=1e-12)
+    sizes = FragmentSizes.open(ex + "example.fragmentsizes.txt")
+    fd = Occ.FragmentMixDistribution(0, upper=251)
+    fd.fragmentsizes = FragmentSizes(0, 251, vals=sizes.get(0, 251))
+    fd.modelNFR()
+    fit = np.loadtxt(ex + "example.occ_fit.txt")
+    check("modelNFR nuc_fit == example.occ_fit.txt", fit[1], fd.nuc_fit.get(), rtol=1e-6, atol=1e-12)
+    check("modelNFR nfr_fit == example.occ_fit.txt", fit[2], fd.nfr_fit.get(), rtol=1e-6, atol=1e-12)
+    ocp = Occ.OccupancyCalcParams(0, 251, fd, ci=0.9)
+    assert ocp.cutoff == O.CHI2_90_DF1
+    pwm = PWM.open("Human")
+    save("params_example", vmat=vmat.mat, vlower=vmat.lower, vupper=vmat.upper,
+         sizes=fd.fragmentsizes.get(0, 251), nuc_probs=ocp.nuc_probs, nfr_probs=ocp.nfr_probs,
+         alphas=ocp.alphas, cutoff=ocp.cutoff, nuc_dist=nuc_dist.get(), nuc_dist_lower=nuc_dist.lower,
+         pwm_mat=pwm.mat, pwm_up=pwm.up, pwm_down=pwm.down, pwm_nucleotides=np.array(pwm.nucleotides))
+    return vmat, fd, pwm
+
+
+# ----------------------------------------------------------------------------------------
+# synthetic "BAM" / "FASTA" (.npz read by the pysam stand-in)
+# ----------------------------------------------------------------------------------------
+def make_synth_genome(seed, chrom_len=14000, holes=()):
+    rng = np.random.default_rng(seed)
+    nf = int(chrom_len * 0.35)
+    n = synth_sizes(rng, nf).astype(np.int64)
+    c = synth_centres(rng, nf, chrom_len - 1600) + 800
+    keep = np.ones(nf, bool)
+    for a, b in holes:
+        keep &= ~((c >= a - 130) & (c < b + 130))
+    n, c = n[keep], c[keep]
+    l = c - (n - 1) // 2
+    o = np.argsort(l, kind="stable")
+    l, n = l[o], n[o]
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=chrom_len)
+    seq[rng.integers(0, chrom_len, size=40)] = ord("N")
+    seq[5000:5030] = ord("N")
+    bam = os.path.join(TMP, "synth_%d.bam.npz" % seed)
+    fa = os.path.join(TMP, "synth_%d.fa.npz" % seed)
+    np.savez(bam, chrom_names=np.array(["chrS"]), chrom_lengths=np.array([chrom_len]),
+             pos_chrS=l - 4, tlen_chrS=n + 8)
+    np.savez(fa, chrom_names=np.array(["chrS"]), chrom_lengths=np.array([chrom_len]), seq_chrS=seq)
+    return bam, fa, l, n, seq
+
+
+def frags_for_chunk(l, n, s, e, margin=2126):
+    a, b = np.searchsorted(l, s - margin, "left"), np.searchsorted(l, e + margin, "left")
+    return l[a:b].copy(), n[a:b].copy()
+
+
+def run_occ_chunk(chunk, params):
+    """OccChunk.process (nucleoatac/Occupancy.py:241-247) step by step, to snapshot the smoothed
+    tracks BEFORE call_peaks fills their NaNs in place (pyatac/utils.py:86-91)."""
+    occ = Occ.OccChunk(chunk)
+    occ.params = params
+    occ.getFragmentMat()
+    occ.makeBiasMat()
+    occ.calculateOcc()
+    pre = (occ.occ.smoothed_vals.copy(), occ.occ.smoothed_lower.copy(), occ.occ.smoothed_upper.copy())
+    occ.getCov()
+    occ.callPeaks()
+    return occ, pre
+
+
+def case_chunks(name, seed, chunks, vmat, fd, pwm, holes=(), use_fasta=True):
+    bam, fa, L, N, seq = make_synth_genome(seed, holes=holes)
+    sizes = FragmentSizes(0, 251, vals=fd.fragmentsizes.get(0, 251))
+    if use_fasta:
+        oparams = Occ.OccupancyParameters(fd, 251, fa, "Human", sep=120, min_occ=0.1, flank=60, bam=bam, ci=0.9, step=5)
+    else:  # OccupancyParameters needs a fasta (Occupancy.py:180); build the fasta-less state by hand
+        oparams = Occ.OccupancyParameters(fd, 251, fa, "Human", sep=120, min_occ=0.1, flank=60, bam=bam, ci=0.9, step=5)
+        oparams.fasta = None
+    nparams = Nuc.NucParameters(vmat=vmat, fragmentsizes=sizes, bam=bam, fasta=fa if use_fasta else None, pwm="Human",
+                                occ_track=None, sd=10, nonredundant_sep=120, redundant_sep=25, min_z=3, min_lr=0,
+                                atac=True)
+    out = dict(n_chunks=len(chunks), chunk_start=np.array([c[0] for c in chunks]),
+               chunk_end=np.array([c[1] for c in chunks]), use_fasta=int(use_fasta))
+    for k, (s, e) in enumerate(chunks):
+        ch = Chunk("chrS", s, e)
+        l, n = frags_for_chunk(L, N, s, e)
+        out["c%d_l" % k], out["c%d_n" % k] = l, n
+        # bias track exactly as the reference builds it (Occupancy.py:212-214)
+        if use_fasta:
+            bt = InsertionBiasTrack("chrS", s - 121 - 125, e + 121 + 125 + 1, log=True)
+            bt.computeBias(fa, oparams.chrs, pwm)
+            assert bt.start == s - 246 and bt.end == e + 247
+            bias_log = bt.vals.copy()
+            seq_str = bytes(seq[s - 256:e + 257]).decode()
+            check(name + " c%d computeBias" % k, bias_log, O.compute_bias_pwm(seq_str, pwm.mat, pwm.nucleotides),
+                  rtol=1e-12, atol=1e-12)
+            out["c%d_bias_log" % k] = bias_log
+            out["c%d_seq" % k] = np.frombuffer(seq_str.encode(), dtype=np.uint8)
+        else:
+            bias_log = None
+        # ---------------- occ ----------------
+        occ, pre = run_occ_chunk(ch, oparams)
+        oc = O.occ_chunk_tracks(l, n, s, e, bias_log, s - 246, oparams.occ_calc_params.nuc_probs,
+                                oparams.occ_calc_params.nfr_probs, upper=251, flank=60, step=5)
+        check(name + " c%d occ.mat" % k, occ.mat.mat, oc["mat"], exact=True)
+        check(name + " c%d occ.bias_mat" % k, occ.bias_mat.mat, oc["b0"], rtol=1e-13)
+        check(name + " c%d occ.vals" % k, occ.occ.vals, oc["occ"], exact=True)
+        check(name + " c%d occ.lower" % k, occ.occ.lower_bound, oc["occ_lower"], exact=True)
+        check(name + " c%d occ.upper" % k, occ.occ.upper_bound, oc["occ_upper"], exact=True)
+        check(name + " c%d occ.smoothed(pre-fill)" % k, pre[0], oc["smoothed_vals"], rtol=1e-12)
+        check(name + " c%d occ.smoothed_lower" % k, occ.occ.smoothed_lower, oc["smoothed_lower"], rtol=1e-12)
+        check(name + " c%d occ.smoothed_upper" % k, occ.occ.smoothed_upper, oc["smoothed_upper"], rtol=1e-12)
+        check(name + " c%d occ.cov" % k, occ.cov.vals, oc["cov"], exact=True)
+        filled = oc["smoothed_vals"].copy()
+        pk = O.call_peaks(filled, sep=120, min_signal=0.1)
+        check(name + " c%d occ.smoothed(post-fill)" % k, occ.occ.smoothed_vals, filled, rtol=1e-12)
+        ref_pk = np.array(sorted(occ.peaks.keys()), dtype=np.int64)
+        okp = [p for p in pk if oc["smoothed_lower"][p] > 0.1 and oc["cov"][p] > 0]
+        check(name + " c%d occ.peaks" % k, ref_pk, np.array(okp, dtype=np.int64), exact=True)
+        nuc_dist = occ.getNucDist()
+        out.update({"c%d_occ" % k: occ.occ.vals, "c%d_occ_lower" % k: occ.occ.lower_bound,
+                    "c%d_occ_upper" % k: occ.occ.upper_bound, "c%d_occ_smoothed_prefill" % k: pre[0],
+                    "c%d_occ_smoothed" % k: occ.occ.smoothed_vals, "c%d_occ_smoothed_lower" % k: occ.occ.smoothed_lower,
+                    "c%d_occ_smoothed_upper" % k: occ.occ.smoothed_upper, "c%d_occ_cov" % k: occ.cov.vals,
+                    "c%d_occ_peaks" % k: ref_pk, "c%d_occ_nuc_dist" % k: nuc_dist,
+                    "c%d_occ_peak_vals" % k: np.array([[occ.peaks[p].occ, occ.peaks[p].occ_lower, occ.peaks[p].occ_upper,
+                                                        occ.peaks[p].reads] for p in ref_pk]).reshape(-1, 4)})
+        # ---------------- nuc ----------------
+        nuc = Nuc.NucChunk(ch)
+        nuc.process(nparams)
+        nt = O.nuc_chunk_tracks(l, n, s, e, bias_log, s - 246, vmat.mat, vmat.lower, vmat.upper,
+                                sizes.get(0, 251), smooth_sd=10)
+        check(name + " c%d nuc.mat" % k, nuc.mat.mat, nt["mat"], exact=True)
+        check(name + " c%d nuc.bias_mat" % k, nuc.bias_mat.mat, nt["bmat"], rtol=1e-13)
+        check(name + " c%d nuc_cov" % k, nuc.nuc_cov.vals, nt["nuc_cov"], exact=True)
+        check(name + " c%d nfr_cov" % k, nuc.nfr_cov.vals, nt["nfr_cov"], exact=True)
+        check(name + " c%d raw" % k, nuc.nuc_signal.vals, nt["raw"], rtol=1e-10, atol=1e-12)
+        check(name + " c%d background" % k, nuc.bias.vals, nt["bg"], rtol=1e-10, atol=1e-12)
+        check(name + " c%d norm" % k, nuc.norm_signal.vals, nt["norm"], rtol=1e-9, atol=1e-11)
+        check(name + " c%d smoothed" % k, nuc.smoothed.vals, nt["smoothed"], rtol=1e-9, atol=1e-11)
+        ins_ref = nuc.ins.vals  # getIns(): spans [mat.start+125, mat.end-125)
+        ins_or, half = O.get_ins_from_mat(nt["mat"], 0, 251)
+        check(name + " c%d getIns" % k, ins_ref, ins_or, exact=True)
+        it = InsertionTrack("chrS", s, e)
+        it.calculateInsertions(bam)
+        check(name + " c%d calculateInsertions" % k, it.vals, O.get_insertions(l, n, s, e, 0, 2000), exact=True)
+        it251 = InsertionTrack("chrS", s, e)
+        it251.calculateInsertions(bam, upper=251)
+        # candidates: every call_peaks candidate gets LR + z, independent of the thresholds
+        combined = nuc.norm_signal.vals + nuc.smoothed.vals
+        cands = call_peaks(combined.copy(), min_signal=0, sep=25, boundary=60, order=12)
+        cands_or = O.call_peaks((nt["norm"] + nt["smoothed"]).copy(), min_signal=0, sep=25, boundary=60, order=12)
+        # the reference's scipy picks an FFT for signal.correlate, so where raw/bg are exactly 0
+        # (fragment-free stretches) it sees ~1e-17 noise and calls spurious "peaks" there; keep
+        # only candidates whose signal is above that noise floor (they are the ones that can
+        # pass nuc_cov > min_reads anyway, nucleoatac/NucleosomeCalling.py:304)
+        cands = np.array([i for i in cands if combined[i] > 1e-9], dtype=np.int64)
+        cands_or = np.array([i for i in cands_or if (nt["norm"] + nt["smoothed"])[i] > 1e-9], dtype=np.int64)
+        check(name + " c%d candidates" % k, cands, cands_or, exact=True)
+        rec = []
+        for i in cands:
+            nn = Nuc.Nucleosome(int(i) + s, nuc)
+            nn.getLR(nuc)
+            if nn.nuc_cov > 0:
+                nn.getZScore(nuc)
+                sd = Nuc.SignalDistribution(nn.start, vmat, nuc.bias_mat, nn.nuc_cov)
+                var_lit = calculateCov(sd.probs, np.ravel(vmat.mat), nn.nuc_cov)
+                z = nn.z
+            else:
+                var_lit, z = np.nan, np.nan
+            lr_or = O.get_lr(nt["mat"], nt["mat_start"], nt["bmat"], nt["b0"], nt["b_start"], vmat.mat, vmat.lower,
+                             vmat.upper, int(i) + s)
+            rec.append([int(i), nn.lr, var_lit, z, nn.nuc_cov, nn.norm_signal])
+            check(name + " c%d cand %d lr" % (k, i), nn.lr, lr_or, rtol=1e-9, atol=1e-9)
+            if nn.nuc_cov > 0:
+                pr = O.signal_distribution_probs(nt["bmat"], nt["b_start"], vmat.lower, vmat.upper, 60, int(i) + s)
+                check(name + " c%d cand %d var(literal)" % (k, i), var_lit,
+                      O.calculate_cov_literal(pr, np.ravel(vmat.mat), nn.nuc_cov), rtol=1e-9, atol=1e-14)
+                check(name + " c%d cand %d var(closed)" % (k, i), var_lit,
+                      O.calculate_cov_closed(pr, np.ravel(vmat.mat), nn.nuc_cov), rtol=1e-8, atol=1e-14)
+        rec = np.array(rec, dtype=np.float64).reshape(-1, 6)
+        nucpos = np.array([[i, nuc.nuc_collection[i].z, nuc.nuc_collection[i].lr, nuc.nuc_collection[i].fuzz,
+                            nuc.nuc_collection[i].norm_signal, nuc.nuc_collection[i].nuc_signal,
+                            nuc.nuc_collection[i].nuc_cov, nuc.nuc_collection[i].nfr_cov]
+                           for i in sorted(nuc.nonredundant)], dtype=np.float64).reshape(-1, 8)
+        nucpos_red = np.array(sorted(nuc.redundant), dtype=np.int64)
+        out.update({"c%d_nuc_cov" % k: nuc.nuc_cov.vals, "c%d_nfr_cov" % k: nuc.nfr_cov.vals,
+                    "c%d_raw" % k: nuc.nuc_signal.vals, "c%d_bg" % k: nuc.bias.vals,
+                    "c%d_norm" % k: nuc.norm_signal.vals, "c%d_smoothed" % k: nuc.smoothed.vals,
+                    "c%d_getins" % k: ins_ref, "c%d_ins2000" % k: it.vals, "c%d_ins251" % k: it251.vals,
+                    "c%d_cands" % k: rec, "c%d_nucpos" % k: nucpos, "c%d_nucpos_redundant" % k: nucpos_red})
+    save(name, **out)
+
+
+# ----------------------------------------------------------------------------------------
+# case E: the reference's tests/test_var.py setup (real example bias + example VMat)
+# ----------------------------------------------------------------------------------------
+def case_cov_var():
+    chunk = ChunkList.read("example/example.bed")[0]
+    vmat = V.VMat.open("example/example.VMat")
+    bt = InsertionBiasTrack(chunk.chrom, chunk.start, chunk.end)
+    bt.read_track("example/example.Scores.bedgraph.gz")
+    bm = BiasMat2D(chunk.chrom, chunk.start + 200, chunk.end - 200, 100, 250)
+    bm.makeBiasMat(bt)
+    sd = Nuc.SignalDistribution(chunk.start + 300, vmat, bm, 35)
+    v = np.ravel(vmat.mat)
+    var = calculateCov(sd.probs, v, 35)
+    var_term = np.sum(sd.prob_mat * (1 - sd.prob_mat) * vmat.mat ** 2)
+    tmp = sd.prob_mat * vmat.mat
+    alt = 35 * (var_term - (np.sum(np.outer(tmp, tmp)) - np.sum(tmp ** 2)))
+    check("test_var: calculateCov vs outer-product form", alt, var, rtol=1e-9)
+    check("test_var: oracle literal", var, O.calculate_cov_literal(sd.probs, v, 35), rtol=1e-12)
+    check("test_var: oracle closed", var, O.calculate_cov_closed(sd.probs, v, 35), rtol=1e-9)
+    bo = O.make_bias_mat(bt.vals, bt.start, chunk.start + 200, chunk.end - 200, 100, 250)
+    check("test_chunkmat2d: makeBiasMat on example scores", bm.mat, bo, rtol=1e-13)
+    save("cov_var_example", p=sd.probs, v=v, r=35, var=var, vmat=vmat.mat, vlower=vmat.lower, vupper=vmat.upper,
+         bias_track=bt.vals, bias_track_start=bt.start, biasmat_start=chunk.start + 200,
+         biasmat_end=chunk.end - 200, biasmat_lower=100, biasmat_upper=250, biasmat_sample_rows=np.array([0, 51, 149]),
+         biasmat_samples=bm.mat[[0, 51, 149]], position=chunk.start + 300)
+
+
+# ----------------------------------------------------------------------------------------
+# case F: tests/test_occupancy.py toy cases + random multinomial draws
+# ----------------------------------------------------------------------------------------
+def case_toy_occ():
+    fd = Occ.FragmentMixDistribution(0, 3)
+    fd.nfr_fit = FragmentSizes(0, 3, vals=np.array([0.5, 0.49, 0.01]))
+    fd.nuc_fit = FragmentSizes(0, 3, vals=np.array([0.01, 0.49, 0.5]))
+    p = Occ.OccupancyCalcParams(0, 3, fd)
+    rng = np.random.default_rng(7)
+    ins_list = [np.array([1, 0, 0]), np.array([1, 1, 1])]
+    bias_list = [np.ones(3), np.ones(3)]
+    for _ in range(40):
+        ins_list.append(rng.multinomial(10, fd.nfr_fit.get()) + rng.multinomial(30, fd.nuc_fit.get()))
+        bias_list.append(np.array([3.0, 2.0, 1.0]) if rng.random() < 0.5 else np.ones(3))
+    res = []
+    for ins, b in zip(ins_list, bias_list):
+        r = Occ.calculateOccupancy(ins, b, p)
+        o = O.calculate_occupancy(ins, b, p.nuc_probs, p.nfr_probs, p.alphas, p.cutoff)
+        check("toy calculateOccupancy", r, o, exact=True)
+        res.append(r)
+    assert res[0][0] == 0 and res[1][0] == 0.5  # tests/test_occupancy.py:15-22
+    save("toy_occupancy", ins=np.array(ins_list), bias=np.array(bias_list), nuc_probs=p.nuc_probs,
+         nfr_probs=p.nfr_probs, alphas=p.alphas, cutoff=p.cutoff, result=np.array(res))
+
+
+# ----------------------------------------------------------------------------------------
+# case G: insertion / V-plot edge cases; case I: single_read.bam (tests/test_tracks.py)
+# ----------------------------------------------------------------------------------------
+def case_ins_edge():
+    s, e = 1000, 1400
+    l = np.array([1000, 999, 1399, 1400, 1200, 1200, 1200, 700, 1398, 990, 1001, 1100, 1100, 2000], dtype=np.int64)
+    n = np.array([1, 2, 3, 50, 1, 2, 3, 301, 1, 12, 250, 251, 2000, 40], dtype=np.int64)
+    o = np.argsort(l, kind="stable")
+    l, n = l[o], n[o]
+    bam = os.path.join(TMP, "edge.bam.npz")
+    np.savez(bam, chrom_names=np.array(["chrS"]), chrom_lengths=np.array([5000]), pos_chrS=l - 4, tlen_chrS=-(n + 8))
+    out = dict(l=l, n=n, start=s, end=e)
+    for lo, up in ((0, 2000), (0, 251), (2, 251), (100, 300)):
+        it = InsertionTrack("chrS", s, e)
+        it.calculateInsertions(bam, lower=lo, upper=up)
+        check("edge getInsertions [%d,%d)" % (lo, up), it.vals, O.get_insertions(l, n, s, e, lo, up), exact=True)
+        out["ins_%d_%d" % (lo, up)] = it.vals
+    fm = FragmentMat2D("chrS", s - 60, e + 60, 0, 251)
+    fm.makeFragmentMat(bam)
+    check("edge makeFragmentMat", fm.mat, O.make_fragment_mat(l, n, s - 60, e + 60, 0, 251), exact=True)
+    rr, cc = np.nonzero(fm.mat)
+    out.update(mat_rows=rr, mat_cols=cc, mat_vals=fm.mat[rr, cc], mat_start=s - 60, mat_end=e + 60)
+    gi = fm.getIns()
+    go, half = O.get_ins_from_mat(fm.mat, 0, 251)
+    check("edge getIns", gi.vals, go, exact=True)
+    out.update(getins=gi.vals, getins_start=gi.start)
+    save("ins_edge", **out)
+    # tests/test_tracks.py:16-23 on the reference's own single_read.bam
+    chunk = ChunkList.read("example/example.bed")[0]
+    ins1 = InsertionTrack(chunk.chrom, chunk.start, chunk.end)
+    ins1.calculateInsertions("example/single_read.bam")
+    mat = FragmentMat2D(chunk.chrom, chunk.start, chunk.end, 0, 100)
+    mat.makeFragmentMat("example/single_read.bam")
+    ins2 = mat.getIns()
+    a = ins1.get(chunk.start + 100, chunk.start + 300)
+    assert np.array_equal(a, ins2.get(chunk.start + 100, chunk.start + 300)) and a.sum() == 1 and ins1.vals.sum() == 2
+    import pysam
+    d = pysam.AlignmentFile("example/single_read.bam")._d
+    sl, sn = d["pos_" + chunk.chrom] + 4, np.abs(d["tlen_" + chunk.chrom]) - 8
+    check("single_read getInsertions", ins1.vals, O.get_insertions(sl, sn, chunk.start, chunk.end, 0, 2000), exact=True)
+    check("single_read makeFragmentMat", mat.mat, O.make_fragment_mat(sl, sn, chunk.start, chunk.end, 0, 100), exact=True)
+    save("single_read", l=sl, n=sn, start=chunk.start, end=chunk.end, ins=ins1.vals,
+         mat_nonzero=np.array(np.nonzero(mat.mat)).T, getins=ins2.vals, getins_start=ins2.start)
+
+
+if __name__ == "__main__":
+    vmat, fd, pwm = case_params()
+    case_chunks("chunks_basic", 11, [(1000, 1803), (4800, 5500), (8000, 9203)], vmat, fd, pwm)
+    case_chunks("chunks_gaps", 12, [(2000, 3204)], vmat, fd, pwm, holes=[(2400, 2700)])
+    case_chunks("chunks_nobias", 13, [(3000, 3650)], vmat, fd, pwm, use_fasta=False)
+    case_cov_var()
+    case_toy_occ()
+    case_ins_edge()
+    print("\n".join(REPORT))
+    print("oracle pinned against the reference on %d checks" % len(REPORT))
+    with open(os.path.join(HERE, "PIN_REPORT.txt"), "w") as f:
+        f.write("oracle/natac_oracle.py vs the reference (scratch py3 copy), tests/golden/make_golden.py\n")
+        f.write("\n".join(REPORT) + "\n")
