@@ -1,0 +1,166 @@
+/* natac.h -- C-ABI of libnatac_hip.so: NucleoATAC's per-chunk occ + nuc signal path on MI355X (gfx950).
+ *
+ * The reference (GreenleafLab/NucleoATAC v0.3.4, Python 2.7 + Cython) has no FFI surface; its de-facto
+ * operator boundary is
+ *   (1) the per-chunk map functions handed to multiprocessing.Pool.map:
+ *         _occHelper  nucleoatac/run_occ.py:23-39   -> natac_run_occ  (+ natac_batch_download)
+ *         _nucHelper  nucleoatac/run_nuc.py:22-39   -> natac_run_nuc, natac_run_candidates
+ *   (2) the two Cython extension modules:
+ *         pyatac/fragments.pyx:17   makeFragmentMat               -> natac_make_fragment_mat
+ *         pyatac/fragments.pyx:43   getInsertions                 -> natac_get_insertions / natac_run_ins
+ *         pyatac/fragments.pyx:123  getFragmentSizesFromChunkList -> natac_fragment_sizes
+ *         nucleoatac/multinomial_cov.pyx:20 calculateCov          -> natac_calculate_cov
+ * Every entry point below names the reference code it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no exceptions, no C++/torch types.  Return value: 0 = ok, <0 = error class
+ *     (NATAC_E_*); natac_last_error() gives the message (thread-local).
+ *   - a context (natac_ctx) owns one HIP device + one stream; one host thread per context.
+ *   - host pointers are caller-owned; the library copies.  Device outputs live in the batch until it is freed.
+ *   - all float tracks are float64 like the reference (pyatac/fragments.pyx:9, chunkmat2d.py:20); insertion
+ *     counts are int32.
+ *   - fragments are (l, n) = (pos+4, |tlen|-8) of forward proper-pair reads (pyatac/fragments.pyx:25-31),
+ *     packed per chunk as in nucleoatac_amd/packing.py and SORTED BY CENTRE l + (n-1)//2 inside a chunk.
+ */
+#ifndef NATAC_H
+#define NATAC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NATAC_ABI_VERSION 1
+
+enum {
+    NATAC_OK = 0,
+    NATAC_E_ARG = -1,   /* bad argument / inconsistent sizes */
+    NATAC_E_HIP = -2,   /* HIP runtime error (no device, launch failure, ...) */
+    NATAC_E_STATE = -3, /* call order: constants not set, stage not run yet */
+    NATAC_E_NOMEM = -4
+};
+
+/* per-base tracks of a batch (concatenated over chunks in chunk order; chunk i occupies
+ * [out_off[i], out_off[i+1]) ).  float64 unless noted. */
+enum {
+    NATAC_T_NUC_COV = 0,    /* CoverageTrack rows [vlower,vupper)   NucleosomeCalling.py:257-260 */
+    NATAC_T_NFR_COV = 1,    /* CoverageTrack rows [0,vlower)        NucleosomeCalling.py:271-273 */
+    NATAC_T_RAW = 2,        /* SignalTrack.calculateSignal           NucleosomeCalling.py:29-36  (nucleoatac_raw) */
+    NATAC_T_BACKGROUND = 3, /* BiasTrack.calculateBackgroundSignal   NucleosomeCalling.py:49-64  (nucleoatac_background) */
+    NATAC_T_NORM = 4,       /* NormSignalTrack                       NucleosomeCalling.py:38-43  (nucleoatac_signal) */
+    NATAC_T_SMOOTH = 5,     /* NucChunk.smoothSignal                 NucleosomeCalling.py:274-283 (nucleoatac_signal.smooth) */
+    NATAC_T_OCC = 6,        /* OccupancyTrack.smoothed_vals AFTER call_peaks' in-place NaN fill (Occupancy.py:147-153, utils.py:86-91) */
+    NATAC_T_OCC_LOWER = 7,  /* smoothed_lower */
+    NATAC_T_OCC_UPPER = 8,  /* smoothed_upper */
+    NATAC_T_OCC_COV = 9,    /* OccChunk.getCov                       Occupancy.py:221-224 */
+    NATAC_T_INS = 10,       /* int32 insertion counts, getInsertions pyatac/fragments.pyx:43-67 */
+    NATAC_T_OCC_PREFILL = 11, /* smoothed_vals BEFORE the NaN fill */
+    NATAC_T_COUNT = 12
+};
+
+/* per-grid-point arrays of the occupancy MLE (one value per `step` bases; chunk i occupies
+ * [grid_off[i], grid_off[i+1]) with grid point k at base halfstep + k*step):
+ * OccupancyTrack.vals / lower_bound / upper_bound before smoothing (Occupancy.py:128-146). */
+enum { NATAC_G_OCC = 0, NATAC_G_LOWER = 1, NATAC_G_UPPER = 2 };
+
+/* kernels, for natac_profile_get */
+enum {
+    NATAC_K_FRAG_GATHER = 0, /* nuc_cov / nfr_cov / raw (sparse V-plot gather) */
+    NATAC_K_BACKGROUND = 1,  /* dense bias x VMat correlation (dominant) */
+    NATAC_K_SMOOTH_NUC = 2,
+    NATAC_K_OCC_MLE = 3,
+    NATAC_K_OCC_SMOOTH = 4,
+    NATAC_K_OCC_FILL = 5,
+    NATAC_K_INS = 6,
+    NATAC_K_CAND = 7,
+    NATAC_K_COUNT = 8
+};
+
+typedef struct natac_ctx natac_ctx;
+typedef struct natac_batch natac_batch;
+
+/* ---- library / context ---------------------------------------------------------------- */
+int natac_abi_version(void);
+const char *natac_last_error(void);
+int natac_device_count(int *count);
+int natac_ctx_create(int device_id, natac_ctx **out);
+void natac_ctx_destroy(natac_ctx *ctx);
+int natac_ctx_sync(natac_ctx *ctx);
+/* device name, CU count, global memory bytes of the context's device */
+int natac_ctx_device_info(natac_ctx *ctx, char *name, size_t name_len, int *n_cu, size_t *mem_bytes);
+
+/* ---- run-level constants --------------------------------------------------------------- */
+/* VMat template (pyatac/VMat.py:24-37): mat[(upper-lower) x (2w+1)] row-major, insert sizes [lower,upper). */
+int natac_set_vmat(natac_ctx *ctx, const double *mat, int lower, int upper, int w);
+/* global insert-size distribution over [0, upper) used by BiasMat2D.normByInsertDist (chunkmat2d.py:154-156). */
+int natac_set_sizes(natac_ctx *ctx, const double *sizes, int upper);
+/* OccupancyCalcParams + OccupancyParameters (Occupancy.py:89-102, 175-193): nuc_probs / nfr_probs over
+ * [0, upper) (already normalised), the alpha grid (np.linspace(0,1,101)), the chi2 cutoff, step (odd), flank. */
+int natac_set_occ_model(natac_ctx *ctx, const double *nuc_probs, const double *nfr_probs, int upper,
+                        const double *alphas, int n_alpha, double cutoff, int step, int flank);
+
+/* ---- batches of packed chunks ---------------------------------------------------------- */
+/* Upload one batch (layout: nucleoatac_amd/packing.py).  bias_off/bias_log may be NULL (no FASTA: bias
+ * matrix of ones, NucleosomeCalling.py:243-250).  bias_log covers [start-bias_left, end+bias_right). */
+int natac_batch_create(natac_ctx *ctx, int32_t n_chunks, const int32_t *chunk_len, const int64_t *frag_off,
+                       const int32_t *frag_lpos, const int32_t *frag_ilen, const int64_t *bias_off,
+                       const double *bias_log, int32_t bias_left, int32_t bias_right, natac_batch **out);
+void natac_batch_free(natac_batch *b);
+int natac_batch_info(natac_batch *b, int64_t *total_bp, int64_t *total_grid, int64_t *n_frags);
+
+/* NucChunk.process up to smoothSignal (NucleosomeCalling.py:328-334): fills NUC_COV, NFR_COV, RAW,
+ * BACKGROUND, NORM, SMOOTH.  smooth_sd = NucParameters.smooth_sd (cli default 10).  Asynchronous. */
+int natac_run_nuc(natac_batch *b, double smooth_sd);
+/* OccChunk.process up to getCov + the call_peaks NaN fill (Occupancy.py:241-247): fills the grid arrays,
+ * OCC_PREFILL, OCC, OCC_LOWER, OCC_UPPER, OCC_COV.  Asynchronous. */
+int natac_run_occ(natac_batch *b);
+/* InsertionTrack.calculateInsertions (pyatac/tracks.py:164-168) for every chunk: fills INS. */
+int natac_run_ins(natac_batch *b, int lower, int upper);
+/* Per-candidate statistics (needs natac_run_nuc first).  cand_chunk[k] = chunk index, cand_pos[k] = position
+ * relative to the chunk start.  Outputs (host, length n_cand):
+ *   lr   Nucleosome.getLR       NucleosomeCalling.py:110-122
+ *   var  calculateCov closed form r*(sum p v^2 - (sum p v)^2), r = int(nuc_cov[pos])  multinomial_cov.pyx:20-31
+ *   z    Nucleosome.getZScore   NucleosomeCalling.py:123-127   (norm_signal / sqrt(var)) */
+int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chunk, const int32_t *cand_pos,
+                         double *lr, double *var, double *z);
+/* copy one per-base track to host (float64[total_bp], or int32[total_bp] for NATAC_T_INS). Synchronises. */
+int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes);
+/* copy one per-grid-point array to host (float64[total_grid]). */
+int natac_batch_download_grid(natac_batch *b, int which, double *dst, size_t dst_bytes);
+/* per-chunk status flags (int32[n_chunks]; 0 = ok, bit0 = occupancy likelihood undefined at some grid point
+ * -- the reference would raise ValueError at Occupancy.py:118). */
+int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes);
+/* raw device pointer of a per-base track (for zero-copy consumers); NULL if the stage has not run. */
+int natac_batch_track_ptr(natac_batch *b, int track, void **dptr);
+
+/* ---- drop-in replacements of the Cython functions (host buffers in / out, synchronous) --- */
+/* makeFragmentMat, pyatac/fragments.pyx:17-40: mat[(upper-lower) x (end-start)] float64, zeroed + filled. */
+int natac_make_fragment_mat(natac_ctx *ctx, int64_t n_frags, const int64_t *l, const int32_t *n, int64_t start,
+                            int64_t end, int lower, int upper, double *mat);
+/* getInsertions, pyatac/fragments.pyx:43-67: out[end-start] float64. */
+int natac_get_insertions(natac_ctx *ctx, int64_t n_frags, const int64_t *l, const int32_t *n, int64_t start,
+                         int64_t end, int lower, int upper, double *out);
+/* getFragmentSizesFromChunkList, pyatac/fragments.pyx:123-145 (one chromosome's fragments, its chunks):
+ * sizes[upper-lower] float64 counts (not normalised). */
+int natac_fragment_sizes(natac_ctx *ctx, int64_t n_frags, const int64_t *l, const int32_t *n, int32_t n_chunks,
+                         const int64_t *chunk_start, const int64_t *chunk_end, int lower, int upper, double *sizes);
+/* calculateCov, nucleoatac/multinomial_cov.pyx:20-31.  mode 0 = closed form O(N), mode 1 = literal O(N^2)
+ * pair sum (same terms as the .pyx, tree-reduced).  r is truncated to int like the .pyx signature. */
+int natac_calculate_cov(natac_ctx *ctx, const double *p, const double *v, int64_t n, int r, int mode, double *out);
+
+/* ---- profiling (HIP events on the context's stream) ------------------------------------ */
+int natac_profile_enable(natac_ctx *ctx, int on);
+/* total milliseconds and launch count of kernel class `k` since the last reset */
+int natac_profile_get(natac_ctx *ctx, int k, double *ms_total, int64_t *launches);
+int natac_profile_reset(natac_ctx *ctx);
+/* stream-ordered timer: natac_timer_start records an event, natac_timer_stop records + syncs + returns ms */
+int natac_timer_start(natac_ctx *ctx);
+int natac_timer_stop(natac_ctx *ctx, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NATAC_H */

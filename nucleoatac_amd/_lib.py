@@ -1,0 +1,90 @@
+"""ctypes binding of libnatac_hip.so (C-ABI declared in include/natac.h).
+
+There is no CPU fallback: if the HIP library is missing, or a compute entry point is
+called without a GPU, this raises -- the product path never routes through oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnatac_hip.so")
+
+# enums of include/natac.h
+T_NUC_COV, T_NFR_COV, T_RAW, T_BACKGROUND, T_NORM, T_SMOOTH = 0, 1, 2, 3, 4, 5
+T_OCC, T_OCC_LOWER, T_OCC_UPPER, T_OCC_COV, T_INS, T_OCC_PREFILL = 6, 7, 8, 9, 10, 11
+G_OCC, G_LOWER, G_UPPER = 0, 1, 2
+K_FRAG_GATHER, K_BACKGROUND, K_SMOOTH_NUC, K_OCC_MLE, K_OCC_SMOOTH, K_OCC_FILL, K_INS, K_CAND = range(8)
+KERNEL_NAMES = ["frag_gather", "background", "smooth_nuc", "occ_mle", "occ_smooth", "occ_fill", "insertions",
+                "candidates"]
+
+_vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+# every exported symbol of include/natac.h with its signature (tests check this list against the header)
+SIGNATURES = {
+    "natac_abi_version": (C.c_int, []),
+    "natac_last_error": (C.c_char_p, []),
+    "natac_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "natac_ctx_create": (C.c_int, [C.c_int, _pp]),
+    "natac_ctx_destroy": (None, [_vp]),
+    "natac_ctx_sync": (C.c_int, [_vp]),
+    "natac_ctx_device_info": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(C.c_int), C.POINTER(_sz)]),
+    "natac_set_vmat": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "natac_set_sizes": (C.c_int, [_vp, _vp, C.c_int]),
+    "natac_set_occ_model": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _f64, C.c_int, C.c_int]),
+    "natac_batch_create": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _pp]),
+    "natac_batch_free": (None, [_vp]),
+    "natac_batch_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "natac_run_nuc": (C.c_int, [_vp, _f64]),
+    "natac_run_occ": (C.c_int, [_vp]),
+    "natac_run_ins": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "natac_run_candidates": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "natac_batch_download": (C.c_int, [_vp, C.c_int, _vp, _sz]),
+    "natac_batch_download_grid": (C.c_int, [_vp, C.c_int, _vp, _sz]),
+    "natac_batch_status": (C.c_int, [_vp, _vp, _sz]),
+    "natac_batch_track_ptr": (C.c_int, [_vp, C.c_int, _pp]),
+    "natac_make_fragment_mat": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
+    "natac_get_insertions": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
+    "natac_fragment_sizes": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "natac_calculate_cov": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.POINTER(_f64)]),
+    "natac_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "natac_profile_get": (C.c_int, [_vp, C.c_int, C.POINTER(_f64), C.POINTER(_i64)]),
+    "natac_profile_reset": (C.c_int, [_vp]),
+    "natac_timer_start": (C.c_int, [_vp]),
+    "natac_timer_stop": (C.c_int, [_vp, C.POINTER(_f64)]),
+}
+
+
+class NatacError(RuntimeError):
+    """error reported by libnatac_hip.so (negative return code of the C-ABI)"""
+
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libnatac_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libnatac_hip.so and bind every symbol; raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("nucleoatac_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.natac_abi_version() != 1:
+        raise ImportError("libnatac_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NatacError(rc, load().natac_last_error().decode("utf-8", "replace"))

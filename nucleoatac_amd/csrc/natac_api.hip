@@ -1,0 +1,824 @@
+// natac_api.hip -- C-ABI (include/natac.h) over the kernels in natac_kernels.hpp.
+// Host-side runtime: contexts, batches of packed chunks resident in HBM, tile tables, launches, profiling.
+#include "../../include/natac.h"
+#include "natac_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace natac;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(e_ == hipErrorOutOfMemory ? NATAC_E_NOMEM : NATAC_E_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                   \
+    } while (0)
+
+struct natac_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    // constants
+    double *d_vmat = nullptr, *d_srow = nullptr, *d_sizes = nullptr;
+    int vlower = 0, vupper = 0, vw = 0, R = 0, W = 0, sizes_upper = 0;
+    bool have_vmat = false, have_sizes = false, srow_dirty = true;
+    double *d_nucp = nullptr, *d_nfrp = nullptr, *d_alphas = nullptr;
+    int occ_upper = 0, n_alpha = 0, step = 0, halfstep = 0, flank = 0;
+    double cutoff = 0;
+    bool have_occ = false;
+    // gaussian windows (cached by (M, sd))
+    double *d_win_nuc = nullptr, *d_win_occ = nullptr;
+    int win_nuc_M = 0, win_occ_M = 0;
+    double win_nuc_sd = -1, win_occ_sd = -1;
+    // profiling
+    bool profiling = false;
+    struct Ev { int k; hipEvent_t a, b; };
+    std::vector<Ev> pending;
+    double prof_ms[NATAC_K_COUNT] = {0};
+    int64_t prof_n[NATAC_K_COUNT] = {0};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+struct natac_batch {
+    natac_ctx *ctx = nullptr;
+    int nc = 0;
+    long long nf = 0, nb = 0, total_bp = 0, total_grid = 0;
+    int bias_left = 0, bias_right = 0;
+    std::vector<int> h_len;
+    std::vector<long long> h_out_off, h_grid_off;
+    int *d_len = nullptr, *d_lpos = nullptr, *d_ilen = nullptr, *d_centre = nullptr, *d_status = nullptr;
+    long long *d_frag_off = nullptr, *d_bias_off = nullptr, *d_out_off = nullptr, *d_grid_off = nullptr;
+    double *d_bias = nullptr;
+    int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr;
+    int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;
+    int grid_step = 0, grid_half = 0;
+    double *d_track[NATAC_T_COUNT] = {nullptr};
+    double *d_grid[3] = {nullptr, nullptr, nullptr};
+    bool nuc_done = false, occ_done = false, ins_done = false;
+};
+
+static void prof_begin(natac_ctx *c, int k, natac_ctx::Ev &ev) {
+    ev.k = k;
+    ev.a = ev.b = nullptr;
+    if (!c->profiling) return;
+    (void)hipEventCreate(&ev.a);
+    (void)hipEventCreate(&ev.b);
+    (void)hipEventRecord(ev.a, c->stream);
+}
+static void prof_end(natac_ctx *c, natac_ctx::Ev &ev) {
+    if (!c->profiling) return;
+    (void)hipEventRecord(ev.b, c->stream);
+    c->pending.push_back(ev);
+}
+static void prof_collect(natac_ctx *c) {
+    for (auto &e : c->pending) {
+        float ms = 0;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_ms[e.k] += ms;
+            c->prof_n[e.k] += 1;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    c->pending.clear();
+}
+
+template <class T>
+static int dev_alloc(T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+    return NATAC_OK;
+}
+template <class T>
+static int dev_upload(natac_ctx *c, T **p, const T *src, size_t n) {
+    int rc = dev_alloc(p, n);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(*p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return NATAC_OK;
+}
+static void dev_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+// pick the per-lane output count G of the background kernel: minimise idle lanes (sum of tile widths) with a small
+// penalty for the halo work of narrow tiles.
+static int choose_bg_G(const natac_batch *b, int W) {
+    const int cand[4] = {7, 9, 13, 17};
+    double best = 1e300;
+    int bestG = 9;
+    // histogram-free: sample up to 65536 chunks evenly
+    const int stride = std::max(1, b->nc / 65536);
+    for (int ci = 0; ci < 4; ++ci) {
+        const int G = cand[ci], TW = 64 * G;
+        double cost = 0;
+        for (int i = 0; i < b->nc; i += stride) {
+            const int nt = (b->h_len[i] + TW - 1) / TW;
+            cost += (double)nt * (TW + (W - 1) * 0.15 * 8);
+        }
+        if (cost < best) { best = cost; bestG = G; }
+    }
+    return bestG;
+}
+
+template <int G>
+static void launch_bg(natac_batch *b, const ChunkTable &ct, const VMatDev &vm) {
+    natac_ctx *c = b->ctx;
+    constexpr int W = 121;
+    const int PW = 64 * G + W - 1;
+    const int EW = PW + ((vm.upper - 2) >> 1) + ((vm.upper - 1) >> 1);
+    const size_t lds = ((size_t)((EW + 1) & ~1) + PW) * sizeof(double);
+    hipLaunchKernelGGL((natac_background<G, W>), dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm,
+                       b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
+                       b->d_track[NATAC_T_NORM]);
+}
+
+extern "C" {
+
+int natac_abi_version(void) { return NATAC_ABI_VERSION; }
+const char *natac_last_error(void) { return g_err.c_str(); }
+
+int natac_device_count(int *count) {
+    if (!count) return fail(NATAC_E_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(NATAC_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return NATAC_OK;
+}
+
+int natac_ctx_create(int device_id, natac_ctx **out) {
+    if (!out) return fail(NATAC_E_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(NATAC_E_ARG, "device %d out of range (%d devices)", device_id, n);
+    HIPCHK(hipSetDevice(device_id));
+    natac_ctx *c = new natac_ctx();
+    c->device = device_id;
+    HIPCHK(hipGetDeviceProperties(&c->prop, device_id));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&c->t0));
+    HIPCHK(hipEventCreate(&c->t1));
+    *out = c;
+    return NATAC_OK;
+}
+
+void natac_ctx_destroy(natac_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    dev_free(c->d_vmat); dev_free(c->d_srow); dev_free(c->d_sizes);
+    dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
+    dev_free(c->d_win_nuc); dev_free(c->d_win_occ);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int natac_ctx_sync(natac_ctx *c) {
+    if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return NATAC_OK;
+}
+
+int natac_ctx_device_info(natac_ctx *c, char *name, size_t name_len, int *n_cu, size_t *mem_bytes) {
+    if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
+    if (name && name_len) {
+        snprintf(name, name_len, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    }
+    if (n_cu) *n_cu = c->prop.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = c->prop.totalGlobalMem;
+    return NATAC_OK;
+}
+
+int natac_set_vmat(natac_ctx *c, const double *mat, int lower, int upper, int w) {
+    if (!c || !mat) return fail(NATAC_E_ARG, "null argument");
+    if (lower < 0 || upper <= lower || w < 0) return fail(NATAC_E_ARG, "bad vmat geometry lower=%d upper=%d w=%d", lower, upper, w);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(c->d_vmat);
+    c->d_vmat = nullptr;
+    c->vlower = lower; c->vupper = upper; c->vw = w; c->R = upper - lower; c->W = 2 * w + 1;
+    int rc = dev_upload(c, &c->d_vmat, mat, (size_t)c->R * c->W);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_vmat = true;
+    c->srow_dirty = true;
+    return NATAC_OK;
+}
+
+int natac_set_sizes(natac_ctx *c, const double *sizes, int upper) {
+    if (!c || !sizes || upper <= 0) return fail(NATAC_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(c->d_sizes);
+    c->d_sizes = nullptr;
+    int rc = dev_upload(c, &c->d_sizes, sizes, (size_t)upper);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->sizes_upper = upper;
+    c->have_sizes = true;
+    c->srow_dirty = true;
+    return NATAC_OK;
+}
+
+int natac_set_occ_model(natac_ctx *c, const double *nuc_probs, const double *nfr_probs, int upper, const double *alphas,
+                        int n_alpha, double cutoff, int step, int flank) {
+    if (!c || !nuc_probs || !nfr_probs || !alphas) return fail(NATAC_E_ARG, "null argument");
+    if (upper < 2 || n_alpha < 1 || n_alpha > 128) return fail(NATAC_E_ARG, "need upper >= 2 and 1 <= n_alpha <= 128");
+    if (upper > 256) return fail(NATAC_E_ARG, "occupancy kernel supports upper <= 256 (got %d)", upper);
+    if (step < 1 || flank < 0) return fail(NATAC_E_ARG, "bad step/flank");
+    if (step % 2 == 0) step -= 1; /* Occupancy.py:190-191 */
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
+    c->d_nucp = c->d_nfrp = c->d_alphas = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &c->d_nucp, nuc_probs, (size_t)upper))) return rc;
+    if ((rc = dev_upload(c, &c->d_nfrp, nfr_probs, (size_t)upper))) return rc;
+    if ((rc = dev_upload(c, &c->d_alphas, alphas, (size_t)n_alpha))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->occ_upper = upper; c->n_alpha = n_alpha; c->cutoff = cutoff; c->step = step;
+    c->halfstep = (step - 1) / 2; c->flank = flank;
+    c->have_occ = true;
+    return NATAC_OK;
+}
+
+static int ensure_srow(natac_ctx *c) {
+    if (!c->have_vmat) return fail(NATAC_E_STATE, "natac_set_vmat has not been called");
+    if (!c->have_sizes) return fail(NATAC_E_STATE, "natac_set_sizes has not been called");
+    if (c->sizes_upper < c->vupper) return fail(NATAC_E_ARG, "sizes cover [0,%d) but vmat.upper is %d", c->sizes_upper, c->vupper);
+    if (!c->srow_dirty) return NATAC_OK;
+    dev_free(c->d_srow);
+    c->d_srow = nullptr;
+    int rc = dev_alloc(&c->d_srow, (size_t)c->R);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_srow, c->d_sizes + c->vlower, (size_t)c->R * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->srow_dirty = false;
+    return NATAC_OK;
+}
+
+static int ensure_window(natac_ctx *c, double **slot, int *slotM, double *slotsd, int M, double sd) {
+    if (*slot && *slotM == M && *slotsd == sd) return NATAC_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(*slot);
+    *slot = nullptr;
+    // scipy.signal.gaussian(M, sd): exp(-0.5 (n/sd)^2), n = arange(M) - (M-1)/2   (pyatac/utils.py:40)
+    std::vector<double> w((size_t)M);
+    for (int i = 0; i < M; ++i) {
+        double n = (double)i - (M - 1) / 2.0;
+        double q = n / sd;
+        w[i] = std::exp(-0.5 * (q * q));
+    }
+    int rc = dev_upload(c, slot, w.data(), (size_t)M);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *slotM = M;
+    *slotsd = sd;
+    return NATAC_OK;
+}
+
+static ChunkTable make_table(natac_batch *b) {
+    ChunkTable t;
+    t.nc = b->nc; t.chunk_len = b->d_len; t.frag_off = b->d_frag_off; t.lpos = b->d_lpos; t.ilen = b->d_ilen;
+    t.centre = b->d_centre; t.bias_off = b->d_bias_off; t.bias = b->d_bias; t.bias_left = b->bias_left;
+    t.bias_right = b->bias_right; t.out_off = b->d_out_off; t.grid_off = b->d_grid_off;
+    return t;
+}
+static VMatDev make_vmat(natac_ctx *c) {
+    VMatDev v;
+    v.mat = c->d_vmat; v.srow = c->d_srow; v.lower = c->vlower; v.upper = c->vupper; v.w = c->vw; v.R = c->R; v.W = c->W;
+    return v;
+}
+static OccModelDev make_occ(natac_ctx *c) {
+    OccModelDev o;
+    o.nuc_probs = c->d_nucp; o.nfr_probs = c->d_nfrp; o.alphas = c->d_alphas; o.upper = c->occ_upper;
+    o.n_alpha = c->n_alpha; o.step = c->step; o.halfstep = c->halfstep; o.flank = c->flank; o.cutoff = c->cutoff;
+    return o;
+}
+
+static int build_tiles(natac_batch *b, int width, int2 **d_out, int *n_out, bool grid_units = false, int step = 1, int half = 0) {
+    std::vector<int2> tiles;
+    tiles.reserve((size_t)(b->total_bp / std::max(1, width)) + b->nc);
+    for (int i = 0; i < b->nc; ++i) {
+        int n = b->h_len[i];
+        if (grid_units) n = (b->h_len[i] > half) ? (b->h_len[i] - half + step - 1) / step : 0;
+        for (int x = 0; x < n; x += width) tiles.push_back(make_int2(i, x));
+    }
+    dev_free(*d_out);
+    *d_out = nullptr;
+    *n_out = (int)tiles.size();
+    int rc = dev_upload(b->ctx, d_out, tiles.data(), tiles.size());
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));  // `tiles` is a local
+    return NATAC_OK;
+}
+
+int natac_batch_create(natac_ctx *c, int32_t nc, const int32_t *chunk_len, const int64_t *frag_off, const int32_t *frag_lpos,
+                       const int32_t *frag_ilen, const int64_t *bias_off, const double *bias_log, int32_t bias_left,
+                       int32_t bias_right, natac_batch **out) {
+    if (!c || !out || !chunk_len || !frag_off) return fail(NATAC_E_ARG, "null argument");
+    *out = nullptr;
+    if (nc <= 0) return fail(NATAC_E_ARG, "n_chunks must be positive");
+    if ((bias_off == nullptr) != (bias_log == nullptr)) return fail(NATAC_E_ARG, "bias_off and bias_log must both be given or both NULL");
+    if (frag_off[0] != 0) return fail(NATAC_E_ARG, "frag_off[0] must be 0");
+    const long long nf = frag_off[nc];
+    if (nf > 0 && (!frag_lpos || !frag_ilen)) return fail(NATAC_E_ARG, "fragment arrays are NULL");
+    HIPCHK(hipSetDevice(c->device));
+    natac_batch *b = new natac_batch();
+    b->ctx = c; b->nc = nc; b->nf = nf; b->bias_left = bias_left; b->bias_right = bias_right;
+    b->h_len.assign(chunk_len, chunk_len + nc);
+    b->h_out_off.resize((size_t)nc + 1);
+    b->h_out_off[0] = 0;
+    for (int i = 0; i < nc; ++i) {
+        if (chunk_len[i] <= 0) { delete b; return fail(NATAC_E_ARG, "chunk %d has length %d", i, chunk_len[i]); }
+        if (frag_off[i + 1] < frag_off[i] || frag_off[i + 1] - frag_off[i] > 0x7fffffffLL) {
+            delete b; return fail(NATAC_E_ARG, "frag_off not monotone (chunk %d)", i);
+        }
+        if (bias_off && bias_off[i + 1] - bias_off[i] != (long long)chunk_len[i] + bias_left + bias_right) {
+            delete b; return fail(NATAC_E_ARG, "bias slice of chunk %d must cover [start-%d, end+%d)", i, bias_left, bias_right);
+        }
+        b->h_out_off[i + 1] = b->h_out_off[i] + chunk_len[i];
+    }
+    b->total_bp = b->h_out_off[nc];
+    b->nb = bias_off ? bias_off[nc] : 0;
+    int rc = NATAC_OK;
+#define TRY(x) do { if ((rc = (x)) != NATAC_OK) { natac_batch_free(b); return rc; } } while (0)
+    TRY(dev_upload(c, &b->d_len, chunk_len, (size_t)nc));
+    TRY(dev_upload(c, (long long **)&b->d_frag_off, (const long long *)frag_off, (size_t)nc + 1));
+    TRY(dev_upload(c, &b->d_lpos, frag_lpos, (size_t)nf));
+    TRY(dev_upload(c, &b->d_ilen, frag_ilen, (size_t)nf));
+    TRY(dev_alloc(&b->d_centre, (size_t)nf));
+    TRY(dev_upload(c, &b->d_out_off, b->h_out_off.data(), (size_t)nc + 1));
+    if (bias_off) {
+        TRY(dev_upload(c, (long long **)&b->d_bias_off, (const long long *)bias_off, (size_t)nc + 1));
+        TRY(dev_upload(c, &b->d_bias, bias_log, (size_t)b->nb));
+    }
+    TRY(dev_alloc(&b->d_status, (size_t)nc));
+    hipError_t e = hipMemsetAsync(b->d_status, 0, (size_t)nc * sizeof(int), c->stream);
+    if (e != hipSuccess) { natac_batch_free(b); return fail(NATAC_E_HIP, "memset: %s", hipGetErrorString(e)); }
+    if (nf > 0) {
+        int blocks = (int)std::min<long long>((nf + 255) / 256, 4096);
+        hipLaunchKernelGGL(natac_frag_centres, dim3(blocks), dim3(256), 0, c->stream, b->d_lpos, b->d_ilen, b->d_centre, nf);
+    }
+    TRY(build_tiles(b, 256, &b->d_tiles256, &b->n_tiles256));
+    e = hipStreamSynchronize(c->stream);  // host buffers may be released by the caller after return
+    if (e != hipSuccess) { natac_batch_free(b); return fail(NATAC_E_HIP, "upload: %s", hipGetErrorString(e)); }
+#undef TRY
+    *out = b;
+    return NATAC_OK;
+}
+
+void natac_batch_free(natac_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    prof_collect(b->ctx);
+    dev_free(b->d_len); dev_free(b->d_lpos); dev_free(b->d_ilen); dev_free(b->d_centre); dev_free(b->d_status);
+    dev_free(b->d_frag_off); dev_free(b->d_bias_off); dev_free(b->d_out_off); dev_free(b->d_grid_off); dev_free(b->d_bias);
+    dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ);
+    for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
+    for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
+    delete b;
+}
+
+int natac_batch_info(natac_batch *b, int64_t *total_bp, int64_t *total_grid, int64_t *n_frags) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    if (total_bp) *total_bp = b->total_bp;
+    if (total_grid) *total_grid = b->total_grid;
+    if (n_frags) *n_frags = b->nf;
+    return NATAC_OK;
+}
+
+static int ensure_track(natac_batch *b, int t) {
+    if (b->d_track[t]) return NATAC_OK;
+    return dev_alloc(&b->d_track[t], (size_t)b->total_bp);  // INS uses the first half of a double slot (int32)
+}
+
+int natac_run_nuc(natac_batch *b, double smooth_sd) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_srow(c);
+    if (rc) return rc;
+    if (!(smooth_sd > 0)) return fail(NATAC_E_ARG, "smooth_sd must be positive");
+    const int M = 6 * (int)smooth_sd + 1;  /* NucleosomeCalling.py:276 (integer sd from the cli) */
+    const int need_l = c->vw + ((c->vupper - 2) >> 1), need_r = c->vw + ((c->vupper - 1) >> 1) + 1;
+    if (b->d_bias && (b->bias_left < need_l || b->bias_right < need_r))
+        return fail(NATAC_E_ARG, "bias track must extend >= %d left / %d right of the chunk (has %d / %d)", need_l, need_r,
+                    b->bias_left, b->bias_right);
+    for (int i = 0; i < b->nc; ++i)
+        if (b->h_len[i] < M) return fail(NATAC_E_ARG, "chunk %d shorter (%d) than the smoothing window (%d)", i, b->h_len[i], M);
+    if ((rc = ensure_window(c, &c->d_win_nuc, &c->win_nuc_M, &c->win_nuc_sd, M, smooth_sd))) return rc;
+    for (int t : {NATAC_T_NUC_COV, NATAC_T_NFR_COV, NATAC_T_RAW, NATAC_T_BACKGROUND, NATAC_T_NORM, NATAC_T_SMOOTH})
+        if ((rc = ensure_track(b, t))) return rc;
+    const bool fast = (c->W == 121 && c->vlower >= 2);
+    if (fast) {
+        const int G = choose_bg_G(b, c->W);
+        if (G != b->bgG) {
+            if ((rc = build_tiles(b, 64 * G, &b->d_tiles_bg, &b->n_tiles_bg))) return rc;
+            b->bgG = G;
+        }
+    }
+    const ChunkTable ct = make_table(b);
+    const VMatDev vm = make_vmat(c);
+    natac_ctx::Ev ev;
+    prof_begin(c, NATAC_K_FRAG_GATHER, ev);
+    hipLaunchKernelGGL(natac_frag_gather, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, vm,
+                       b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_RAW]);
+    prof_end(c, ev);
+    prof_begin(c, NATAC_K_BACKGROUND, ev);
+    if (fast) {
+        switch (b->bgG) {
+            case 7: launch_bg<7>(b, ct, vm); break;
+            case 9: launch_bg<9>(b, ct, vm); break;
+            case 13: launch_bg<13>(b, ct, vm); break;
+            default: launch_bg<17>(b, ct, vm); break;
+        }
+    } else {
+        hipLaunchKernelGGL(natac_background_generic, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, vm,
+                           b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
+                           b->d_track[NATAC_T_NORM]);
+    }
+    prof_end(c, ev);
+    prof_begin(c, NATAC_K_SMOOTH_NUC, ev);
+    {
+        const int h = (M - 1) / 2;
+        const size_t lds = ((size_t)2 * (256 + 2 * h) + M) * sizeof(double);
+        hipLaunchKernelGGL((natac_smooth_same<true>), dim3(b->n_tiles256), dim3(256), lds, c->stream, ct, b->d_tiles256,
+                           c->d_win_nuc, M, b->d_track[NATAC_T_NORM], b->d_track[NATAC_T_SMOOTH]);
+    }
+    prof_end(c, ev);
+    HIPCHK(hipGetLastError());
+    b->nuc_done = true;
+    return NATAC_OK;
+}
+
+int natac_run_occ(natac_batch *b) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->have_occ) return fail(NATAC_E_STATE, "natac_set_occ_model has not been called");
+    const int M = 2 * c->flank + 1;              /* OccupancyParameters.window, Occupancy.py:184 */
+    const double sd = c->flank / 3.0;            /* Occupancy.py:220 */
+    const int need_l = c->flank + ((c->occ_upper - 2) >> 1), need_r = c->flank + ((c->occ_upper - 1) >> 1) + 1;
+    if (b->d_bias && (b->bias_left < need_l || b->bias_right < need_r))
+        return fail(NATAC_E_ARG, "bias track must extend >= %d left / %d right of the chunk (has %d / %d)", need_l, need_r,
+                    b->bias_left, b->bias_right);
+    for (int i = 0; i < b->nc; ++i)
+        if (b->h_len[i] < M) return fail(NATAC_E_ARG, "chunk %d shorter (%d) than the occupancy window (%d)", i, b->h_len[i], M);
+    int rc;
+    if ((rc = ensure_window(c, &c->d_win_occ, &c->win_occ_M, &c->win_occ_sd, M, sd))) return rc;
+    if (!b->d_grid_off || b->grid_step != c->step) {
+        b->h_grid_off.assign((size_t)b->nc + 1, 0);
+        for (int i = 0; i < b->nc; ++i) {
+            const int nk = (b->h_len[i] > c->halfstep) ? (b->h_len[i] - c->halfstep + c->step - 1) / c->step : 0;
+            b->h_grid_off[i + 1] = b->h_grid_off[i] + nk;
+        }
+        b->total_grid = b->h_grid_off[b->nc];
+        HIPCHK(hipStreamSynchronize(c->stream));
+        dev_free(b->d_grid_off);
+        b->d_grid_off = nullptr;
+        if ((rc = dev_upload(c, &b->d_grid_off, b->h_grid_off.data(), (size_t)b->nc + 1))) return rc;
+        for (int i = 0; i < 3; ++i) {
+            dev_free(b->d_grid[i]);
+            b->d_grid[i] = nullptr;
+            if ((rc = dev_alloc(&b->d_grid[i], (size_t)b->total_grid))) return rc;
+        }
+        if ((rc = build_tiles(b, OCC_T, &b->d_tiles_occ, &b->n_tiles_occ, true, c->step, c->halfstep))) return rc;
+        b->grid_step = c->step;
+        b->grid_half = c->halfstep;
+    }
+    for (int t : {NATAC_T_OCC, NATAC_T_OCC_LOWER, NATAC_T_OCC_UPPER, NATAC_T_OCC_COV, NATAC_T_OCC_PREFILL})
+        if ((rc = ensure_track(b, t))) return rc;
+    const ChunkTable ct = make_table(b);
+    const OccModelDev om = make_occ(c);
+    natac_ctx::Ev ev;
+    prof_begin(c, NATAC_K_OCC_MLE, ev);
+    {
+        const int U = c->occ_upper, UP = (U + 1) & ~1;
+        const int span = (OCC_T - 1) * c->step + M;
+        const int EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
+        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 8 * (size_t)UP) * sizeof(double);
+        hipLaunchKernelGGL(natac_occ_mle, dim3(b->n_tiles_occ), dim3(256), lds, c->stream, ct, b->d_tiles_occ, om, b->d_grid[0],
+                           b->d_grid[1], b->d_grid[2], b->d_status);
+    }
+    prof_end(c, ev);
+    prof_begin(c, NATAC_K_OCC_SMOOTH, ev);
+    {
+        const int h = (M - 1) / 2;
+        const size_t lds = ((size_t)4 * (256 + 2 * h) + M) * sizeof(double);
+        hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream, ct, b->d_tiles256, om, c->d_win_occ, M,
+                           b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_track[NATAC_T_OCC_PREFILL],
+                           b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER]);
+        hipLaunchKernelGGL(natac_occ_cov, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, c->occ_upper, c->flank,
+                           b->d_track[NATAC_T_OCC_COV]);
+    }
+    prof_end(c, ev);
+    prof_begin(c, NATAC_K_OCC_FILL, ev);
+    hipLaunchKernelGGL(natac_fill_nan_min, dim3(b->nc), dim3(256), 0, c->stream, ct, b->d_track[NATAC_T_OCC_PREFILL],
+                       b->d_track[NATAC_T_OCC]);
+    prof_end(c, ev);
+    HIPCHK(hipGetLastError());
+    b->occ_done = true;
+    return NATAC_OK;
+}
+
+int natac_run_ins(natac_batch *b, int lower, int upper) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_track(b, NATAC_T_INS);
+    if (rc) return rc;
+    const ChunkTable ct = make_table(b);
+    natac_ctx::Ev ev;
+    prof_begin(c, NATAC_K_INS, ev);
+    HIPCHK(hipMemsetAsync(b->d_track[NATAC_T_INS], 0, (size_t)b->total_bp * sizeof(int), c->stream));
+    hipLaunchKernelGGL(natac_insertions, dim3(b->nc), dim3(256), 0, c->stream, ct, lower, upper, (int *)b->d_track[NATAC_T_INS]);
+    prof_end(c, ev);
+    HIPCHK(hipGetLastError());
+    b->ins_done = true;
+    return NATAC_OK;
+}
+
+int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chunk, const int32_t *cand_pos, double *lr,
+                         double *var, double *z) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    natac_ctx *c = b->ctx;
+    if (!b->nuc_done) return fail(NATAC_E_STATE, "natac_run_nuc must run before natac_run_candidates");
+    if (n_cand < 0 || (n_cand > 0 && (!cand_chunk || !cand_pos || !lr || !var || !z))) return fail(NATAC_E_ARG, "null argument");
+    if (n_cand == 0) return NATAC_OK;
+    if (n_cand > 0x7fffffffLL) return fail(NATAC_E_ARG, "too many candidates");
+    HIPCHK(hipSetDevice(c->device));
+    for (int64_t k = 0; k < n_cand; ++k) {
+        const int ci = cand_chunk[k];
+        if (ci < 0 || ci >= b->nc || cand_pos[k] < 0 || cand_pos[k] >= b->h_len[ci])
+            return fail(NATAC_E_ARG, "candidate %lld out of range (chunk %d pos %d)", (long long)k, ci, cand_pos[k]);
+    }
+    int *d_cc = nullptr, *d_cp = nullptr;
+    double *d_out = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_cc, cand_chunk, (size_t)n_cand))) return rc;
+    if ((rc = dev_upload(c, &d_cp, cand_pos, (size_t)n_cand))) { dev_free(d_cc); return rc; }
+    if ((rc = dev_alloc(&d_out, (size_t)3 * n_cand))) { dev_free(d_cc); dev_free(d_cp); return rc; }
+    const ChunkTable ct = make_table(b);
+    const VMatDev vm = make_vmat(c);
+    const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
+    natac_ctx::Ev ev;
+    prof_begin(c, NATAC_K_CAND, ev);
+    hipLaunchKernelGGL(natac_candidates, dim3((unsigned)n_cand), dim3(256), (size_t)(EW + 2) * sizeof(double), c->stream, ct, vm,
+                       d_cc, d_cp, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM], d_out, d_out + n_cand,
+                       d_out + 2 * n_cand);
+    prof_end(c, ev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(lr, d_out, (size_t)n_cand * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(var, d_out + n_cand, (size_t)n_cand * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(z, d_out + 2 * n_cand, (size_t)n_cand * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_cc); dev_free(d_cp); dev_free(d_out);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "candidates: %s", hipGetErrorString(e));
+    prof_collect(c);
+    return NATAC_OK;
+}
+
+static int track_ready(natac_batch *b, int t) {
+    if (t < 0 || t >= NATAC_T_COUNT) return fail(NATAC_E_ARG, "bad track id %d", t);
+    const bool nuc = (t <= NATAC_T_SMOOTH), occ = (t >= NATAC_T_OCC && t <= NATAC_T_OCC_COV) || t == NATAC_T_OCC_PREFILL;
+    if ((nuc && !b->nuc_done) || (occ && !b->occ_done) || (t == NATAC_T_INS && !b->ins_done))
+        return fail(NATAC_E_STATE, "track %d has not been computed yet", t);
+    return NATAC_OK;
+}
+
+int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes) {
+    if (!b || !dst) return fail(NATAC_E_ARG, "null argument");
+    int rc = track_ready(b, track);
+    if (rc) return rc;
+    const size_t need = (size_t)b->total_bp * (track == NATAC_T_INS ? sizeof(int) : sizeof(double));
+    if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, track needs %zu", dst_bytes, need);
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, b->d_track[track], need, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    prof_collect(b->ctx);
+    return NATAC_OK;
+}
+
+int natac_batch_download_grid(natac_batch *b, int which, double *dst, size_t dst_bytes) {
+    if (!b || !dst) return fail(NATAC_E_ARG, "null argument");
+    if (which < 0 || which > 2) return fail(NATAC_E_ARG, "bad grid id");
+    if (!b->occ_done) return fail(NATAC_E_STATE, "natac_run_occ has not run");
+    const size_t need = (size_t)b->total_grid * sizeof(double);
+    if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, grid needs %zu", dst_bytes, need);
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, b->d_grid[which], need, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return NATAC_OK;
+}
+
+int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes) {
+    if (!b || !dst) return fail(NATAC_E_ARG, "null argument");
+    if (dst_bytes != (size_t)b->nc * sizeof(int)) return fail(NATAC_E_ARG, "status buffer must hold n_chunks int32");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, b->d_status, dst_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return NATAC_OK;
+}
+
+int natac_batch_track_ptr(natac_batch *b, int track, void **dptr) {
+    if (!b || !dptr) return fail(NATAC_E_ARG, "null argument");
+    if (track < 0 || track >= NATAC_T_COUNT) return fail(NATAC_E_ARG, "bad track id");
+    *dptr = b->d_track[track];
+    return NATAC_OK;
+}
+
+/* ---------------- Cython-function drop-ins ---------------- */
+
+int natac_make_fragment_mat(natac_ctx *c, int64_t nf, const int64_t *l, const int32_t *n, int64_t start, int64_t end, int lower,
+                            int upper, double *mat) {
+    if (!c || !mat || (nf > 0 && (!l || !n))) return fail(NATAC_E_ARG, "null argument");
+    if (end <= start || upper <= lower) return fail(NATAC_E_ARG, "empty matrix");
+    const long long ncol = end - start, nrow = upper - lower;
+    if (ncol > 0x7fffffffLL) return fail(NATAC_E_ARG, "region too long");
+    HIPCHK(hipSetDevice(c->device));
+    long long *d_l = nullptr; int *d_n = nullptr; double *d_m = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_l, (const long long *)l, (size_t)nf))) return rc;
+    if ((rc = dev_upload(c, &d_n, n, (size_t)nf))) { dev_free(d_l); return rc; }
+    if ((rc = dev_alloc(&d_m, (size_t)(nrow * ncol)))) { dev_free(d_l); dev_free(d_n); return rc; }
+    hipError_t e = hipMemsetAsync(d_m, 0, (size_t)(nrow * ncol) * sizeof(double), c->stream);
+    if (e == hipSuccess && nf > 0) {
+        int blocks = (int)std::min<long long>((nf + 255) / 256, 4096);
+        hipLaunchKernelGGL(natac_fragment_mat, dim3(blocks), dim3(256), 0, c->stream, d_l, d_n, (long long)nf, (long long)start,
+                           (int)ncol, lower, (int)nrow, d_m);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(mat, d_m, (size_t)(nrow * ncol) * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_l); dev_free(d_n); dev_free(d_m);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "make_fragment_mat: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
+int natac_get_insertions(natac_ctx *c, int64_t nf, const int64_t *l, const int32_t *n, int64_t start, int64_t end, int lower,
+                         int upper, double *out) {
+    if (!c || !out || (nf > 0 && (!l || !n))) return fail(NATAC_E_ARG, "null argument");
+    if (end <= start) return fail(NATAC_E_ARG, "empty region");
+    const long long npos = end - start;
+    if (npos > 0x7fffffffLL) return fail(NATAC_E_ARG, "region too long");
+    HIPCHK(hipSetDevice(c->device));
+    long long *d_l = nullptr; int *d_n = nullptr, *d_i = nullptr; double *d_o = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_l, (const long long *)l, (size_t)nf))) return rc;
+    if ((rc = dev_upload(c, &d_n, n, (size_t)nf))) { dev_free(d_l); return rc; }
+    if ((rc = dev_alloc(&d_i, (size_t)npos))) { dev_free(d_l); dev_free(d_n); return rc; }
+    if ((rc = dev_alloc(&d_o, (size_t)npos))) { dev_free(d_l); dev_free(d_n); dev_free(d_i); return rc; }
+    hipError_t e = hipMemsetAsync(d_i, 0, (size_t)npos * sizeof(int), c->stream);
+    if (e == hipSuccess) {
+        if (nf > 0) {
+            int blocks = (int)std::min<long long>((nf + 255) / 256, 4096);
+            hipLaunchKernelGGL(natac_insertions_region, dim3(blocks), dim3(256), 0, c->stream, d_l, d_n, (long long)nf,
+                               (long long)start, (int)npos, lower, upper, d_i);
+        }
+        int blocks = (int)std::min<long long>((npos + 255) / 256, 4096);
+        hipLaunchKernelGGL(natac_i32_to_f64, dim3(blocks), dim3(256), 0, c->stream, d_i, d_o, npos);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, (size_t)npos * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_l); dev_free(d_n); dev_free(d_i); dev_free(d_o);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "get_insertions: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
+int natac_fragment_sizes(natac_ctx *c, int64_t nf, const int64_t *l, const int32_t *n, int32_t nchunks, const int64_t *cs,
+                         const int64_t *ce, int lower, int upper, double *sizes) {
+    if (!c || !sizes || (nf > 0 && (!l || !n)) || (nchunks > 0 && (!cs || !ce))) return fail(NATAC_E_ARG, "null argument");
+    if (upper <= lower) return fail(NATAC_E_ARG, "upper <= lower");
+    const int nb = upper - lower;
+    if (nb > 16384) return fail(NATAC_E_ARG, "size range too wide");
+    HIPCHK(hipSetDevice(c->device));
+    long long *d_l = nullptr, *d_cs = nullptr, *d_ce = nullptr; int *d_n = nullptr; unsigned long long *d_h = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_l, (const long long *)l, (size_t)nf))) return rc;
+    if ((rc = dev_upload(c, &d_n, n, (size_t)nf))) { dev_free(d_l); return rc; }
+    if ((rc = dev_upload(c, &d_cs, (const long long *)cs, (size_t)nchunks))) { dev_free(d_l); dev_free(d_n); return rc; }
+    if ((rc = dev_upload(c, &d_ce, (const long long *)ce, (size_t)nchunks))) { dev_free(d_l); dev_free(d_n); dev_free(d_cs); return rc; }
+    if ((rc = dev_alloc(&d_h, (size_t)nb))) { dev_free(d_l); dev_free(d_n); dev_free(d_cs); dev_free(d_ce); return rc; }
+    std::vector<unsigned long long> h((size_t)nb, 0);
+    hipError_t e = hipMemsetAsync(d_h, 0, (size_t)nb * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess && nf > 0 && nchunks > 0) {
+        int blocks = (int)std::min<long long>((nf + 255) / 256, 1024);
+        hipLaunchKernelGGL(natac_size_hist, dim3(blocks), dim3(256), (size_t)nb * sizeof(unsigned), c->stream, d_l, d_n, (long long)nf,
+                           d_cs, d_ce, (int)nchunks, lower, upper, d_h);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_h, (size_t)nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_l); dev_free(d_n); dev_free(d_cs); dev_free(d_ce); dev_free(d_h);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "fragment_sizes: %s", hipGetErrorString(e));
+    for (int i = 0; i < nb; ++i) sizes[i] = (double)h[i];
+    return NATAC_OK;
+}
+
+int natac_calculate_cov(natac_ctx *c, const double *p, const double *v, int64_t n, int r, int mode, double *out) {
+    if (!c || !p || !v || !out) return fail(NATAC_E_ARG, "null argument");
+    if (n <= 0) return fail(NATAC_E_ARG, "p and v must be non-empty");
+    if (mode != 0 && mode != 1) return fail(NATAC_E_ARG, "mode must be 0 (closed form) or 1 (literal)");
+    HIPCHK(hipSetDevice(c->device));
+    double *d_p = nullptr, *d_v = nullptr, *d_part = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_p, p, (size_t)n))) return rc;
+    if ((rc = dev_upload(c, &d_v, v, (size_t)n))) { dev_free(d_p); return rc; }
+    const int blocks = mode == 0 ? (int)std::min<int64_t>((n + 255) / 256, 1024) : (int)std::min<int64_t>(n, 4096);
+    if ((rc = dev_alloc(&d_part, (size_t)2 * blocks))) { dev_free(d_p); dev_free(d_v); return rc; }
+    std::vector<double> part((size_t)2 * blocks);
+    if (mode == 0)
+        hipLaunchKernelGGL(natac_cov_closed, dim3(blocks), dim3(256), 0, c->stream, d_p, d_v, (long long)n, d_part);
+    else
+        hipLaunchKernelGGL(natac_cov_literal, dim3(blocks), dim3(256), 0, c->stream, d_p, d_v, (long long)n, d_part);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_part, (size_t)(mode == 0 ? 2 : 1) * blocks * sizeof(double),
+                                            hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_p); dev_free(d_v); dev_free(d_part);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "calculate_cov: %s", hipGetErrorString(e));
+    if (mode == 0) {
+        double s1 = 0, s2 = 0;
+        for (int i = 0; i < blocks; ++i) { s1 += part[2 * i]; s2 += part[2 * i + 1]; }
+        *out = (s1 - s2 * s2) * r;
+    } else {
+        double s = 0;
+        for (int i = 0; i < blocks; ++i) s += part[i];
+        *out = s * r;
+    }
+    return NATAC_OK;
+}
+
+/* ---------------- profiling ---------------- */
+
+int natac_profile_enable(natac_ctx *c, int on) {
+    if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
+    c->profiling = on != 0;
+    return NATAC_OK;
+}
+int natac_profile_get(natac_ctx *c, int k, double *ms_total, int64_t *launches) {
+    if (!c || k < 0 || k >= NATAC_K_COUNT) return fail(NATAC_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (ms_total) *ms_total = c->prof_ms[k];
+    if (launches) *launches = c->prof_n[k];
+    return NATAC_OK;
+}
+int natac_profile_reset(natac_ctx *c) {
+    if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    for (int i = 0; i < NATAC_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    return NATAC_OK;
+}
+int natac_timer_start(natac_ctx *c) {
+    if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->t0, c->stream));
+    return NATAC_OK;
+}
+int natac_timer_stop(natac_ctx *c, double *ms) {
+    if (!c || !ms) return fail(NATAC_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->t1, c->stream));
+    HIPCHK(hipEventSynchronize(c->t1));
+    float f = 0;
+    HIPCHK(hipEventElapsedTime(&f, c->t0, c->t1));
+    *ms = f;
+    prof_collect(c);
+    return NATAC_OK;
+}
+
+}  // extern "C"

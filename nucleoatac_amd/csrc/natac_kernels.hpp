@@ -1,0 +1,795 @@
+// natac_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4) for NucleoATAC's occ + nuc signal path.
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is an explicit fma(); everything else
+// rounds like the reference's numpy expressions.  Wave = 64 lanes throughout.
+//
+// Geometry (reference: SURVEY.md Appendix C).  Inside a chunk all coordinates are relative to the chunk
+// start; `bias` is the chunk's log-bias slice, index j <-> coordinate j - bias_left.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace natac {
+
+constexpr int WAVE = 64;
+
+struct ChunkTable {
+    int nc;
+    const int *chunk_len;       // [nc]
+    const long long *frag_off;  // [nc+1]
+    const int *lpos;            // [nf]
+    const int *ilen;            // [nf]
+    const int *centre;          // [nf]  lpos + floor((ilen-1)/2), non-decreasing inside a chunk
+    const long long *bias_off;  // [nc+1] or null
+    const double *bias;         // log-bias or null
+    int bias_left, bias_right;
+    const long long *out_off;   // [nc+1]
+    const long long *grid_off;  // [nc+1]
+};
+
+struct VMatDev {
+    const double *mat;   // R x W row-major
+    const double *srow;  // [R] sizes[lower + r]
+    int lower, upper, w, R, W;
+};
+
+__device__ __forceinline__ int floor_half(int x) { return x >> 1; }  // arithmetic shift == python x//2
+
+__device__ __forceinline__ int lower_bound_i32(const int *a, int lo, int hi, int key) {
+    // first index in [lo,hi) with a[idx] >= key
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+__device__ __forceinline__ int wave_or(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fragment centres: c = l + (n-1)//2   (pyatac/fragments.pyx:36)
+// ------------------------------------------------------------------------------------------------
+__global__ void natac_frag_centres(const int *__restrict__ lpos, const int *__restrict__ ilen, int *__restrict__ centre,
+                                   long long nf) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < nf; i += stride) centre[i] = lpos[i] + floor_half(ilen[i] - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0  sparse V-plot gather: nuc_cov, nfr_cov, raw signal.
+//   nuc_cov[g] = #{frag: vlower <= n < vupper, |c-g| <= w}          tracks.py:209-222 via NucleosomeCalling.py:257-260
+//   nfr_cov[g] = #{frag: 0 <= n < vlower,      |c-g| <= w}          NucleosomeCalling.py:271-273
+//   raw[g]     = sum_{frag: vlower<=n<vupper, |c-g|<=w} V[n-vlower, c-g+w]   NucleosomeCalling.py:29-36
+// The reference builds the dense (upper x L) count matrix and correlates it with V (17,666 MAC/base);
+// only ~F*W entries are non-zero, so one thread per base walks the (centre-sorted) fragments in its window.
+// tile = (chunk, x0): 256 consecutive bases of one chunk.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
+                                                           double *__restrict__ nuc_cov, double *__restrict__ nfr_cov,
+                                                           double *__restrict__ raw) {
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, g = t.y + threadIdx.x;
+    const int L = ct.chunk_len[chunk];
+    if (g >= L) return;
+    const int fa = (int)0, nfr = (int)(ct.frag_off[chunk + 1] - ct.frag_off[chunk]);
+    const int *cen = ct.centre + ct.frag_off[chunk];
+    const int *iln = ct.ilen + ct.frag_off[chunk];
+    int f = lower_bound_i32(cen, fa, nfr, g - vm.w);
+    int cnt_nuc = 0, cnt_nfr = 0;
+    double acc = 0.0;
+    for (; f < nfr; ++f) {
+        const int c = cen[f];
+        if (c > g + vm.w) break;
+        const int n = iln[f];
+        if (n >= vm.lower) {
+            if (n < vm.upper) {
+                ++cnt_nuc;
+                acc += vm.mat[(n - vm.lower) * vm.W + (c - g + vm.w)];
+            }
+        } else if (n >= 0) {
+            ++cnt_nfr;
+        }
+    }
+    const long long o = ct.out_off[chunk] + g;
+    nuc_cov[o] = (double)cnt_nuc;
+    nfr_cov[o] = (double)cnt_nfr;
+    raw[o] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  dense background: the dominant kernel.
+//   B[i,x]   = sizes[i] * E[x-(i-1)//2] * E[x+i//2],  E = exp(log-bias)      chunkmat2d.py:140-156
+//   num[g]   = sum_{r<R} sum_{c<W} B[lower+r, g-w+c] * V[r,c]                 NucleosomeCalling.py:60-63
+//   covB[g]  = sum_{r<R} sum_{c<W} B[lower+r, g-w+c]                          NucleosomeCalling.py:56-58
+//   bg[g]    = num[g] * nuc_cov[g] / covB[g];  norm[g] = raw[g] - bg[g]       NucleosomeCalling.py:64, 38-43
+// 17,666 fp64 FMA per base.  The reference materialises B (4.7 MB / chunk); here B never exists:
+//   * one 64-lane workgroup owns a tile of TW = 64*G consecutive bases of one chunk;
+//   * E for the tile (+halo) is computed once into LDS;
+//   * per V-plot row r the product row P_r[u] = s_r E[.] E[.] (TW+2w values) is built in LDS (1/121 of the work),
+//     its running column sum Q[u] = sum_r P_r[u] stays in registers (gives covB for free);
+//   * each lane then slides over P_r for its G consecutive outputs: one ds_read_b64 feeds G FMAs whose
+//     V[r,c] operand is wave-uniform (scalar loads -> SGPR operand of v_fma_f64);
+//   * G is odd so that the lane stride (2G dwords) is conflict-free on the 64-bank LDS without padding.
+// fp64 VALU bound (arithmetic intensity ~440 flop/B); MFMA is not applicable (matrix-vector shaped,
+// and fp64 MFMA has no rate advantage on gfx950).
+// Template W: fast path for the default V-plot width 121; natac_background_generic handles any other width.
+// ------------------------------------------------------------------------------------------------
+template <int G, int W>
+__global__ void __launch_bounds__(64) natac_background(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
+                                                         const double *__restrict__ nuc_cov, const double *__restrict__ raw,
+                                                         double *__restrict__ bg, double *__restrict__ norm) {
+    constexpr int TW = WAVE * G;
+    constexpr int HW = W / 2;
+    constexpr int PW = TW + W - 1;               // product-row length
+    constexpr int NQ = (PW + WAVE - 1) / WAVE;   // product elements per lane
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, x0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    const int A = (vm.upper - 2) >> 1;           // max left half-length  (i-1)//2, i = upper-1
+    const int Bh = (vm.upper - 1) >> 1;          // max right half-length i//2
+    const int EW = PW + A + Bh;
+    double *Et = smem;                           // [EW]
+    double *Pb = smem + ((EW + 1) & ~1);         // [PW]
+
+    // --- E tile: coordinate of Et[u] is x0 - HW - A + u
+    {
+        const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
+        const int nb = L + ct.bias_left + ct.bias_right;
+        const int j0 = x0 - HW - A + ct.bias_left;
+        for (int u = lane; u < EW; u += WAVE) {
+            const int j = j0 + u;
+            double e = 1.0;
+            if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+            Et[u] = e;
+        }
+    }
+    __syncthreads();
+
+    double acc[G];
+    double q[NQ];
+#pragma unroll
+    for (int k = 0; k < G; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) q[k] = 0.0;
+
+    const int ub = lane * G;
+    for (int r = 0; r < vm.R; ++r) {
+        const int i = vm.lower + r;
+        const int hl = floor_half(i - 1), hr = floor_half(i);
+        const double s = vm.srow[r];
+        const double *el = Et + (A - hl);
+        const double *er = Et + (A + hr);
+        // phase A: product row (i == 1 would be a single-cell row; rows of a V-plot start far above 1,
+        // the host rejects lower < 2 for this kernel)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int u = lane + WAVE * k;
+            if (u < PW) {
+                const double p = (s * el[u]) * er[u];
+                q[k] += p;
+                Pb[u] = p;
+            }
+        }
+        __syncthreads();
+        // phase B: sliding FMA; V row operand is wave-uniform
+        const double *__restrict__ vr = vm.mat + r * W;
+        const double *pl = Pb + ub;
+#pragma unroll
+        for (int j = 0; j < G + W - 1; ++j) {
+            const double p = pl[j];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int c = j - k;
+                if (c >= 0 && c < W) acc[k] = fma(p, vr[c], acc[k]);
+            }
+        }
+        __syncthreads();
+    }
+    // --- covB: box sum of Q over W columns
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int u = lane + WAVE * k;
+        if (u < PW) Pb[u] = q[k];
+    }
+    __syncthreads();
+    const long long ob = ct.out_off[chunk];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const int g = x0 + ub + k;
+        double cv = 0.0;
+        for (int c = 0; c < W; ++c) cv += Pb[ub + k + c];
+        if (g < L) {
+            const long long o = ob + g;
+            const double b = (acc[k] * nuc_cov[o]) / cv;
+            bg[o] = b;
+            norm[o] = raw[o] - b;
+        }
+    }
+}
+
+// generic-width fallback (any W, any lower >= 0): one thread per base, E read through exp() each time.
+__global__ void __launch_bounds__(256) natac_background_generic(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
+                                                                  const double *__restrict__ nuc_cov,
+                                                                  const double *__restrict__ raw, double *__restrict__ bg,
+                                                                  double *__restrict__ norm) {
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, g = t.y + threadIdx.x;
+    const int L = ct.chunk_len[chunk];
+    if (g >= L) return;
+    const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] + ct.bias_left : nullptr;
+    double num = 0.0, cov = 0.0;
+    for (int r = 0; r < vm.R; ++r) {
+        const int i = vm.lower + r;
+        const int hl = floor_half(i - 1), hr = floor_half(i);
+        const double s = vm.srow[r];
+        for (int c = 0; c < vm.W; ++c) {
+            const int x = g - vm.w + c;
+            double p = s;
+            if (b) p = (hl == -hr) ? s * exp(b[x]) : (s * exp(b[x - hl])) * exp(b[x + hr]);
+            num = fma(p, vm.mat[r * vm.W + c], num);
+            cov += p;
+        }
+    }
+    const long long o = ct.out_off[chunk] + g;
+    const double v = (num * nuc_cov[o]) / cov;
+    bg[o] = v;
+    norm[o] = raw[o] - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 / K4  NaN-aware Gaussian smoothing, numpy 'same' alignment (pyatac/utils.py:23-52):
+//   y[t] = sum_n w[n] x0[t-h+n] / sum_n w[n] ok[t-h+n],  h = (M-1)/2, x0 = x with NaN->0, zero padded;
+//   denominator 0 -> NaN.   CLAMP: x<0 -> 0 first (NucleosomeCalling.py:280).
+// tile = 256 bases of one chunk; input tile (+halo) staged in LDS.
+// ------------------------------------------------------------------------------------------------
+template <bool CLAMP>
+__global__ void __launch_bounds__(256) natac_smooth_same(ChunkTable ct, const int2 *__restrict__ tiles,
+                                                           const double *__restrict__ win, int M,
+                                                           const double *__restrict__ x, double *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int h = (M - 1) / 2;
+    double *xs = smem;               // [256 + 2h]  value (NaN -> 0)
+    double *ok = smem + 256 + 2 * h; // [256 + 2h]  1 / 0
+    double *wl = ok + 256 + 2 * h;   // [M]
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, x0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    const long long ob = ct.out_off[chunk];
+    for (int u = threadIdx.x; u < 256 + 2 * h; u += 256) {
+        const int g = x0 - h + u;
+        double v = 0.0, o = 0.0;
+        if (g >= 0 && g < L) {
+            v = x[ob + g];
+            if (v != v) { v = 0.0; } else { o = 1.0; if (CLAMP && v < 0) v = 0.0; }
+        }
+        xs[u] = v;
+        ok[u] = o;
+    }
+    for (int u = threadIdx.x; u < M; u += 256) wl[u] = win[u];
+    __syncthreads();
+    const int g = x0 + threadIdx.x;
+    if (g >= L) return;
+    double num = 0.0, den = 0.0;
+    for (int n = 0; n < M; ++n) {
+        // np.convolve(w, x)[t+h] = sum_k w[k] x[t+h-k]
+        const double wv = wl[n];
+        const int u = threadIdx.x + 2 * h - n;
+        num = fma(wv, xs[u], num);
+        den = fma(wv, ok[u], den);
+    }
+    y[ob + g] = (den == 0.0) ? __builtin_nan("") : num / den;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  occupancy grid MLE (nucleoatac/Occupancy.py:104-146).
+// For grid point k of a chunk (base g = halfstep + k*step):
+//   ins[j]  = #{frag: n == j, |c-g| <= flank}                 j in [0, upper)
+//   bias[j] = sum_{|d|<=flank} B0[j, g+d],  B0[j,x] = E[x-(j-1)//2] E[x+j//2]  (j == 1: E[x])
+//   pn = nuc_probs*bias / sum,  pf = nfr_probs*bias / sum
+//   ll[a] = sum_j ins[j] log(alpha_a pn[j] + (1-alpha_a) pf[j]);  NaN -> -inf
+//   occ = alpha[argmax ll] (first max), lower/upper = min/max alpha with 2(max-ll) < cutoff
+//   only if sum(ins) > 0, else the three outputs stay NaN.
+// Workgroup = 256 threads = tile of T grid points:
+//   phase 1: thread j owns insert size j and slides the flank window along the tile (products of LDS-staged E),
+//            writing bias[k][j] into LDS;
+//   phase 2: one wave per grid point; lanes own alphas (a = lane, lane+64).  The log-likelihood is accumulated as
+//            a running PRODUCT with frexp renormalisation (mantissa product + integer exponent), so each
+//            (fragment, alpha) costs a handful of fp64 ops instead of a log(); one log per alpha at the end.
+//            `0 * log(0) = NaN -> -inf` of the reference is reproduced with the zero-probability flags.
+// ------------------------------------------------------------------------------------------------
+constexpr int OCC_T = 16;
+
+struct OccModelDev {
+    const double *nuc_probs, *nfr_probs, *alphas;
+    int upper, n_alpha, step, halfstep, flank;
+    double cutoff;
+};
+
+__global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *__restrict__ tiles, OccModelDev om,
+                                                       double *__restrict__ g_occ, double *__restrict__ g_lo,
+                                                       double *__restrict__ g_hi, int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int U = om.upper, UP = (U + 1) & ~1;
+    const int fl = om.flank, WIN = 2 * fl + 1;
+    const int A = (U - 2) >> 1, Bh = (U - 1) >> 1;
+    const int span = (OCC_T - 1) * om.step + WIN;     // centre positions covered by the tile
+    const int EW = span + A + Bh + 2;                  // +1 left for j == 0 (left offset -1 -> x+1) handled by Bh>=1
+    double *Et = smem;                                 // [EW]
+    double *bw = smem + ((EW + 1) & ~1);               // [OCC_T][UP]
+    double *pnl = bw + OCC_T * UP;                     // [4][UP]
+    double *pfl = pnl + 4 * UP;                        // [4][UP]
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, k0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    const int nk = (L - om.halfstep + om.step - 1) / om.step;   // len(range(halfstep, L, step))
+    const int gfirst = om.halfstep + k0 * om.step;               // base of the tile's first grid point
+    // Et[u] <-> coordinate gfirst - fl - A + u
+    {
+        const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
+        const int nb = L + ct.bias_left + ct.bias_right;
+        const int j0 = gfirst - fl - A + ct.bias_left;
+        for (int u = threadIdx.x; u < EW; u += 256) {
+            const int j = j0 + u;
+            double e = 1.0;
+            if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+            Et[u] = e;
+        }
+    }
+    __syncthreads();
+    // ---- phase 1: sliding window sums of B0 for every insert size
+    {
+        const int j = threadIdx.x;
+        if (j < U) {
+            const int hl = floor_half(j - 1), hr = floor_half(j);
+            const bool single = (hl == -hr);   // j == 1: the two pattern ones coincide (chunkmat2d.py:150-151)
+            const double *el = Et + (A - hl);
+            const double *er = Et + (A + hr);
+            double S = 0.0;
+            for (int u = 0; u < WIN; ++u) S += single ? el[u] : el[u] * er[u];
+            bw[j] = S;
+            for (int k = 1; k < OCC_T; ++k) {
+                const int u0 = (k - 1) * om.step;
+                for (int d = 0; d < om.step; ++d) {
+                    const int ua = u0 + d, ub = u0 + WIN + d;
+                    S -= single ? el[ua] : el[ua] * er[ua];
+                    S += single ? el[ub] : el[ub] * er[ub];
+                }
+                bw[k * UP + j] = S;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: one wave per grid point
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nfr = (int)(ct.frag_off[chunk + 1] - ct.frag_off[chunk]);
+    const int *cen = ct.centre + ct.frag_off[chunk];
+    const int *iln = ct.ilen + ct.frag_off[chunk];
+    double *pn = pnl + wave * UP, *pf = pfl + wave * UP;
+    for (int kk = wave; kk < OCC_T; kk += 4) {
+        const int k = k0 + kk;
+        if (k >= nk) break;                      // wave-uniform
+        const int g = om.halfstep + k * om.step;
+        const double *bj = bw + kk * UP;
+        // normalisers
+        double sn = 0.0, sf = 0.0;
+        for (int j = lane; j < U; j += WAVE) {
+            const double b = bj[j];
+            sn += om.nuc_probs[j] * b;
+            sf += om.nfr_probs[j] * b;
+        }
+        sn = wave_sum(sn);
+        sf = wave_sum(sf);
+        int flags = 0;   // 1: some pn == 0, 2: some pf == 0, 4: some both == 0, 8: some NaN
+        for (int j = lane; j < U; j += WAVE) {
+            const double b = bj[j];
+            const double a = (om.nuc_probs[j] * b) / sn;
+            const double c = (om.nfr_probs[j] * b) / sf;
+            pn[j] = a;
+            pf[j] = c;
+            if (a == 0.0) flags |= 1;
+            if (c == 0.0) flags |= 2;
+            if (a == 0.0 && c == 0.0) flags |= 4;
+            if (a != a || c != c) flags |= 8;
+        }
+        flags = wave_or(flags);
+        // fragments of the window (sorted by centre)
+        int f0 = lower_bound_i32(cen, 0, nfr, g - fl);
+        int f1 = lower_bound_i32(cen, f0, nfr, g + fl + 1);
+        const int a0 = lane, a1 = lane + WAVE;
+        const double al0 = (a0 < om.n_alpha) ? om.alphas[a0] : 0.0;
+        const double al1 = (a1 < om.n_alpha) ? om.alphas[a1] : 0.0;
+        const double be0 = 1 - al0, be1 = 1 - al1;
+        double m0 = 1.0, m1 = 1.0;
+        int e0 = 0, e1 = 0, nins = 0;
+        for (int f = f0; f < f1; ++f) {
+            const int n = iln[f];
+            if (n < 0 || n >= U) continue;      // wave-uniform
+            ++nins;
+            const double a = pn[n], c = pf[n];
+            const double x0v = al0 * a + be0 * c;
+            const double x1v = al1 * a + be1 * c;
+            int ex;
+            m0 = frexp(m0 * x0v, &ex); e0 += ex;
+            m1 = frexp(m1 * x1v, &ex); e1 += ex;
+        }
+        const long long go = ct.grid_off[chunk] + k;
+        if (nins == 0) {                         // sum(new_inserts) > 0 fails: stay NaN (Occupancy.py:143)
+            if (lane == 0) { g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan(""); }
+            continue;
+        }
+        const double LN2 = 0.693147180559945309417232121458;
+        const double NINF = -__builtin_inf();
+        double ll0 = log(m0) + (double)e0 * LN2;
+        double ll1 = log(m1) + (double)e1 * LN2;
+        // reference: a zero-probability insert size gives log(0)*ins = -inf (ins>0) or NaN (ins==0) -> -inf
+        if (flags & 8) { ll0 = NINF; ll1 = NINF; }
+        if (flags & 4) { ll0 = NINF; ll1 = NINF; }
+        if ((flags & 2) && al0 == 0.0) ll0 = NINF;
+        if ((flags & 2) && al1 == 0.0) ll1 = NINF;
+        if ((flags & 1) && be0 == 0.0) ll0 = NINF;
+        if ((flags & 1) && be1 == 0.0) ll1 = NINF;
+        if (ll0 != ll0) ll0 = NINF;
+        if (ll1 != ll1) ll1 = NINF;
+        if (a0 >= om.n_alpha) ll0 = NINF;
+        if (a1 >= om.n_alpha) ll1 = NINF;
+        // max + first argmax
+        double mx = fmax(ll0, ll1);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, WAVE));
+        const unsigned long long eq0 = __ballot(ll0 == mx && a0 < om.n_alpha);
+        const unsigned long long eq1 = __ballot(ll1 == mx && a1 < om.n_alpha);
+        const int imax = eq0 ? (__ffsll((long long)eq0) - 1) : (WAVE + __ffsll((long long)eq1) - 1);
+        const double r0 = 2 * (mx - ll0), r1 = 2 * (mx - ll1);
+        const unsigned long long c0 = __ballot(a0 < om.n_alpha && r0 < om.cutoff);
+        const unsigned long long c1 = __ballot(a1 < om.n_alpha && r1 < om.cutoff);
+        if (lane == 0) {
+            if ((c0 | c1) == 0ull) {
+                // every likelihood is -inf: the reference raises ValueError (min of empty, Occupancy.py:118)
+                g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan("");
+                atomicOr(&status[chunk], 1);
+            } else {
+                const int ilo = c0 ? (__ffsll((long long)c0) - 1) : (WAVE + __ffsll((long long)c1) - 1);
+                const int ihi = c1 ? (WAVE + 63 - __clzll((long long)c1)) : (63 - __clzll((long long)c0));
+                g_occ[go] = om.alphas[imax];
+                g_lo[go] = om.alphas[ilo];
+                g_hi[go] = om.alphas[ihi];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  occupancy smoothing: expand the per-grid values to bases ([i-halfstep, min(i+halfstep+1, L)),
+//     Occupancy.py:144-146; bases past the last grid block stay NaN) and apply the NaN-aware Gaussian
+//     (makeSmoothed, Occupancy.py:147-153) to vals / lower / upper; also occ cov = nuc_cov+nfr_cov is
+//     produced by natac_occ_cov below.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) natac_occ_smooth(ChunkTable ct, const int2 *__restrict__ tiles, OccModelDev om,
+                                                          const double *__restrict__ win, int M,
+                                                          const double *__restrict__ g_occ, const double *__restrict__ g_lo,
+                                                          const double *__restrict__ g_hi, double *__restrict__ s_occ,
+                                                          double *__restrict__ s_lo, double *__restrict__ s_hi) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int h = (M - 1) / 2;
+    const int NX = 256 + 2 * h;
+    double *xv = smem, *xl = xv + NX, *xh = xl + NX, *ok = xh + NX, *wl = ok + NX;
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, x0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    const int nk = (L - om.halfstep + om.step - 1) / om.step;
+    const long long gb = ct.grid_off[chunk];
+    for (int u = threadIdx.x; u < NX; u += 256) {
+        const int g = x0 - h + u;
+        double v = 0.0, lo = 0.0, hi = 0.0, o = 0.0;
+        if (g >= 0 && g < L) {
+            const int k = g / om.step;
+            if (k < nk) {
+                v = g_occ[gb + k];
+                if (v == v) { lo = g_lo[gb + k]; hi = g_hi[gb + k]; o = 1.0; } else v = 0.0;
+            }
+        }
+        xv[u] = v; xl[u] = lo; xh[u] = hi; ok[u] = o;
+    }
+    for (int u = threadIdx.x; u < M; u += 256) wl[u] = win[u];
+    __syncthreads();
+    const int g = x0 + threadIdx.x;
+    if (g >= L) return;
+    double nv = 0.0, nl = 0.0, nh = 0.0, den = 0.0;
+    for (int n = 0; n < M; ++n) {
+        const double wv = wl[n];
+        const int u = threadIdx.x + 2 * h - n;
+        nv = fma(wv, xv[u], nv);
+        nl = fma(wv, xl[u], nl);
+        nh = fma(wv, xh[u], nh);
+        den = fma(wv, ok[u], den);
+    }
+    const long long o = ct.out_off[chunk] + g;
+    const double qn = __builtin_nan("");
+    s_occ[o] = den == 0.0 ? qn : nv / den;
+    s_lo[o] = den == 0.0 ? qn : nl / den;
+    s_hi[o] = den == 0.0 ? qn : nh / den;
+}
+
+// occ coverage (all insert sizes < upper, window 2*flank+1): Occupancy.py:221-224.  When the occupancy window
+// equals the V-plot window and upper == vupper this is nuc_cov + nfr_cov; computed independently so that the occ
+// stage does not depend on the nuc stage.
+__global__ void __launch_bounds__(256) natac_occ_cov(ChunkTable ct, const int2 *__restrict__ tiles, int upper, int flank,
+                                                       double *__restrict__ cov) {
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, g = t.y + threadIdx.x;
+    const int L = ct.chunk_len[chunk];
+    if (g >= L) return;
+    const int nfr = (int)(ct.frag_off[chunk + 1] - ct.frag_off[chunk]);
+    const int *cen = ct.centre + ct.frag_off[chunk];
+    const int *iln = ct.ilen + ct.frag_off[chunk];
+    int f = lower_bound_i32(cen, 0, nfr, g - flank);
+    int cnt = 0;
+    for (; f < nfr; ++f) {
+        if (cen[f] > g + flank) break;
+        const int n = iln[f];
+        cnt += (n >= 0 && n < upper);
+    }
+    cov[ct.out_off[chunk] + g] = (double)cnt;
+}
+
+// call_peaks' in-place NaN fill (pyatac/utils.py:86-91) applied to smoothed_vals before it is written
+// (Occupancy.py:227 -> run_occ.py:47): NaNs become the chunk's minimum finite value; all-NaN chunks stay.
+// One workgroup per chunk.
+__global__ void __launch_bounds__(256) natac_fill_nan_min(ChunkTable ct, const double *__restrict__ src,
+                                                            double *__restrict__ dst) {
+    __shared__ double red[4];
+    __shared__ int anynan[4];
+    const int chunk = blockIdx.x;
+    const int L = ct.chunk_len[chunk];
+    const long long ob = ct.out_off[chunk];
+    double mn = __builtin_inf();
+    int nn = 0;
+    for (int g = threadIdx.x; g < L; g += 256) {
+        const double v = src[ob + g];
+        if (v != v) nn = 1; else mn = fmin(mn, v);
+    }
+    mn = wave_min(mn);
+    nn = wave_or(nn);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mn; anynan[threadIdx.x >> 6] = nn; }
+    __syncthreads();
+    mn = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    nn = anynan[0] | anynan[1] | anynan[2] | anynan[3];
+    const bool fill = nn && (mn != __builtin_inf());
+    for (int g = threadIdx.x; g < L; g += 256) {
+        const double v = src[ob + g];
+        dst[ob + g] = (fill && v != v) ? mn : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  per-base insertion counts (pyatac/fragments.pyx:43-67): +1 at l and at r = l+n-1 for lower<=n<upper.
+// One workgroup walks the fragments of one chunk; integer atomics (order-independent, bit-exact).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) natac_insertions(ChunkTable ct, int lower, int upper, int *__restrict__ ins) {
+    const int chunk = blockIdx.x;
+    const int L = ct.chunk_len[chunk];
+    const long long fa = ct.frag_off[chunk], fb = ct.frag_off[chunk + 1];
+    int *out = ins + ct.out_off[chunk];
+    for (long long f = fa + threadIdx.x; f < fb; f += 256) {
+        const int n = ct.ilen[f];
+        if (n < lower || n >= upper) continue;
+        const int l = ct.lpos[f], r = l + n - 1;
+        if (l >= 0 && l < L) atomicAdd(&out[l], 1);
+        if (r >= 0 && r < L) atomicAdd(&out[r], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7  candidate statistics: one workgroup per candidate position p of a chunk.
+//   window cells (r, c): insert size i = vlower + r, centre x = p - w + c
+//   B0 = E[x-(i-1)//2] E[x+i//2],  B = sizes[i] B0
+//   S_B = sum B, S_BV = sum B V, S_BV2 = sum B V^2, S_B0V = sum V B0
+//   var = int(nuc_cov[p]) * (S_BV2/S_B - (S_BV/S_B)^2)                 multinomial_cov.pyx:20-31 (closed form)
+//   lr  = sum_frag log(V B0 / S_B0V) - sum_frag log(B / S_B)           NucleosomeCalling.py:110-122
+//   z   = norm[p] / sqrt(var)                                          NucleosomeCalling.py:123-127
+// A zero cell in either model makes log(0)*0 = NaN in the reference -> lr = NaN here as well.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) natac_candidates(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
+                                                          const int *__restrict__ cand_pos,
+                                                          const double *__restrict__ nuc_cov, const double *__restrict__ norm,
+                                                          double *__restrict__ out_lr, double *__restrict__ out_var,
+                                                          double *__restrict__ out_z) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[5][4];
+    __shared__ int redz[4];
+    const int k = blockIdx.x;
+    const int chunk = cand_chunk[k], p = cand_pos[k];
+    const int L = ct.chunk_len[chunk];
+    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
+    const int EW = vm.W + A + Bh;
+    double *Et = smem;  // Et[u] <-> coordinate p - w - A + u
+    {
+        const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
+        const int nb = L + ct.bias_left + ct.bias_right;
+        const int j0 = p - vm.w - A + ct.bias_left;
+        for (int u = threadIdx.x; u < EW; u += 256) {
+            const int j = j0 + u;
+            double e = 1.0;
+            if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+            Et[u] = e;
+        }
+    }
+    __syncthreads();
+    double sB = 0, sBV = 0, sBV2 = 0, sB0V = 0;
+    int zero = 0;
+    const int ncell = vm.R * vm.W;
+    for (int cell = threadIdx.x; cell < ncell; cell += 256) {
+        const int r = cell / vm.W, c = cell - r * vm.W;
+        const int i = vm.lower + r;
+        const int hl = floor_half(i - 1), hr = floor_half(i);
+        const double b0 = (hl == -hr) ? Et[c + A] : Et[c + A - hl] * Et[c + A + hr];
+        const double bb = vm.srow[r] * b0;
+        const double v = vm.mat[cell];
+        const double vb0 = v * b0;
+        sB += bb;
+        sBV = fma(bb, v, sBV);
+        sBV2 = fma(bb * v, v, sBV2);
+        sB0V += vb0;
+        if (vb0 == 0.0 || bb == 0.0) zero = 1;
+    }
+    sB = wave_sum(sB); sBV = wave_sum(sBV); sBV2 = wave_sum(sBV2); sB0V = wave_sum(sB0V);
+    zero = wave_or(zero);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = sB; red[1][wv] = sBV; red[2][wv] = sBV2; red[3][wv] = sB0V; redz[wv] = zero; }
+    __syncthreads();
+    sB = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sBV = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    sBV2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    sB0V = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+    zero = redz[0] | redz[1] | redz[2] | redz[3];
+    // likelihoods over the window's fragments
+    const int nfr = (int)(ct.frag_off[chunk + 1] - ct.frag_off[chunk]);
+    const int *cen = ct.centre + ct.frag_off[chunk];
+    const int *iln = ct.ilen + ct.frag_off[chunk];
+    const int f0 = lower_bound_i32(cen, 0, nfr, p - vm.w);
+    const int f1 = lower_bound_i32(cen, f0, nfr, p + vm.w + 1);
+    double nl = 0.0, ul = 0.0;
+    for (int f = f0 + threadIdx.x; f < f1; f += 256) {
+        const int n = iln[f];
+        if (n < vm.lower || n >= vm.upper) continue;
+        const int r = n - vm.lower, c = cen[f] - p + vm.w;
+        const int hl = floor_half(n - 1), hr = floor_half(n);
+        const double b0 = (hl == -hr) ? Et[c + A] : Et[c + A - hl] * Et[c + A + hr];
+        nl += log((vm.mat[r * vm.W + c] * b0) / sB0V);
+        ul += log((vm.srow[r] * b0) / sB);
+    }
+    nl = wave_sum(nl); ul = wave_sum(ul);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = nl; red[1][wv] = ul; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        nl = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        ul = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const long long o = ct.out_off[chunk] + p;
+        const double m1 = sBV / sB;
+        const int reads = (int)nuc_cov[o];
+        const double var = (double)reads * (sBV2 / sB - m1 * m1);
+        out_lr[k] = zero ? __builtin_nan("") : (nl - ul);
+        out_var[k] = var;
+        out_z[k] = norm[o] / sqrt(var);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// drop-in kernels for the Cython functions (single region, absolute coordinates)
+// ------------------------------------------------------------------------------------------------
+// makeFragmentMat, pyatac/fragments.pyx:17-40 (mat pre-zeroed; float64 atomics are exact for integer counts)
+__global__ void natac_fragment_mat(const long long *__restrict__ l, const int *__restrict__ n, long long nf,
+                                   long long start, int ncol, int lower, int nrow, double *__restrict__ mat) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < nf; i += stride) {
+        const int ilen = n[i];
+        const long long row = ilen - lower;
+        const long long col = (long long)floor_half(ilen - 1) + l[i] - start;
+        if (col >= 0 && col < ncol && row >= 0 && row < nrow) atomicAdd(&mat[row * ncol + col], 1.0);
+    }
+}
+
+// getInsertions, pyatac/fragments.pyx:43-67 (int32 counts; converted to float64 on the way out)
+__global__ void natac_insertions_region(const long long *__restrict__ l, const int *__restrict__ n, long long nf,
+                                        long long start, int npos, int lower, int upper, int *__restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < nf; i += stride) {
+        const int ilen = n[i];
+        if (ilen < lower || ilen >= upper) continue;
+        const long long lp = l[i] - start, rp = lp + ilen - 1;
+        if (lp >= 0 && lp < npos) atomicAdd(&out[lp], 1);
+        if (rp >= 0 && rp < npos) atomicAdd(&out[rp], 1);
+    }
+}
+
+__global__ void natac_i32_to_f64(const int *__restrict__ a, double *__restrict__ b, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) b[i] = (double)a[i];
+}
+
+// getFragmentSizesFromChunkList, pyatac/fragments.pyx:123-145: a fragment counts once per chunk containing its
+// centre.  Chunks sorted by start; per-workgroup LDS histogram, then one global atomic per bin.
+__global__ void __launch_bounds__(256) natac_size_hist(const long long *__restrict__ l, const int *__restrict__ n,
+                                                         long long nf, const long long *__restrict__ cs,
+                                                         const long long *__restrict__ ce, int nchunks, int lower, int upper,
+                                                         unsigned long long *__restrict__ hist) {
+    extern __shared__ unsigned int lh[];
+    const int nb = upper - lower;
+    for (int b = threadIdx.x; b < nb; b += 256) lh[b] = 0;
+    __syncthreads();
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < nf; i += stride) {
+        const int ilen = n[i];
+        if (ilen < lower || ilen >= upper) continue;
+        const long long c = l[i] + floor_half(ilen - 1);
+        unsigned int cnt = 0;
+        for (int k = 0; k < nchunks; ++k) cnt += (c >= cs[k] && c < ce[k]);
+        if (cnt) atomicAdd(&lh[ilen - lower], cnt);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 256)
+        if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
+// calculateCov, nucleoatac/multinomial_cov.pyx:20-31.
+// mode 0: closed form, partial sums {sum p v^2, sum p v, sum p^2 v^2}: value = r*(S1 - S2^2) where the .pyx's
+//         diagonal p(1-p)v^2 and off-diagonal -2 p_i p_j v_i v_j terms regroup to S1 - S2^2.
+__global__ void __launch_bounds__(256) natac_cov_closed(const double *__restrict__ p, const double *__restrict__ v,
+                                                          long long n, double *__restrict__ partial) {
+    __shared__ double red[2][4];
+    double s1 = 0, s2 = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double pv = p[i] * v[i];
+        s1 = fma(pv, v[i], s1);
+        s2 += pv;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+// mode 1: literal pair sum.  Workgroup b owns rows i = b, b+gridDim, ...; for each i the 256 threads stride over
+// j >= i with the .pyx's own term expressions.  partial[b] = sum of its terms.
+__global__ void __launch_bounds__(256) natac_cov_literal(const double *__restrict__ p, const double *__restrict__ v,
+                                                           long long n, double *__restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+        const double pi = p[i], vi = v[i];
+        for (long long j = i + threadIdx.x; j < n; j += 256) {
+            if (j == i) acc += pi * (1 - pi) * (vi * vi);
+            else acc += pi * p[j] * -2 * vi * v[j];
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace natac

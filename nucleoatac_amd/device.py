@@ -1,0 +1,238 @@
+"""Thin object layer over the C-ABI: one Context per GPU, DeviceBatch = packed chunks resident in HBM.
+
+All numerics run in libnatac_hip.so (HIP, gfx950).  numpy is only used for the host buffers
+that cross the boundary.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .packing import PackedChunks
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context(object):
+    """one HIP device + stream (natac_ctx)"""
+
+    def __init__(self, device_id=0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        L.check(self._lib.natac_ctx_create(int(device_id), C.byref(h)))
+        self._h = h
+        self.device_id = int(device_id)
+        self.vmat_shape = None
+        self.occ_step = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.natac_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @staticmethod
+    def device_count():
+        n = C.c_int(0)
+        L.load().natac_device_count(C.byref(n))
+        return n.value
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu = C.c_int(0)
+        mem = C.c_size_t(0)
+        L.check(self._lib.natac_ctx_device_info(self._h, name, 256, C.byref(ncu), C.byref(mem)))
+        return dict(name=name.value.decode(), n_cu=ncu.value, mem_bytes=mem.value)
+
+    def sync(self):
+        L.check(self._lib.natac_ctx_sync(self._h))
+
+    # ---- constants -------------------------------------------------------------------------
+    def set_vmat(self, mat, lower, upper):
+        """VMat template: mat (upper-lower, 2w+1) for insert sizes [lower, upper) (pyatac/VMat.py:24-37)."""
+        mat = _f64(mat)
+        if mat.ndim != 2 or mat.shape[0] != upper - lower or mat.shape[1] % 2 != 1:
+            raise ValueError("mat shape is not consistent with insert limits")
+        L.check(self._lib.natac_set_vmat(self._h, _ptr(mat), int(lower), int(upper), mat.shape[1] // 2))
+        self.vmat_shape = mat.shape
+
+    def set_sizes(self, sizes):
+        """global insert-size distribution over [0, len(sizes)) (pyatac/chunkmat2d.py:154-156)."""
+        sizes = _f64(sizes)
+        L.check(self._lib.natac_set_sizes(self._h, _ptr(sizes), sizes.shape[0]))
+
+    def set_occ_model(self, nuc_probs, nfr_probs, alphas=None, cutoff=None, step=5, flank=60):
+        """OccupancyCalcParams / OccupancyParameters (nucleoatac/Occupancy.py:89-102, 175-193)."""
+        nuc_probs, nfr_probs = _f64(nuc_probs), _f64(nfr_probs)
+        if nuc_probs.shape != nfr_probs.shape:
+            raise ValueError("nuc_probs / nfr_probs shape mismatch")
+        if alphas is None:
+            alphas = np.linspace(0, 1, 101)
+        alphas = _f64(alphas)
+        if cutoff is None:
+            from scipy import stats
+            cutoff = float(stats.chi2.ppf(0.9, 1))
+        L.check(self._lib.natac_set_occ_model(self._h, _ptr(nuc_probs), _ptr(nfr_probs), nuc_probs.shape[0],
+                                              _ptr(alphas), alphas.shape[0], float(cutoff), int(step), int(flank)))
+        step = int(step)
+        self.occ_step = step - 1 if step % 2 == 0 else step
+
+    # ---- Cython-function drop-ins ------------------------------------------------------------
+    def make_fragment_mat(self, l, n, start, end, lower, upper):
+        """makeFragmentMat (pyatac/fragments.pyx:17-40) on packed fragments (l = pos+4, n = |tlen|-8)."""
+        l = np.ascontiguousarray(l, dtype=np.int64)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        mat = np.empty((upper - lower, end - start), dtype=np.float64)
+        L.check(self._lib.natac_make_fragment_mat(self._h, l.shape[0], _ptr(l), _ptr(n), int(start), int(end),
+                                                  int(lower), int(upper), _ptr(mat)))
+        return mat
+
+    def get_insertions(self, l, n, start, end, lower=0, upper=2000):
+        """getInsertions (pyatac/fragments.pyx:43-67)."""
+        l = np.ascontiguousarray(l, dtype=np.int64)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        out = np.empty(end - start, dtype=np.float64)
+        L.check(self._lib.natac_get_insertions(self._h, l.shape[0], _ptr(l), _ptr(n), int(start), int(end),
+                                               int(lower), int(upper), _ptr(out)))
+        return out
+
+    def fragment_sizes(self, l, n, chunk_starts, chunk_ends, lower, upper):
+        """getFragmentSizesFromChunkList (pyatac/fragments.pyx:123-145), one chromosome."""
+        l = np.ascontiguousarray(l, dtype=np.int64)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        cs = np.ascontiguousarray(chunk_starts, dtype=np.int64)
+        ce = np.ascontiguousarray(chunk_ends, dtype=np.int64)
+        out = np.empty(upper - lower, dtype=np.float64)
+        L.check(self._lib.natac_fragment_sizes(self._h, l.shape[0], _ptr(l), _ptr(n), cs.shape[0], _ptr(cs), _ptr(ce),
+                                               int(lower), int(upper), _ptr(out)))
+        return out
+
+    def calculate_cov(self, p, v, r, literal=False):
+        """calculateCov (nucleoatac/multinomial_cov.pyx:20-31); raises ValueError on a shape mismatch (:21-22)."""
+        p, v = _f64(p), _f64(v)
+        if p.ndim != 1 or v.ndim != 1 or p.shape[0] != v.shape[0]:
+            raise ValueError("p and v must be same shape")
+        out = C.c_double(0)
+        L.check(self._lib.natac_calculate_cov(self._h, _ptr(p), _ptr(v), p.shape[0], int(r), 1 if literal else 0,
+                                              C.byref(out)))
+        return out.value
+
+    # ---- profiling ---------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        L.check(self._lib.natac_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        L.check(self._lib.natac_profile_reset(self._h))
+
+    def profile(self):
+        """{kernel name: (total ms, launches)} from HIP events on the context's stream"""
+        out = {}
+        for k, name in enumerate(L.KERNEL_NAMES):
+            ms, n = C.c_double(0), C.c_int64(0)
+            L.check(self._lib.natac_profile_get(self._h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def timer_start(self):
+        L.check(self._lib.natac_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_double(0)
+        L.check(self._lib.natac_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def upload(self, packed):
+        return DeviceBatch(self, packed)
+
+
+class DeviceBatch(object):
+    """a PackedChunks batch resident in HBM (natac_batch) and its per-base output tracks"""
+
+    def __init__(self, ctx, packed):
+        if not isinstance(packed, PackedChunks):
+            raise TypeError("expected PackedChunks")
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.packed = packed
+        h = C.c_void_p()
+        L.check(self._lib.natac_batch_create(
+            ctx._h, packed.n_chunks, _ptr(packed.chunk_len), _ptr(packed.frag_off), _ptr(packed.frag_lpos),
+            _ptr(packed.frag_ilen), _ptr(packed.bias_off) if packed.bias_log is not None else None,
+            _ptr(packed.bias_log), int(packed.bias_left), int(packed.bias_right), C.byref(h)))
+        self._h = h
+        self.total_bp = packed.total_bp
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.natac_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def run_nuc(self, smooth_sd=10):
+        L.check(self._lib.natac_run_nuc(self._h, float(smooth_sd)))
+
+    def run_occ(self):
+        L.check(self._lib.natac_run_occ(self._h))
+
+    def run_ins(self, lower=0, upper=2000):
+        L.check(self._lib.natac_run_ins(self._h, int(lower), int(upper)))
+
+    def run_candidates(self, cand_chunk, cand_pos):
+        cc = np.ascontiguousarray(cand_chunk, dtype=np.int32)
+        cp = np.ascontiguousarray(cand_pos, dtype=np.int32)
+        if cc.shape != cp.shape:
+            raise ValueError("cand_chunk / cand_pos shape mismatch")
+        n = cc.shape[0]
+        lr, var, z = (np.empty(n, dtype=np.float64) for _ in range(3))
+        L.check(self._lib.natac_run_candidates(self._h, n, _ptr(cc), _ptr(cp), _ptr(lr), _ptr(var), _ptr(z)))
+        return lr, var, z
+
+    def track(self, t):
+        """download one per-base track (concatenated over chunks)"""
+        dt = np.int32 if t == L.T_INS else np.float64
+        out = np.empty(self.total_bp, dtype=dt)
+        L.check(self._lib.natac_batch_download(self._h, int(t), _ptr(out), out.nbytes))
+        return out
+
+    def grid_info(self):
+        bp, grid, nf = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        L.check(self._lib.natac_batch_info(self._h, C.byref(bp), C.byref(grid), C.byref(nf)))
+        return bp.value, grid.value, nf.value
+
+    def grid(self, which):
+        _, total_grid, _ = self.grid_info()
+        out = np.empty(total_grid, dtype=np.float64)
+        L.check(self._lib.natac_batch_download_grid(self._h, int(which), _ptr(out), out.nbytes))
+        return out
+
+    def status(self):
+        out = np.empty(self.packed.n_chunks, dtype=np.int32)
+        L.check(self._lib.natac_batch_status(self._h, _ptr(out), out.nbytes))
+        return out
+
+    def split(self, flat):
+        """split a concatenated per-base array into per-chunk views"""
+        off = self.packed.out_off
+        return [flat[int(off[i]):int(off[i + 1])] for i in range(self.packed.n_chunks)]

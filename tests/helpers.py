@@ -1,0 +1,65 @@
+"""shared helpers for the parity tests (tests only)."""
+import os
+
+import numpy as np
+
+from nucleoatac_amd.packing import PackedChunks, sort_by_centre
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# float tracks: north-star tolerance 1e-5 relative (BASELINE.json); the absolute floor covers
+# values that are exactly 0 in one implementation and ~1e-17 in the other (FFT vs direct sums).
+RTOL = 1e-5
+ATOL = 1e-9
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def packed_from_golden(g, with_bias=True):
+    """PackedChunks from a tests/golden/chunks_*.npz case (absolute l/n per chunk, reference bias track)."""
+    nc = int(g["n_chunks"])
+    starts, lens, offs, ls, ns, boffs, bvals = [], [], [0], [], [], [0], []
+    for k in range(nc):
+        s, e = int(g["chunk_start"][k]), int(g["chunk_end"][k])
+        l = (g["c%d_l" % k] - s).astype(np.int32)
+        n = g["c%d_n" % k].astype(np.int32)
+        o = sort_by_centre(l, n)
+        ls.append(l[o])
+        ns.append(n[o])
+        offs.append(offs[-1] + len(l))
+        starts.append(s)
+        lens.append(e - s)
+        if with_bias:
+            b = g["c%d_bias_log" % k]
+            bvals.append(b)
+            boffs.append(boffs[-1] + len(b))
+    return PackedChunks(chunk_start=np.array(starts), chunk_len=np.array(lens), frag_off=np.array(offs),
+                        frag_lpos=np.concatenate(ls), frag_ilen=np.concatenate(ns),
+                        bias_off=np.array(boffs) if with_bias else None,
+                        bias_log=np.concatenate(bvals) if with_bias else None)
+
+
+def assert_track(got, ref, name, exact=False, rtol=RTOL, atol=ATOL):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (name, got.shape, ref.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), "%s: NaN pattern differs" % name
+    m = ~np.isnan(ref)
+    if exact:
+        assert np.array_equal(got[m], ref[m]), "%s: not bit-exact (max |d| = %g)" % (name, np.max(np.abs(got[m] - ref[m])))
+    else:
+        d = np.abs(got[m] - ref[m])
+        bad = d > atol + rtol * np.abs(ref[m])
+        assert not bad.any(), "%s: %d values off, max |d| = %g (ref %g)" % (
+            name, int(bad.sum()), float(d.max()), float(np.abs(ref[m][np.argmax(d)])))
+
+
+def expand_grid(vals, L, step=5):
+    """per-grid-point values -> per-base track, as OccupancyTrack.calculateOccupancyMLE assigns them
+    (nucleoatac/Occupancy.py:136-146): grid point k covers [k*step, min((k+1)*step, L)); the tail stays NaN."""
+    out = np.full(L, np.nan)
+    nk = len(vals)
+    rep = np.repeat(vals, step)[:L]
+    out[:min(L, nk * step)] = rep[:min(L, nk * step)]
+    return out
