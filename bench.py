@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- Mbp/s through the occ + nuc signal pipeline on N MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path over one batch of synthetic chunks that is already
+resident in HBM: nuc tracks (coverage, raw, background, norm, smooth) + occupancy tracks (grid MLE,
+smoothing, cov, NaN fill) + per-base insertion counts + per-candidate LR / variance / z.
+Workload at N=1 = BASELINE.json configs[2]: synthetic 100k windows x 2 kb (2,120 bp after the +-60
+slop), 50 M fragments, default VMat (146 x 121).  With N > 1 every rank owns its own shard of the
+same shape (chunk list sharded across GPUs, no data-path collective): weak scaling.
+
+Launch: python bench.py --gpus 1            (default)
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_BP = 79.8          # SURVEY.md section 8(d), config 3 (compulsory HBM traffic of the whole path)
+FLOP_PER_BP_BG = 2 * 146 * 121   # fp64 flop per base of the dominant kernel (dense background correlation)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chunks", type=int, default=100000, help="chunks per GPU")
+    ap.add_argument("--chunk-len", type=int, default=2120)
+    ap.add_argument("--frags-per-chunk", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def _cpu_chunk(args):
+    """one chunk through the CPU oracle in the reference's execution shape (dense per-chunk numpy/scipy)."""
+    from scipy import signal
+    from oracle import natac_oracle as O
+    (l, n, L, bias, bl, vmat, vlo, vup, sizes, nucp, nfrp) = args
+    l = l.astype(np.int64)
+    n = n.astype(np.int64)
+    dense = lambda sub, vm: signal.correlate(sub, vm, mode="valid")[0]   # what the reference calls (NucleosomeCalling.py:34)
+    nt = O.nuc_chunk_tracks(l, n, 0, L, bias, -bl, vmat, vlo, vup, sizes, dense_correlate=dense)
+    oc = O.occ_chunk_tracks(l, n, 0, L, bias, -bl, nucp, nfrp)
+    O.get_insertions(l, n, 0, L)
+    return float(np.nansum(nt["norm"]) + np.nansum(oc["smoothed_vals"]))
+
+
+def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks):
+    """reference execution shape: multiprocessing.Pool(cores-1), chunk per task (run_occ.py:101-123)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    workers = max(1, cores - 1)
+    if n_chunks <= 0:
+        n_chunks = min(4096, max(8, 32 * workers))   # ~15 s of wall time at ~0.45 core-s per chunk
+    n_chunks = min(n_chunks, pk.n_chunks)
+    tasks = []
+    for k in range(n_chunks):
+        l, n = pk.chunk_frags(k)
+        tasks.append((l, n, int(pk.chunk_len[k]), pk.chunk_bias(k), pk.bias_left, par["vmat"], int(par["vlower"]),
+                      int(par["vupper"]), sizes, nucp, nfrp))
+    bp = int(pk.chunk_len[:n_chunks].sum())
+    ctx = mp.get_context("fork")
+    with ctx.Pool(workers) as pool:
+        pool.map(_cpu_chunk, tasks[:workers])      # warm the workers (imports)
+        t0 = time.time()
+        pool.map(_cpu_chunk, tasks)
+        dt = time.time() - t0
+    return dict(value=bp / dt / 1e6, unit="Mbp/s", cores=workers, kind="port",
+                sample="%d of the workload's chunks (%d bp) through oracle/natac_oracle.py, occ+nuc+ins, "
+                       "Pool(%d) one chunk per task, %.1f s" % (n_chunks, bp, workers, dt))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from nucleoatac_amd import _lib as L
+    from nucleoatac_amd.device import Context
+    from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions, synth_size_distribution
+
+    par = np.load(os.path.join(ROOT, "tests", "golden", "params_example.npz"))
+    sizes = synth_size_distribution(251)
+    nucp, nfrp = synth_occ_distributions(251)
+    t_gen = time.time()
+    pk = make_synthetic_chunks(a.chunks, a.chunk_len, a.frags_per_chunk, seed=a.seed + 1000 * rank)
+    t_gen = time.time() - t_gen
+    # candidate dyads: the generator's phased positions (every 190 bp), kept 60 bp off the chunk edges
+    per = np.arange(95 - 126, a.chunk_len - 60, 190)
+    per = per[per >= 60]
+    cand_pos = np.tile(per, pk.n_chunks).astype(np.int32)
+    cand_chunk = np.repeat(np.arange(pk.n_chunks, dtype=np.int32), len(per))
+
+    # CPU baseline first (rank 0, N=1 only): it forks worker processes, so run it before the HIP context exists
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(pk, par, sizes, nucp, nfrp, a.cpu_chunks)
+
+    ctx = Context(local_rank)
+    ctx.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
+    ctx.set_sizes(sizes)
+    ctx.set_occ_model(nucp, nfrp, step=5, flank=60)
+    t_up = time.time()
+    batch = ctx.upload(pk)
+    ctx.sync()
+    t_up = time.time() - t_up
+
+    def step():
+        batch.run_nuc(10)
+        batch.run_occ()
+        batch.run_ins(0, 2000)
+        return batch.run_candidates(cand_chunk, cand_pos)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    ctx.sync()
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = ctx.profile()
+    total_bp = pk.total_bp * world
+    ms_per_step = dt / a.steps * 1e3
+    value = total_bp * a.steps / dt / 1e6
+
+    # PCIe-inclusive figure (never `value`): one upload + one download of the per-base tracks that the writers consume
+    t_dn = time.time()
+    for t in (L.T_NORM, L.T_SMOOTH, L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER):
+        batch.track(t)
+    t_dn = time.time() - t_dn
+
+    if rank == 0:
+        bg_ms, bg_n = prof["background"]
+        bg_avg_s = (bg_ms / max(1, bg_n)) / 1e3
+        alg_bytes = ALG_BYTES_PER_BP * pk.total_bp
+        achieved = alg_bytes / bg_avg_s / 1e9 if bg_avg_s > 0 else 0.0
+        tflops = FLOP_PER_BP_BG * pk.total_bp / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
+        out = {
+            "metric": "Mbp/s through occ+nuc signal pipeline", "value": round(value, 3), "unit": "Mbp/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2]: synthetic %d windows x 2 kb (L=%d after slop), %d fragments, default VMat "
+                                   "146x121, 1 GPU-shard per rank" % (a.chunks, a.chunk_len, pk.n_frags),
+                       "chunks_per_gpu": a.chunks, "chunk_len": a.chunk_len, "fragments_per_gpu": pk.n_frags,
+                       "candidates_per_gpu": int(len(cand_pos)), "sharding": "chunk list split across ranks, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "natac_background (dense bias x VMat correlation)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(bg_avg_s * 1e3, 3), "launches": int(bg_n),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "the kernel is fp64-VALU bound (17,666 FMA/base vs 79.8 B/base); see valu_f64",
+                         "valu_f64": {"achieved": round(tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(tflops / FP64_PEAK_TFLOPS, 4)}},
+            "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
+            "host": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2), "download_5_tracks_s": round(t_dn, 2),
+                     "pcie_inclusive_mbp_s": round(pk.total_bp / (dt / a.steps + t_up + t_dn) / 1e6, 2)},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    batch.free()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,8 +57,12 @@ def make_synthetic_chunks(n_chunks, chunk_len, frags_per_chunk, seed=0, with_bia
     c = synth_centres(rng, nf, span) - flank  # centre relative to chunk start
     lpos = (c - (n.astype(np.int64) - 1) // 2).astype(np.int32)
     # sort by (chunk, centre): chunk id is implicit in the CSR slices
-    cid = np.repeat(np.arange(nc, dtype=np.int64), per)
-    order = np.lexsort((c, cid))
+    if poisson:
+        cid = np.repeat(np.arange(nc, dtype=np.int64), per)
+        order = np.lexsort((c, cid))
+    else:  # equal-sized CSR segments: sort every row of the (nc, F) view
+        F = int(frags_per_chunk)
+        order = (np.argsort(c.reshape(nc, F), axis=1, kind="stable") + (np.arange(nc, dtype=np.int64) * F)[:, None]).ravel()
     lpos, n = lpos[order], n[order]
     chunk_start = (np.arange(nc, dtype=np.int64) * (L + genome_gap)) + 10000
     bias_off = bias_log = None
