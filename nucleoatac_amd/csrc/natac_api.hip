@@ -68,7 +68,7 @@ struct natac_batch {
     int *d_len = nullptr, *d_lpos = nullptr, *d_ilen = nullptr, *d_centre = nullptr, *d_status = nullptr;
     long long *d_frag_off = nullptr, *d_bias_off = nullptr, *d_out_off = nullptr, *d_grid_off = nullptr;
     double *d_bias = nullptr;
-    int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr;
+    int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr;
     int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;
     int grid_step = 0, grid_half = 0;
     double *d_track[NATAC_T_COUNT] = {nullptr};
@@ -403,7 +403,7 @@ void natac_batch_free(natac_batch *b) {
     prof_collect(b->ctx);
     dev_free(b->d_len); dev_free(b->d_lpos); dev_free(b->d_ilen); dev_free(b->d_centre); dev_free(b->d_status);
     dev_free(b->d_frag_off); dev_free(b->d_bias_off); dev_free(b->d_out_off); dev_free(b->d_grid_off); dev_free(b->d_bias);
-    dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ);
+    dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
     for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
     delete b;
@@ -513,6 +513,9 @@ int natac_run_occ(natac_batch *b) {
             if ((rc = dev_alloc(&b->d_grid[i], (size_t)b->total_grid))) return rc;
         }
         if ((rc = build_tiles(b, OCC_T, &b->d_tiles_occ, &b->n_tiles_occ, true, c->step, c->halfstep))) return rc;
+        dev_free(b->d_ranges_occ);
+        b->d_ranges_occ = nullptr;
+        if ((rc = dev_alloc(&b->d_ranges_occ, (size_t)b->n_tiles_occ))) return rc;
         b->grid_step = c->step;
         b->grid_half = c->halfstep;
     }
@@ -526,9 +529,16 @@ int natac_run_occ(natac_batch *b) {
         const int U = c->occ_upper, UP = (U + 1) & ~1;
         const int span = (OCC_T - 1) * c->step + M;
         const int EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
-        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 8 * (size_t)UP) * sizeof(double);
-        hipLaunchKernelGGL(natac_occ_mle, dim3(b->n_tiles_occ), dim3(256), lds, c->stream, ct, b->d_tiles_occ, om, b->d_grid[0],
-                           b->d_grid[1], b->d_grid[2], b->d_status);
+        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + ((span + 3) & ~1) + 512) * sizeof(double) +
+                           (size_t)2 * OCC_FMAX * sizeof(int);
+        hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream, ct, b->d_tiles_occ,
+                           b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
+        if (c->step == 5 && c->flank == 60)
+            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream, ct, b->d_tiles_occ,
+                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
+        else
+            hipLaunchKernelGGL((natac_occ_mle<0, 0, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream, ct, b->d_tiles_occ,
+                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
     }
     prof_end(c, ev);
     prof_begin(c, NATAC_K_OCC_SMOOTH, ev);

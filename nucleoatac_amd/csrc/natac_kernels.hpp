@@ -315,6 +315,7 @@ __global__ void __launch_bounds__(256) natac_smooth_same(ChunkTable ct, const in
 //            `0 * log(0) = NaN -> -inf` of the reference is reproduced with the zero-probability flags.
 // ------------------------------------------------------------------------------------------------
 constexpr int OCC_T = 16;
+constexpr int OCC_FMAX = 1024;   // fragments of a tile staged in LDS (larger tiles read them from global memory)
 
 struct OccModelDev {
     const double *nuc_probs, *nfr_probs, *alphas;
@@ -322,26 +323,77 @@ struct OccModelDev {
     double cutoff;
 };
 
-__global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *__restrict__ tiles, OccModelDev om,
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// number of leading entries of the sorted array a[from, n) that are < key, found 64 at a time with a ballot
+__device__ __forceinline__ int advance_while_less(const int *a, int from, int n, int key, int lane) {
+    int f = from;
+    while (f < n) {
+        const int i = f + lane;
+        const int v = (i < n) ? a[i] : 0x7fffffff;
+        const int cnt = __popcll(__ballot(v < key));
+        f += cnt;
+        if (cnt < WAVE) break;
+    }
+    return f;
+}
+
+// fragment range [t0, t1) of every occupancy tile (centres within the tile's windows); one thread per tile so the
+// dependent binary-search loads are hidden by occupancy instead of stalling a whole MLE workgroup.
+__global__ void __launch_bounds__(256) natac_occ_tile_ranges(ChunkTable ct, const int2 *__restrict__ tiles, int ntiles,
+                                                               int step, int halfstep, int flank, int2 *__restrict__ ranges) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntiles) return;
+    const int2 t = tiles[i];
+    const int nfr = (int)(ct.frag_off[t.x + 1] - ct.frag_off[t.x]);
+    const int *cen = ct.centre + ct.frag_off[t.x];
+    const int gfirst = halfstep + t.y * step;
+    const int t0 = lower_bound_i32(cen, 0, nfr, gfirst - flank);
+    const int t1 = lower_bound_i32(cen, t0, nfr, gfirst + (OCC_T - 1) * step + flank + 1);
+    ranges[i] = make_int2(t0, t1);
+}
+
+// STEP/FLANK > 0: compile-time fast path (defaults 5 / 60, requires (2*FLANK) % STEP == 0); STEP == 0: runtime values.
+template <int STEP, int FLANK, int ABL = 0>   // ABL != 0: ablation variants for tools/microbench_occ.hip only
+__global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *__restrict__ tiles,
+                                                       const int2 *__restrict__ ranges, OccModelDev om,
                                                        double *__restrict__ g_occ, double *__restrict__ g_lo,
                                                        double *__restrict__ g_hi, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int U = om.upper, UP = (U + 1) & ~1;
-    const int fl = om.flank, WIN = 2 * fl + 1;
+    const int step = STEP ? STEP : om.step;
+    const int fl = STEP ? FLANK : om.flank, WIN = 2 * fl + 1;
     const int A = (U - 2) >> 1, Bh = (U - 1) >> 1;
-    const int span = (OCC_T - 1) * om.step + WIN;     // centre positions covered by the tile
-    const int EW = span + A + Bh + 2;                  // +1 left for j == 0 (left offset -1 -> x+1) handled by Bh>=1
+    const int span = (OCC_T - 1) * step + WIN;        // centre positions covered by the tile
+    const int EW = span + A + Bh + 2;
     double *Et = smem;                                 // [EW]
     double *bw = smem + ((EW + 1) & ~1);               // [OCC_T][UP]
-    double *pnl = bw + OCC_T * UP;                     // [4][UP]
-    double *pfl = pnl + 4 * UP;                        // [4][UP]
+    double *nucp = bw + OCC_T * UP;                    // [UP]
+    double *nfrp = nucp + UP;                          // [UP]
+    double *ones = nfrp + UP;                          // [span + 2] of 1.0: right factor of the single-cell row j == 1
+    double *acl = ones + ((span + 3) & ~1);            // [4 waves][64 x (pn, pf)]
+    int *cen_s = (int *)(acl + 4 * 2 * WAVE);          // [OCC_FMAX]
+    int *iln_s = cen_s + OCC_FMAX;                     // [OCC_FMAX]
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, k0 = t.y;
     const int L = ct.chunk_len[chunk];
-    const int nk = (L - om.halfstep + om.step - 1) / om.step;   // len(range(halfstep, L, step))
-    const int gfirst = om.halfstep + k0 * om.step;               // base of the tile's first grid point
-    // Et[u] <-> coordinate gfirst - fl - A + u
-    {
+    const int nk = (L - om.halfstep + step - 1) / step;         // len(range(halfstep, L, step))
+    const int gfirst = om.halfstep + k0 * step;                 // base of the tile's first grid point
+    const int *cen = ct.centre + ct.frag_off[chunk];
+    const int *iln = ct.ilen + ct.frag_off[chunk];
+    // ---- phase 0: stage the tile's fragments, the model and exp(bias) in LDS
+    const int2 tr = ranges[blockIdx.x];
+    const int t0 = tr.x, nt = tr.y - tr.x;
+    const bool staged = nt <= OCC_FMAX;
+    if (staged)
+        for (int i = threadIdx.x; i < nt; i += 256) { cen_s[i] = cen[t0 + i]; iln_s[i] = iln[t0 + i]; }
+    for (int j = threadIdx.x; j < U; j += 256) { nucp[j] = om.nuc_probs[j]; nfrp[j] = om.nfr_probs[j]; }
+    for (int u = threadIdx.x; u < span + 2; u += 256) ones[u] = 1.0;
+    {   // Et[u] <-> coordinate gfirst - fl - A + u
         const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
         const int nb = L + ct.bias_left + ct.bias_right;
         const int j0 = gfirst - fl - A + ct.bias_left;
@@ -353,81 +405,145 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
         }
     }
     __syncthreads();
-    // ---- phase 1: sliding window sums of B0 for every insert size
+    // ---- phase 1: window sums of B0 for every insert size j (thread j), all OCC_T grid points of the tile
     {
         const int j = threadIdx.x;
-        if (j < U) {
+        if (ABL == 2) { for (int k = 0; k < OCC_T; ++k) if (j < U) bw[k * UP + j] = 1.0; }
+        else if (j < U) {
             const int hl = floor_half(j - 1), hr = floor_half(j);
             const bool single = (hl == -hr);   // j == 1: the two pattern ones coincide (chunkmat2d.py:150-151)
+            // branch-free: the j == 1 row multiplies by a row of ones (exact) instead of selecting per element
             const double *el = Et + (A - hl);
-            const double *er = Et + (A + hr);
-            double S = 0.0;
-            for (int u = 0; u < WIN; ++u) S += single ? el[u] : el[u] * er[u];
-            bw[j] = S;
-            for (int k = 1; k < OCC_T; ++k) {
-                const int u0 = (k - 1) * om.step;
-                for (int d = 0; d < om.step; ++d) {
-                    const int ua = u0 + d, ub = u0 + WIN + d;
-                    S -= single ? el[ua] : el[ua] * er[ua];
-                    S += single ? el[ub] : el[ub] * er[ub];
+            const double *er = single ? ones : Et + (A + hr);
+            if (STEP) {
+                // window k = columns [k*STEP, k*STEP + WIN), WIN = Q*STEP + 1: sum of Q aligned STEP-blocks + the first
+                // element of block k+Q.  Every product is formed once; block sums stay in registers (static indices).
+                constexpr int SS = STEP ? STEP : 1;
+                constexpr int Q = (2 * FLANK) / SS;
+                double blk[OCC_T + Q];
+                double first[OCC_T + Q];
+#pragma unroll
+                for (int m = 0; m < OCC_T + Q; ++m) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int d = 0; d < SS; ++d) {
+                        if (m == OCC_T + Q - 1 && d > 0) break;        // last block: only its first element is used
+                        const int u = m * SS + d;
+                        const double p = el[u] * er[u];
+                        if (d == 0) first[m] = p;
+                        sacc += p;
+                    }
+                    blk[m] = sacc;
                 }
-                bw[k * UP + j] = S;
+                double T = 0.0;
+#pragma unroll
+                for (int m = 0; m < Q; ++m) T += blk[m];
+#pragma unroll
+                for (int k = 0; k < OCC_T; ++k) {
+                    bw[k * UP + j] = T + first[k + Q];
+                    T = (T - blk[k]) + blk[k + Q];
+                }
+            } else {
+                double S = 0.0;
+                for (int u = 0; u < WIN; ++u) S += el[u] * er[u];
+                bw[j] = S;
+                for (int k = 1; k < OCC_T; ++k) {
+                    const int u0 = (k - 1) * step;
+                    for (int d = 0; d < step; ++d) {
+                        const int ua = u0 + d, ub = u0 + WIN + d;
+                        S -= el[ua] * er[ua];
+                        S += el[ub] * er[ub];
+                    }
+                    bw[k * UP + j] = S;
+                }
             }
         }
     }
     __syncthreads();
-    // ---- phase 2: one wave per grid point
+    // ---- phase 2: one wave per grid point; lanes own alphas a = lane, lane + 64
+    if (ABL == 1) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nfr = (int)(ct.frag_off[chunk + 1] - ct.frag_off[chunk]);
-    const int *cen = ct.centre + ct.frag_off[chunk];
-    const int *iln = ct.ilen + ct.frag_off[chunk];
-    double *pn = pnl + wave * UP, *pf = pfl + wave * UP;
+    const int *cs = staged ? cen_s : cen + t0;   // window search + gather source (LDS copy, or global for huge tiles)
+    const int *is = staged ? iln_s : iln + t0;
+    double *ac = acl + wave * 2 * WAVE;
+    const int a0 = lane, a1 = lane + WAVE;
+    const double al0 = (a0 < om.n_alpha) ? om.alphas[a0] : 0.0;
+    const double al1 = (a1 < om.n_alpha) ? om.alphas[a1] : 0.0;
+    const double be0 = 1 - al0, be1 = 1 - al1;
+    int f0 = 0, f1 = 0;
     for (int kk = wave; kk < OCC_T; kk += 4) {
         const int k = k0 + kk;
         if (k >= nk) break;                      // wave-uniform
-        const int g = om.halfstep + k * om.step;
+        const int g = om.halfstep + k * step;
         const double *bj = bw + kk * UP;
-        // normalisers
+        // normalisers of  nuc_probs * bias / sum(...)  (Occupancy.py:108-111) + zero / NaN flags of the quotients:
+        // a quotient is 0 iff its product is 0 (sum finite, > 0) and NaN iff the product or the sum is.
         double sn = 0.0, sf = 0.0;
-        for (int j = lane; j < U; j += WAVE) {
-            const double b = bj[j];
-            sn += om.nuc_probs[j] * b;
-            sf += om.nfr_probs[j] * b;
-        }
-        sn = wave_sum(sn);
-        sf = wave_sum(sf);
         int flags = 0;   // 1: some pn == 0, 2: some pf == 0, 4: some both == 0, 8: some NaN
         for (int j = lane; j < U; j += WAVE) {
             const double b = bj[j];
-            const double a = (om.nuc_probs[j] * b) / sn;
-            const double c = (om.nfr_probs[j] * b) / sf;
-            pn[j] = a;
-            pf[j] = c;
-            if (a == 0.0) flags |= 1;
-            if (c == 0.0) flags |= 2;
-            if (a == 0.0 && c == 0.0) flags |= 4;
-            if (a != a || c != c) flags |= 8;
+            const double pa = nucp[j] * b, pc = nfrp[j] * b;
+            sn += pa;
+            sf += pc;
+            if (pa == 0.0) flags |= 1;
+            if (pc == 0.0) flags |= 2;
+            if (pa == 0.0 && pc == 0.0) flags |= 4;
+            if (pa != pa || pc != pc) flags |= 8;
         }
+        sn = wave_sum(sn);
+        sf = wave_sum(sf);
         flags = wave_or(flags);
-        // fragments of the window (sorted by centre)
-        int f0 = lower_bound_i32(cen, 0, nfr, g - fl);
-        int f1 = lower_bound_i32(cen, f0, nfr, g + fl + 1);
-        const int a0 = lane, a1 = lane + WAVE;
-        const double al0 = (a0 < om.n_alpha) ? om.alphas[a0] : 0.0;
-        const double al1 = (a1 < om.n_alpha) ? om.alphas[a1] : 0.0;
-        const double be0 = 1 - al0, be1 = 1 - al1;
-        double m0 = 1.0, m1 = 1.0;
+        if (!(sn > 0.0 && sn < __builtin_inf() && sf > 0.0 && sf < __builtin_inf())) flags |= 8;  // 0/0, x/inf, NaN sums
+        // fragments of the window [g-fl, g+fl] (sorted by centre; windows only move right)
+        f0 = advance_while_less(cs, f0, nt, g - fl, lane);
+        f1 = advance_while_less(cs, (f1 > f0 ? f1 : f0), nt, g + fl + 1, lane);
+        // log-likelihood as a running product (mantissa x 2^exponent); two independent chains (A/B) per alpha
+        double m0 = 1.0, m1 = 1.0, m0b = 1.0, m1b = 1.0;
         int e0 = 0, e1 = 0, nins = 0;
-        for (int f = f0; f < f1; ++f) {
-            const int n = iln[f];
-            if (n < 0 || n >= U) continue;      // wave-uniform
-            ++nins;
-            const double a = pn[n], c = pf[n];
-            const double x0v = al0 * a + be0 * c;
-            const double x1v = al1 * a + be1 * c;
-            int ex;
-            m0 = frexp(m0 * x0v, &ex); e0 += ex;
-            m1 = frexp(m1 * x1v, &ex); e1 += ex;
+        for (int base = f0; base < f1 && ABL != 3; base += WAVE) {
+            const int i = base + lane;
+            int n = -1;
+            if (i < f1) n = is[i];
+            const bool ok = (n >= 0 && n < U);
+            const unsigned long long mask = __ballot(ok);
+            const int cnt = __popcll(mask);
+            nins += cnt;
+            if (ok) {                            // lane-parallel: one fragment per lane, compacted into LDS
+                const double b = bj[n];
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                ac[2 * pos] = (nucp[n] * b) / sn;
+                ac[2 * pos + 1] = (nfrp[n] * b) / sf;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int q = 0;
+            for (; q + 1 < cnt; q += 2) {        // wave-uniform loop, LDS broadcast reads
+                const double au = ac[2 * q], cu = ac[2 * q + 1], av = ac[2 * q + 2], cv = ac[2 * q + 3];
+                const double x0u = al0 * au + be0 * cu, x1u = al1 * au + be1 * cu;
+                const double x0v = al0 * av + be0 * cv, x1v = al1 * av + be1 * cv;
+                int ex0, ex1, ex2, ex3;
+                m0 = frexp(m0 * x0u, &ex0);
+                m1 = frexp(m1 * x1u, &ex1);
+                m0b = frexp(m0b * x0v, &ex2);
+                m1b = frexp(m1b * x1v, &ex3);
+                e0 += ex0 + ex2;
+                e1 += ex1 + ex3;
+            }
+            if (q < cnt) {
+                const double au = ac[2 * q], cu = ac[2 * q + 1];
+                int ex0, ex1;
+                m0 = frexp(m0 * (al0 * au + be0 * cu), &ex0);
+                m1 = frexp(m1 * (al1 * au + be1 * cu), &ex1);
+                e0 += ex0;
+                e1 += ex1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            int ex0, ex1;
+            m0 = frexp(m0 * m0b, &ex0);
+            m1 = frexp(m1 * m1b, &ex1);
+            e0 += ex0;
+            e1 += ex1;
         }
         const long long go = ct.grid_off[chunk] + k;
         if (nins == 0) {                         // sum(new_inserts) > 0 fails: stay NaN (Occupancy.py:143)
