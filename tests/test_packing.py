@@ -1,0 +1,65 @@
+"""CPU: packed chunk layout, synthetic workloads, sharding helpers."""
+import numpy as np
+import pytest
+
+from nucleoatac_amd.packing import PackedChunks, pack_chunks, sort_by_centre
+from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions, synth_size_distribution
+
+
+def test_synthetic_is_seeded_and_sorted():
+    a = make_synthetic_chunks(50, 2120, 500, seed=3)
+    b = make_synthetic_chunks(50, 2120, 500, seed=3)
+    assert np.array_equal(a.frag_lpos, b.frag_lpos) and np.array_equal(a.bias_log, b.bias_log)
+    assert a.n_chunks == 50 and a.n_frags == 25000 and a.total_bp == 50 * 2120
+    for k in range(a.n_chunks):
+        l, n = a.chunk_frags(k)
+        c = l.astype(np.int64) + (n.astype(np.int64) - 1) // 2
+        assert np.all(np.diff(c) >= 0)
+        assert c.min() >= -126 and c.max() < 2120 + 126
+        assert len(a.chunk_bias(k)) == 2120 + 246 + 247
+    p = make_synthetic_chunks(200, 700, 100, seed=1, poisson=True)
+    assert p.n_frags == int(np.diff(p.frag_off).sum()) and np.diff(p.frag_off).std() > 0
+
+
+def test_subset_is_consistent():
+    a = make_synthetic_chunks(20, 600, 100, seed=4)
+    s = a.subset(5, 12)
+    assert s.n_chunks == 7 and s.total_bp == 7 * 600
+    for k in range(7):
+        assert np.array_equal(s.chunk_frags(k)[0], a.chunk_frags(5 + k)[0])
+        assert np.array_equal(s.chunk_bias(k), a.chunk_bias(5 + k))
+
+
+def test_pack_chunks_from_sorted_fragments():
+    rng = np.random.default_rng(0)
+    l = np.sort(rng.integers(0, 20000, size=3000))
+    n = rng.integers(20, 400, size=3000)
+    bias = rng.normal(size=21000)
+    pk = pack_chunks([("chr1", 2000, 3000), ("chr1", 7000, 9000)], {"chr1": l}, {"chr1": n},
+                     bias_tracks={"chr1": (0, bias)})
+    assert pk.n_chunks == 2 and list(pk.chunk_len) == [1000, 2000]
+    for k, (s, e) in enumerate(((2000, 3000), (7000, 9000))):
+        lr, nr = pk.chunk_frags(k)
+        assert np.all(lr + s >= s - 2126) and np.all(lr + s < e + 2126)
+        o = sort_by_centre(lr, nr)
+        assert np.array_equal(o, np.arange(len(o)))
+        assert np.array_equal(pk.chunk_bias(k), bias[s - 246:e + 247])
+    with pytest.raises(ValueError):
+        pack_chunks([("chr1", 100, 300)], {"chr1": l}, {"chr1": n}, bias_tracks={"chr1": (0, bias)})
+
+
+def test_validation_errors():
+    with pytest.raises(ValueError):
+        PackedChunks(chunk_start=[0], chunk_len=[10], frag_off=[0, 2], frag_lpos=[1], frag_ilen=[1], bias_off=None, bias_log=None)
+    with pytest.raises(ValueError):
+        PackedChunks(chunk_start=[0], chunk_len=[0], frag_off=[0, 0], frag_lpos=[], frag_ilen=[], bias_off=None, bias_log=None)
+    with pytest.raises(ValueError):
+        PackedChunks(chunk_start=[0], chunk_len=[10], frag_off=[0, 0], frag_lpos=[], frag_ilen=[], bias_off=[0, 5],
+                     bias_log=np.zeros(5))
+
+
+def test_synthetic_distributions():
+    s = synth_size_distribution(251)
+    a, b = synth_occ_distributions(251)
+    assert abs(s.sum() - 1) < 1e-12 and abs(a.sum() - 1) < 1e-12 and abs(b.sum() - 1) < 1e-12
+    assert (a > 0).all() and (b > 0).all()

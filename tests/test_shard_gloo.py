@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: the N>1 path (contiguous balanced shards, rank-local processing, ordered gather)
+gives exactly the single-process result.  The per-chunk work is done by the CPU oracle here (no GPU in this tier)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from nucleoatac_amd.shard import balanced_ranges, gather_in_chunk_order, my_shard, ordered_sum
+from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _chunk_result(pk, k, nucp, nfrp, gk=None):
+    gk = k if gk is None else gk
+    from oracle import natac_oracle as O
+    l, n = pk.chunk_frags(k)
+    L = int(pk.chunk_len[k])
+    oc = O.occ_chunk_tracks(l.astype(np.int64), n.astype(np.int64), 0, L, pk.chunk_bias(k), -pk.bias_left, nucp, nfrp)
+    ins = O.get_insertions(l.astype(np.int64), n.astype(np.int64), 0, L)
+    dist = np.sum(oc["mat"][:, 60:60 + 121], axis=1) * (1.0 / (gk + 3))
+    return dict(occ_sum=float(np.nansum(oc["smoothed_vals"])), ins=ins.astype(np.int32), nuc_dist=dist)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pk = make_synthetic_chunks(6, 420, 60, seed=9, poisson=True)
+    nucp, nfrp = synth_occ_distributions(251)
+    lo, hi, sub = my_shard(pk, rank, world)
+    local = [_chunk_result(sub, k, nucp, nfrp, lo + k) for k in range(hi - lo)] if sub is not None else []
+    allr = gather_in_chunk_order(local, dst=0)
+    if rank == 0:
+        q.put((lo, hi, allr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_balanced_ranges_cover_and_balance():
+    pk = make_synthetic_chunks(1000, 700, 100, seed=2, poisson=True)
+    for world in (1, 2, 3, 8):
+        r = balanced_ranges(pk.chunk_len, pk.frag_off, world)
+        assert r[0][0] == 0 and r[-1][1] == pk.n_chunks
+        assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        cost = [(pk.chunk_len[a:b].sum() + 4.0 * (pk.frag_off[b] - pk.frag_off[a])) for a, b in r]
+        assert max(cost) <= 1.05 * (sum(cost) / world) + 2000
+    # more ranks than chunks: empty shards are allowed
+    r = balanced_ranges([100, 100], [0, 5, 10], 4)
+    assert r[0][0] == 0 and r[-1][1] == 2 and sum(b - a for a, b in r) == 2
+
+
+def test_two_rank_gloo_equals_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    lo, hi, allr = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    pk = make_synthetic_chunks(6, 420, 60, seed=9, poisson=True)
+    nucp, nfrp = synth_occ_distributions(251)
+    ref = [_chunk_result(pk, k, nucp, nfrp) for k in range(pk.n_chunks)]
+    assert lo == 0 and 0 < hi < pk.n_chunks and len(allr) == pk.n_chunks
+    for a, b in zip(allr, ref):
+        assert a["occ_sum"] == b["occ_sum"] and np.array_equal(a["ins"], b["ins"])
+    # the cross-chunk reduction is done in chunk order -> bit-identical to the unsharded sum
+    assert np.array_equal(ordered_sum([a["nuc_dist"] for a in allr]), ordered_sum([b["nuc_dist"] for b in ref]))
