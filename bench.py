@@ -82,6 +82,28 @@ def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks):
                        "Pool(%d) one chunk per task, %.1f s" % (n_chunks, bp, workers, dt))
 
 
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*/pmc_summary.csv):
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE under-counts streaming reads 2x on gfx950
+    (MI355X_MICROARCH.md, HBM section).  None when no profile is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.csv")))
+    if not files:
+        return None
+    f = w = None
+    with open(files[-1]) as fh:
+        for row in csv.reader(l for l in fh if not l.startswith("#")):
+            if len(row) == 4 and kernel_substr in row[0]:
+                if row[1] == "FETCH_SIZE":
+                    f = float(row[2]) / float(row[3])
+                if row[1] == "WRITE_SIZE":
+                    w = float(row[2]) / float(row[3])
+    if f is None or w is None:
+        return None
+    return (2.0 * f + w) * 1024.0
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -168,6 +190,7 @@ def main():
     t_dn = time.time() - t_dn
 
     if rank == 0:
+        traffic = pmc_traffic_bytes("natac_background")
         bg_ms, bg_n = prof["background"]
         bg_avg_s = (bg_ms / max(1, bg_n)) / 1e3
         alg_bytes = ALG_BYTES_PER_BP * pk.total_bp
@@ -183,7 +206,7 @@ def main():
                        "candidates_per_gpu": int(len(cand_pos)), "sharding": "chunk list split across ranks, no collective"},
             "roofline": {"bound": "hbm", "kernel": "natac_background (dense bias x VMat correlation)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(bg_avg_s * 1e3, 3), "launches": int(bg_n),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the kernel is fp64-VALU bound (17,666 FMA/base vs 79.8 B/base); see valu_f64",
