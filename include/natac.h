@@ -151,6 +151,28 @@ int natac_fragment_sizes(natac_ctx *ctx, int64_t n_frags, const int64_t *l, cons
  * pair sum (same terms as the .pyx, tree-reduced).  r is truncated to int like the .pyx signature. */
 int natac_calculate_cov(natac_ctx *ctx, const double *p, const double *v, int64_t n, int r, int mode, double *out);
 
+/* ---- operator-level entry points behind the Track / BiasMat2D / bias / occupancy classes ------ */
+/* utils.smooth, pyatac/utils.py:23-52, on one host array.  w[M] is the window (ones for 'flat', scipy's
+ * gaussian(M, sd) otherwise; M odd).  mode 0 = 'valid' (out[n-M+1]), 1 = 'same' (out[n], needs n >= M).
+ * norm != 0: NaN-aware normalisation (0 weight -> NaN). */
+int natac_smooth(natac_ctx *ctx, const double *x, int64_t n, const double *w, int M, int mode, int norm, double *out);
+/* BiasMat2D.makeBiasMat, pyatac/chunkmat2d.py:140-153 (log-scale track): mat[(upper-lower) x (end-start)].
+ * bias_log[nb] starts at genomic coordinate track_start; returns NATAC_E_ARG if the track does not cover
+ * [start - upper//2, end + upper//2). */
+int natac_make_bias_mat(natac_ctx *ctx, const double *bias_log, int64_t nb, int64_t track_start, int64_t start,
+                        int64_t end, int lower, int upper, double *mat);
+/* InsertionBiasTrack.computeBias, pyatac/bias.py:85-92: seq[n] (upper-case ASCII) covers [start-up, end+down);
+ * log_pwm[nrow x K] = log(PWM.mat), nucleotides[nrow] the PWM's row letters; out[n-K+1]. */
+int natac_pwm_bias(natac_ctx *ctx, const uint8_t *seq, int64_t n, const double *log_pwm, const uint8_t *nucleotides,
+                   int nrow, int K, double *out);
+/* signal.correlate(sub, vmat, mode='valid')[0] as used by SignalTrack.calculateSignal / BiasTrack
+ * (nucleoatac/NucleosomeCalling.py:34-36, 60-63): sub[R x ncol], vmat[R x W] row-major, out[ncol-W+1]. */
+int natac_correlate_valid(natac_ctx *ctx, const double *sub, int64_t ncol, const double *vmat, int R, int W, double *out);
+/* calculateOccupancy, nucleoatac/Occupancy.py:104-120, for one window: inserts[upper], bias[upper] with the model
+ * set by natac_set_occ_model; out[3] = {occ, lower, upper}.  Returns NATAC_E_ARG with the message
+ * "no alpha passes the likelihood-ratio test" where the reference raises ValueError (Occupancy.py:118). */
+int natac_calculate_occupancy(natac_ctx *ctx, const double *inserts, const double *bias, double *out);
+
 /* ---- profiling (HIP events on the context's stream) ------------------------------------ */
 int natac_profile_enable(natac_ctx *ctx, int on);
 /* total milliseconds and launch count of kernel class `k` since the last reset */

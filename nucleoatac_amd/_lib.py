@@ -47,6 +47,11 @@ SIGNATURES = {
     "natac_get_insertions": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
     "natac_fragment_sizes": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _vp, C.c_int, C.c_int, _vp]),
     "natac_calculate_cov": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.POINTER(_f64)]),
+    "natac_smooth": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "natac_make_bias_mat": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, C.c_int, C.c_int, _vp]),
+    "natac_pwm_bias": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "natac_correlate_valid": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, C.c_int, _vp]),
+    "natac_calculate_occupancy": (C.c_int, [_vp, _vp, _vp, _vp]),
     "natac_profile_enable": (C.c_int, [_vp, C.c_int]),
     "natac_profile_get": (C.c_int, [_vp, C.c_int, C.POINTER(_f64), C.POINTER(_i64)]),
     "natac_profile_reset": (C.c_int, [_vp]),

@@ -790,6 +790,123 @@ int natac_calculate_cov(natac_ctx *c, const double *p, const double *v, int64_t 
     return NATAC_OK;
 }
 
+/* ---------------- operator-level entry points ---------------- */
+
+int natac_smooth(natac_ctx *c, const double *x, int64_t n, const double *w, int M, int mode, int norm, double *out) {
+    if (!c || !x || !w || !out) return fail(NATAC_E_ARG, "null argument");
+    if (M < 1 || M % 2 != 1) return fail(NATAC_E_ARG, "window length must be odd (got %d)", M);
+    if (mode != 0 && mode != 1) return fail(NATAC_E_ARG, "mode must be 0 (valid) or 1 (same)");
+    if (n < M) return fail(NATAC_E_ARG, "signal (%lld) shorter than the window (%d)", (long long)n, M);
+    const long long nout = mode == 0 ? n - M + 1 : n;
+    HIPCHK(hipSetDevice(c->device));
+    double *d_x = nullptr, *d_w = nullptr, *d_y = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_x, x, (size_t)n))) return rc;
+    if ((rc = dev_upload(c, &d_w, w, (size_t)M))) { dev_free(d_x); return rc; }
+    if ((rc = dev_alloc(&d_y, (size_t)nout))) { dev_free(d_x); dev_free(d_w); return rc; }
+    hipLaunchKernelGGL(natac_smooth1d, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream, d_x, (long long)n, d_w, M, mode,
+                       norm, d_y, nout);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_y, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_x); dev_free(d_w); dev_free(d_y);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "smooth: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
+int natac_make_bias_mat(natac_ctx *c, const double *bias_log, int64_t nb, int64_t track_start, int64_t start, int64_t end,
+                        int lower, int upper, double *mat) {
+    if (!c || !bias_log || !mat) return fail(NATAC_E_ARG, "null argument");
+    if (end <= start || upper <= lower || lower < 0) return fail(NATAC_E_ARG, "empty matrix");
+    const long long ncol = end - start, nrow = upper - lower;
+    if (ncol > 0x7fffffffLL) return fail(NATAC_E_ARG, "region too long");
+    HIPCHK(hipSetDevice(c->device));
+    double *d_b = nullptr, *d_m = nullptr;
+    int *d_oob = nullptr, oob = 0;
+    int rc;
+    if ((rc = dev_upload(c, &d_b, bias_log, (size_t)nb))) return rc;
+    if ((rc = dev_alloc(&d_m, (size_t)(nrow * ncol)))) { dev_free(d_b); return rc; }
+    if ((rc = dev_alloc(&d_oob, 1))) { dev_free(d_b); dev_free(d_m); return rc; }
+    hipError_t e = hipMemsetAsync(d_oob, 0, sizeof(int), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(natac_bias_mat_dense, dim3((unsigned)((nrow * ncol + 255) / 256)), dim3(256), 0, c->stream, d_b, (long long)nb,
+                           (long long)(start - track_start), (int)ncol, lower, (int)nrow, d_m, d_oob);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(mat, d_m, (size_t)(nrow * ncol) * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&oob, d_oob, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_b); dev_free(d_m); dev_free(d_oob);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "make_bias_mat: %s", hipGetErrorString(e));
+    if (oob) return fail(NATAC_E_ARG, "bias track does not cover [start - upper//2, end + upper//2)");
+    return NATAC_OK;
+}
+
+int natac_pwm_bias(natac_ctx *c, const uint8_t *seq, int64_t n, const double *log_pwm, const uint8_t *nucleotides, int nrow, int K,
+                   double *out) {
+    if (!c || !seq || !log_pwm || !nucleotides || !out) return fail(NATAC_E_ARG, "null argument");
+    if (nrow < 1 || K < 1 || n < K) return fail(NATAC_E_ARG, "sequence shorter than the PWM");
+    HIPCHK(hipSetDevice(c->device));
+    unsigned char *d_s = nullptr, *d_n = nullptr;
+    double *d_p = nullptr, *d_o = nullptr;
+    const long long nout = n - K + 1;
+    int rc;
+    if ((rc = dev_upload(c, &d_s, (const unsigned char *)seq, (size_t)n))) return rc;
+    if ((rc = dev_upload(c, &d_n, (const unsigned char *)nucleotides, (size_t)nrow))) { dev_free(d_s); return rc; }
+    if ((rc = dev_upload(c, &d_p, log_pwm, (size_t)nrow * K))) { dev_free(d_s); dev_free(d_n); return rc; }
+    if ((rc = dev_alloc(&d_o, (size_t)nout))) { dev_free(d_s); dev_free(d_n); dev_free(d_p); return rc; }
+    hipLaunchKernelGGL(natac_pwm_score, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream, d_s, (long long)n, d_p, d_n, nrow, K,
+                       d_o);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_s); dev_free(d_n); dev_free(d_p); dev_free(d_o);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "pwm_bias: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
+int natac_correlate_valid(natac_ctx *c, const double *sub, int64_t ncol, const double *vmat, int R, int W, double *out) {
+    if (!c || !sub || !vmat || !out) return fail(NATAC_E_ARG, "null argument");
+    if (R < 1 || W < 1 || ncol < W) return fail(NATAC_E_ARG, "matrix narrower than the template");
+    const long long nout = ncol - W + 1;
+    HIPCHK(hipSetDevice(c->device));
+    double *d_s = nullptr, *d_v = nullptr, *d_o = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_s, sub, (size_t)R * ncol))) return rc;
+    if ((rc = dev_upload(c, &d_v, vmat, (size_t)R * W))) { dev_free(d_s); return rc; }
+    if ((rc = dev_alloc(&d_o, (size_t)nout))) { dev_free(d_s); dev_free(d_v); return rc; }
+    hipLaunchKernelGGL(natac_correlate_dense, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream, d_s, (long long)ncol, d_v, R, W,
+                       d_o, nout);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_s); dev_free(d_v); dev_free(d_o);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "correlate_valid: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
+int natac_calculate_occupancy(natac_ctx *c, const double *inserts, const double *bias, double *out) {
+    if (!c || !inserts || !bias || !out) return fail(NATAC_E_ARG, "null argument");
+    if (!c->have_occ) return fail(NATAC_E_STATE, "natac_set_occ_model has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    double *d_i = nullptr, *d_b = nullptr, *d_o = nullptr;
+    int *d_s = nullptr, st = 0;
+    int rc;
+    if ((rc = dev_upload(c, &d_i, inserts, (size_t)c->occ_upper))) return rc;
+    if ((rc = dev_upload(c, &d_b, bias, (size_t)c->occ_upper))) { dev_free(d_i); return rc; }
+    if ((rc = dev_alloc(&d_o, 3))) { dev_free(d_i); dev_free(d_b); return rc; }
+    if ((rc = dev_alloc(&d_s, 1))) { dev_free(d_i); dev_free(d_b); dev_free(d_o); return rc; }
+    hipLaunchKernelGGL(natac_occupancy_single, dim3(1), dim3(128), 0, c->stream, d_i, d_b, make_occ(c), d_o, d_s);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&st, d_s, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_i); dev_free(d_b); dev_free(d_o); dev_free(d_s);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "calculate_occupancy: %s", hipGetErrorString(e));
+    if (st) return fail(NATAC_E_ARG, "no alpha passes the likelihood-ratio test");
+    return NATAC_OK;
+}
+
 /* ---------------- profiling ---------------- */
 
 int natac_profile_enable(natac_ctx *c, int on) {

@@ -908,4 +908,110 @@ __global__ void __launch_bounds__(256) natac_cov_literal(const double *__restric
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// operator-level kernels behind the Track / BiasMat2D / InsertionBiasTrack / calculateOccupancy mirrors
+// ------------------------------------------------------------------------------------------------
+// utils.smooth (pyatac/utils.py:23-52) on one array.  mode 0 = 'valid' (nout = n-M+1), 1 = 'same' (nout = n, n >= M).
+// np.convolve(w, x)[m] = sum_k w[k] x[m-k]; NaNs of x count as 0; norm: divide by the same convolution of the
+// not-NaN indicator (0 -> NaN).
+__global__ void __launch_bounds__(256) natac_smooth1d(const double *__restrict__ x, long long n, const double *__restrict__ w,
+                                                        int M, int mode, int norm, double *__restrict__ y, long long nout) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nout) return;
+    const long long m = mode == 0 ? t + (M - 1) : t + (M - 1) / 2;   // index into the 'full' convolution
+    double num = 0.0, den = 0.0;
+    for (int k = 0; k < M; ++k) {
+        const long long i = m - k;
+        if (i < 0 || i >= n) continue;
+        const double v = x[i];
+        if (v == v) { num = fma(w[k], v, num); den += w[k]; }
+    }
+    y[t] = norm ? (den == 0.0 ? __builtin_nan("") : num / den) : num;
+}
+
+// BiasMat2D.makeBiasMat (pyatac/chunkmat2d.py:140-153), dense: mat[i-lower, x] = exp(b[g-(i-1)//2] + b[g+i//2]),
+// g = start + x; the i == 1 row is exp(b[g]) (both pattern ones on one cell).  b index = g - track_start.
+__global__ void __launch_bounds__(256) natac_bias_mat_dense(const double *__restrict__ b, long long nb, long long off0,
+                                                              int ncol, int lower, int nrow, double *__restrict__ mat,
+                                                              int *__restrict__ oob) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)nrow * ncol) return;
+    const int r = (int)(idx / ncol), x = (int)(idx - (long long)r * ncol);
+    const int i = lower + r;
+    const int hl = floor_half(i - 1), hr = floor_half(i);
+    const long long jl = off0 + x - hl, jr = off0 + x + hr;
+    if (jl < 0 || jr < 0 || jl >= nb || jr >= nb) { atomicOr(oob, 1); mat[idx] = __builtin_nan(""); return; }
+    mat[idx] = (hl == -hr) ? exp(b[jl]) : exp(b[jl] + b[jr]);
+}
+
+// InsertionBiasTrack.computeBias (pyatac/bias.py:85-92) + seq_to_mat (pyatac/seq.py:37-45):
+// out[x] = sum_k logpwm[row(seq[x+k]), k]; characters that are not one of the PWM's nucleotides add 0.
+__global__ void __launch_bounds__(256) natac_pwm_score(const unsigned char *__restrict__ seq, long long n,
+                                                         const double *__restrict__ logpwm, const unsigned char *__restrict__ nucs,
+                                                         int nrow, int K, double *__restrict__ out) {
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= n - K + 1) return;
+    double acc = 0.0;
+    for (int r = 0; r < nrow; ++r) {          // same association as the reference's row-by-row correlate
+        double rs = 0.0;
+        const unsigned char c = nucs[r];
+        for (int k = 0; k < K; ++k) if (seq[x + k] == c) rs += logpwm[r * K + k];
+        acc += rs;
+    }
+    out[x] = acc;
+}
+
+// calculateOccupancy (nucleoatac/Occupancy.py:104-120) for ONE window given dense inserts / bias vectors -- the literal
+// formula (sum_j ins[j] * log(alpha pn[j] + (1-alpha) pf[j]), NaN -> -inf); one thread per alpha, n_alpha <= 128.
+// out = {occ, lower, upper}; status 1 when no alpha passes the ratio test (the reference raises ValueError).
+__global__ void __launch_bounds__(128) natac_occupancy_single(const double *__restrict__ ins, const double *__restrict__ bias,
+                                                                OccModelDev om, double *__restrict__ out, int *__restrict__ status) {
+    __shared__ double ll[128];
+    const int a = threadIdx.x;
+    double sn = 0.0, sf = 0.0;
+    for (int j = 0; j < om.upper; ++j) { sn += om.nuc_probs[j] * bias[j]; sf += om.nfr_probs[j] * bias[j]; }
+    double v = -__builtin_inf();
+    if (a < om.n_alpha) {
+        const double al = om.alphas[a], be = 1 - al;
+        double acc = 0.0;
+        for (int j = 0; j < om.upper; ++j) {
+            const double pn = (om.nuc_probs[j] * bias[j]) / sn, pf = (om.nfr_probs[j] * bias[j]) / sf;
+            acc += log(al * pn + be * pf) * ins[j];
+        }
+        v = (acc != acc) ? -__builtin_inf() : acc;
+    }
+    ll[a] = v;
+    __syncthreads();
+    if (a == 0) {
+        double mx = ll[0];
+        int im = 0;
+        for (int k = 1; k < om.n_alpha; ++k) if (ll[k] > mx) { mx = ll[k]; im = k; }
+        int lo = -1, hi = -1;
+        for (int k = 0; k < om.n_alpha; ++k) if (2 * (mx - ll[k]) < om.cutoff) { if (lo < 0) lo = k; hi = k; }
+        if (lo < 0) { out[0] = om.alphas[im]; out[1] = out[2] = __builtin_nan(""); *status = 1; }
+        else { out[0] = om.alphas[im]; out[1] = om.alphas[lo]; out[2] = om.alphas[hi]; *status = 0; }
+    }
+}
+
+
+// signal.correlate(sub, vmat, mode='valid')[0] on dense matrices (nucleoatac/NucleosomeCalling.py:34-36, 60-63):
+// out[g] = sum_{r<R} sum_{c<W} sub[r, g+c] * vmat[r, c].  Operator-level entry for SignalTrack / BiasTrack on
+// materialised matrices (the batched path never builds them).
+__global__ void __launch_bounds__(256) natac_correlate_dense(const double *__restrict__ sub, long long ncol,
+                                                               const double *__restrict__ vmat, int R, int W,
+                                                               double *__restrict__ out, long long nout) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nout) return;
+    double acc = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const double *row = sub + (long long)r * ncol + g;
+        const double *vr = vmat + r * W;
+        double racc = 0.0;
+        for (int c = 0; c < W; ++c) racc = fma(row[c], vr[c], racc);
+        acc += racc;
+    }
+    out[g] = acc;
+}
+
 }  // namespace natac

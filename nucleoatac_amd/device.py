@@ -134,6 +134,71 @@ class Context(object):
                                               C.byref(out)))
         return out.value
 
+    # ---- operator-level entry points ------------------------------------------------------------
+    def smooth(self, sig, window_len, window="flat", sd=None, mode="valid", norm=True):
+        """utils.smooth (pyatac/utils.py:23-52) on the GPU."""
+        import warnings
+        if window not in ("flat", "gaussian"):
+            raise Exception("Incorrect window input for smooth. Options are flat, gaussian")
+        if mode not in ("valid", "same"):
+            raise Exception("mode must be 'valid' or 'same'")
+        if window_len % 2 != 1:
+            warnings.warn("Window length is even number.  Needs to be odd so adding 1.")
+            window_len += 1
+        if window == "gaussian":
+            if sd is None:
+                sd = (window_len - 1) / 6.0
+            nn = np.arange(window_len) - (window_len - 1) / 2.0
+            w = np.exp(-0.5 * (nn / sd) ** 2)     # scipy.signal.gaussian
+        else:
+            w = np.ones(window_len)
+        sig = _f64(sig)
+        w = _f64(w)
+        out = np.empty(sig.shape[0] - window_len + 1 if mode == "valid" else sig.shape[0], dtype=np.float64)
+        L.check(self._lib.natac_smooth(self._h, _ptr(sig), sig.shape[0], _ptr(w), int(window_len),
+                                       0 if mode == "valid" else 1, 1 if norm else 0, _ptr(out)))
+        return out
+
+    def make_bias_mat(self, bias_log, track_start, start, end, lower, upper):
+        """BiasMat2D.makeBiasMat (pyatac/chunkmat2d.py:140-153) for a log-scale bias track."""
+        b = _f64(bias_log)
+        mat = np.empty((upper - lower, end - start), dtype=np.float64)
+        L.check(self._lib.natac_make_bias_mat(self._h, _ptr(b), b.shape[0], int(track_start), int(start), int(end),
+                                              int(lower), int(upper), _ptr(mat)))
+        return mat
+
+    def pwm_bias(self, sequence, pwm_mat, nucleotides):
+        """InsertionBiasTrack.computeBias (pyatac/bias.py:85-92): log-bias of every position of `sequence`."""
+        seq = np.frombuffer(sequence.encode("ascii") if isinstance(sequence, str) else bytes(sequence), dtype=np.uint8)
+        logp = _f64(np.log(np.asarray(pwm_mat, dtype=np.float64)))
+        nucs = np.frombuffer("".join(nucleotides).encode("ascii"), dtype=np.uint8)
+        if len(nucs) != logp.shape[0]:
+            raise Exception("Usage Error! Nucleotides must all be of same length! No mixing single nucleotides with dinucleotides, etc")
+        out = np.empty(len(seq) - logp.shape[1] + 1, dtype=np.float64)
+        L.check(self._lib.natac_pwm_bias(self._h, _ptr(seq), len(seq), _ptr(logp), _ptr(nucs), logp.shape[0],
+                                         logp.shape[1], _ptr(out)))
+        return out
+
+    def correlate_valid(self, sub, vmat):
+        """signal.correlate(sub, vmat, mode='valid')[0] (nucleoatac/NucleosomeCalling.py:34-36)."""
+        sub, vmat = _f64(sub), _f64(vmat)
+        if sub.ndim != 2 or vmat.ndim != 2 or sub.shape[0] != vmat.shape[0]:
+            raise ValueError("sub and vmat must have the same number of rows")
+        out = np.empty(sub.shape[1] - vmat.shape[1] + 1, dtype=np.float64)
+        L.check(self._lib.natac_correlate_valid(self._h, _ptr(sub), sub.shape[1], _ptr(vmat), vmat.shape[0],
+                                                vmat.shape[1], _ptr(out)))
+        return out
+
+    def calculate_occupancy(self, inserts, bias):
+        """calculateOccupancy (nucleoatac/Occupancy.py:104-120) with the model of set_occ_model."""
+        ins, b = _f64(inserts), _f64(bias)
+        out = np.empty(3, dtype=np.float64)
+        rc = self._lib.natac_calculate_occupancy(self._h, _ptr(ins), _ptr(b), _ptr(out))
+        if rc == -1 and b"likelihood-ratio" in self._lib.natac_last_error():
+            raise ValueError("min() arg is an empty sequence")   # what the reference raises (Occupancy.py:118)
+        L.check(rc)
+        return float(out[0]), float(out[1]), float(out[2])
+
     # ---- profiling ---------------------------------------------------------------------------
     def profile_enable(self, on=True):
         L.check(self._lib.natac_profile_enable(self._h, 1 if on else 0))

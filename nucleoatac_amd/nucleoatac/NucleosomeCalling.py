@@ -1,0 +1,304 @@
+"""Nucleosome signal + calling (API of the reference's nucleoatac/NucleosomeCalling.py:25-345).
+
+GPU (libnatac_hip.so): coverage, raw signal, background, normalised + smoothed signal (natac_run_nuc), per-candidate
+log-likelihood ratio / multinomial variance / z (natac_run_candidates), dense correlate for the operator-level
+SignalTrack / BiasTrack classes.  Host: peak calling, thresholds, the L-BFGS fuzziness fit.
+"""
+from bisect import bisect_left
+from copy import copy
+
+import numpy as np
+from scipy import optimize
+
+from .. import get_context
+from ..pipeline import BatchRunner, pack
+from ..pyatac.bias import PWM
+from ..pyatac.chunk import Chunk
+from ..pyatac.tracks import CoverageTrack, Track, _py2_float_str
+from ..pyatac.utils import call_peaks, read_chrom_sizes_from_bam, reduce_peaks
+
+
+class SignalTrack(Track):
+    """V-plot cross-correlation signal (NucleosomeCalling.py:25-36)"""
+
+    def __init__(self, chrom, start, end):
+        Track.__init__(self, chrom, start, end, "signal")
+
+    def calculateSignal(self, mat, vmat):
+        offset = self.start - mat.start - vmat.w
+        if offset < 0:
+            raise Exception("Insufficient flanking region on mat to calculate signal")
+        sub = mat.get(vmat.lower, vmat.upper, mat.start + offset, mat.end - offset)
+        self.vals = get_context().correlate_valid(sub, vmat.mat)
+
+
+class NormSignalTrack(Track):
+    def __init__(self, chrom, start, end):
+        Track.__init__(self, chrom, start, end, "normalized signal")
+
+    def calculateNormSignal(self, raw, bias):
+        self.vals = raw.get(self.start, self.end) - bias.get(self.start, self.end)
+
+
+class BiasTrack(Track):
+    """background model of the signal (NucleosomeCalling.py:45-64)"""
+
+    def __init__(self, chrom, start, end):
+        Track.__init__(self, chrom, start, end, "bias")
+
+    def calculateBackgroundSignal(self, mat, vmat, nuc_cov):
+        offset = self.start - mat.start - vmat.w
+        if offset < 0:
+            raise Exception("Insufficient flanking region on mat to calculate signal")
+        self.vmat = vmat
+        self.bias_mat = mat
+        self.cov = CoverageTrack(self.chrom, self.start, self.end)
+        self.cov.calculateCoverage(self.bias_mat, vmat.lower, vmat.upper, vmat.w * 2 + 1)
+        self.nuc_cov = nuc_cov.vals
+        sub = self.bias_mat.get(vmat.lower, vmat.upper, self.bias_mat.start + offset, self.bias_mat.end - offset)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            self.vals = get_context().correlate_valid(sub, vmat.mat) * self.nuc_cov / self.cov.vals
+
+
+class SignalDistribution(object):
+    """distribution of the signal at one position under the background model (NucleosomeCalling.py:68-88)"""
+
+    def __init__(self, position, vmat, bias_mat, reads):
+        self.position = position
+        self.reads = reads
+        self.vmat = vmat
+        sub = bias_mat.get(vmat.lower, vmat.upper, position - vmat.w, position + vmat.w + 1)
+        self.prob_mat = sub / np.sum(sub)
+        self.probs = self.prob_mat.flatten()
+
+    def simulateReads(self):
+        return np.reshape(np.random.multinomial(self.reads, self.probs), self.vmat.mat.shape)
+
+    def simulateDist(self, numiters=1000):
+        self.scores = [np.sum(self.simulateReads() * self.vmat.mat) for _ in range(numiters)]
+
+    def analStd(self):
+        """sqrt of calculateCov (nucleoatac/multinomial_cov.pyx:20-31) -- natac_calculate_cov"""
+        return np.sqrt(get_context().calculate_cov(self.probs, np.ravel(self.vmat.mat), int(self.reads)))
+
+    def analMean(self):
+        return np.sum(self.prob_mat * self.vmat.mat * self.reads)
+
+
+def norm(x, v, w, mean):
+    """normal pdf with variance v scaled to height w (NucleosomeCalling.py:92-97)"""
+    y = 1.0 / np.sqrt(2 * np.pi * v) * np.exp(-(x - mean) ** 2 / (2 * v))
+    return y * (w / max(y))
+
+
+class Nucleosome(Chunk):
+    """one candidate / called nucleosome (NucleosomeCalling.py:99-202)"""
+
+    def __init__(self, pos, nuctrack):
+        self.chrom = nuctrack.chrom
+        self.start = pos
+        self.end = pos + 1
+        self.nfr_cov = nuctrack.nfr_cov.get(pos=pos)
+        self.nuc_cov = nuctrack.nuc_cov.get(pos=pos)
+        self.nuc_signal = nuctrack.nuc_signal.get(pos=pos)
+        self.norm_signal = nuctrack.norm_signal.get(pos=pos)
+        self.smoothed = nuctrack.smoothed.get(pos=pos)
+
+    def getOcc(self, nuctrack):
+        try:
+            self.occ = nuctrack.occ.get(pos=self.start)
+            self.occ_lower = nuctrack.occ_lower.get(pos=self.start)
+            self.occ_upper = nuctrack.occ_upper.get(pos=self.start)
+        except Exception:
+            self.occ = self.occ_lower = self.occ_upper = np.nan
+
+    def getFuzz(self, nuctrack):
+        """sd of a (mixture of up to 3) Gaussian(s) fitted to the smoothed signal around the call
+        (NucleosomeCalling.py:137-194; scipy L-BFGS-B on the host)"""
+        p = nuctrack.params
+        third = p.nonredundant_sep // 3
+        index = self.start - nuctrack.start
+        allnucs = nuctrack.sorted_nuc_keys
+        x = bisect_left(allnucs, index)
+        if x > 0 and index - allnucs[x - 1] < p.nonredundant_sep:
+            left = allnucs[x - 1]
+            means = (index - allnucs[x - 1], 0)
+        else:
+            left = index - third
+            means = (third,)
+        if x < len(allnucs) - 1 and allnucs[x + 1] - index < p.nonredundant_sep:
+            right = allnucs[x + 1]
+            means += (allnucs[x + 1] - left,)
+        else:
+            right = index + third + 1
+        sig = nuctrack.smoothed.vals[left:right]
+        sig[sig < 0] = 0
+        top = max(sig)
+        bounds, guess = (), ()
+        for m in means:
+            bounds += ((2 ** 2, 50 ** 2), (0.001, top * 1.1), (m - 10, m + 10))
+            guess += (p.smooth_sd ** 2, top * 0.9, m)
+        xs = np.linspace(0, len(sig) - 1, len(sig))
+
+        def err(pars):
+            fit = np.zeros(len(xs))
+            for j in range(len(pars) // 3):
+                fit += norm(xs, pars[3 * j], pars[3 * j + 1], pars[3 * j + 2])
+            return np.sum((fit - sig) ** 2)
+
+        res = optimize.minimize(err, guess, bounds=bounds, method="L-BFGS-B")
+        self.fuzz = np.sqrt(res["x"][0])
+        self.weight = res["x"][1]
+        self.fit_pos = res["x"][2] + left
+
+    def asBed(self):
+        s = _py2_float_str
+        return "\t".join([str(self.chrom), str(self.start), str(self.end)] + [
+            s(float(v)) for v in (self.z, self.occ, self.occ_lower, self.occ_upper, self.lr, self.norm_signal,
+                                  self.nuc_signal, self.nuc_cov, self.nfr_cov, self.fuzz)])
+
+    def write(self, handle):
+        handle.write(self.asBed() + "\n")
+
+
+class NucParameters(object):
+    """run-level parameters of nucleosome calling (NucleosomeCalling.py:204-226)"""
+
+    def __init__(self, vmat, fragmentsizes, bam, fasta, pwm, occ_track=None, atac=True, sd=25, nonredundant_sep=120,
+                 redundant_sep=25, min_z=3, min_lr=0, min_reads=1):
+        self.atac = atac
+        self.vmat = vmat
+        self.lower = vmat.lower
+        self.upper = vmat.upper
+        self.window = vmat.mat.shape[1]
+        self.fragmentsizes = fragmentsizes
+        self.min_reads = min_reads
+        self.min_z = min_z
+        self.min_lr = min_lr
+        self.smooth_sd = sd
+        self.redundant_sep = redundant_sep
+        self.nonredundant_sep = nonredundant_sep
+        self.fasta = fasta
+        self.pwm = PWM.open(pwm)
+        self.chrs = read_chrom_sizes_from_bam(bam)
+        self.bam = bam
+        self.occ_track = occ_track
+
+    def install(self, ctx):
+        ctx.set_vmat(self.vmat.mat, self.vmat.lower, self.vmat.upper)
+        ctx.set_sizes(self.fragmentsizes.get(0, self.vmat.upper))
+
+
+def nuc_batch(chunks, params, ctx=None):
+    """NucChunk.process for a list of chunks in one GPU batch; returns the processed NucChunk objects"""
+    ctx = ctx or get_context()
+    params.install(ctx)
+    if params.fasta is not None:
+        from ..pyatac.utils import read_chrom_sizes_from_fasta
+        chrs = read_chrom_sizes_from_fasta(params.fasta)
+    else:
+        chrs = params.chrs
+    pk = pack(chunks, params.bam, params.fasta, chrs, params.pwm, atac=params.atac)
+    run = BatchRunner(pk, ctx)
+    out = []
+    try:
+        res = run.nuc(params.smooth_sd)
+        for k, ch in enumerate(chunks):
+            nc = NucChunk(ch)
+            nc.initialize(params)
+            for name, cls in (("nuc_cov", CoverageTrack), ("nfr_cov", CoverageTrack)):
+                t = cls(ch.chrom, ch.start, ch.end)
+                t.vals = res[name][k].copy()
+                setattr(nc, name, t)
+            for name, label in (("nuc_signal", "signal"), ("bias", "bias"), ("norm_signal", "normalized signal"),
+                                ("smoothed", "Smooth Signal")):
+                setattr(nc, name, Track(ch.chrom, ch.start, ch.end, label, vals=res[name][k].copy()))
+            if params.occ_track is not None:
+                nc.getOcc()
+            out.append(nc)
+        # candidates of every chunk -> one candidate launch
+        cc, cp = [], []
+        for k, nc in enumerate(out):
+            nc._cands = nc.candidatePositions()
+            cc += [k] * len(nc._cands)
+            cp += [int(i) for i in nc._cands]
+        lr, var, z = run.candidates(cc, cp) if cc else (np.zeros(0),) * 3
+        o = 0
+        for nc in out:
+            n = len(nc._cands)
+            nc.findAllNucs(stats=(lr[o:o + n], z[o:o + n]))
+            o += n
+            nc.fit()
+    finally:
+        run.close()
+    return out
+
+
+class NucChunk(Chunk):
+    """nucleosome signal + calls of one chunk (NucleosomeCalling.py:230-345)"""
+
+    def __init__(self, chunk):
+        self.start = chunk.start
+        self.end = chunk.end
+        self.chrom = chunk.chrom
+
+    def initialize(self, parameters):
+        self.params = parameters
+
+    def getOcc(self):
+        """occupancy tracks written by `occ` (NucleosomeCalling.py:284-293)"""
+        base = self.params.occ_track[:-11]
+        for attr, f in (("occ", self.params.occ_track), ("occ_lower", base + "lower_bound.bedgraph.gz"),
+                        ("occ_upper", base + "upper_bound.bedgraph.gz")):
+            t = Track(self.chrom, self.start, self.end, "Occupancy")
+            t.read_track(f)
+            setattr(self, attr, t)
+
+    def candidatePositions(self):
+        """local maxima of norm + smoothed signal (NucleosomeCalling.py:297-301)"""
+        combined = self.norm_signal.vals + self.smoothed.vals
+        return call_peaks(combined, min_signal=0, sep=self.params.redundant_sep,
+                          boundary=self.params.nonredundant_sep // 2, order=self.params.redundant_sep // 2)
+
+    def findAllNucs(self, stats=None):
+        """threshold the candidates in the reference's order: reads, LR, z (NucleosomeCalling.py:294-315)"""
+        if stats is None:
+            raise Exception("findAllNucs needs the candidate statistics of natac_run_candidates (use nuc_batch / process)")
+        lr, z = stats
+        self.nuc_collection = {}
+        for j, i in enumerate(self._cands):
+            nuc = Nucleosome(int(i) + self.start, self)
+            if nuc.nuc_cov > self.params.min_reads:
+                nuc.lr = lr[j]
+                if nuc.lr > self.params.min_lr:
+                    nuc.z = z[j]
+                    if nuc.z >= self.params.min_z:
+                        if hasattr(self, "occ"):
+                            nuc.getOcc(self)
+                        else:
+                            nuc.occ = nuc.occ_lower = nuc.occ_upper = np.nan
+                        self.nuc_collection[int(i)] = nuc
+        self.sorted_nuc_keys = np.array(sorted(self.nuc_collection.keys()))
+        self.nonredundant = reduce_peaks(self.sorted_nuc_keys, [self.nuc_collection[x].z for x in self.sorted_nuc_keys],
+                                         self.params.nonredundant_sep)
+        self.redundant = np.setdiff1d(self.sorted_nuc_keys, self.nonredundant)
+
+    def fit(self):
+        x = np.linspace(0, self.length() - 1, self.length())
+        fit = np.zeros(self.length())
+        for k in self.sorted_nuc_keys:
+            n = self.nuc_collection[int(k)]
+            n.getFuzz(self)
+            fit += norm(x, n.fuzz ** 2, n.weight, n.fit_pos)
+        self.fitted = Track(self.chrom, self.start, self.end, "Fitted Nucleosome Signal")
+        self.fitted.assign_track(fit)
+
+    def process(self, params):
+        """signal tracks + calls on the GPU (a batch of one chunk); makeInsertionTrack is skipped -- its result is
+        discarded by the reference's _nucHelper (run_nuc.py:30-32)"""
+        done = nuc_batch([Chunk(self.chrom, self.start, self.end)], params)[0]
+        self.__dict__.update(done.__dict__)
+
+    def removeData(self):
+        for name in list(self.__dict__.keys()):
+            delattr(self, name)

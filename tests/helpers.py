@@ -63,3 +63,33 @@ def expand_grid(vals, L, step=5):
     rep = np.repeat(vals, step)[:L]
     out[:min(L, nk * step)] = rep[:min(L, nk * step)]
     return out
+
+
+def synth_genome(seed, chrom_len=14000, holes=()):
+    """the synthetic chromosome of tests/golden/make_golden.py::make_synth_genome (must stay identical to it):
+    returns (l, n, seq) -- absolute left insertion, insert size, sequence bytes"""
+    from nucleoatac_amd.synth import synth_centres, synth_sizes
+    rng = np.random.default_rng(seed)
+    nf = int(chrom_len * 0.35)
+    n = synth_sizes(rng, nf).astype(np.int64)
+    c = synth_centres(rng, nf, chrom_len - 1600) + 800
+    keep = np.ones(nf, bool)
+    for a, b in holes:
+        keep &= ~((c >= a - 130) & (c < b + 130))
+    n, c = n[keep], c[keep]
+    l = c - (n - 1) // 2
+    o = np.argsort(l, kind="stable")
+    l, n = l[o], n[o]
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=chrom_len)
+    seq[rng.integers(0, chrom_len, size=40)] = ord("N")
+    seq[5000:5030] = ord("N")
+    return l, n, seq
+
+
+def synth_stores(seed, holes=()):
+    """FragmentStore + FastaStore of the golden synthetic chromosome `chrS`"""
+    from nucleoatac_amd.pyatac.fragments import FragmentStore
+    from nucleoatac_amd.pyatac.seq import FastaStore
+    l, n, seq = synth_genome(seed, holes=holes)
+    frags = FragmentStore(["chrS"], [len(seq)], {"chrS": l - 4}, {"chrS": n + 8})
+    return frags, FastaStore({"chrS": seq.copy()})

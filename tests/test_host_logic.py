@@ -1,0 +1,159 @@
+"""CPU: host-side mirror of the reference API (no GPU needed): intervals, text formats, peak logic, parsers."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, golden
+from nucleoatac_amd.pyatac.bias import PWM
+from nucleoatac_amd.pyatac.chunk import Chunk, ChunkList
+from nucleoatac_amd.pyatac.chunkmat2d import ChunkMat2D, FragmentMat2D
+from nucleoatac_amd.pyatac.fragments import FragmentStore
+from nucleoatac_amd.pyatac.fragmentsizes import FragmentSizes
+from nucleoatac_amd.pyatac.tracks import Track
+from nucleoatac_amd.pyatac.utils import call_peaks, reduce_peaks
+from nucleoatac_amd.pyatac.VMat import VMat, VMat_Error
+
+BED = os.path.join(GOLDEN, "ref_example.bed")
+CHRS = {"chrII": 813184, "chrIV": 1531933, "chrVII": 1090940, "chrX": 745751, "chrXII": 1078177, "chrXV": 1091291,
+        "chrXVI": 948066, "chrI": 230218, "chrIII": 316620, "chrV": 576874, "chrVI": 270161, "chrVIII": 562643,
+        "chrIX": 439888, "chrXI": 666816, "chrXIII": 924431, "chrXIV": 784333, "chrM": 85779}
+
+
+def test_call_peaks_reference_cases():
+    """the reference's tests/test_utils.py:8-19"""
+    sig = np.array([1, 2, 3, 2, 1, 4, 1, 2, 1, 0, 0])
+    assert np.array_equal(call_peaks(sig.copy(), min_signal=1, sep=3), [2, 5])
+    assert np.array_equal(call_peaks(sig.copy(), min_signal=1, sep=1), [2, 5, 7])
+    assert np.array_equal(call_peaks(sig.copy(), min_signal=3, sep=2), [2, 5])
+
+
+def test_call_peaks_fills_nan_in_place():
+    x = np.array([np.nan, 1.0, 3.0, 1.0, np.nan, 0.5, 2.0, 0.5, np.nan])
+    call_peaks(x, sep=2, boundary=0)
+    assert not np.isnan(x).any() and x[0] == 0.5
+    assert call_peaks(np.full(5, np.nan)).size == 0
+    assert np.array_equal(reduce_peaks(np.array([10, 20, 25, 60]), [1.0, 5.0, 4.0, 2.0], 30), [20, 60])
+
+
+def test_chunklist_read_slop_merge_split():
+    chunks = ChunkList.read(BED, chromDict=CHRS, min_offset=255)
+    assert len(chunks) == 19 and chunks[0].chrom == "chrII" and (chunks[0].start, chunks[0].end) == (706612, 707705)
+    n0 = chunks[0].length()
+    chunks.slop(CHRS, up=60, down=60)
+    assert chunks[0].length() == n0 + 120
+    chunks.merge()
+    assert chunks.isSorted()
+    sets = chunks.split(items=5)
+    assert sum(len(s) for s in sets) == len(chunks) and len(sets[0]) == 5
+    assert sum(len(s) for s in chunks.split(bases=5000)) == len(chunks)
+    with pytest.raises(Exception):
+        chunks.split()
+    # merge joins regions closer than sep (+1): gap of exactly `sep` merges
+    cl = ChunkList(Chunk("c", 0, 100), Chunk("c", 100, 150), Chunk("c", 152, 160), Chunk("d", 0, 5))
+    cl.merge(sep=0)
+    assert [(c.chrom, c.start, c.end) for c in cl] == [("c", 0, 150), ("c", 152, 160), ("d", 0, 5)]
+    with pytest.raises(ValueError):
+        cl.append("not a chunk")
+    # min_offset clipping / min_length filter / unknown chromosomes
+    with pytest.warns(UserWarning):
+        few = ChunkList.read(BED, chromDict={"chrII": 813184}, min_offset=255, min_length=1000)
+    assert all(c.chrom == "chrII" and c.length() >= 1000 for c in few)
+
+
+def test_chunk_slop_strand_and_center():
+    c = Chunk("chr1", 100, 200, strand="-")
+    c.slop({"chr1": 1000}, up=10, down=30)
+    assert (c.start, c.end) == (70, 210)
+    d = Chunk("chr1", 5, 20).slop({"chr1": 22}, up=10, down=10, new=True)
+    assert (d.start, d.end) == (0, 22)
+    e = Chunk("chr1", 10, 21)
+    e.center()
+    assert (e.start, e.end) == (15, 16)
+    assert Chunk("chr1", 1, 2, name="n").asBed() == "chr1\t1\t2\t1\tn\t*"
+
+
+def test_track_write_bedgraph_format():
+    """run-length text with python-2 float formatting, NaN runs skipped (pyatac/tracks.py:37-74)"""
+    t = Track("chr1", 10, 20, vals=np.array([0, 0, 1.5, 1.5, np.nan, np.nan, 1 / 3.0, 1 / 3.0, 0, 0]))
+    h = io.StringIO()
+    t.write_track(h)
+    assert h.getvalue() == "chr1\t10\t12\t0.0\nchr1\t12\t14\t1.5\nchr1\t16\t18\t0.333333333333\nchr1\t18\t20\t0.0\n"
+    h = io.StringIO()
+    t.write_track(h, write_zero=False)
+    assert h.getvalue() == "chr1\t12\t14\t1.5\nchr1\t16\t18\t0.333333333333\n"
+    with pytest.raises(Exception):
+        t.write_track(io.StringIO(), vals=np.zeros(3))
+    with pytest.raises(Exception):
+        Track("chr1", 0, 5, vals=[1, 2])
+    assert t.get(pos=12) == 1.5 and len(t.get(12, 16)) == 4
+
+
+def test_track_read_example_scores():
+    """the reference's tests/test_tracks.py:31-36 pin"""
+    chunk = ChunkList.read(BED)[0]
+    t = Track(chunk.chrom, chunk.start, chunk.end)
+    t.read_track(os.path.join(GOLDEN, "ref_example.Scores.bedgraph.gz"))
+    assert abs(1.35994655714 - t.get(pos=706661)) < 0.001
+
+
+def test_bam_decoder_on_reference_fixture():
+    st = FragmentStore.from_bam(os.path.join(GOLDEN, "ref_single_read.bam"))
+    sr = golden("single_read")
+    l, n = st.fetch("chrII", int(sr["start"]), int(sr["end"]))
+    assert np.array_equal(l, sr["l"]) and np.array_equal(n, sr["n"])
+    assert st.chrom_sizes()["chrII"] == 813184 and len(st.references) == 17
+    with pytest.raises(ValueError):
+        FragmentStore.open("reads.sam")
+
+
+def test_vmat_text_roundtrip(tmp_path):
+    v = VMat.open(os.path.join(GOLDEN, "ref_example.VMat"))
+    assert v.mat.shape == (130, 121) and (v.lower, v.upper, v.w) == (115, 245, 60)
+    d = VMat.default()
+    assert d.mat.shape == (146, 121) and (d.lower, d.upper, d.w) == (105, 251, 60)
+    p = str(tmp_path / "x.VMat")
+    d.save(p)
+    r = VMat.open(p)
+    assert np.allclose(r.mat, d.mat, rtol=1e-11) and r.lower == 105
+    d.trim(110, 250, 50)
+    assert d.mat.shape == (140, 101) and d.w == 50
+    with pytest.raises(VMat_Error):
+        d.trim(100, 250, 50)
+    with pytest.raises(VMat_Error):
+        VMat(np.zeros((3, 5)), 0, 4)
+
+
+def test_pwm_and_fragmentsizes_io(tmp_path):
+    p = PWM.open("Human")
+    assert p.mat.shape == (4, 21) and (p.up, p.down) == (10, 10) and p.nucleotides == ["A", "C", "G", "T"]
+    f = str(tmp_path / "h.PWM.txt")
+    p.save(f)
+    q = PWM.open(f)
+    assert np.allclose(q.mat, p.mat) and q.nucleotides == p.nucleotides
+    fs = FragmentSizes(0, 5, vals=np.array([0.0, 0.25, 0.5, 0.125, 0.125]))
+    g = str(tmp_path / "s.txt")
+    fs.save(g)
+    back = FragmentSizes.open(g)
+    assert np.array_equal(back.get(), fs.get()) and back.get(size=2) == 0.5 and list(back.get(1, 3)) == [0.25, 0.5]
+
+
+def test_chunkmat2d_get_and_getins():
+    """the reference's tests/test_chunkmat2d.py:13-18 + getIns geometry"""
+    x = FragmentMat2D("chr1", 500, 1000, 0, 200)
+    x.mat[100, 5] = 1
+    assert np.array_equal(x.get(start=505, end=507, lower=100, upper=102), np.array([[1, 0], [0, 0]]))
+    g = golden("ins_edge")
+    m = ChunkMat2D("chrS", int(g["mat_start"]), int(g["mat_end"]), 0, 251)
+    m.mat[g["mat_rows"], g["mat_cols"]] = g["mat_vals"]
+    ins = m.getIns()
+    assert np.array_equal(ins.vals, g["getins"]) and ins.start == int(g["getins_start"])
+
+
+def test_cli_defaults_match_reference():
+    from nucleoatac_amd.nucleoatac.cli import nucleoatac_parser
+    a = nucleoatac_parser().parse_args(["occ", "--bed", "b", "--bam", "x", "--out", "o"])
+    assert (a.upper, a.flank, a.min_occ, a.nuc_sep, a.confidence_interval, a.step, a.pwm) == (251, 60, 0.1, 120, 0.9, 5, "Human")
+    n = nucleoatac_parser().parse_args(["nuc", "--bed", "b", "--bam", "x", "--out", "o", "--vmat", "v"])
+    assert (n.min_z, n.min_lr, n.nuc_sep, n.redundant_sep, n.sd, n.atac, n.write_all) == (3, 0, 120, 25, 10, True, False)
