@@ -4,6 +4,7 @@ All numerics run in libnatac_hip.so (HIP, gfx950).  numpy is only used for the h
 that cross the boundary.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -30,9 +31,13 @@ class Context(object):
         self.device_id = int(device_id)
         self.vmat_shape = None
         self.occ_step = None
+        self._batches = weakref.WeakSet()
 
     def close(self):
+        """destroy the context; batches that are still alive are freed first (they hold a pointer to it)"""
         if getattr(self, "_h", None):
+            for b in list(self._batches):
+                b.free()
             self._lib.natac_ctx_destroy(self._h)
             self._h = None
 
@@ -243,10 +248,12 @@ class DeviceBatch(object):
             _ptr(packed.bias_log), int(packed.bias_left), int(packed.bias_right), C.byref(h)))
         self._h = h
         self.total_bp = packed.total_bp
+        ctx._batches.add(self)
 
     def free(self):
         if getattr(self, "_h", None):
-            self._lib.natac_batch_free(self._h)
+            if getattr(self.ctx, "_h", None):       # never touch a batch whose context is gone
+                self._lib.natac_batch_free(self._h)
             self._h = None
 
     def __del__(self):

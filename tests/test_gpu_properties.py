@@ -1,0 +1,226 @@
+"""GPU: size-independent properties at BASELINE.json's full configs[2] size (100k chunks x 2,120 bp, 50 M fragments)
+plus ragged / empty / extreme edge cases.  Oracle comparisons are limited to a random sample of chunks."""
+import numpy as np
+import pytest
+
+from helpers import assert_track, golden
+from nucleoatac_amd import _lib as L
+from nucleoatac_amd.packing import PackedChunks
+from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions, synth_size_distribution
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from nucleoatac_amd.device import Context
+    par = golden("params_example")
+    c = Context(0)
+    c.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
+    c.set_sizes(synth_size_distribution(251))
+    nucp, nfrp = synth_occ_distributions(251)
+    c.set_occ_model(nucp, nfrp, step=5, flank=60)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def full(ctx):
+    pk = make_synthetic_chunks(100000, 2120, 500, seed=0)
+    b = ctx.upload(pk)
+    b.run_nuc(10)
+    b.run_occ()
+    b.run_ins(0, 2000)
+    yield pk, b
+    b.free()
+
+
+def test_full_size_integer_checksums(full):
+    pk, b = full
+    nuc_cov, nfr_cov, occ_cov = b.track(L.T_NUC_COV), b.track(L.T_NFR_COV), b.track(L.T_OCC_COV)
+    assert np.array_equal(occ_cov, nuc_cov + nfr_cov)          # same window (121) and size range [0, 251)
+    Lc = 2120
+    c = pk.frag_lpos.astype(np.int64) + (pk.frag_ilen.astype(np.int64) - 1) // 2
+    n = pk.frag_ilen.astype(np.int64)
+    ov = np.clip(np.minimum(c + 60, Lc - 1) - np.maximum(c - 60, 0) + 1, 0, None)   # bases whose window holds the centre
+    assert int(nuc_cov.sum()) == int(ov[(n >= 105) & (n < 251)].sum())
+    assert int(nfr_cov.sum()) == int(ov[(n >= 0) & (n < 105)].sum())
+    ins = b.track(L.T_INS)
+    l = pk.frag_lpos.astype(np.int64)
+    r = l + n - 1
+    keep = (n >= 0) & (n < 2000)
+    assert int(ins.sum()) == int(((l >= 0) & (l < Lc) & keep).sum() + ((r >= 0) & (r < Lc) & keep).sum())
+    assert ins.dtype == np.int32 and ins.min() >= 0
+
+
+def test_full_size_float_sanity(full):
+    pk, b = full
+    raw, bg, norm, sm = (b.track(t) for t in (L.T_RAW, L.T_BACKGROUND, L.T_NORM, L.T_SMOOTH))
+    assert np.isfinite(raw).all() and np.isfinite(bg).all() and (bg >= 0).all() and (raw >= 0).all()
+    assert np.array_equal(norm, raw - bg)
+    assert (sm >= 0).all() and np.isfinite(sm).all()
+    occ, lo, hi = (b.track(t) for t in (L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER))
+    m = ~np.isnan(lo)
+    assert m.mean() > 0.99
+    assert (occ[m] >= -1e-12).all() and (occ[m] <= 1 + 1e-12).all()
+    assert (lo[m] <= occ[m] + 1e-9).all() and (occ[m] <= hi[m] + 1e-9).all()
+    g = b.grid(L.G_OCC)
+    gm = ~np.isnan(g)
+    assert np.all(np.abs(g[gm] * 100 - np.rint(g[gm] * 100)) < 1e-9)   # values of the alpha grid
+    assert not b.status().any()
+
+
+def test_full_size_sample_matches_oracle(full, ctx):
+    from oracle import natac_oracle as O
+    pk, b = full
+    par = golden("params_example")
+    sizes = synth_size_distribution(251)
+    nucp, nfrp = synth_occ_distributions(251)
+    tr = {t: b.track(t) for t in (L.T_NORM, L.T_SMOOTH, L.T_BACKGROUND, L.T_OCC_PREFILL, L.T_OCC_LOWER, L.T_INS)}
+    rng = np.random.default_rng(123)
+    for k in rng.integers(0, pk.n_chunks, size=6):
+        k = int(k)
+        l, n = pk.chunk_frags(k)
+        l, n = l.astype(np.int64), n.astype(np.int64)
+        a, e = int(pk.out_off[k]), int(pk.out_off[k + 1])
+        nt = O.nuc_chunk_tracks(l, n, 0, 2120, pk.chunk_bias(k), -pk.bias_left, par["vmat"], 105, 251, sizes)
+        oc = O.occ_chunk_tracks(l, n, 0, 2120, pk.chunk_bias(k), -pk.bias_left, nucp, nfrp)
+        assert_track(tr[L.T_BACKGROUND][a:e], nt["bg"], "bg")
+        assert_track(tr[L.T_NORM][a:e], nt["norm"], "norm")
+        assert_track(tr[L.T_SMOOTH][a:e], nt["smoothed"], "smoothed")
+        assert_track(tr[L.T_OCC_PREFILL][a:e], oc["smoothed_vals"], "occ smoothed")
+        assert_track(tr[L.T_OCC_LOWER][a:e], oc["smoothed_lower"], "occ lower")
+        assert np.array_equal(tr[L.T_INS][a:e], O.get_insertions(l, n, 0, 2120).astype(np.int32))
+
+
+def test_results_do_not_depend_on_batching(full, ctx):
+    """a chunk gives bit-identical tracks alone, in a shard, or in the 100k batch (what sharding over GPUs relies on)"""
+    pk, b = full
+    sub = pk.subset(4321, 4330)
+    sb = ctx.upload(sub)
+    sb.run_nuc(10)
+    sb.run_occ()
+    a, e = int(pk.out_off[4321]), int(pk.out_off[4330])
+    for t in (L.T_NORM, L.T_SMOOTH, L.T_BACKGROUND, L.T_OCC, L.T_OCC_UPPER, L.T_NUC_COV):
+        assert np.array_equal(sb.track(t), b.track(t)[a:e], equal_nan=True), t
+    sb.free()
+    again = b.track(L.T_NORM).copy()
+    b.run_nuc(10)
+    assert np.array_equal(again, b.track(L.T_NORM))           # deterministic
+
+
+def test_zero_bias_equals_no_bias(ctx):
+    pk = make_synthetic_chunks(50, 900, 200, seed=7)
+    zero = PackedChunks(pk.chunk_start, pk.chunk_len, pk.frag_off, pk.frag_lpos, pk.frag_ilen, pk.bias_off,
+                        np.zeros_like(pk.bias_log))
+    none = PackedChunks(pk.chunk_start, pk.chunk_len, pk.frag_off, pk.frag_lpos, pk.frag_ilen, None, None)
+    outs = []
+    for p in (zero, none):
+        b = ctx.upload(p)
+        b.run_nuc(10)
+        b.run_occ()
+        outs.append([b.track(t) for t in (L.T_BACKGROUND, L.T_NORM, L.T_OCC, L.T_OCC_LOWER)])
+        b.free()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_duplicated_fragments_scale_signal(ctx):
+    pk = make_synthetic_chunks(20, 800, 150, seed=8)
+    rep = lambda a: np.repeat(a, 2)
+    dbl = PackedChunks(pk.chunk_start, pk.chunk_len, pk.frag_off * 2, rep(pk.frag_lpos), rep(pk.frag_ilen), pk.bias_off,
+                       pk.bias_log)
+    res = []
+    for p in (pk, dbl):
+        b = ctx.upload(p)
+        b.run_nuc(10)
+        b.run_ins(0, 2000)
+        res.append([b.track(t) for t in (L.T_NUC_COV, L.T_RAW, L.T_BACKGROUND, L.T_INS)])
+        b.free()
+    assert np.array_equal(res[1][0], 2 * res[0][0]) and np.array_equal(res[1][3], 2 * res[0][3])
+    np.testing.assert_allclose(res[1][1], 2 * res[0][1], rtol=1e-13)
+    np.testing.assert_allclose(res[1][2], 2 * res[0][2], rtol=1e-13)
+
+
+def test_ragged_and_empty_chunks_match_oracle(ctx):
+    """ragged lengths (incl. the minimum 121 and L % 5 != 0), a chunk without fragments, fragments outside every window,
+    huge insert sizes, a crowded chunk (> 1024 fragments per occupancy tile: un-staged path)"""
+    from oracle import natac_oracle as O
+    par = golden("params_example")
+    sizes = synth_size_distribution(251)
+    nucp, nfrp = synth_occ_distributions(251)
+    rng = np.random.default_rng(5)
+    lens = [121, 122, 333, 1204, 700, 640]
+    fr = []
+    for i, Lc in enumerate(lens):
+        if i == 2:
+            l, n = np.zeros(0, np.int64), np.zeros(0, np.int64)           # no fragments at all
+        elif i == 5:
+            n = rng.integers(20, 300, size=12000)                          # crowded: ~15 fragments per bp
+            l = rng.integers(-150, Lc + 100, size=12000)
+        else:
+            n = np.concatenate((rng.integers(1, 400, size=60 + i * 40), [1, 2, 0, 1999, 2500, 250, 251]))
+            l = rng.integers(-300, Lc + 200, size=len(n))
+        c = l + (n - 1) // 2
+        o = np.argsort(c, kind="stable")
+        fr.append((l[o], n[o]))
+    off = np.concatenate(([0], np.cumsum([len(x[0]) for x in fr])))
+    nb = [Lc + 493 for Lc in lens]
+    bias = rng.normal(0, 0.7, size=sum(nb))
+    pk = PackedChunks(np.arange(len(lens)) * 5000, lens, off, np.concatenate([x[0] for x in fr]),
+                      np.concatenate([x[1] for x in fr]), np.concatenate(([0], np.cumsum(nb))), bias)
+    b = ctx.upload(pk)
+    b.run_nuc(10)
+    b.run_occ()
+    b.run_ins(0, 2000)
+    assert not b.status().any()
+    tr = {t: b.split(b.track(t)) for t in (L.T_NUC_COV, L.T_NFR_COV, L.T_RAW, L.T_BACKGROUND, L.T_NORM, L.T_SMOOTH,
+                                           L.T_OCC_PREFILL, L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER, L.T_OCC_COV, L.T_INS)}
+    for k, Lc in enumerate(lens):
+        l, n = fr[k]
+        nt = O.nuc_chunk_tracks(l, n, 0, Lc, pk.chunk_bias(k), -246, par["vmat"], 105, 251, sizes)
+        oc = O.occ_chunk_tracks(l, n, 0, Lc, pk.chunk_bias(k), -246, nucp, nfrp)
+        assert_track(tr[L.T_NUC_COV][k], nt["nuc_cov"], "nuc_cov", exact=True)
+        assert_track(tr[L.T_NFR_COV][k], nt["nfr_cov"], "nfr_cov", exact=True)
+        assert_track(tr[L.T_RAW][k], nt["raw"], "raw")
+        assert_track(tr[L.T_BACKGROUND][k], nt["bg"], "bg")
+        assert_track(tr[L.T_NORM][k], nt["norm"], "norm", atol=1e-8)
+        assert_track(tr[L.T_SMOOTH][k], nt["smoothed"], "smoothed", atol=1e-8)
+        assert_track(tr[L.T_OCC_PREFILL][k], oc["smoothed_vals"], "occ")
+        assert_track(tr[L.T_OCC_LOWER][k], oc["smoothed_lower"], "occ lower")
+        assert_track(tr[L.T_OCC_UPPER][k], oc["smoothed_upper"], "occ upper")
+        assert_track(tr[L.T_OCC_COV][k], oc["cov"], "occ cov", exact=True)
+        assert np.array_equal(tr[L.T_INS][k], O.get_insertions(l, n, 0, Lc).astype(np.int32))
+        filled = oc["smoothed_vals"].copy()
+        O.call_peaks(filled)
+        assert_track(tr[L.T_OCC][k], filled, "occ post-fill")
+    assert np.isnan(tr[L.T_OCC][2]).all() and not tr[L.T_NUC_COV][2].any()       # the empty chunk stays NaN / 0
+    b.free()
+
+
+def test_argument_errors(ctx):
+    pk = make_synthetic_chunks(3, 100, 10, seed=1)            # shorter than the 121-bp windows
+    b = ctx.upload(pk)
+    with pytest.raises(L.NatacError):
+        b.run_occ()                                            # 100 < 121
+    with pytest.raises(L.NatacError):
+        b.run_nuc(20)                                          # 100 < 6*20+1
+    with pytest.raises(L.NatacError):
+        b.track(L.T_NORM)                                      # stage has not run
+    b.run_ins()
+    with pytest.raises(L.NatacError):
+        b.run_candidates([0], [5])                             # needs run_nuc first
+    b.free()
+    ok = make_synthetic_chunks(2, 400, 50, seed=1)
+    b = ctx.upload(ok)
+    b.run_nuc(10)
+    with pytest.raises(L.NatacError):
+        b.run_candidates([5], [10])                            # chunk index out of range
+    assert b.run_candidates([], [])[0].shape == (0,)
+    b.free()
+    short = PackedChunks(ok.chunk_start, ok.chunk_len, ok.frag_off, ok.frag_lpos, ok.frag_ilen,
+                         np.arange(3) * (400 + 200), np.zeros(2 * 600), bias_left=100, bias_right=100)
+    b = ctx.upload(short)
+    with pytest.raises(L.NatacError):
+        b.run_nuc(10)                                          # bias halo too small for the 185-bp reach
+    b.free()
