@@ -35,7 +35,8 @@ static int fail(int code, const char *fmt, ...) {
 
 struct natac_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // nuc stage, candidates, uploads, drop-ins
+    hipStream_t stream2 = nullptr;   // occ stage + insertions: independent of the nuc stage, overlaps with it
     hipDeviceProp_t prop;
     // constants
     double *d_vmat = nullptr, *d_srow = nullptr, *d_sizes = nullptr;
@@ -51,7 +52,7 @@ struct natac_ctx {
     double win_nuc_sd = -1, win_occ_sd = -1;
     // profiling
     bool profiling = false;
-    struct Ev { int k; hipEvent_t a, b; };
+    struct Ev { int k; hipEvent_t a, b; hipStream_t st; };
     std::vector<Ev> pending;
     double prof_ms[NATAC_K_COUNT] = {0};
     int64_t prof_n[NATAC_K_COUNT] = {0};
@@ -68,7 +69,8 @@ struct natac_batch {
     int *d_len = nullptr, *d_lpos = nullptr, *d_ilen = nullptr, *d_centre = nullptr, *d_status = nullptr;
     long long *d_frag_off = nullptr, *d_bias_off = nullptr, *d_out_off = nullptr, *d_grid_off = nullptr;
     double *d_bias = nullptr;
-    int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr;
+    int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
+    int ranges256_w = -1;
     int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;
     int grid_step = 0, grid_half = 0;
     double *d_track[NATAC_T_COUNT] = {nullptr};
@@ -76,17 +78,25 @@ struct natac_batch {
     bool nuc_done = false, occ_done = false, ins_done = false;
 };
 
-static void prof_begin(natac_ctx *c, int k, natac_ctx::Ev &ev) {
+static hipError_t sync_all(natac_ctx *c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e2 = (c->stream2 != c->stream) ? hipStreamSynchronize(c->stream2) : hipSuccess;
+    return e != hipSuccess ? e : e2;
+}
+
+static void prof_begin(natac_ctx *c, int k, natac_ctx::Ev &ev, hipStream_t st = nullptr) {
     ev.k = k;
     ev.a = ev.b = nullptr;
+    ev.st = nullptr;
     if (!c->profiling) return;
     (void)hipEventCreate(&ev.a);
     (void)hipEventCreate(&ev.b);
-    (void)hipEventRecord(ev.a, c->stream);
+    ev.st = st ? st : c->stream;
+    (void)hipEventRecord(ev.a, ev.st);
 }
 static void prof_end(natac_ctx *c, natac_ctx::Ev &ev) {
     if (!c->profiling) return;
-    (void)hipEventRecord(ev.b, c->stream);
+    (void)hipEventRecord(ev.b, ev.st);
     c->pending.push_back(ev);
 }
 static void prof_collect(natac_ctx *c) {
@@ -180,6 +190,9 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
     c->device = device_id;
     HIPCHK(hipGetDeviceProperties(&c->prop, device_id));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // measured on MI355X: a second stream for the occ stage does not overlap with the nuc stage (the background
+    // kernel's workgroups keep every CU's LDS full), so both stages share one stream -- keeps per-kernel timing exact
+    c->stream2 = c->stream;
     HIPCHK(hipEventCreate(&c->t0));
     HIPCHK(hipEventCreate(&c->t1));
     *out = c;
@@ -189,7 +202,7 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
 void natac_ctx_destroy(natac_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     prof_collect(c);
     dev_free(c->d_vmat); dev_free(c->d_srow); dev_free(c->d_sizes);
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
@@ -203,7 +216,7 @@ void natac_ctx_destroy(natac_ctx *c) {
 int natac_ctx_sync(natac_ctx *c) {
     if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     prof_collect(c);
     return NATAC_OK;
 }
@@ -222,13 +235,13 @@ int natac_set_vmat(natac_ctx *c, const double *mat, int lower, int upper, int w)
     if (!c || !mat) return fail(NATAC_E_ARG, "null argument");
     if (lower < 0 || upper <= lower || w < 0) return fail(NATAC_E_ARG, "bad vmat geometry lower=%d upper=%d w=%d", lower, upper, w);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     dev_free(c->d_vmat);
     c->d_vmat = nullptr;
     c->vlower = lower; c->vupper = upper; c->vw = w; c->R = upper - lower; c->W = 2 * w + 1;
     int rc = dev_upload(c, &c->d_vmat, mat, (size_t)c->R * c->W);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     c->have_vmat = true;
     c->srow_dirty = true;
     return NATAC_OK;
@@ -237,12 +250,12 @@ int natac_set_vmat(natac_ctx *c, const double *mat, int lower, int upper, int w)
 int natac_set_sizes(natac_ctx *c, const double *sizes, int upper) {
     if (!c || !sizes || upper <= 0) return fail(NATAC_E_ARG, "bad argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     dev_free(c->d_sizes);
     c->d_sizes = nullptr;
     int rc = dev_upload(c, &c->d_sizes, sizes, (size_t)upper);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     c->sizes_upper = upper;
     c->have_sizes = true;
     c->srow_dirty = true;
@@ -257,14 +270,14 @@ int natac_set_occ_model(natac_ctx *c, const double *nuc_probs, const double *nfr
     if (step < 1 || flank < 0) return fail(NATAC_E_ARG, "bad step/flank");
     if (step % 2 == 0) step -= 1; /* Occupancy.py:190-191 */
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
     c->d_nucp = c->d_nfrp = c->d_alphas = nullptr;
     int rc;
     if ((rc = dev_upload(c, &c->d_nucp, nuc_probs, (size_t)upper))) return rc;
     if ((rc = dev_upload(c, &c->d_nfrp, nfr_probs, (size_t)upper))) return rc;
     if ((rc = dev_upload(c, &c->d_alphas, alphas, (size_t)n_alpha))) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     c->occ_upper = upper; c->n_alpha = n_alpha; c->cutoff = cutoff; c->step = step;
     c->halfstep = (step - 1) / 2; c->flank = flank;
     c->have_occ = true;
@@ -287,7 +300,7 @@ static int ensure_srow(natac_ctx *c) {
 
 static int ensure_window(natac_ctx *c, double **slot, int *slotM, double *slotsd, int M, double sd) {
     if (*slot && *slotM == M && *slotsd == sd) return NATAC_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     dev_free(*slot);
     *slot = nullptr;
     // scipy.signal.gaussian(M, sd): exp(-0.5 (n/sd)^2), n = arange(M) - (M-1)/2   (pyatac/utils.py:40)
@@ -299,7 +312,7 @@ static int ensure_window(natac_ctx *c, double **slot, int *slotM, double *slotsd
     }
     int rc = dev_upload(c, slot, w.data(), (size_t)M);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     *slotM = M;
     *slotsd = sd;
     return NATAC_OK;
@@ -337,7 +350,7 @@ static int build_tiles(natac_batch *b, int width, int2 **d_out, int *n_out, bool
     *n_out = (int)tiles.size();
     int rc = dev_upload(b->ctx, d_out, tiles.data(), tiles.size());
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));  // `tiles` is a local
+    HIPCHK(sync_all(b->ctx));  // `tiles` is a local
     return NATAC_OK;
 }
 
@@ -399,11 +412,11 @@ int natac_batch_create(natac_ctx *c, int32_t nc, const int32_t *chunk_len, const
 void natac_batch_free(natac_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)sync_all(b->ctx);
     prof_collect(b->ctx);
     dev_free(b->d_len); dev_free(b->d_lpos); dev_free(b->d_ilen); dev_free(b->d_centre); dev_free(b->d_status);
     dev_free(b->d_frag_off); dev_free(b->d_bias_off); dev_free(b->d_out_off); dev_free(b->d_grid_off); dev_free(b->d_bias);
-    dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ);
+    dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
     for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
     delete b;
@@ -450,8 +463,14 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     const ChunkTable ct = make_table(b);
     const VMatDev vm = make_vmat(c);
     natac_ctx::Ev ev;
+    if (!b->d_ranges256 && (rc = dev_alloc(&b->d_ranges256, (size_t)b->n_tiles256))) return rc;
     prof_begin(c, NATAC_K_FRAG_GATHER, ev);
-    hipLaunchKernelGGL(natac_frag_gather, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, vm,
+    if (b->ranges256_w != c->vw) {
+        hipLaunchKernelGGL(natac_tile_ranges256, dim3((b->n_tiles256 + 255) / 256), dim3(256), 0, c->stream, ct, b->d_tiles256,
+                           b->n_tiles256, c->vw, b->d_ranges256);
+        b->ranges256_w = c->vw;
+    }
+    hipLaunchKernelGGL(natac_frag_gather, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, b->d_ranges256, vm,
                        b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_RAW]);
     prof_end(c, ev);
     prof_begin(c, NATAC_K_BACKGROUND, ev);
@@ -503,7 +522,7 @@ int natac_run_occ(natac_batch *b) {
             b->h_grid_off[i + 1] = b->h_grid_off[i] + nk;
         }
         b->total_grid = b->h_grid_off[b->nc];
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(sync_all(c));
         dev_free(b->d_grid_off);
         b->d_grid_off = nullptr;
         if ((rc = dev_upload(c, &b->d_grid_off, b->h_grid_off.data(), (size_t)b->nc + 1))) return rc;
@@ -524,36 +543,41 @@ int natac_run_occ(natac_batch *b) {
     const ChunkTable ct = make_table(b);
     const OccModelDev om = make_occ(c);
     natac_ctx::Ev ev;
-    prof_begin(c, NATAC_K_OCC_MLE, ev);
+    prof_begin(c, NATAC_K_OCC_MLE, ev, c->stream2);
     {
         const int U = c->occ_upper, UP = (U + 1) & ~1;
         const int span = (OCC_T - 1) * c->step + M;
         const int EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
         const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + ((span + 3) & ~1) + 512) * sizeof(double) +
                            (size_t)2 * OCC_FMAX * sizeof(int);
-        hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream, ct, b->d_tiles_occ,
+        hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
                            b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
         if (c->step == 5 && c->flank == 60)
-            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream, ct, b->d_tiles_occ,
+            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
                                b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
         else
-            hipLaunchKernelGGL((natac_occ_mle<0, 0, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream, ct, b->d_tiles_occ,
+            hipLaunchKernelGGL((natac_occ_mle<0, 0, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
                                b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
     }
     prof_end(c, ev);
-    prof_begin(c, NATAC_K_OCC_SMOOTH, ev);
+    prof_begin(c, NATAC_K_OCC_SMOOTH, ev, c->stream2);
     {
         const int h = (M - 1) / 2;
-        const size_t lds = ((size_t)4 * (256 + 2 * h) + M) * sizeof(double);
-        hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream, ct, b->d_tiles256, om, c->d_win_occ, M,
+        const int NB = 2 * ((h + c->step - 1) / c->step) + 2, NG = (255 + 2 * h) / c->step + 3;
+        const size_t lds = ((size_t)((M + 1) & ~1) + (size_t)c->step * NB + 3 * (size_t)NG) * sizeof(double);
+        hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream2, ct, b->d_tiles256, om, c->d_win_occ, M,
                            b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_track[NATAC_T_OCC_PREFILL],
                            b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER]);
-        hipLaunchKernelGGL(natac_occ_cov, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, c->occ_upper, c->flank,
-                           b->d_track[NATAC_T_OCC_COV]);
+        if (b->nuc_done && c->have_vmat && c->flank == c->vw && c->occ_upper == c->vupper)
+            hipLaunchKernelGGL(natac_add_tracks, dim3(4096), dim3(256), 0, c->stream2, b->d_track[NATAC_T_NUC_COV],
+                               b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_OCC_COV], b->total_bp);
+        else
+            hipLaunchKernelGGL(natac_occ_cov, dim3(b->n_tiles256), dim3(256), 0, c->stream2, ct, b->d_tiles256, c->occ_upper, c->flank,
+                               b->d_track[NATAC_T_OCC_COV]);
     }
     prof_end(c, ev);
-    prof_begin(c, NATAC_K_OCC_FILL, ev);
-    hipLaunchKernelGGL(natac_fill_nan_min, dim3(b->nc), dim3(256), 0, c->stream, ct, b->d_track[NATAC_T_OCC_PREFILL],
+    prof_begin(c, NATAC_K_OCC_FILL, ev, c->stream2);
+    hipLaunchKernelGGL(natac_fill_nan_min, dim3(b->nc), dim3(256), 0, c->stream2, ct, b->d_track[NATAC_T_OCC_PREFILL],
                        b->d_track[NATAC_T_OCC]);
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
@@ -569,9 +593,9 @@ int natac_run_ins(natac_batch *b, int lower, int upper) {
     if (rc) return rc;
     const ChunkTable ct = make_table(b);
     natac_ctx::Ev ev;
-    prof_begin(c, NATAC_K_INS, ev);
-    HIPCHK(hipMemsetAsync(b->d_track[NATAC_T_INS], 0, (size_t)b->total_bp * sizeof(int), c->stream));
-    hipLaunchKernelGGL(natac_insertions, dim3(b->nc), dim3(256), 0, c->stream, ct, lower, upper, (int *)b->d_track[NATAC_T_INS]);
+    prof_begin(c, NATAC_K_INS, ev, c->stream2);
+    HIPCHK(hipMemsetAsync(b->d_track[NATAC_T_INS], 0, (size_t)b->total_bp * sizeof(int), c->stream2));
+    hipLaunchKernelGGL(natac_insertions, dim3(b->nc), dim3(256), 0, c->stream2, ct, lower, upper, (int *)b->d_track[NATAC_T_INS]);
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
     b->ins_done = true;
@@ -634,7 +658,7 @@ int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes)
     if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, track needs %zu", dst_bytes, need);
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipMemcpyAsync(dst, b->d_track[track], need, hipMemcpyDeviceToHost, b->ctx->stream));
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(sync_all(b->ctx));
     prof_collect(b->ctx);
     return NATAC_OK;
 }
@@ -647,7 +671,7 @@ int natac_batch_download_grid(natac_batch *b, int which, double *dst, size_t dst
     if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, grid needs %zu", dst_bytes, need);
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipMemcpyAsync(dst, b->d_grid[which], need, hipMemcpyDeviceToHost, b->ctx->stream));
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(sync_all(b->ctx));
     return NATAC_OK;
 }
 
@@ -656,7 +680,7 @@ int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes) {
     if (dst_bytes != (size_t)b->nc * sizeof(int)) return fail(NATAC_E_ARG, "status buffer must hold n_chunks int32");
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipMemcpyAsync(dst, b->d_status, dst_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
-    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(sync_all(b->ctx));
     return NATAC_OK;
 }
 
@@ -917,7 +941,7 @@ int natac_profile_enable(natac_ctx *c, int on) {
 int natac_profile_get(natac_ctx *c, int k, double *ms_total, int64_t *launches) {
     if (!c || k < 0 || k >= NATAC_K_COUNT) return fail(NATAC_E_ARG, "bad argument");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     prof_collect(c);
     if (ms_total) *ms_total = c->prof_ms[k];
     if (launches) *launches = c->prof_n[k];
@@ -925,7 +949,7 @@ int natac_profile_get(natac_ctx *c, int k, double *ms_total, int64_t *launches) 
 }
 int natac_profile_reset(natac_ctx *c) {
     if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(sync_all(c));
     prof_collect(c);
     for (int i = 0; i < NATAC_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
     return NATAC_OK;

@@ -44,20 +44,47 @@ __device__ __forceinline__ int lower_bound_i32(const int *a, int lo, int hi, int
     return lo;
 }
 
+// Wave-wide reductions without the LDS crossbar: 4 DPP steps (quad xor 1, quad xor 2, half-row mirror, row mirror)
+// leave every 16-lane row holding its row total; the four row totals are combined through v_readlane (SGPRs), so
+// every lane ends with the same value.  (__shfl_xor lowers to ds_bpermute: ~100+ cycles per dependent step.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
+    v += dpp_mov_f64<0xB1>(v);
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0x141>(v);
+    v += dpp_mov_f64<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, WAVE));
-    return v;
+    v = fmin(v, dpp_mov_f64<0xB1>(v));
+    v = fmin(v, dpp_mov_f64<0x4E>(v));
+    v = fmin(v, dpp_mov_f64<0x141>(v));
+    v = fmin(v, dpp_mov_f64<0x140>(v));
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
-__device__ __forceinline__ int wave_or(int v) {
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ int wave_or(int v) {      // OR of 4-bit flag words: per-bit ballots, no data movement at all
+    int r = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, WAVE);
-    return v;
+    for (int bit = 1; bit <= 8; bit <<= 1)
+        if (__ballot((v & bit) != 0) != 0ull) r |= bit;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -79,20 +106,46 @@ __global__ void natac_frag_centres(const int *__restrict__ lpos, const int *__re
 // only ~F*W entries are non-zero, so one thread per base walks the (centre-sorted) fragments in its window.
 // tile = (chunk, x0): 256 consecutive bases of one chunk.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
+constexpr int GATHER_FMAX = 1024;   // fragments of a 256-base tile staged in LDS (denser tiles read global memory)
+
+// fragment range [t0, t1) of every 256-base tile: centres within [x0 - w, x0 + 255 + w]; one thread per tile
+__global__ void __launch_bounds__(256) natac_tile_ranges256(ChunkTable ct, const int2 *__restrict__ tiles, int ntiles, int w,
+                                                              int2 *__restrict__ ranges) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntiles) return;
+    const int2 t = tiles[i];
+    const int nfr = (int)(ct.frag_off[t.x + 1] - ct.frag_off[t.x]);
+    const int *cen = ct.centre + ct.frag_off[t.x];
+    const int t0 = lower_bound_i32(cen, 0, nfr, t.y - w);
+    const int t1 = lower_bound_i32(cen, t0, nfr, t.y + 255 + w + 1);
+    ranges[i] = make_int2(t0, t1);
+}
+
+__global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const int2 *__restrict__ tiles,
+                                                           const int2 *__restrict__ ranges, VMatDev vm,
                                                            double *__restrict__ nuc_cov, double *__restrict__ nfr_cov,
                                                            double *__restrict__ raw) {
+    __shared__ int cen_s[GATHER_FMAX];
+    __shared__ int iln_s[GATHER_FMAX];
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, g = t.y + threadIdx.x;
     const int L = ct.chunk_len[chunk];
+    const int2 tr = ranges[blockIdx.x];
+    const int nt = tr.y - tr.x;
+    const int *cen = ct.centre + ct.frag_off[chunk] + tr.x;
+    const int *iln = ct.ilen + ct.frag_off[chunk] + tr.x;
+    const bool staged = nt <= GATHER_FMAX;
+    if (staged) {
+        for (int i = threadIdx.x; i < nt; i += 256) { cen_s[i] = cen[i]; iln_s[i] = iln[i]; }
+        __syncthreads();
+        cen = cen_s;
+        iln = iln_s;
+    }
     if (g >= L) return;
-    const int fa = (int)0, nfr = (int)(ct.frag_off[chunk + 1] - ct.frag_off[chunk]);
-    const int *cen = ct.centre + ct.frag_off[chunk];
-    const int *iln = ct.ilen + ct.frag_off[chunk];
-    int f = lower_bound_i32(cen, fa, nfr, g - vm.w);
+    int f = lower_bound_i32(cen, 0, nt, g - vm.w);
     int cnt_nuc = 0, cnt_nfr = 0;
     double acc = 0.0;
-    for (; f < nfr; ++f) {
+    for (; f < nt; ++f) {
         const int c = cen[f];
         if (c > g + vm.w) break;
         const int n = iln[f];
@@ -109,6 +162,14 @@ __global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const in
     nuc_cov[o] = (double)cnt_nuc;
     nfr_cov[o] = (double)cnt_nfr;
     raw[o] = acc;
+}
+
+// occ coverage when the occupancy window / size range coincide with the V-plot's: cov = nuc_cov + nfr_cov (exact integers)
+__global__ void __launch_bounds__(256) natac_add_tracks(const double *__restrict__ a, const double *__restrict__ b,
+                                                          double *__restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = a[i] + b[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -323,12 +384,6 @@ struct OccModelDev {
     double cutoff;
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
 // number of leading entries of the sorted array a[from, n) that are < key, found 64 at a time with a ballot
 __device__ __forceinline__ int advance_while_less(const int *a, int from, int n, int key, int lane) {
     int f = from;
@@ -480,7 +535,7 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
         // a quotient is 0 iff its product is 0 (sum finite, > 0) and NaN iff the product or the sum is.
         double sn = 0.0, sf = 0.0;
         int flags = 0;   // 1: some pn == 0, 2: some pf == 0, 4: some both == 0, 8: some NaN
-        for (int j = lane; j < U; j += WAVE) {
+        for (int j = lane; j < U && ABL != 6; j += WAVE) {
             const double b = bj[j];
             const double pa = nucp[j] * b, pc = nfrp[j] * b;
             sn += pa;
@@ -490,6 +545,7 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
             if (pa == 0.0 && pc == 0.0) flags |= 4;
             if (pa != pa || pc != pc) flags |= 8;
         }
+        if (ABL == 6) { sn = 1.0; sf = 1.0; }
         sn = wave_sum(sn);
         sf = wave_sum(sf);
         flags = wave_or(flags);
@@ -497,8 +553,12 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
         // fragments of the window [g-fl, g+fl] (sorted by centre; windows only move right)
         f0 = advance_while_less(cs, f0, nt, g - fl, lane);
         f1 = advance_while_less(cs, (f1 > f0 ? f1 : f0), nt, g + fl + 1, lane);
-        // log-likelihood as a running product (mantissa x 2^exponent); two independent chains (A/B) per alpha
-        double m0 = 1.0, m1 = 1.0, m0b = 1.0, m1b = 1.0;
+        // log-likelihood as a running product (mantissa x 2^exponent), 4 independent chains per alpha.  frexp only
+        // rescales by an exact power of two, so renormalising every 4th multiply instead of every multiply leaves the
+        // mantissa bits unchanged as long as nothing underflows: safe when every factor is >= 2^-200 (then the product
+        // of a mantissa in [0.5,1) and 4 factors stays >= 2^-801).  Windows holding a smaller probability take the
+        // renormalise-every-multiply path.
+        double m0[4] = {1.0, 1.0, 1.0, 1.0}, m1[4] = {1.0, 1.0, 1.0, 1.0};
         int e0 = 0, e1 = 0, nins = 0;
         for (int base = f0; base < f1 && ABL != 3; base += WAVE) {
             const int i = base + lane;
@@ -508,52 +568,80 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
             const unsigned long long mask = __ballot(ok);
             const int cnt = __popcll(mask);
             nins += cnt;
+            bool tiny = false;
             if (ok) {                            // lane-parallel: one fragment per lane, compacted into LDS
                 const double b = bj[n];
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                ac[2 * pos] = (nucp[n] * b) / sn;
-                ac[2 * pos + 1] = (nfrp[n] * b) / sf;
+                const double a = (nucp[n] * b) / sn, c = (nfrp[n] * b) / sf;
+                ac[2 * pos] = a;
+                ac[2 * pos + 1] = c;
+                tiny = !(a >= 0x1p-200 && c >= 0x1p-200);
             }
+            const bool safe = __ballot(tiny) == 0ull;
             __builtin_amdgcn_wave_barrier();
             int q = 0;
-            for (; q + 1 < cnt; q += 2) {        // wave-uniform loop, LDS broadcast reads
-                const double au = ac[2 * q], cu = ac[2 * q + 1], av = ac[2 * q + 2], cv = ac[2 * q + 3];
-                const double x0u = al0 * au + be0 * cu, x1u = al1 * au + be1 * cu;
-                const double x0v = al0 * av + be0 * cv, x1v = al1 * av + be1 * cv;
-                int ex0, ex1, ex2, ex3;
-                m0 = frexp(m0 * x0u, &ex0);
-                m1 = frexp(m1 * x1u, &ex1);
-                m0b = frexp(m0b * x0v, &ex2);
-                m1b = frexp(m1b * x1v, &ex3);
-                e0 += ex0 + ex2;
-                e1 += ex1 + ex3;
+            if (safe) {
+                for (; q + 16 <= cnt; q += 16) {           // 16 fragments: 4 multiplies on each of the 8 chains, one renorm
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double au = ac[2 * (q + 4 * u + v)], cu = ac[2 * (q + 4 * u + v) + 1];
+                            m0[v] *= al0 * au + be0 * cu;
+                            m1[v] *= al1 * au + be1 * cu;
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        int ex0, ex1;
+                        m0[v] = frexp(m0[v], &ex0);
+                        m1[v] = frexp(m1[v], &ex1);
+                        e0 += ex0;
+                        e1 += ex1;
+                    }
+                }
+                for (; q + 4 <= cnt; q += 4) {             // 4 fragments: one multiply per chain
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double au = ac[2 * (q + v)], cu = ac[2 * (q + v) + 1];
+                        int ex0, ex1;
+                        m0[v] = frexp(m0[v] * (al0 * au + be0 * cu), &ex0);
+                        m1[v] = frexp(m1[v] * (al1 * au + be1 * cu), &ex1);
+                        e0 += ex0;
+                        e1 += ex1;
+                    }
+                }
             }
-            if (q < cnt) {
+            for (; q < cnt; ++q) {                         // tail / unsafe windows: renormalise every multiply
                 const double au = ac[2 * q], cu = ac[2 * q + 1];
                 int ex0, ex1;
-                m0 = frexp(m0 * (al0 * au + be0 * cu), &ex0);
-                m1 = frexp(m1 * (al1 * au + be1 * cu), &ex1);
+                m0[0] = frexp(m0[0] * (al0 * au + be0 * cu), &ex0);   // static index: keeps the chains in registers
+                m1[0] = frexp(m1[0] * (al1 * au + be1 * cu), &ex1);
                 e0 += ex0;
                 e1 += ex1;
             }
             __builtin_amdgcn_wave_barrier();
         }
+        double mm0, mm1;
         {
-            int ex0, ex1;
-            m0 = frexp(m0 * m0b, &ex0);
-            m1 = frexp(m1 * m1b, &ex1);
-            e0 += ex0;
-            e1 += ex1;
+            int ex0, ex1, ex2, ex3, ex4, ex5;
+            const double p0 = frexp(m0[0] * m0[1], &ex0), p1 = frexp(m0[2] * m0[3], &ex1);
+            const double r0 = frexp(m1[0] * m1[1], &ex2), r1 = frexp(m1[2] * m1[3], &ex3);
+            mm0 = frexp(p0 * p1, &ex4);
+            mm1 = frexp(r0 * r1, &ex5);
+            e0 += ex0 + ex1 + ex4;
+            e1 += ex2 + ex3 + ex5;
         }
         const long long go = ct.grid_off[chunk] + k;
         if (nins == 0) {                         // sum(new_inserts) > 0 fails: stay NaN (Occupancy.py:143)
             if (lane == 0) { g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan(""); }
             continue;
         }
+        if (ABL == 5) { if (lane == 0) g_occ[go] = mm0 + mm1 + e0 + e1; continue; }
         const double LN2 = 0.693147180559945309417232121458;
         const double NINF = -__builtin_inf();
-        double ll0 = log(m0) + (double)e0 * LN2;
-        double ll1 = log(m1) + (double)e1 * LN2;
+        double ll0 = log(mm0) + (double)e0 * LN2;
+        double ll1 = log(mm1) + (double)e1 * LN2;
         // reference: a zero-probability insert size gives log(0)*ins = -inf (ins>0) or NaN (ins==0) -> -inf
         if (flags & 8) { ll0 = NINF; ll1 = NINF; }
         if (flags & 4) { ll0 = NINF; ll1 = NINF; }
@@ -566,9 +654,7 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
         if (a0 >= om.n_alpha) ll0 = NINF;
         if (a1 >= om.n_alpha) ll1 = NINF;
         // max + first argmax
-        double mx = fmax(ll0, ll1);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, WAVE));
+        const double mx = wave_max(fmax(ll0, ll1));
         const unsigned long long eq0 = __ballot(ll0 == mx && a0 < om.n_alpha);
         const unsigned long long eq1 = __ballot(ll1 == mx && a1 < om.n_alpha);
         const int imax = eq0 ? (__ffsll((long long)eq0) - 1) : (WAVE + __ffsll((long long)eq1) - 1);
@@ -591,6 +677,12 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
     }
 }
 
+__device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// The un-smoothed tracks are piecewise constant on `step`-bp blocks (block k = bases [k*step, (k+1)*step)), so the
+// 2h+1-tap convolution collapses to <= 2*ceil(h/step)+2 block terms per base: y[t] = sum_b W[j][b] v[b] / sum_b W[j][b] ok[b]
+// with W[j][b] = the window weights that fall on block b for a base at offset j inside its own block (the same for every
+// block, computed once per workgroup).  The last block of a chunk can be cut by the chunk end; its weight is summed directly.
 // ------------------------------------------------------------------------------------------------
 // K4  occupancy smoothing: expand the per-grid values to bases ([i-halfstep, min(i+halfstep+1, L)),
 //     Occupancy.py:144-146; bases past the last grid block stay NaN) and apply the NaN-aware Gaussian
@@ -603,41 +695,64 @@ __global__ void __launch_bounds__(256) natac_occ_smooth(ChunkTable ct, const int
                                                           const double *__restrict__ g_hi, double *__restrict__ s_occ,
                                                           double *__restrict__ s_lo, double *__restrict__ s_hi) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int h = (M - 1) / 2;
-    const int NX = 256 + 2 * h;
-    double *xv = smem, *xl = xv + NX, *xh = xl + NX, *ok = xh + NX, *wl = ok + NX;
+    const int h = (M - 1) / 2, step = om.step;
+    const int NB = 2 * ((h + step - 1) / step) + 2;
+    const int NG = (255 + 2 * h) / step + 3;
+    double *wl = smem;                  // [M]
+    double *wb = wl + ((M + 1) & ~1);   // [step][NB]
+    double *gv = wb + step * NB;        // [NG] x 3
+    double *gl = gv + NG, *gh = gl + NG;
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, x0 = t.y;
     const int L = ct.chunk_len[chunk];
-    const int nk = (L - om.halfstep + om.step - 1) / om.step;
+    const int nk = (L - om.halfstep + step - 1) / step;
     const long long gb = ct.grid_off[chunk];
-    for (int u = threadIdx.x; u < NX; u += 256) {
-        const int g = x0 - h + u;
-        double v = 0.0, lo = 0.0, hi = 0.0, o = 0.0;
-        if (g >= 0 && g < L) {
-            const int k = g / om.step;
-            if (k < nk) {
-                v = g_occ[gb + k];
-                if (v == v) { lo = g_lo[gb + k]; hi = g_hi[gb + k]; o = 1.0; } else v = 0.0;
-            }
-        }
-        xv[u] = v; xl[u] = lo; xh[u] = hi; ok[u] = o;
-    }
+    const int kfirst = floor_div(x0 - h, step);
+    const double qn = __builtin_nan("");
     for (int u = threadIdx.x; u < M; u += 256) wl[u] = win[u];
+    for (int u = threadIdx.x; u < NG; u += 256) {
+        const int kb = kfirst + u;
+        double v = qn, lo = qn, hi = qn;
+        if (kb >= 0 && kb < nk) { v = g_occ[gb + kb]; lo = g_lo[gb + kb]; hi = g_hi[gb + kb]; }
+        gv[u] = v; gl[u] = lo; gh[u] = hi;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < step * NB; idx += 256) {
+        const int j = idx / NB, bi = idx - j * NB;
+        const int bmin = floor_div(j - h, step);
+        double sacc = 0.0;
+        for (int d = 0; d < step; ++d) {
+            const int n = j + h - (bmin + bi) * step - d;      // tap that lands on position d of block bmin+bi
+            if (n >= 0 && n < M) sacc += wl[n];
+        }
+        wb[idx] = sacc;
+    }
     __syncthreads();
     const int g = x0 + threadIdx.x;
     if (g >= L) return;
+    const int k0 = g / step, j = g - k0 * step;
+    const int bmin = floor_div(j - h, step);
     double nv = 0.0, nl = 0.0, nh = 0.0, den = 0.0;
-    for (int n = 0; n < M; ++n) {
-        const double wv = wl[n];
-        const int u = threadIdx.x + 2 * h - n;
-        nv = fma(wv, xv[u], nv);
-        nl = fma(wv, xl[u], nl);
-        nh = fma(wv, xh[u], nh);
-        den = fma(wv, ok[u], den);
+    for (int bi = 0; bi < NB; ++bi) {
+        const int kb = k0 + bmin + bi;
+        const int u = kb - kfirst;
+        if (u < 0 || u >= NG) continue;
+        const double v = gv[u];
+        if (v != v) continue;                               // NaN block (no inserts) or outside the chunk
+        double w = wb[j * NB + bi];
+        if ((kb + 1) * step > L) {                          // block cut by the chunk end: only existing bases count
+            w = 0.0;
+            for (int p = kb * step; p < L; ++p) {
+                const int n = g + h - p;
+                if (n >= 0 && n < M) w += wl[n];
+            }
+        }
+        nv = fma(w, v, nv);
+        nl = fma(w, gl[u], nl);
+        nh = fma(w, gh[u], nh);
+        den += w;
     }
     const long long o = ct.out_off[chunk] + g;
-    const double qn = __builtin_nan("");
     s_occ[o] = den == 0.0 ? qn : nv / den;
     s_lo[o] = den == 0.0 ? qn : nl / den;
     s_hi[o] = den == 0.0 ? qn : nh / den;
@@ -750,20 +865,24 @@ __global__ void __launch_bounds__(256) natac_candidates(ChunkTable ct, VMatDev v
     __syncthreads();
     double sB = 0, sBV = 0, sBV2 = 0, sB0V = 0;
     int zero = 0;
-    const int ncell = vm.R * vm.W;
-    for (int cell = threadIdx.x; cell < ncell; cell += 256) {
-        const int r = cell / vm.W, c = cell - r * vm.W;
-        const int i = vm.lower + r;
-        const int hl = floor_half(i - 1), hr = floor_half(i);
-        const double b0 = (hl == -hr) ? Et[c + A] : Et[c + A - hl] * Et[c + A + hr];
-        const double bb = vm.srow[r] * b0;
-        const double v = vm.mat[cell];
-        const double vb0 = v * b0;
-        sB += bb;
-        sBV = fma(bb, v, sBV);
-        sBV2 = fma(bb * v, v, sBV2);
-        sB0V += vb0;
-        if (vb0 == 0.0 || bb == 0.0) zero = 1;
+    // 2-D sweep without integer division: 128 lanes across the window columns, two row phases
+    {
+        const int c = threadIdx.x & 127;
+        if (c < vm.W) {
+            for (int r = threadIdx.x >> 7; r < vm.R; r += 2) {
+                const int i = vm.lower + r;
+                const int hl = floor_half(i - 1), hr = floor_half(i);
+                const double b0 = (hl == -hr) ? Et[c + A] : Et[c + A - hl] * Et[c + A + hr];
+                const double bb = vm.srow[r] * b0;
+                const double v = vm.mat[r * vm.W + c];
+                const double vb0 = v * b0;
+                sB += bb;
+                sBV = fma(bb, v, sBV);
+                sBV2 = fma(bb * v, v, sBV2);
+                sB0V += vb0;
+                if (vb0 == 0.0 || bb == 0.0) zero = 1;
+            }
+        }
     }
     sB = wave_sum(sB); sBV = wave_sum(sBV); sBV2 = wave_sum(sBV2); sB0V = wave_sum(sB0V);
     zero = wave_or(zero);

@@ -65,5 +65,7 @@ int main(int argc, char **argv) {
     run<1>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
     run<2>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
     run<3>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
+    run<5>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
+    run<6>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
     return 0;
 }
