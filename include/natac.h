@@ -173,6 +173,16 @@ int natac_correlate_valid(natac_ctx *ctx, const double *sub, int64_t ncol, const
  * "no alpha passes the likelihood-ratio test" where the reference raises ValueError (Occupancy.py:118). */
 int natac_calculate_occupancy(natac_ctx *ctx, const double *inserts, const double *bias, double *out);
 
+/* ---- native track writer (host side, multi-threaded) ------------- */
+/* Track.write_track, pyatac/tracks.py:37-74, for n_chunks tracks at once (chunk i: chroms[i], chunk_start[i], values
+ * vals[out_off[i] .. out_off[i+1]) ), run-length bedGraph text with python-2 float formatting, NaN runs skipped.
+ * compress: 0 = plain text, 1..9 = BGZF at that deflate level (bgzip-compatible; run_occ.py:130-136).  append != 0
+ * appends to `path`; finish != 0 terminates a BGZF file with the EOF marker block.  n_threads <= 0: automatic.
+ * No GPU involved; usable on the arrays natac_batch_download returns. */
+int natac_write_bedgraph(const char *path, int append, int compress, int finish, int32_t n_chunks, const char *const *chroms,
+                         const int64_t *chunk_start, const int64_t *out_off, const double *vals, int write_zero,
+                         int n_threads, int64_t *bytes_written);
+
 /* ---- profiling (HIP events on the context's stream) ------------------------------------ */
 int natac_profile_enable(natac_ctx *ctx, int on);
 /* total milliseconds and launch count of kernel class `k` since the last reset */

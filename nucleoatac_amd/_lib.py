@@ -52,6 +52,8 @@ SIGNATURES = {
     "natac_pwm_bias": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp]),
     "natac_correlate_valid": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, C.c_int, _vp]),
     "natac_calculate_occupancy": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "natac_write_bedgraph": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, _i32, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
+                             C.POINTER(_i64)]),
     "natac_profile_enable": (C.c_int, [_vp, C.c_int]),
     "natac_profile_get": (C.c_int, [_vp, C.c_int, C.POINTER(_f64), C.POINTER(_i64)]),
     "natac_profile_reset": (C.c_int, [_vp]),

@@ -2,6 +2,7 @@
 // Host-side runtime: contexts, batches of packed chunks resident in HBM, tile tables, launches, profiling.
 #include "../../include/natac.h"
 #include "natac_kernels.hpp"
+#include "natac_writer.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -928,6 +929,26 @@ int natac_calculate_occupancy(natac_ctx *c, const double *inserts, const double 
     dev_free(d_i); dev_free(d_b); dev_free(d_o); dev_free(d_s);
     if (e != hipSuccess) return fail(NATAC_E_HIP, "calculate_occupancy: %s", hipGetErrorString(e));
     if (st) return fail(NATAC_E_ARG, "no alpha passes the likelihood-ratio test");
+    return NATAC_OK;
+}
+
+/* ---------------- native track writer ---------------- */
+
+int natac_write_bedgraph(const char *path, int append, int compress, int finish, int32_t n_chunks, const char *const *chroms,
+                         const int64_t *chunk_start, const int64_t *out_off, const double *vals, int write_zero, int n_threads,
+                         int64_t *bytes_written) {
+    if (!path || n_chunks < 0 || (n_chunks > 0 && (!chroms || !chunk_start || !out_off || !vals)))
+        return fail(NATAC_E_ARG, "null argument");
+    if (compress < 0 || compress > 9) return fail(NATAC_E_ARG, "compress must be 0 (text) or a deflate level 1..9");
+    for (int i = 0; i < n_chunks; ++i) {
+        if (!chroms[i] || std::strlen(chroms[i]) > 100) return fail(NATAC_E_ARG, "bad chromosome name for chunk %d", i);
+        if (out_off[i + 1] < out_off[i]) return fail(NATAC_E_ARG, "out_off must be non-decreasing");
+    }
+    const int rc = natac_writer::write_bedgraph(path, append != 0, compress, finish != 0, n_chunks, chroms, chunk_start, out_off, vals,
+                                                write_zero != 0, n_threads, bytes_written);
+    if (rc == 1) return fail(NATAC_E_ARG, "cannot open %s", path);
+    if (rc == 2) return fail(NATAC_E_ARG, "write to %s failed", path);
+    if (rc == 3) return fail(NATAC_E_NOMEM, "deflate failed");
     return NATAC_OK;
 }
 

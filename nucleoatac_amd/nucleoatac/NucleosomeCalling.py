@@ -189,7 +189,7 @@ class NucParameters(object):
         ctx.set_sizes(self.fragmentsizes.get(0, self.vmat.upper))
 
 
-def nuc_batch(chunks, params, ctx=None):
+def nuc_batch(chunks, params, ctx=None, with_flat=False):
     """NucChunk.process for a list of chunks in one GPU batch; returns the processed NucChunk objects"""
     ctx = ctx or get_context()
     params.install(ctx)
@@ -231,6 +231,8 @@ def nuc_batch(chunks, params, ctx=None):
             nc.fit()
     finally:
         run.close()
+    if with_flat:
+        return out, dict(out_off=pk.out_off, **run.flat)
     return out
 
 

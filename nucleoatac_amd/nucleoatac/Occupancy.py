@@ -163,8 +163,9 @@ class OccupancyParameters(object):
         self.halfstep = (self.step - 1) // 2
 
 
-def occ_batch(chunks, params, ctx=None):
-    """OccChunk.process for a whole list of chunks in one GPU batch; returns the processed OccChunk objects"""
+def occ_batch(chunks, params, ctx=None, with_flat=False):
+    """OccChunk.process for a whole list of chunks in one GPU batch; returns the processed OccChunk objects
+    (with_flat: also the concatenated per-base arrays + offsets, for the native track writer)"""
     ctx = ctx or get_context()
     params.occ_calc_params.install(ctx, step=params.step, flank=params.flank)
     pk = pack(chunks, params.bam, params.fasta, params.chrs, params.pwm if params.fasta is not None else None)
@@ -188,6 +189,10 @@ def occ_batch(chunks, params, ctx=None):
         oc.cov.vals = res["cov"][k].copy()
         oc.callPeaks()
         out.append(oc)
+    if with_flat:
+        # smoothed_vals was NaN-filled on the device exactly like call_peaks does in place, so the flat array is what
+        # the reference's writer sees (run_occ.py:47)
+        return out, dict(out_off=pk.out_off, **run.flat)
     return out
 
 

@@ -11,9 +11,11 @@ from ..pyatac.fragmentsizes import FragmentSizes
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
 from ..pyatac.VMat import VMat
 from ..shard import balanced_ranges, env_rank_world
+from ..writer import write_bedgraph
 from .NucleosomeCalling import NucParameters, nuc_batch
 
 BATCH_CHUNKS = 4096
+COMPRESS_LEVEL = 4
 
 
 def _nucHelper(arg):
@@ -61,16 +63,33 @@ def run_nuc(args):
     lo, hi = balanced_ranges([c.length() for c in chunks], np.arange(len(chunks) + 1), world)[rank]
     mine = chunks[lo:hi]
     suffix = "" if world == 1 else ".rank%d" % rank
-    ext = lambda n: ".bed" if n.startswith("nucpos") else ".bedgraph"
-    handles = {n: open(args.out + "." + n + ext(n) + suffix, "w") for n in outputs}
-    for i in range(0, len(mine), BATCH_CHUNKS):
-        for res in _nucHelperBatch(mine[i:i + BATCH_CHUNKS], params):
-            for n in outputs:
-                if n.startswith("nucpos"):
-                    for pos in res[n]:
-                        pos.write(handles[n])
-                else:
-                    res[n].write_track(handles[n])
+    track_keys = {"nucleoatac_signal": "norm_signal", "nucleoatac_signal.smooth": "smoothed",
+                  "nucleoatac_background": "bias", "nucleoatac_raw": "nuc_signal"}
+    tracks = [n for n in outputs if n in track_keys]
+    paths = {n: args.out + "." + n + ".bedgraph.gz" + suffix for n in tracks}
+    handles = {n: open(args.out + "." + n + ".bed" + suffix, "w") for n in outputs if n.startswith("nucpos")}
+    nb = max(1, (len(mine) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
+    for bi in range(nb):
+        part = mine[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
+        if not part:
+            for n in tracks:
+                write_bedgraph(paths[n], [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL, finish=True)
+            break
+        try:
+            nucs, flat = nuc_batch(part, params, with_flat=True)
+        except Exception:
+            print("Caught exception when processing:\n" + "\n".join(c.asBed() for c in part[:3]) + "\n")
+            raise
+        chroms, starts = [c.chrom for c in part], [c.start for c in part]
+        for n in tracks:
+            write_bedgraph(paths[n], chroms, starts, flat["out_off"], flat[track_keys[n]], append=bi > 0,
+                           compress=COMPRESS_LEVEL, finish=(bi == nb - 1 and rank == world - 1))
+        for nuc in nucs:
+            for i in sorted(nuc.nonredundant):
+                nuc.nuc_collection[i].write(handles["nucpos"])
+            for i in sorted(nuc.redundant):
+                nuc.nuc_collection[i].write(handles["nucpos.redundant"])
+            nuc.removeData()
     for h in handles.values():
         h.close()
     if world > 1:
@@ -79,13 +98,14 @@ def run_nuc(args):
             dist.barrier()
     if rank == 0:
         for n in outputs:
-            base = args.out + "." + n + ext(n)
+            base = args.out + "." + n + (".bed" if n.startswith("nucpos") else ".bedgraph.gz")
             if world > 1:
-                with open(base, "w") as fo:
+                with open(base, "wb") as fo:
                     for r in range(world):
-                        with open(base + ".rank%d" % r) as fi:
+                        with open(base + ".rank%d" % r, "rb") as fi:
                             shutil.copyfileobj(fi, fo)
                         os.remove(base + ".rank%d" % r)
-            with open(base, "rb") as fi, gzip.open(base + ".gz", "wb") as fo:
-                shutil.copyfileobj(fi, fo)
-            os.remove(base)
+            if n.startswith("nucpos"):
+                with open(base, "rb") as fi, gzip.open(base + ".gz", "wb") as fo:
+                    shutil.copyfileobj(fi, fo)
+                os.remove(base)

@@ -13,9 +13,11 @@ from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
 from ..shard import balanced_ranges, env_rank_world, gather_in_chunk_order, ordered_sum
+from ..writer import write_bedgraph
 from .Occupancy import FragmentMixDistribution, OccupancyParameters, occ_batch
 
 BATCH_CHUNKS = 4096   # chunks per GPU batch (the reference maps cores*5 chunks per pool.map round)
+COMPRESS_LEVEL = 4     # BGZF deflate level of the track files
 
 
 def _occHelper(arg):
@@ -68,35 +70,46 @@ def run_occ(args):
     lo, hi = balanced_ranges([c.length() for c in chunks], np.concatenate(([0], np.cumsum(nfr_per_chunk))), world)[rank]
     mine = chunks[lo:hi]
     suffix = "" if world == 1 else ".rank%d" % rank
-    names = ("occ", "occ.lower_bound", "occ.upper_bound")
-    handles = [open(args.out + "." + n + ".bedgraph" + suffix, "w") for n in names]
+    names = {"occ": "smoothed_vals", "occ.lower_bound": "smoothed_lower", "occ.upper_bound": "smoothed_upper"}
+    paths = {n: args.out + "." + n + ".bedgraph.gz" + suffix for n in names}
     peaks_handle = open(args.out + ".occpeaks.bed" + suffix, "w")
     dists = []
-    for i in range(0, len(mine), BATCH_CHUNKS):
-        for nuc_dist, track, peaks in _occHelperBatch(mine[i:i + BATCH_CHUNKS], params):
-            dists.append(nuc_dist)
-            track.write_track(handles[0], vals=track.smoothed_vals)
-            track.write_track(handles[1], vals=track.smoothed_lower)
-            track.write_track(handles[2], vals=track.smoothed_upper)
-            for p in peaks:
-                p.write(peaks_handle)
-    for h in handles + [peaks_handle]:
-        h.close()
+    nb = max(1, (len(mine) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
+    for bi in range(nb):
+        part = mine[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
+        if not part:
+            for n in names:
+                write_bedgraph(paths[n], [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL, finish=True)
+            break
+        try:
+            occs, flat = occ_batch(part, params, with_flat=True)
+        except Exception:
+            print("Caught exception when processing:\n" + "\n".join(c.asBed() for c in part[:3]) + "\n")
+            raise
+        chroms, starts = [c.chrom for c in part], [c.start for c in part]
+        for n, key in names.items():     # native multi-threaded run-length writer + BGZF (tracks.py:37-74, run_occ.py:130-136)
+            write_bedgraph(paths[n], chroms, starts, flat["out_off"], flat[key], append=bi > 0, compress=COMPRESS_LEVEL,
+                           finish=(bi == nb - 1 and rank == world - 1))
+        for oc in occs:
+            dists.append(oc.getNucDist())
+            for i in sorted(oc.peaks.keys()):
+                oc.peaks[i].write(peaks_handle)
+            oc.removeData()
+    peaks_handle.close()
     dists = gather_in_chunk_order(dists, dst=0)
     if world > 1:
         import torch.distributed as dist
         if dist.is_initialized():
             dist.barrier()
     if rank == 0:
-        for n in list(names) + ["occpeaks"]:
-            ext = ".bed" if n == "occpeaks" else ".bedgraph"
-            base = args.out + "." + n + ext
-            if world > 1:
-                with open(base, "w") as fo:
+        if world > 1:   # BGZF members / text lines concatenate: rank order == chunk order
+            for n in list(names) + ["occpeaks"]:
+                base = args.out + "." + n + (".bed" if n == "occpeaks" else ".bedgraph.gz")
+                with open(base, "wb") as fo:
                     for r in range(world):
-                        with open(base + ".rank%d" % r) as fi:
+                        with open(base + ".rank%d" % r, "rb") as fi:
                             shutil.copyfileobj(fi, fo)
                         os.remove(base + ".rank%d" % r)
-            _compress(base)
+        _compress(args.out + ".occpeaks.bed")
         nuc_dist = ordered_sum(dists) if dists else np.zeros(args.upper)
         FragmentSizes(0, args.upper, vals=nuc_dist).save(args.out + ".nuc_dist.txt")

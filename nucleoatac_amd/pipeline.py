@@ -77,9 +77,11 @@ class BatchRunner(object):
             b.free()
             raise ValueError("min() arg is an empty sequence (occupancy likelihood undefined in chunk %d)" % k)
         out = {}
+        self.flat = getattr(self, "flat", {})
         for name, t in (("smoothed_vals", L.T_OCC), ("smoothed_lower", L.T_OCC_LOWER), ("smoothed_upper", L.T_OCC_UPPER),
                         ("cov", L.T_OCC_COV), ("smoothed_prefill", L.T_OCC_PREFILL)):
-            out[name] = b.split(b.track(t))
+            self.flat[name] = b.track(t)
+            out[name] = b.split(self.flat[name])
         grids = [b.grid(g) for g in (L.G_OCC, L.G_LOWER, L.G_UPPER)]
         step = self.ctx.occ_step
         half = (step - 1) // 2
@@ -98,9 +100,13 @@ class BatchRunner(object):
     def nuc(self, smooth_sd):
         b = self.batch
         b.run_nuc(smooth_sd)
-        return {name: b.split(b.track(t)) for name, t in (
-            ("nuc_cov", L.T_NUC_COV), ("nfr_cov", L.T_NFR_COV), ("nuc_signal", L.T_RAW), ("bias", L.T_BACKGROUND),
-            ("norm_signal", L.T_NORM), ("smoothed", L.T_SMOOTH))}
+        self.flat = getattr(self, "flat", {})
+        out = {}
+        for name, t in (("nuc_cov", L.T_NUC_COV), ("nfr_cov", L.T_NFR_COV), ("nuc_signal", L.T_RAW), ("bias", L.T_BACKGROUND),
+                        ("norm_signal", L.T_NORM), ("smoothed", L.T_SMOOTH)):
+            self.flat[name] = b.track(t)
+            out[name] = b.split(self.flat[name])
+        return out
 
     def ins(self, lower=0, upper=2000):
         self.batch.run_ins(lower, upper)
