@@ -76,3 +76,29 @@ def test_empty_and_errors(tmp_path):
         write_bedgraph(p, ["c"], [0], [0, 50], allnan, compress=11)
     with pytest.raises(ValueError):
         write_bedgraph(p, ["c"], [0, 1], [0, 50], allnan)
+
+
+@pytest.mark.parametrize("name", ["nucleoatac_signal", "occ", "ins"])
+def test_text_matches_reference_output_files(tmp_path, name):
+    """format pin against the REFERENCE's own output (example/example_results/*.bedgraph.gz, first 3000 lines):
+    parse -> per-base values -> native writer reproduces the file text byte for byte (12 significant digits, run lengths)"""
+    import os
+    from helpers import GOLDEN
+    src = os.path.join(GOLDEN, "ref_results_%s.head3000.bedgraph.gz" % name)
+    ref = gzip.open(src, "rt").read()
+    chunks = []          # contiguous runs of lines form one chunk each
+    for line in ref.strip().split("\n"):
+        c, s, e, v = line.split("\t")
+        s, e, v = int(s), int(e), float(v)
+        if chunks and chunks[-1][0] == c and chunks[-1][2] == s:
+            chunks[-1][2] = e
+            chunks[-1][3].append(np.full(e - s, v))
+        else:
+            chunks.append([c, s, e, [np.full(e - s, v)]])
+    chroms = [c[0] for c in chunks]
+    starts = [c[1] for c in chunks]
+    vals = np.concatenate([np.concatenate(c[3]) for c in chunks])
+    off = np.concatenate(([0], np.cumsum([c[2] - c[1] for c in chunks])))
+    p = str(tmp_path / "o.bedgraph")
+    write_bedgraph(p, chroms, starts, off, vals)
+    assert open(p).read() == ref
