@@ -57,13 +57,22 @@ def _cpu_chunk(args):
     return float(np.nansum(nt["norm"]) + np.nansum(oc["smoothed_vals"]))
 
 
+def _cpu_worker_init():
+    """the reference's workers are single-threaded numpy processes: pin BLAS/OpenMP pools to one thread each"""
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+
+
 def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks):
     """reference execution shape: multiprocessing.Pool(cores-1), chunk per task (run_occ.py:101-123)."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
     workers = max(1, cores - 1)
     if n_chunks <= 0:
-        n_chunks = min(4096, max(8, 32 * workers))   # ~15 s of wall time at ~0.45 core-s per chunk
+        n_chunks = min(1024, max(64, 2 * workers))   # ~10-20 s of wall time at ~0.5-2 core-s per chunk
     n_chunks = min(n_chunks, pk.n_chunks)
     tasks = []
     for k in range(n_chunks):
@@ -72,7 +81,7 @@ def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks):
                       int(par["vupper"]), sizes, nucp, nfrp))
     bp = int(pk.chunk_len[:n_chunks].sum())
     ctx = mp.get_context("fork")
-    with ctx.Pool(workers) as pool:
+    with ctx.Pool(workers, initializer=_cpu_worker_init) as pool:
         pool.map(_cpu_chunk, tasks[:workers])      # warm the workers (imports)
         t0 = time.time()
         pool.map(_cpu_chunk, tasks)

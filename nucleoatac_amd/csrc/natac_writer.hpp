@@ -116,7 +116,7 @@ static const unsigned char BGZF_EOF[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff
 inline int write_bedgraph(const char *path, bool append, int compress, bool finish, int nc, const char *const *chroms,
                           const int64_t *chunk_start, const int64_t *out_off, const double *vals, bool write_zero, int n_threads,
                           int64_t *bytes_written) {
-    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128u);
     n_threads = std::max(1, std::min(n_threads, std::max(1, nc)));
     // contiguous chunk ranges with ~equal numbers of bases
     std::vector<int> cut(n_threads + 1, nc);

@@ -48,9 +48,9 @@ __global__ void __launch_bounds__(64) bg_variant(ChunkTable ct, const int2 *__re
 #pragma unroll
         for (int k = 0; k < NQ; ++k) { const int u = lane + WAVE * k; if (u < PW) { const double p = (s * el[u]) * er[u]; q[k] += p; Pb[u] = p; } }
         if (MODE == 1 && r + 1 < vm.R) { vn0 = vm.mat[(r + 1) * W + lane]; vn1 = (lane + 64 < W) ? vm.mat[(r + 1) * W + lane + 64] : 0.0; }
-        __syncthreads();
+        if (MODE == 4) __builtin_amdgcn_wave_barrier(); else __syncthreads();
         const double *pl = Pb + ub;
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 4) {
             const double *__restrict__ vr = vm.mat + r * W;
 #pragma unroll
             for (int j = 0; j < G + W - 1; ++j) { const double p = pl[j];
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) bg_variant(ChunkTable ct, const int2 *__re
 #pragma unroll
                 for (int k = 0; k < G; ++k) { const int c = j - k; if (c >= 0 && c < W) acc[k] = fma(p, vconst, acc[k]); } }
         }
-        __syncthreads();
+        if (MODE == 4) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     }
     const long long ob = ct.out_off[chunk];
 #pragma unroll
@@ -205,9 +205,10 @@ int main(int argc, char **argv) {
     ct.nc = nc; ct.chunk_len = d_len; ct.frag_off = d_foff; ct.bias_off = d_boff; ct.bias = d_bias; ct.bias_left = bl; ct.bias_right = br; ct.out_off = d_ooff;
     v.mat = d_vm; v.srow = d_srow; v.lower = lo; v.upper = up; v.w = 60; v.R = R; v.W = W;
     (void)F;
-    run3<9>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
-    run3<17>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
-    run3<13>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
+    run<9, 4>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
+    run<17, 4>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
+    run<13, 4>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
+    run<13, 0>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
     run<9, 2>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
     run<17, 2>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
     run<9, 0>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
