@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="functional test of the N>1 path on a 1-GPU box: every rank uses GPU 0 (use with --dist-backend gloo)")
     return ap.parse_args()
 
 
@@ -119,11 +122,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if a.share_device:
+        local_rank = 0
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=a.dist_backend)
 
     from nucleoatac_amd import _lib as L
     from nucleoatac_amd.device import Context
@@ -161,11 +169,14 @@ def main():
         batch.run_ins(0, 2000)
         return batch.run_candidates(cand_chunk, cand_pos)
 
+    on_gpu = dist is not None and a.dist_backend == "nccl"
+
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if on_gpu:
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(a.warmup):
@@ -177,14 +188,14 @@ def main():
     for _ in range(a.steps):
         step()
     ctx.sync()
-    if dist is not None:
+    if on_gpu:
         import torch
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = ctx.profile()

@@ -1,0 +1,39 @@
+"""GPU: bench.py's N > 1 code path (rank-local shards, barrier, max-over-ranks, one JSON line on rank 0), exercised
+with 2 ranks over gloo that share GPU 0 (the box has one GPU; the driver runs the real 2/4/8-GPU RCCL launch)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_share_device():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--chunks", "4000", "--dist-backend", "gloo", "--share-device", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "Mbp/s"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 4000 * 2120 * 2 / (d["ms_per_step"] * 2 / 1e3) / 1e6) < 1e-3 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline"]["launches"] == 2
+
+
+def test_single_rank_default_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chunks", "3000", "--cpu-chunks", "16"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
