@@ -3,7 +3,8 @@
 
 One "step" = one pass of the whole hot path over one batch of synthetic chunks that is already
 resident in HBM: nuc tracks (coverage, raw, background, norm, smooth) + occupancy tracks (grid MLE,
-smoothing, cov, NaN fill) + per-base insertion counts + per-candidate LR / variance / z.
+smoothing, cov, NaN fill) + per-base insertion counts + device-side candidate search (call_peaks) with per-candidate
+LR / variance / z.
 Workload at N=1 = BASELINE.json configs[2]: synthetic 100k windows x 2 kb (2,120 bp after the +-60
 slop), 50 M fragments, default VMat (146 x 121).  With N > 1 every rank owns its own shard of the
 same shape (chunk list sharded across GPUs, no data-path collective): weak scaling.
@@ -143,12 +144,6 @@ def main():
     t_gen = time.time()
     pk = make_synthetic_chunks(a.chunks, a.chunk_len, a.frags_per_chunk, seed=a.seed + 1000 * rank)
     t_gen = time.time() - t_gen
-    # candidate dyads: the generator's phased positions (every 190 bp), kept 60 bp off the chunk edges
-    per = np.arange(95 - 126, a.chunk_len - 60, 190)
-    per = per[per >= 60]
-    cand_pos = np.tile(per, pk.n_chunks).astype(np.int32)
-    cand_chunk = np.repeat(np.arange(pk.n_chunks, dtype=np.int32), len(per))
-
     # CPU baseline first (rank 0, N=1 only): it forks worker processes, so run it before the HIP context exists
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -163,11 +158,15 @@ def main():
     ctx.sync()
     t_up = time.time() - t_up
 
+    n_cand = [0]
+
     def step():
         batch.run_nuc(10)
         batch.run_occ()
         batch.run_ins(0, 2000)
-        return batch.run_candidates(cand_chunk, cand_pos)
+        # candidate search (call_peaks, sep 25 / order 12 / boundary 60 as NucChunk.findAllNucs) + LR / var / z, on the device
+        cc, cp, lr, var, z = batch.run_peaks(min_signal=0, sep=25, boundary=60, order=12)
+        n_cand[0] = len(cc)
 
     on_gpu = dist is not None and a.dist_backend == "nccl"
 
@@ -223,7 +222,7 @@ def main():
             "config": {"workload": "configs[2]: synthetic %d windows x 2 kb (L=%d after slop), %d fragments, default VMat "
                                    "146x121, 1 GPU-shard per rank" % (a.chunks, a.chunk_len, pk.n_frags),
                        "chunks_per_gpu": a.chunks, "chunk_len": a.chunk_len, "fragments_per_gpu": pk.n_frags,
-                       "candidates_per_gpu": int(len(cand_pos)), "sharding": "chunk list split across ranks, no collective"},
+                       "candidates_per_gpu": int(n_cand[0]), "sharding": "chunk list split across ranks, no collective"},
             "roofline": {"bound": "hbm", "kernel": "natac_background (dense bias x VMat correlation)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

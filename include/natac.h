@@ -126,6 +126,16 @@ int natac_run_ins(natac_batch *b, int lower, int upper);
  *   z    Nucleosome.getZScore   NucleosomeCalling.py:123-127   (norm_signal / sqrt(var)) */
 int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chunk, const int32_t *cand_pos,
                          double *lr, double *var, double *z);
+/* Candidate search + statistics entirely on the device (needs natac_run_nuc first):
+ * utils.call_peaks(norm + smoothed, min_signal, sep, boundary, order) exactly as NucChunk.findAllNucs calls it
+ * (nucleoatac/NucleosomeCalling.py:297-301, pyatac/utils.py:56-102), followed by LR / variance / z for every candidate.
+ * jitter[n_jitter] is the reference's tie-break stream np.random.RandomState(25).uniform(0, 1e-12, n) generated by the
+ * host (n_jitter >= longest chunk).  *n_cand receives the number of candidates (chunk order, ascending position);
+ * fetch them with natac_download_peaks.  Chunks longer than 2048*(order+1) bases set status bit 1 (list truncated). */
+int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, int order, const double *jitter,
+                    int64_t n_jitter, int64_t *n_cand);
+int natac_download_peaks(natac_batch *b, int64_t n_cand, int32_t *cand_chunk, int32_t *cand_pos, double *lr, double *var,
+                         double *z);
 /* copy one per-base track to host (float64[total_bp], or int32[total_bp] for NATAC_T_INS). Synchronises. */
 int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes);
 /* copy one per-grid-point array to host (float64[total_grid]). */

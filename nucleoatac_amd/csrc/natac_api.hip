@@ -77,6 +77,13 @@ struct natac_batch {
     double *d_track[NATAC_T_COUNT] = {nullptr};
     double *d_grid[3] = {nullptr, nullptr, nullptr};
     bool nuc_done = false, occ_done = false, ins_done = false;
+    // device-side candidate search
+    double *d_cmin = nullptr, *d_jitter = nullptr, *d_pk_out = nullptr;
+    unsigned char *d_pkflag = nullptr;
+    long long *d_cap_off = nullptr, *d_pk_offs = nullptr;
+    int *d_slot = nullptr, *d_pk_count = nullptr, *d_pk_chunk = nullptr, *d_pk_pos = nullptr;
+    long long n_jitter = 0, pk_cap = 0, pk_n = -1, slot_total = 0;
+    int pk_order = -1;
 };
 
 static hipError_t sync_all(natac_ctx *c) {
@@ -418,6 +425,8 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_len); dev_free(b->d_lpos); dev_free(b->d_ilen); dev_free(b->d_centre); dev_free(b->d_status);
     dev_free(b->d_frag_off); dev_free(b->d_bias_off); dev_free(b->d_out_off); dev_free(b->d_grid_off); dev_free(b->d_bias);
     dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
+    dev_free(b->d_cmin); dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_pkflag); dev_free(b->d_cap_off);
+    dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
     for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
     delete b;
@@ -639,6 +648,99 @@ int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chu
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     dev_free(d_cc); dev_free(d_cp); dev_free(d_out);
     if (e != hipSuccess) return fail(NATAC_E_HIP, "candidates: %s", hipGetErrorString(e));
+    prof_collect(c);
+    return NATAC_OK;
+}
+
+int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, int order, const double *jitter, int64_t n_jitter,
+                    int64_t *n_cand) {
+    if (!b || !jitter || !n_cand) return fail(NATAC_E_ARG, "null argument");
+    natac_ctx *c = b->ctx;
+    if (!b->nuc_done) return fail(NATAC_E_STATE, "natac_run_nuc must run before natac_run_peaks");
+    if (order < 1 || order > 255 || sep < 1 || boundary < 0) return fail(NATAC_E_ARG, "bad peak parameters");
+    int maxL = 0;
+    for (int i = 0; i < b->nc; ++i) maxL = std::max(maxL, b->h_len[i]);
+    if (n_jitter < maxL) return fail(NATAC_E_ARG, "jitter stream (%lld) shorter than the longest chunk (%d)", (long long)n_jitter, maxL);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_all(c));
+    int rc;
+    if (!b->d_jitter || b->n_jitter < maxL) {
+        dev_free(b->d_jitter);
+        b->d_jitter = nullptr;
+        if ((rc = dev_upload(c, &b->d_jitter, jitter, (size_t)maxL))) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        b->n_jitter = maxL;
+    } else {
+        HIPCHK(hipMemcpyAsync(b->d_jitter, jitter, (size_t)maxL * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (b->pk_order != order) {   // slot regions: a chunk of L bases holds at most L/(order+1) + 1 maxima
+        std::vector<long long> cap((size_t)b->nc + 1, 0);
+        for (int i = 0; i < b->nc; ++i) cap[i + 1] = cap[i] + b->h_len[i] / (order + 1) + 2;
+        b->slot_total = cap[b->nc];
+        dev_free(b->d_cap_off); dev_free(b->d_slot);
+        b->d_cap_off = nullptr; b->d_slot = nullptr;
+        if ((rc = dev_upload(c, &b->d_cap_off, cap.data(), (size_t)b->nc + 1))) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((rc = dev_alloc(&b->d_slot, (size_t)b->slot_total))) return rc;
+        b->pk_order = order;
+    }
+    if (!b->d_cmin && (rc = dev_alloc(&b->d_cmin, (size_t)b->nc))) return rc;
+    if (!b->d_pkflag && (rc = dev_alloc(&b->d_pkflag, (size_t)b->total_bp))) return rc;
+    if (!b->d_pk_count && (rc = dev_alloc(&b->d_pk_count, (size_t)b->nc))) return rc;
+    if (!b->d_pk_offs && (rc = dev_alloc(&b->d_pk_offs, (size_t)b->nc + 1))) return rc;
+    const ChunkTable ct = make_table(b);
+    const double *norm = b->d_track[NATAC_T_NORM], *sm = b->d_track[NATAC_T_SMOOTH];
+    natac_ctx::Ev ev;
+    prof_begin(c, NATAC_K_CAND, ev);
+    hipLaunchKernelGGL(natac_chunk_min_combined, dim3(b->nc), dim3(256), 0, c->stream, ct, norm, sm, b->d_cmin);
+    hipLaunchKernelGGL(natac_peak_flags, dim3(b->n_tiles256), dim3(256), (size_t)(256 + 2 * order) * sizeof(double), c->stream, ct,
+                       b->d_tiles256, norm, sm, b->d_cmin, b->d_jitter, min_signal, boundary, order, b->d_pkflag);
+    hipLaunchKernelGGL(natac_peak_reduce, dim3(b->nc), dim3(256), 0, c->stream, ct, b->d_pkflag, norm, sm, b->d_cmin, sep, b->d_cap_off,
+                       b->d_slot, b->d_pk_count, b->d_status);
+    hipLaunchKernelGGL(natac_scan_counts, dim3(1), dim3(1024), 0, c->stream, b->d_pk_count, b->nc, b->d_pk_offs);
+    long long total = 0;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&total, b->d_pk_offs + b->nc, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (total > b->pk_cap) {
+        dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos); dev_free(b->d_pk_out);
+        b->d_pk_chunk = b->d_pk_pos = nullptr; b->d_pk_out = nullptr;
+        b->pk_cap = total + total / 4 + 16;
+        if ((rc = dev_alloc(&b->d_pk_chunk, (size_t)b->pk_cap))) return rc;
+        if ((rc = dev_alloc(&b->d_pk_pos, (size_t)b->pk_cap))) return rc;
+        if ((rc = dev_alloc(&b->d_pk_out, (size_t)3 * b->pk_cap))) return rc;
+    }
+    if (total > 0) {
+        hipLaunchKernelGGL(natac_compact_candidates, dim3((b->nc + 3) / 4), dim3(256), 0, c->stream, b->nc, b->d_pk_count, b->d_pk_offs,
+                           b->d_cap_off, b->d_slot, b->d_pk_chunk, b->d_pk_pos);
+        const VMatDev vm = make_vmat(c);
+        const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
+        hipLaunchKernelGGL(natac_candidates, dim3((unsigned)total), dim3(256), (size_t)(EW + 2) * sizeof(double), c->stream, ct, vm,
+                           b->d_pk_chunk, b->d_pk_pos, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM], b->d_pk_out,
+                           b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap);
+    }
+    prof_end(c, ev);
+    HIPCHK(hipGetLastError());
+    b->pk_n = total;
+    *n_cand = total;
+    return NATAC_OK;
+}
+
+int natac_download_peaks(natac_batch *b, int64_t n, int32_t *cand_chunk, int32_t *cand_pos, double *lr, double *var, double *z) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    if (b->pk_n < 0) return fail(NATAC_E_STATE, "natac_run_peaks has not run");
+    if (n != b->pk_n) return fail(NATAC_E_ARG, "expected %lld candidates, got buffers for %lld", b->pk_n, (long long)n);
+    if (n == 0) return NATAC_OK;
+    if (!cand_chunk || !cand_pos || !lr || !var || !z) return fail(NATAC_E_ARG, "null argument");
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(cand_chunk, b->d_pk_chunk, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(cand_pos, b->d_pk_pos, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(lr, b->d_pk_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(var, b->d_pk_out + b->pk_cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(z, b->d_pk_out + 2 * b->pk_cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
     return NATAC_OK;
 }

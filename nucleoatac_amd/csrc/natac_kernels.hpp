@@ -928,6 +928,170 @@ __global__ void __launch_bounds__(256) natac_candidates(ChunkTable ct, VMatDev v
 }
 
 // ------------------------------------------------------------------------------------------------
+// K8  candidate search on the device: utils.call_peaks (pyatac/utils.py:82-102) applied to norm + smoothed signal as in
+// NucChunk.findAllNucs (nucleoatac/NucleosomeCalling.py:297-301).
+//   1. NaNs of the combined signal are replaced by the chunk's minimum finite value (all-NaN chunk: no candidates);
+//   2. local maxima: y[g] > y[clip(g +- s)] for s = 1..order on the jittered signal y = x * (1 + u[g]); u is the host
+//      generated RandomState(25).uniform(0, 1e-12) stream of the reference (same tie-break, bit for bit);
+//   3. x[g] >= min_signal, boundary <= g < L - boundary;
+//   4. reduce_peaks: visit peaks by decreasing x, keep a peak and drop every peak closer than `sep` (utils.py:56-78).
+// ------------------------------------------------------------------------------------------------
+constexpr int PEAK_MAX = 2048;   // peaks per chunk held in LDS by natac_peak_reduce (L <= 2048 * (order + 1))
+
+__global__ void __launch_bounds__(256) natac_chunk_min_combined(ChunkTable ct, const double *__restrict__ norm,
+                                                                  const double *__restrict__ smooth, double *__restrict__ cmin) {
+    __shared__ double red[4];
+    const int chunk = blockIdx.x;
+    const int L = ct.chunk_len[chunk];
+    const long long ob = ct.out_off[chunk];
+    double mn = __builtin_inf();
+    for (int g = threadIdx.x; g < L; g += 256) {
+        const double v = norm[ob + g] + smooth[ob + g];
+        if (v == v) mn = fmin(mn, v);
+    }
+    mn = wave_min(mn);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) cmin[chunk] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+}
+
+__global__ void __launch_bounds__(256) natac_peak_flags(ChunkTable ct, const int2 *__restrict__ tiles,
+                                                          const double *__restrict__ norm, const double *__restrict__ smooth,
+                                                          const double *__restrict__ cmin, const double *__restrict__ jitter,
+                                                          double min_signal, int boundary, int order,
+                                                          unsigned char *__restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *ys = smem;   // [256 + 2*order] jittered signal, index u <-> base clip(x0 - order + u)
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, x0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    const long long ob = ct.out_off[chunk];
+    const double fillv = cmin[chunk];
+    for (int u = threadIdx.x; u < 256 + 2 * order; u += 256) {
+        int g = x0 - order + u;
+        g = g < 0 ? 0 : (g > L - 1 ? L - 1 : g);                 // numpy take(..., mode='clip')
+        double v = norm[ob + g] + smooth[ob + g];
+        if (v != v) v = fillv;
+        ys[u] = v * (1 + jitter[g]);
+    }
+    __syncthreads();
+    const int g = x0 + threadIdx.x;
+    if (g >= L) return;
+    bool pk = (fillv != __builtin_inf());                          // all-NaN chunk: nothing
+    const double y = ys[threadIdx.x + order];
+    for (int sft = 1; sft <= order && pk; ++sft)
+        pk = (y > ys[threadIdx.x + order + sft]) && (y > ys[threadIdx.x + order - sft]);
+    if (pk) {
+        double v = norm[ob + g] + smooth[ob + g];
+        if (v != v) v = fillv;
+        pk = (v >= min_signal) && (g >= boundary) && (g < L - boundary);
+    }
+    flag[ob + g] = pk ? 1 : 0;
+}
+
+// one workgroup per chunk: compact the flagged bases, order them by decreasing signal, greedy thinning, write the kept
+// positions (ascending) into the chunk's slot region cand_slot[cap_off[chunk] ...] and their number into count[chunk].
+__global__ void __launch_bounds__(256) natac_peak_reduce(ChunkTable ct, const unsigned char *__restrict__ flag,
+                                                           const double *__restrict__ norm, const double *__restrict__ smooth,
+                                                           const double *__restrict__ cmin, int sep,
+                                                           const long long *__restrict__ cap_off, int *__restrict__ cand_slot,
+                                                           int *__restrict__ count, int *__restrict__ status) {
+    __shared__ int pos[PEAK_MAX];
+    __shared__ double sig[PEAK_MAX];
+    __shared__ int ord[PEAK_MAX];
+    __shared__ unsigned char state[PEAK_MAX];   // 0 free, 1 kept, 2 excluded
+    __shared__ int wave_cnt[4];
+    __shared__ int n_sh;
+    const int chunk = blockIdx.x;
+    const int L = ct.chunk_len[chunk];
+    const long long ob = ct.out_off[chunk];
+    const double fillv = cmin[chunk];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int n = 0;
+    bool overflow = false;
+    for (int base = 0; base < L; base += 256) {
+        const int g = base + threadIdx.x;
+        const bool f = (g < L) && flag[ob + g];
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = n;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (f) {
+            const int i = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (i < PEAK_MAX) {
+                double v = norm[ob + g] + smooth[ob + g];
+                if (v != v) v = fillv;
+                pos[i] = g;
+                sig[i] = v;
+                state[i] = 0;
+            }
+        }
+        n += tot;
+        __syncthreads();
+    }
+    if (n > PEAK_MAX) { overflow = true; n = PEAK_MAX; }
+    // rank by decreasing signal (ties: later position first, like a stable ascending sort read backwards)
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double si = sig[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (sig[j] > si) || (sig[j] == si && j > i);
+        ord[r] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int t = 0; t < n; ++t) {
+            const int i = ord[t];
+            if (state[i]) continue;
+            state[i] = 1;
+            for (int k = i - 1; k >= 0 && pos[i] - pos[k] < sep; --k) if (!state[k]) state[k] = 2;
+            for (int k = i + 1; k < n && pos[k] - pos[i] < sep; ++k) if (!state[k]) state[k] = 2;
+        }
+        int m = 0;
+        int *dst = cand_slot + cap_off[chunk];
+        for (int i = 0; i < n; ++i) if (state[i] == 1) dst[m++] = pos[i];
+        count[chunk] = m;
+        if (overflow) atomicOr(&status[chunk], 2);
+        n_sh = m;
+    }
+}
+
+// exclusive prefix sum of per-chunk counts (single workgroup) + total
+__global__ void __launch_bounds__(1024) natac_scan_counts(const int *__restrict__ count, int nc, long long *__restrict__ offs) {
+    __shared__ long long part[1024];
+    const int t = threadIdx.x;
+    const int per = (nc + 1023) / 1024;
+    const int a = t * per, b = (a + per < nc) ? a + per : nc;
+    long long sum = 0;
+    for (int i = a; i < b; ++i) sum += count[i];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
+        offs[nc] = run;
+    }
+    __syncthreads();
+    long long run = part[t];
+    for (int i = a; i < b; ++i) { offs[i] = run; run += count[i]; }
+}
+
+__global__ void __launch_bounds__(256) natac_compact_candidates(int nc, const int *__restrict__ count,
+                                                                  const long long *__restrict__ offs,
+                                                                  const long long *__restrict__ cap_off,
+                                                                  const int *__restrict__ cand_slot, int *__restrict__ cand_chunk,
+                                                                  int *__restrict__ cand_pos) {
+    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (chunk >= nc) return;
+    const int lane = threadIdx.x & 63;
+    const int n = count[chunk];
+    const long long o = offs[chunk];
+    const int *src = cand_slot + cap_off[chunk];
+    for (int i = lane; i < n; i += 64) { cand_chunk[o + i] = chunk; cand_pos[o + i] = src[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // drop-in kernels for the Cython functions (single region, absolute coordinates)
 // ------------------------------------------------------------------------------------------------
 // makeFragmentMat, pyatac/fragments.pyx:17-40 (mat pre-zeroed; float64 atomics are exact for integer counts)

@@ -281,6 +281,20 @@ class DeviceBatch(object):
         L.check(self._lib.natac_run_candidates(self._h, n, _ptr(cc), _ptr(cp), _ptr(lr), _ptr(var), _ptr(z)))
         return lr, var, z
 
+    def run_peaks(self, min_signal=0.0, sep=25, boundary=60, order=12):
+        """candidate search + LR / var / z on the device (natac_run_peaks): call_peaks(norm + smoothed, ...) of every chunk
+        as NucChunk.findAllNucs does it (nucleoatac/NucleosomeCalling.py:297-301).  Returns (chunk, pos, lr, var, z)."""
+        maxL = int(self.packed.chunk_len.max())
+        jitter = np.ascontiguousarray(np.random.RandomState(seed=25).uniform(0, 10 ** -12, maxL))   # utils.py:94-97
+        n = C.c_int64(0)
+        L.check(self._lib.natac_run_peaks(self._h, float(min_signal), int(sep), int(boundary), int(order), _ptr(jitter), maxL,
+                                          C.byref(n)))
+        n = n.value
+        cc, cp = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        lr, var, z = (np.empty(n, dtype=np.float64) for _ in range(3))
+        L.check(self._lib.natac_download_peaks(self._h, n, _ptr(cc), _ptr(cp), _ptr(lr), _ptr(var), _ptr(z)))
+        return cc, cp, lr, var, z
+
     def track(self, t):
         """download one per-base track (concatenated over chunks)"""
         dt = np.int32 if t == L.T_INS else np.float64

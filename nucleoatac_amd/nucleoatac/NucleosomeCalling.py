@@ -216,18 +216,17 @@ def nuc_batch(chunks, params, ctx=None, with_flat=False):
             if params.occ_track is not None:
                 nc.getOcc()
             out.append(nc)
-        # candidates of every chunk -> one candidate launch
-        cc, cp = [], []
+        # candidate search (call_peaks on norm + smoothed, NucleosomeCalling.py:297-301) and LR / z for every candidate
+        # of every chunk on the device: nothing round-trips between the signal kernels and the statistics
+        cc, cp, lr, var, z = run.batch.run_peaks(min_signal=0, sep=params.redundant_sep,
+                                                 boundary=params.nonredundant_sep // 2, order=params.redundant_sep // 2)
+        if (run.batch.status() & 2).any():
+            raise Exception("chunk too long for the device peak finder (more than 2048 local maxima)")
+        bounds = np.searchsorted(cc, np.arange(len(out) + 1))
         for k, nc in enumerate(out):
-            nc._cands = nc.candidatePositions()
-            cc += [k] * len(nc._cands)
-            cp += [int(i) for i in nc._cands]
-        lr, var, z = run.candidates(cc, cp) if cc else (np.zeros(0),) * 3
-        o = 0
-        for nc in out:
-            n = len(nc._cands)
-            nc.findAllNucs(stats=(lr[o:o + n], z[o:o + n]))
-            o += n
+            a, b = int(bounds[k]), int(bounds[k + 1])
+            nc._cands = cp[a:b]
+            nc.findAllNucs(stats=(lr[a:b], z[a:b]))
             nc.fit()
     finally:
         run.close()
