@@ -158,6 +158,20 @@ static int choose_bg_G(const natac_batch *b, int W) {
     return bestG;
 }
 
+static void launch_candidates(natac_ctx *c, const ChunkTable &ct, const VMatDev &vm, const int *d_cc, const int *d_cp, long long n,
+                              const double *nuc_cov, const double *norm, double *lr, double *var, double *z) {
+    const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
+    const size_t lds4 = (size_t)4 * CAND_PER_WAVE * ((EW + 1) & ~1) * sizeof(double);
+    if (lds4 <= 64 * 1024) {
+        const long long per_block = 4 * CAND_PER_WAVE;
+        hipLaunchKernelGGL(natac_candidates4, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), lds4, c->stream, ct, vm, d_cc,
+                           d_cp, (int)n, nuc_cov, norm, lr, var, z);
+    } else {   // very wide templates: one workgroup per candidate
+        hipLaunchKernelGGL(natac_candidates, dim3((unsigned)n), dim3(256), (size_t)(EW + 2) * sizeof(double), c->stream, ct, vm, d_cc,
+                           d_cp, nuc_cov, norm, lr, var, z);
+    }
+}
+
 template <int G>
 static void launch_bg(natac_batch *b, const ChunkTable &ct, const VMatDev &vm) {
     natac_ctx *c = b->ctx;
@@ -634,12 +648,10 @@ int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chu
     if ((rc = dev_alloc(&d_out, (size_t)3 * n_cand))) { dev_free(d_cc); dev_free(d_cp); return rc; }
     const ChunkTable ct = make_table(b);
     const VMatDev vm = make_vmat(c);
-    const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
     natac_ctx::Ev ev;
     prof_begin(c, NATAC_K_CAND, ev);
-    hipLaunchKernelGGL(natac_candidates, dim3((unsigned)n_cand), dim3(256), (size_t)(EW + 2) * sizeof(double), c->stream, ct, vm,
-                       d_cc, d_cp, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM], d_out, d_out + n_cand,
-                       d_out + 2 * n_cand);
+    launch_candidates(c, ct, vm, d_cc, d_cp, n_cand, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM], d_out, d_out + n_cand,
+                      d_out + 2 * n_cand);
     prof_end(c, ev);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(lr, d_out, (size_t)n_cand * sizeof(double), hipMemcpyDeviceToHost, c->stream);
@@ -715,10 +727,8 @@ int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, in
         hipLaunchKernelGGL(natac_compact_candidates, dim3((b->nc + 3) / 4), dim3(256), 0, c->stream, b->nc, b->d_pk_count, b->d_pk_offs,
                            b->d_cap_off, b->d_slot, b->d_pk_chunk, b->d_pk_pos);
         const VMatDev vm = make_vmat(c);
-        const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
-        hipLaunchKernelGGL(natac_candidates, dim3((unsigned)total), dim3(256), (size_t)(EW + 2) * sizeof(double), c->stream, ct, vm,
-                           b->d_pk_chunk, b->d_pk_pos, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM], b->d_pk_out,
-                           b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap);
+        launch_candidates(c, ct, vm, b->d_pk_chunk, b->d_pk_pos, total, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM],
+                          b->d_pk_out, b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap);
     }
     prof_end(c, ev);
     HIPCHK(hipGetLastError());

@@ -927,6 +927,129 @@ __global__ void __launch_bounds__(256) natac_candidates(ChunkTable ct, VMatDev v
     }
 }
 
+// K7b  the same statistics, four candidates per wave: every template value V[r,c] is loaded once per lane and applied to
+// four candidate windows whose exp(bias) slices sit in LDS (4x less L2 template traffic, 4 independent dependency chains,
+// no block-level synchronisation: DPP wave reductions only).  Workgroup = 4 waves = 16 candidates.
+constexpr int CAND_PER_WAVE = 4;
+
+__global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
+                                                           const int *__restrict__ cand_pos, int ncand,
+                                                           const double *__restrict__ nuc_cov, const double *__restrict__ norm,
+                                                           double *__restrict__ out_lr, double *__restrict__ out_var,
+                                                           double *__restrict__ out_z) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
+    const int EW = vm.W + A + Bh, EWP = (EW + 1) & ~1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *Et = smem + (size_t)wave * CAND_PER_WAVE * EWP;     // [4][EWP];  Et[q][u] <-> coordinate p_q - w - A + u
+    const int k0 = (blockIdx.x * 4 + wave) * CAND_PER_WAVE;
+    if (k0 >= ncand) return;
+    int chunk[CAND_PER_WAVE], pos[CAND_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < CAND_PER_WAVE; ++q) {
+        const int k = (k0 + q < ncand) ? k0 + q : k0;          // tail: recompute candidate k0 (result discarded)
+        chunk[q] = cand_chunk[k];
+        pos[q] = cand_pos[k];
+        const int L = ct.chunk_len[chunk[q]];
+        const double *b = ct.bias ? ct.bias + ct.bias_off[chunk[q]] : nullptr;
+        const int nb = L + ct.bias_left + ct.bias_right;
+        const int j0 = pos[q] - vm.w - A + ct.bias_left;
+        for (int u = lane; u < EW; u += WAVE) {
+            const int j = j0 + u;
+            double e = 1.0;
+            if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+            Et[q * EWP + u] = e;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    double sB[CAND_PER_WAVE], sBV[CAND_PER_WAVE], sBV2[CAND_PER_WAVE], sB0V[CAND_PER_WAVE];
+    bool zero[CAND_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < CAND_PER_WAVE; ++q) { sB[q] = sBV[q] = sBV2[q] = sB0V[q] = 0.0; zero[q] = false; }
+    const int c1 = lane, c2 = lane + WAVE;
+    const bool h2 = c2 < vm.W;
+    // template values are prefetched four rows ahead (L2 latency >> the ~320 cycles of arithmetic per row)
+    constexpr int PF = 4;
+    double pv1[PF], pv2[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        pv1[u] = (u < vm.R && c1 < vm.W) ? vm.mat[u * vm.W + c1] : 0.0;
+        pv2[u] = (u < vm.R && h2) ? vm.mat[u * vm.W + c2] : 0.0;
+    }
+    for (int rb = 0; rb < vm.R; rb += PF) {
+      double nv1[PF], nv2[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+          const int rn = rb + PF + u;
+          nv1[u] = (rn < vm.R && c1 < vm.W) ? vm.mat[rn * vm.W + c1] : 0.0;
+          nv2[u] = (rn < vm.R && h2) ? vm.mat[rn * vm.W + c2] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int r = rb + u;
+        if (r >= vm.R) break;
+        const int i = vm.lower + r;
+        const int hl = floor_half(i - 1), hr = floor_half(i);
+        const bool single = (hl == -hr);
+        const double sr = vm.srow[r];
+        const double v1 = pv1[u];
+        const double v2 = pv2[u];
+        const int ol = A - hl, orr = A + hr;
+#pragma unroll
+        for (int q = 0; q < CAND_PER_WAVE; ++q) {
+            const double *e = Et + q * EWP;
+            if (c1 < vm.W) {
+                const double b0 = single ? e[c1 + ol] : e[c1 + ol] * e[c1 + orr];
+                const double bb = sr * b0, vb0 = v1 * b0;
+                sB[q] += bb; sBV[q] = fma(bb, v1, sBV[q]); sBV2[q] = fma(bb * v1, v1, sBV2[q]); sB0V[q] += vb0;
+                zero[q] |= (vb0 == 0.0 || bb == 0.0);
+            }
+            if (h2) {
+                const double b0 = single ? e[c2 + ol] : e[c2 + ol] * e[c2 + orr];
+                const double bb = sr * b0, vb0 = v2 * b0;
+                sB[q] += bb; sBV[q] = fma(bb, v2, sBV[q]); sBV2[q] = fma(bb * v2, v2, sBV2[q]); sB0V[q] += vb0;
+                zero[q] |= (vb0 == 0.0 || bb == 0.0);
+            }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) { pv1[u] = nv1[u]; pv2[u] = nv2[u]; }
+    }
+#pragma unroll
+    for (int q = 0; q < CAND_PER_WAVE; ++q) {
+        const double tB = wave_sum(sB[q]), tBV = wave_sum(sBV[q]), tBV2 = wave_sum(sBV2[q]), tB0V = wave_sum(sB0V[q]);
+        const bool anyzero = __ballot(zero[q]) != 0ull;
+        const int p = pos[q];
+        const int nfr = (int)(ct.frag_off[chunk[q] + 1] - ct.frag_off[chunk[q]]);
+        const int *cen = ct.centre + ct.frag_off[chunk[q]];
+        const int *iln = ct.ilen + ct.frag_off[chunk[q]];
+        const int f0 = lower_bound_i32(cen, 0, nfr, p - vm.w);
+        const int f1 = lower_bound_i32(cen, f0, nfr, p + vm.w + 1);
+        const double *e = Et + q * EWP;
+        double nl = 0.0, ul = 0.0;
+        for (int f = f0 + lane; f < f1; f += WAVE) {
+            const int n = iln[f];
+            if (n < vm.lower || n >= vm.upper) continue;
+            const int r = n - vm.lower, c = cen[f] - p + vm.w;
+            const int hl = floor_half(n - 1), hr = floor_half(n);
+            const double b0 = (hl == -hr) ? e[c + A] : e[c + A - hl] * e[c + A + hr];
+            nl += log((vm.mat[r * vm.W + c] * b0) / tB0V);
+            ul += log((vm.srow[r] * b0) / tB);
+        }
+        nl = wave_sum(nl);
+        ul = wave_sum(ul);
+        if (lane == 0 && k0 + q < ncand) {
+            const long long o = ct.out_off[chunk[q]] + p;
+            const double m1 = tBV / tB;
+            const int reads = (int)nuc_cov[o];
+            const double var = (double)reads * (tBV2 / tB - m1 * m1);
+            out_lr[k0 + q] = anyzero ? __builtin_nan("") : (nl - ul);
+            out_var[k0 + q] = var;
+            out_z[k0 + q] = norm[o] / sqrt(var);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K8  candidate search on the device: utils.call_peaks (pyatac/utils.py:82-102) applied to norm + smoothed signal as in
 // NucChunk.findAllNucs (nucleoatac/NucleosomeCalling.py:297-301).
