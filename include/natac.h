@@ -193,6 +193,16 @@ int natac_write_bedgraph(const char *path, int append, int compress, int finish,
                          const int64_t *chunk_start, const int64_t *out_off, const double *vals, int write_zero,
                          int n_threads, int64_t *bytes_written);
 
+/* ---- native BAM -> fragment arrays extractor (host side) -------------- */
+/* Decode a BAM once (parallel BGZF inflate) into per-reference arrays of the reads pyatac/fragments.pyx:25 keeps
+ * (`is_proper_pair and not is_reverse`): pos = leftmost 0-based coordinate, tlen = |template length|, in file order. */
+typedef struct natac_bam natac_bam;
+int natac_bam_open(const char *path, int n_threads, natac_bam **out);
+void natac_bam_close(natac_bam *bam);
+int natac_bam_counts(natac_bam *bam, int32_t *n_refs, int64_t *n_records, int64_t *n_kept);
+int natac_bam_ref_info(natac_bam *bam, int32_t ref, char *name, size_t name_len, int64_t *length, int64_t *n_reads);
+int natac_bam_ref_reads(natac_bam *bam, int32_t ref, int64_t *pos, int64_t *tlen, int64_t n);
+
 /* ---- profiling (HIP events on the context's stream) ------------------------------------ */
 int natac_profile_enable(natac_ctx *ctx, int on);
 /* total milliseconds and launch count of kernel class `k` since the last reset */

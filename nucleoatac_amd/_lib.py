@@ -56,6 +56,11 @@ SIGNATURES = {
     "natac_calculate_occupancy": (C.c_int, [_vp, _vp, _vp, _vp]),
     "natac_write_bedgraph": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, _i32, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                              C.POINTER(_i64)]),
+    "natac_bam_open": (C.c_int, [C.c_char_p, C.c_int, _pp]),
+    "natac_bam_close": (None, [_vp]),
+    "natac_bam_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
+    "natac_bam_ref_info": (C.c_int, [_vp, _i32, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(_i64)]),
+    "natac_bam_ref_reads": (C.c_int, [_vp, _i32, _vp, _vp, _i64]),
     "natac_profile_enable": (C.c_int, [_vp, C.c_int]),
     "natac_profile_get": (C.c_int, [_vp, C.c_int, C.POINTER(_f64), C.POINTER(_i64)]),
     "natac_profile_reset": (C.c_int, [_vp]),

@@ -3,6 +3,7 @@
 #include "../../include/natac.h"
 #include "natac_kernels.hpp"
 #include "natac_writer.hpp"
+#include "natac_bam.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -58,6 +59,10 @@ struct natac_ctx {
     double prof_ms[NATAC_K_COUNT] = {0};
     int64_t prof_n[NATAC_K_COUNT] = {0};
     hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+struct natac_bam {
+    natac_bamio::Bam *impl = nullptr;
 };
 
 struct natac_batch {
@@ -1061,6 +1066,55 @@ int natac_write_bedgraph(const char *path, int append, int compress, int finish,
     if (rc == 1) return fail(NATAC_E_ARG, "cannot open %s", path);
     if (rc == 2) return fail(NATAC_E_ARG, "write to %s failed", path);
     if (rc == 3) return fail(NATAC_E_NOMEM, "deflate failed");
+    return NATAC_OK;
+}
+
+/* ---------------- native BAM extractor ---------------- */
+
+int natac_bam_open(const char *path, int n_threads, natac_bam **out) {
+    if (!path || !out) return fail(NATAC_E_ARG, "null argument");
+    *out = nullptr;
+    std::string err;
+    natac_bamio::Bam *impl = natac_bamio::decode(path, n_threads, err);
+    if (!impl) return fail(NATAC_E_ARG, "%s: %s", path, err.c_str());
+    natac_bam *h = new natac_bam();
+    h->impl = impl;
+    *out = h;
+    return NATAC_OK;
+}
+
+void natac_bam_close(natac_bam *bam) {
+    if (!bam) return;
+    delete bam->impl;
+    delete bam;
+}
+
+int natac_bam_counts(natac_bam *bam, int32_t *n_refs, int64_t *n_records, int64_t *n_kept) {
+    if (!bam) return fail(NATAC_E_ARG, "bam is NULL");
+    if (n_refs) *n_refs = (int32_t)bam->impl->refs.size();
+    if (n_records) *n_records = bam->impl->n_records;
+    if (n_kept) *n_kept = bam->impl->n_kept;
+    return NATAC_OK;
+}
+
+int natac_bam_ref_info(natac_bam *bam, int32_t ref, char *name, size_t name_len, int64_t *length, int64_t *n_reads) {
+    if (!bam || ref < 0 || ref >= (int32_t)bam->impl->refs.size()) return fail(NATAC_E_ARG, "bad reference index");
+    const natac_bamio::Ref &r = bam->impl->refs[ref];
+    if (name && name_len) snprintf(name, name_len, "%s", r.name.c_str());
+    if (length) *length = r.length;
+    if (n_reads) *n_reads = (int64_t)r.pos.size();
+    return NATAC_OK;
+}
+
+int natac_bam_ref_reads(natac_bam *bam, int32_t ref, int64_t *pos, int64_t *tlen, int64_t n) {
+    if (!bam || ref < 0 || ref >= (int32_t)bam->impl->refs.size()) return fail(NATAC_E_ARG, "bad reference index");
+    const natac_bamio::Ref &r = bam->impl->refs[ref];
+    if (n != (int64_t)r.pos.size()) return fail(NATAC_E_ARG, "reference holds %zu reads, buffers are for %lld", r.pos.size(), (long long)n);
+    if (n && (!pos || !tlen)) return fail(NATAC_E_ARG, "null argument");
+    if (n) {
+        std::memcpy(pos, r.pos.data(), (size_t)n * sizeof(int64_t));
+        std::memcpy(tlen, r.tlen.data(), (size_t)n * sizeof(int64_t));
+    }
     return NATAC_OK;
 }
 

@@ -61,8 +61,36 @@ class FragmentStore(object):
         np.savez_compressed(path, **arrs)
 
     @staticmethod
-    def from_bam(path):
-        """minimal BGZF/BAM decoder (SAM spec section 4): keeps FLAG & 0x2 (proper pair) and not FLAG & 0x10 (reverse)"""
+    def from_bam(path, n_threads=0):
+        """native decoder (natac_bam_open: parallel BGZF inflate + record walk in libnatac_hip.so)"""
+        import ctypes as C
+        from .. import _lib as L
+        lib = L.load()
+        h = C.c_void_p()
+        L.check(lib.natac_bam_open(str(path).encode(), int(n_threads), C.byref(h)))
+        try:
+            nref = C.c_int32(0)
+            L.check(lib.natac_bam_counts(h, C.byref(nref), None, None))
+            names, lens, pos, tl = [], [], {}, {}
+            for r in range(nref.value):
+                name = C.create_string_buffer(512)
+                ln, nr = C.c_int64(0), C.c_int64(0)
+                L.check(lib.natac_bam_ref_info(h, r, name, 512, C.byref(ln), C.byref(nr)))
+                c = name.value.decode()
+                p = np.empty(nr.value, dtype=np.int64)
+                t = np.empty(nr.value, dtype=np.int64)
+                L.check(lib.natac_bam_ref_reads(h, r, p.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), nr.value))
+                names.append(c)
+                lens.append(ln.value)
+                pos[c], tl[c] = p, t
+        finally:
+            lib.natac_bam_close(h)
+        return FragmentStore(names, lens, pos, tl)
+
+    @staticmethod
+    def from_bam_python(path):
+        """pure-Python BGZF/BAM decoder (SAM spec section 4), kept as an independent check of the native one:
+        keeps FLAG & 0x2 (proper pair) and not FLAG & 0x10 (reverse)"""
         with gzip.open(path, "rb") as fh:
             b = fh.read()
         if b[:4] != b"BAM\x01":

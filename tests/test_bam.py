@@ -1,0 +1,89 @@
+"""CPU: native BAM extractor (natac_bam_*, host code in libnatac_hip.so) vs the pure-Python decoder vs ground truth,
+on a synthetic multi-block BAM written here and on the reference's own single_read.bam fixture."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, golden
+from nucleoatac_amd.pyatac.fragments import FragmentStore
+
+
+def _bgzf(data, blk=3000):
+    out = bytearray()
+    for o in range(0, len(data), blk):
+        chunk = data[o:o + blk]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        bsize = 18 + len(comp) + 8
+        out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", bsize - 1)
+        out += comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    return bytes(out)
+
+
+def _write_bam(path, refs, records):
+    text = b"@HD\tVN:1.0\tSO:coordinate\n"
+    d = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    for name, ln in refs:
+        nm = name.encode() + b"\0"
+        d += struct.pack("<i", len(nm)) + nm + struct.pack("<i", ln)
+    for ref_id, pos, flag, tlen in records:
+        rn = b"r\0"
+        seq_len = 10
+        body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(rn), 30, 4680, 1, flag, seq_len, ref_id, pos + 50, tlen)
+        body += rn + struct.pack("<I", (seq_len << 4) | 0) + bytes((seq_len + 1) // 2) + bytes([30] * seq_len)
+        d += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as f:
+        f.write(_bgzf(d))
+
+
+def test_native_decoder_matches_truth_and_python(tmp_path):
+    rng = np.random.default_rng(0)
+    refs = [("chrA", 50000), ("chrB", 80000), ("chrEmpty", 1000)]
+    recs = []
+    for ref_id, ln in ((0, 50000), (1, 80000)):
+        pos = np.sort(rng.integers(0, ln - 1000, size=4000))
+        for p in pos:
+            flag = int(rng.choice([0x63, 0x53, 0x93, 0xa3, 0x41, 0x4, 0x163]))   # fwd proper, rev proper, improper, unmapped, ...
+            tl = int(rng.integers(30, 700)) * (1 if not (flag & 0x10) else -1)
+            recs.append((ref_id, int(p), flag, tl))
+    recs.append((-1, -1, 0x4, 0))                                             # unplaced read
+    path = str(tmp_path / "synth.bam")
+    _write_bam(path, refs, recs)
+    nat = FragmentStore.from_bam(path)
+    py = FragmentStore.from_bam_python(path)
+    assert nat.references == ["chrA", "chrB", "chrEmpty"] and nat.lengths == [50000, 80000, 1000]
+    for i, c in enumerate(["chrA", "chrB"]):
+        keep = [(p, abs(t)) for (r, p, f, t) in recs if r == i and (f & 0x2) and not (f & 0x10)]
+        assert len(keep) > 500
+        assert np.array_equal(nat.pos[c], [k[0] for k in keep]) and np.array_equal(nat.tlen[c], [k[1] for k in keep])
+        assert np.array_equal(nat.pos[c], py.pos[c]) and np.array_equal(nat.tlen[c], py.tlen[c])
+    assert len(nat.pos["chrEmpty"]) == 0
+    l, n = nat.fetch("chrA", 1000, 3000)
+    assert np.all(np.diff(l) >= 0) and len(l) == len(n)
+
+
+def test_reference_fixture_single_read():
+    st = FragmentStore.from_bam(os.path.join(GOLDEN, "ref_single_read.bam"))
+    sr = golden("single_read")
+    l, n = st.fetch("chrII", int(sr["start"]), int(sr["end"]))
+    assert np.array_equal(l, sr["l"]) and np.array_equal(n, sr["n"])
+    assert len(st.references) == 17 and st.chrom_sizes()["chrII"] == 813184
+
+
+def test_corrupt_inputs_fail_loudly(tmp_path):
+    from nucleoatac_amd._lib import NatacError
+    p = str(tmp_path / "x.bam")
+    open(p, "wb").write(b"not a bam")
+    with pytest.raises(NatacError):
+        FragmentStore.from_bam(p)
+    _write_bam(p, [("c", 100)], [(0, 5, 0x63, 100)])
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(NatacError):
+        FragmentStore.from_bam(p)
+    with pytest.raises(NatacError):
+        FragmentStore.from_bam(str(tmp_path / "missing.bam"))
