@@ -20,6 +20,7 @@ def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN)
     [start-246, end+247) (InsertionBiasTrack.computeBias, as in nucleoatac/Occupancy.py:212-214) or None."""
     st = FragmentStore.open(bam)
     starts, lens, offs, ls, ns, boffs, bvals, chroms = [], [], [0], [], [], [0], [], []
+    bias_of = _bias_spans(chunks, fasta, chrs, pwm) if fasta is not None else None
     for ch in chunks:
         l, n = st.fetch(ch.chrom, ch.start - margin, ch.end + margin, 1 if atac else 0)
         keep = l >= ch.start - margin
@@ -33,17 +34,51 @@ def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN)
         lens.append(ch.end - ch.start)
         chroms.append(ch.chrom)
         if fasta is not None:
-            bt = InsertionBiasTrack(ch.chrom, ch.start - BIAS_LEFT, ch.end + BIAS_RIGHT, log=True)
-            bt.computeBias(fasta, chrs, pwm)
-            if len(bt.vals) != ch.end - ch.start + BIAS_LEFT + BIAS_RIGHT:
-                raise Exception("chunk %s too close to the chromosome end for the bias window" % ch.asBed())
-            bvals.append(bt.vals)
-            boffs.append(boffs[-1] + len(bt.vals))
+            vals = bias_of(ch)
+            bvals.append(vals)
+            boffs.append(boffs[-1] + len(vals))
     cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
     return PackedChunks(chunk_start=np.array(starts, np.int64), chunk_len=np.array(lens, np.int32),
                         frag_off=np.array(offs, np.int64), frag_lpos=cat(ls, np.int32), frag_ilen=cat(ns, np.int32),
                         bias_off=np.array(boffs, np.int64) if fasta is not None else None,
                         bias_log=cat(bvals, np.float64) if fasta is not None else None, chroms=chroms)
+
+
+def _bias_spans(chunks, fasta, chrs, pwm, max_gap=4096):
+    """PWM log-bias for [start-246, end+247) of every chunk (InsertionBiasTrack.computeBias, pyatac/bias.py:85-92).
+    Windows of nearby chunks are merged into spans that are scored with ONE natac_pwm_bias launch each and then sliced,
+    instead of one sequence fetch + launch per chunk as in the reference (Occupancy.py:212-214)."""
+    by_chrom = {}
+    for ch in chunks:
+        by_chrom.setdefault(ch.chrom, []).append((ch.start - BIAS_LEFT, ch.end + BIAS_RIGHT))
+    spans = {}
+    for chrom, iv in by_chrom.items():
+        iv.sort()
+        cur = list(iv[0])
+        merged = []
+        for a, b in iv[1:]:
+            if a <= cur[1] + max_gap:
+                cur[1] = max(cur[1], b)
+            else:
+                merged.append(cur)
+                cur = [a, b]
+        merged.append(cur)
+        tracks = []
+        for a, b in merged:
+            bt = InsertionBiasTrack(chrom, a, b, log=True)
+            bt.computeBias(fasta, chrs, pwm)
+            tracks.append((bt.start, bt.end, bt.vals))
+        spans[chrom] = (np.array([t[0] for t in tracks]), tracks)
+
+    def lookup(ch):
+        a, b = ch.start - BIAS_LEFT, ch.end + BIAS_RIGHT
+        s0, tracks = spans[ch.chrom]
+        t = tracks[int(np.searchsorted(s0, a, "right")) - 1]
+        if a < t[0] or b > t[1]:
+            raise Exception("chunk %s too close to the chromosome end for the bias window" % ch.asBed())
+        return t[2][a - t[0]:b - t[0]]
+
+    return lookup
 
 
 def window_size_hist(pk, k, pos, flank, upper):
