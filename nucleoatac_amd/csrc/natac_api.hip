@@ -361,6 +361,7 @@ static OccModelDev make_occ(natac_ctx *c) {
     OccModelDev o;
     o.nuc_probs = c->d_nucp; o.nfr_probs = c->d_nfrp; o.alphas = c->d_alphas; o.upper = c->occ_upper;
     o.n_alpha = c->n_alpha; o.step = c->step; o.halfstep = c->halfstep; o.flank = c->flank; o.cutoff = c->cutoff;
+    o.ci_factor = std::exp(-0.5 * c->cutoff);
     return o;
 }
 

@@ -382,6 +382,7 @@ struct OccModelDev {
     const double *nuc_probs, *nfr_probs, *alphas;
     int upper, n_alpha, step, halfstep, flank;
     double cutoff;
+    double ci_factor;   // exp(-cutoff / 2): likelihood-ratio threshold in the product domain
 };
 
 // number of leading entries of the sorted array a[from, n) that are < key, found 64 at a time with a ballot
@@ -638,41 +639,43 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
             continue;
         }
         if (ABL == 5) { if (lane == 0) g_occ[go] = mm0 + mm1 + e0 + e1; continue; }
-        const double LN2 = 0.693147180559945309417232121458;
-        const double NINF = -__builtin_inf();
-        double ll0 = log(mm0) + (double)e0 * LN2;
-        double ll1 = log(mm1) + (double)e1 * LN2;
+        // Decision without logarithms.  The likelihood of alpha is L = mm * 2^e with mm in [0.5, 1) (0 stands for
+        // log L = -inf).  argmax ll == argmax (e, mm) lexicographically, and the reference's likelihood-ratio test
+        //   2 (max ll - ll) < cutoff   <=>   L > Lmax * exp(-cutoff / 2)
+        // is evaluated as  ldexp(mm, e - emax) > mmax * ci_factor  (ci_factor = exp(-cutoff/2) from the host).
         // reference: a zero-probability insert size gives log(0)*ins = -inf (ins>0) or NaN (ins==0) -> -inf
-        if (flags & 8) { ll0 = NINF; ll1 = NINF; }
-        if (flags & 4) { ll0 = NINF; ll1 = NINF; }
-        if ((flags & 2) && al0 == 0.0) ll0 = NINF;
-        if ((flags & 2) && al1 == 0.0) ll1 = NINF;
-        if ((flags & 1) && be0 == 0.0) ll0 = NINF;
-        if ((flags & 1) && be1 == 0.0) ll1 = NINF;
-        if (ll0 != ll0) ll0 = NINF;
-        if (ll1 != ll1) ll1 = NINF;
-        if (a0 >= om.n_alpha) ll0 = NINF;
-        if (a1 >= om.n_alpha) ll1 = NINF;
-        // max + first argmax
-        const double mx = wave_max(fmax(ll0, ll1));
-        const unsigned long long eq0 = __ballot(ll0 == mx && a0 < om.n_alpha);
-        const unsigned long long eq1 = __ballot(ll1 == mx && a1 < om.n_alpha);
+        if (flags & (8 | 4)) { mm0 = 0.0; mm1 = 0.0; }
+        if ((flags & 2) && al0 == 0.0) mm0 = 0.0;
+        if ((flags & 2) && al1 == 0.0) mm1 = 0.0;
+        if ((flags & 1) && be0 == 0.0) mm0 = 0.0;
+        if ((flags & 1) && be1 == 0.0) mm1 = 0.0;
+        if (!(mm0 > 0.0) || a0 >= om.n_alpha) mm0 = 0.0;      // NaN likelihood -> -inf as well
+        if (!(mm1 > 0.0) || a1 >= om.n_alpha) mm1 = 0.0;
+        const double NONE = -1e300;
+        const double ed0 = mm0 > 0.0 ? (double)e0 : NONE, ed1 = mm1 > 0.0 ? (double)e1 : NONE;
+        const double emax = wave_max(fmax(ed0, ed1));
+        if (emax == NONE) {
+            // every likelihood is -inf: the reference raises ValueError (min of empty, Occupancy.py:118)
+            if (lane == 0) { g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan(""); atomicOr(&status[chunk], 1); }
+            continue;
+        }
+        const double mmax = wave_max(fmax(ed0 == emax ? mm0 : 0.0, ed1 == emax ? mm1 : 0.0));
+        const unsigned long long eq0 = __ballot(ed0 == emax && mm0 == mmax);
+        const unsigned long long eq1 = __ballot(ed1 == emax && mm1 == mmax);
         const int imax = eq0 ? (__ffsll((long long)eq0) - 1) : (WAVE + __ffsll((long long)eq1) - 1);
-        const double r0 = 2 * (mx - ll0), r1 = 2 * (mx - ll1);
-        const unsigned long long c0 = __ballot(a0 < om.n_alpha && r0 < om.cutoff);
-        const unsigned long long c1 = __ballot(a1 < om.n_alpha && r1 < om.cutoff);
+        const double thr = mmax * om.ci_factor;
+        const int iemax = (int)emax;
+        const int d0 = e0 - iemax, d1 = e1 - iemax;
+        const bool in0 = mm0 > 0.0 && d0 > -1100 && ldexp(mm0, d0) > thr;
+        const bool in1 = mm1 > 0.0 && d1 > -1100 && ldexp(mm1, d1) > thr;
+        const unsigned long long c0 = __ballot(in0);
+        const unsigned long long c1 = __ballot(in1);
         if (lane == 0) {
-            if ((c0 | c1) == 0ull) {
-                // every likelihood is -inf: the reference raises ValueError (min of empty, Occupancy.py:118)
-                g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan("");
-                atomicOr(&status[chunk], 1);
-            } else {
-                const int ilo = c0 ? (__ffsll((long long)c0) - 1) : (WAVE + __ffsll((long long)c1) - 1);
-                const int ihi = c1 ? (WAVE + 63 - __clzll((long long)c1)) : (63 - __clzll((long long)c0));
-                g_occ[go] = om.alphas[imax];
-                g_lo[go] = om.alphas[ilo];
-                g_hi[go] = om.alphas[ihi];
-            }
+            const int ilo = c0 ? (__ffsll((long long)c0) - 1) : (WAVE + __ffsll((long long)c1) - 1);
+            const int ihi = c1 ? (WAVE + 63 - __clzll((long long)c1)) : (63 - __clzll((long long)c0));
+            g_occ[go] = om.alphas[imax];
+            g_lo[go] = om.alphas[ilo];
+            g_hi[go] = om.alphas[ihi];
         }
     }
 }

@@ -224,3 +224,37 @@ def test_argument_errors(ctx):
     with pytest.raises(L.NatacError):
         b.run_nuc(10)                                          # bias halo too small for the 185-bp reach
     b.free()
+
+
+def test_zero_probability_bins_reproduce_reference_failure():
+    """a size bin with probability 0 in BOTH distributions makes every log-likelihood -inf (0*log 0 = NaN -> -inf,
+    Occupancy.py:112-114): the reference dies with ValueError at :118; the library flags the chunk and writes NaN.
+    A zero in only ONE distribution just forces alpha = 0 / 1 to -inf."""
+    from nucleoatac_amd.device import Context
+    from oracle import natac_oracle as O
+    pk = make_synthetic_chunks(2, 400, 120, seed=4)
+    nucp, nfrp = synth_occ_distributions(251)
+    l0, n0 = pk.chunk_frags(0)
+    with Context(0) as c:
+        both = (nucp.copy(), nfrp.copy())
+        both[0][7] = 0.0
+        both[1][7] = 0.0
+        c.set_occ_model(both[0] / both[0].sum(), both[1] / both[1].sum(), step=5, flank=60)
+        b = c.upload(pk)
+        b.run_occ()
+        assert (b.status() & 1).all() and np.isnan(b.grid(L.G_OCC)).all()
+        with pytest.raises(ValueError):
+            O.occ_chunk_tracks(l0.astype(np.int64), n0.astype(np.int64), 0, 400, pk.chunk_bias(0), -246,
+                               both[0] / both[0].sum(), both[1] / both[1].sum())
+        b.free()
+        one = nucp.copy()
+        one[7] = 0.0
+        one /= one.sum()
+        c.set_occ_model(one, nfrp, step=5, flank=60)
+        b = c.upload(pk)
+        b.run_occ()
+        assert not b.status().any()
+        oc = O.occ_chunk_tracks(l0.astype(np.int64), n0.astype(np.int64), 0, 400, pk.chunk_bias(0), -246, one, nfrp)
+        g = b.grid(L.G_UPPER)[:len(range(2, 400, 5))]
+        assert np.array_equal(np.repeat(g, 5)[:400], oc["occ_upper"], equal_nan=True) and np.nanmax(g) < 1.0
+        b.free()
