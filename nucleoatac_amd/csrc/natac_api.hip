@@ -44,6 +44,8 @@ struct natac_ctx {
     double *d_vmat = nullptr, *d_srow = nullptr, *d_sizes = nullptr;
     int vlower = 0, vupper = 0, vw = 0, R = 0, W = 0, sizes_upper = 0;
     bool have_vmat = false, have_sizes = false, srow_dirty = true;
+    bool vmat_zero = false, srow_zero = false;
+    std::vector<double> h_sizes;
     double *d_nucp = nullptr, *d_nfrp = nullptr, *d_alphas = nullptr;
     int occ_upper = 0, n_alpha = 0, step = 0, halfstep = 0, flank = 0;
     double cutoff = 0;
@@ -268,6 +270,8 @@ int natac_set_vmat(natac_ctx *c, const double *mat, int lower, int upper, int w)
     c->vlower = lower; c->vupper = upper; c->vw = w; c->R = upper - lower; c->W = 2 * w + 1;
     int rc = dev_upload(c, &c->d_vmat, mat, (size_t)c->R * c->W);
     if (rc) return rc;
+    c->vmat_zero = false;
+    for (size_t i = 0; i < (size_t)c->R * c->W; ++i) if (mat[i] == 0.0) { c->vmat_zero = true; break; }
     HIPCHK(sync_all(c));
     c->have_vmat = true;
     c->srow_dirty = true;
@@ -282,6 +286,7 @@ int natac_set_sizes(natac_ctx *c, const double *sizes, int upper) {
     c->d_sizes = nullptr;
     int rc = dev_upload(c, &c->d_sizes, sizes, (size_t)upper);
     if (rc) return rc;
+    c->h_sizes.assign(sizes, sizes + upper);
     HIPCHK(sync_all(c));
     c->sizes_upper = upper;
     c->have_sizes = true;
@@ -321,6 +326,8 @@ static int ensure_srow(natac_ctx *c) {
     int rc = dev_alloc(&c->d_srow, (size_t)c->R);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->d_srow, c->d_sizes + c->vlower, (size_t)c->R * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->srow_zero = false;
+    for (int r = 0; r < c->R; ++r) if (c->h_sizes[(size_t)c->vlower + r] == 0.0) c->srow_zero = true;
     c->srow_dirty = false;
     return NATAC_OK;
 }
@@ -355,6 +362,7 @@ static ChunkTable make_table(natac_batch *b) {
 static VMatDev make_vmat(natac_ctx *c) {
     VMatDev v;
     v.mat = c->d_vmat; v.srow = c->d_srow; v.lower = c->vlower; v.upper = c->vupper; v.w = c->vw; v.R = c->R; v.W = c->W;
+    v.has_zero = (c->vmat_zero || c->srow_zero) ? 1 : 0;
     return v;
 }
 static OccModelDev make_occ(natac_ctx *c) {

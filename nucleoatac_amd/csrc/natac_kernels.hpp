@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace natac {
 
 constexpr int WAVE = 64;
@@ -31,6 +33,7 @@ struct VMatDev {
     const double *mat;   // R x W row-major
     const double *srow;  // [R] sizes[lower + r]
     int lower, upper, w, R, W;
+    int has_zero;        // the template or srow holds an exact 0 (host-computed)
 };
 
 __device__ __forceinline__ int floor_half(int x) { return x >> 1; }  // arithmetic shift == python x//2
@@ -948,6 +951,7 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
     const int k0 = (blockIdx.x * 4 + wave) * CAND_PER_WAVE;
     if (k0 >= ncand) return;
     int chunk[CAND_PER_WAVE], pos[CAND_PER_WAVE];
+    bool esmall[CAND_PER_WAVE];
 #pragma unroll
     for (int q = 0; q < CAND_PER_WAVE; ++q) {
         const int k = (k0 + q < ncand) ? k0 + q : k0;          // tail: recompute candidate k0 (result discarded)
@@ -957,20 +961,27 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
         const double *b = ct.bias ? ct.bias + ct.bias_off[chunk[q]] : nullptr;
         const int nb = L + ct.bias_left + ct.bias_right;
         const int j0 = pos[q] - vm.w - A + ct.bias_left;
+        double emin = __builtin_inf();
         for (int u = lane; u < EW; u += WAVE) {
             const int j = j0 + u;
             double e = 1.0;
             if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
             Et[q * EWP + u] = e;
+            emin = fmin(emin, e);
         }
+        esmall[q] = !(wave_min(emin) > 0x1p-500);     // no product of two window values can underflow to 0 above this
     }
     __builtin_amdgcn_wave_barrier();
     double sB[CAND_PER_WAVE], sBV[CAND_PER_WAVE], sBV2[CAND_PER_WAVE], sB0V[CAND_PER_WAVE];
     bool zero[CAND_PER_WAVE];
 #pragma unroll
     for (int q = 0; q < CAND_PER_WAVE; ++q) { sB[q] = sBV[q] = sBV2[q] = sB0V[q] = 0.0; zero[q] = false; }
+    // a model cell is exactly 0 only if the template or the size distribution holds a 0 (host-known flags in vm) or a
+    // product of two exp(bias) values underflows; the per-cell test runs only in those (wave-uniform) cases
+    const bool check_any = vm.has_zero || esmall[0] || esmall[1] || esmall[2] || esmall[3];
     const int c1 = lane, c2 = lane + WAVE;
     const bool h2 = c2 < vm.W;
+    auto sweep = [&](auto CHECK) {
     // template values are prefetched four rows ahead (L2 latency >> the ~320 cycles of arithmetic per row)
     constexpr int PF = 4;
     double pv1[PF], pv2[PF];
@@ -995,29 +1006,31 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
         const int hl = floor_half(i - 1), hr = floor_half(i);
         const bool single = (hl == -hr);
         const double sr = vm.srow[r];
-        const double v1 = pv1[u];
-        const double v2 = pv2[u];
+        const double v1 = pv1[u], v2 = pv2[u];
+        const double v1sq = v1 * v1, v2sq = v2 * v2;
         const int ol = A - hl, orr = A + hr;
 #pragma unroll
         for (int q = 0; q < CAND_PER_WAVE; ++q) {
             const double *e = Et + q * EWP;
             if (c1 < vm.W) {
                 const double b0 = single ? e[c1 + ol] : e[c1 + ol] * e[c1 + orr];
-                const double bb = sr * b0, vb0 = v1 * b0;
-                sB[q] += bb; sBV[q] = fma(bb, v1, sBV[q]); sBV2[q] = fma(bb * v1, v1, sBV2[q]); sB0V[q] += vb0;
-                zero[q] |= (vb0 == 0.0 || bb == 0.0);
+                const double bb = sr * b0;
+                sB[q] += bb; sB0V[q] = fma(v1, b0, sB0V[q]); sBV[q] = fma(bb, v1, sBV[q]); sBV2[q] = fma(bb, v1sq, sBV2[q]);
+                if (decltype(CHECK)::value) zero[q] |= (v1 * b0 == 0.0 || bb == 0.0);
             }
             if (h2) {
                 const double b0 = single ? e[c2 + ol] : e[c2 + ol] * e[c2 + orr];
-                const double bb = sr * b0, vb0 = v2 * b0;
-                sB[q] += bb; sBV[q] = fma(bb, v2, sBV[q]); sBV2[q] = fma(bb * v2, v2, sBV2[q]); sB0V[q] += vb0;
-                zero[q] |= (vb0 == 0.0 || bb == 0.0);
+                const double bb = sr * b0;
+                sB[q] += bb; sB0V[q] = fma(v2, b0, sB0V[q]); sBV[q] = fma(bb, v2, sBV[q]); sBV2[q] = fma(bb, v2sq, sBV2[q]);
+                if (decltype(CHECK)::value) zero[q] |= (v2 * b0 == 0.0 || bb == 0.0);
             }
         }
       }
 #pragma unroll
       for (int u = 0; u < PF; ++u) { pv1[u] = nv1[u]; pv2[u] = nv2[u]; }
     }
+    };
+    if (check_any) sweep(std::true_type{}); else sweep(std::false_type{});   // one wave-uniform branch, two straight-line bodies
 #pragma unroll
     for (int q = 0; q < CAND_PER_WAVE; ++q) {
         const double tB = wave_sum(sB[q]), tBV = wave_sum(sBV[q]), tBV2 = wave_sum(sBV2[q]), tB0V = wave_sum(sB0V[q]);
