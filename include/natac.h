@@ -136,6 +136,11 @@ int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, in
                     int64_t n_jitter, int64_t *n_cand);
 int natac_download_peaks(natac_batch *b, int64_t n_cand, int32_t *cand_chunk, int32_t *cand_pos, double *lr, double *var,
                          double *z);
+/* The same peak search on ONE per-base track (no candidate statistics): utils.call_peaks(track, min_signal, sep, boundary,
+ * order), e.g. OccChunk.callPeaks on NATAC_T_OCC (nucleoatac/Occupancy.py:225-231: sep = nuc_sep, min_signal = min_occ,
+ * boundary = sep/2, order = 1).  Fetch positions with natac_download_peaks (lr / var / z may be NULL). */
+int natac_run_track_peaks(natac_batch *b, int track, double min_signal, int sep, int boundary, int order,
+                          const double *jitter, int64_t n_jitter, int64_t *n_peaks);
 /* copy one per-base track to host (float64[total_bp], or int32[total_bp] for NATAC_T_INS). Synchronises. */
 int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes);
 /* copy one per-grid-point array to host (float64[total_grid]). */

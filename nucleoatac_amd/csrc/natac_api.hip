@@ -91,6 +91,7 @@ struct natac_batch {
     int *d_slot = nullptr, *d_pk_count = nullptr, *d_pk_chunk = nullptr, *d_pk_pos = nullptr;
     long long n_jitter = 0, pk_cap = 0, pk_n = -1, slot_total = 0;
     int pk_order = -1;
+    bool pk_has_stats = false;
 };
 
 static hipError_t sync_all(natac_ctx *c) {
@@ -98,6 +99,8 @@ static hipError_t sync_all(natac_ctx *c) {
     hipError_t e2 = (c->stream2 != c->stream) ? hipStreamSynchronize(c->stream2) : hipSuccess;
     return e != hipSuccess ? e : e2;
 }
+
+static int track_ready(natac_batch *b, int t);
 
 static void prof_begin(natac_ctx *c, int k, natac_ctx::Ev &ev, hipStream_t st = nullptr) {
     ev.k = k;
@@ -678,11 +681,10 @@ int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chu
     return NATAC_OK;
 }
 
-int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, int order, const double *jitter, int64_t n_jitter,
-                    int64_t *n_cand) {
+static int run_peaks_impl(natac_batch *b, const double *sig_a, const double *sig_b, bool with_stats, double min_signal, int sep,
+                          int boundary, int order, const double *jitter, int64_t n_jitter, int64_t *n_cand) {
     if (!b || !jitter || !n_cand) return fail(NATAC_E_ARG, "null argument");
     natac_ctx *c = b->ctx;
-    if (!b->nuc_done) return fail(NATAC_E_STATE, "natac_run_nuc must run before natac_run_peaks");
     if (order < 1 || order > 255 || sep < 1 || boundary < 0) return fail(NATAC_E_ARG, "bad peak parameters");
     int maxL = 0;
     for (int i = 0; i < b->nc; ++i) maxL = std::max(maxL, b->h_len[i]);
@@ -716,7 +718,7 @@ int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, in
     if (!b->d_pk_count && (rc = dev_alloc(&b->d_pk_count, (size_t)b->nc))) return rc;
     if (!b->d_pk_offs && (rc = dev_alloc(&b->d_pk_offs, (size_t)b->nc + 1))) return rc;
     const ChunkTable ct = make_table(b);
-    const double *norm = b->d_track[NATAC_T_NORM], *sm = b->d_track[NATAC_T_SMOOTH];
+    const double *norm = sig_a, *sm = sig_b;
     natac_ctx::Ev ev;
     prof_begin(c, NATAC_K_CAND, ev);
     hipLaunchKernelGGL(natac_chunk_min_combined, dim3(b->nc), dim3(256), 0, c->stream, ct, norm, sm, b->d_cmin);
@@ -740,10 +742,13 @@ int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, in
     if (total > 0) {
         hipLaunchKernelGGL(natac_compact_candidates, dim3((b->nc + 3) / 4), dim3(256), 0, c->stream, b->nc, b->d_pk_count, b->d_pk_offs,
                            b->d_cap_off, b->d_slot, b->d_pk_chunk, b->d_pk_pos);
-        const VMatDev vm = make_vmat(c);
-        launch_candidates(c, ct, vm, b->d_pk_chunk, b->d_pk_pos, total, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM],
-                          b->d_pk_out, b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap);
+        if (with_stats) {
+            const VMatDev vm = make_vmat(c);
+            launch_candidates(c, ct, vm, b->d_pk_chunk, b->d_pk_pos, total, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM],
+                              b->d_pk_out, b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap);
+        }
     }
+    b->pk_has_stats = with_stats;
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
     b->pk_n = total;
@@ -751,19 +756,40 @@ int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, in
     return NATAC_OK;
 }
 
+int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, int order, const double *jitter, int64_t n_jitter,
+                    int64_t *n_cand) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    if (!b->nuc_done) return fail(NATAC_E_STATE, "natac_run_nuc must run before natac_run_peaks");
+    return run_peaks_impl(b, b->d_track[NATAC_T_NORM], b->d_track[NATAC_T_SMOOTH], true, min_signal, sep, boundary, order, jitter,
+                          n_jitter, n_cand);
+}
+
+int natac_run_track_peaks(natac_batch *b, int track, double min_signal, int sep, int boundary, int order, const double *jitter,
+                          int64_t n_jitter, int64_t *n_peaks) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    if (track == NATAC_T_INS) return fail(NATAC_E_ARG, "peak search needs a float64 track");
+    int rc = track_ready(b, track);
+    if (rc) return rc;
+    return run_peaks_impl(b, b->d_track[track], nullptr, false, min_signal, sep, boundary, order, jitter, n_jitter, n_peaks);
+}
+
 int natac_download_peaks(natac_batch *b, int64_t n, int32_t *cand_chunk, int32_t *cand_pos, double *lr, double *var, double *z) {
     if (!b) return fail(NATAC_E_ARG, "batch is NULL");
     if (b->pk_n < 0) return fail(NATAC_E_STATE, "natac_run_peaks has not run");
     if (n != b->pk_n) return fail(NATAC_E_ARG, "expected %lld candidates, got buffers for %lld", b->pk_n, (long long)n);
     if (n == 0) return NATAC_OK;
-    if (!cand_chunk || !cand_pos || !lr || !var || !z) return fail(NATAC_E_ARG, "null argument");
+    if (!cand_chunk || !cand_pos) return fail(NATAC_E_ARG, "null argument");
+    if ((lr || var || z) && !b->pk_has_stats) return fail(NATAC_E_STATE, "the last peak search computed no candidate statistics");
+    if (b->pk_has_stats && (!lr || !var || !z)) return fail(NATAC_E_ARG, "null argument");
     natac_ctx *c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(cand_chunk, b->d_pk_chunk, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(cand_pos, b->d_pk_pos, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(lr, b->d_pk_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(var, b->d_pk_out + b->pk_cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(z, b->d_pk_out + 2 * b->pk_cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (b->pk_has_stats) {
+        HIPCHK(hipMemcpyAsync(lr, b->d_pk_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(var, b->d_pk_out + b->pk_cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(z, b->d_pk_out + 2 * b->pk_cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
     return NATAC_OK;

@@ -1085,7 +1085,7 @@ __global__ void __launch_bounds__(256) natac_chunk_min_combined(ChunkTable ct, c
     const long long ob = ct.out_off[chunk];
     double mn = __builtin_inf();
     for (int g = threadIdx.x; g < L; g += 256) {
-        const double v = norm[ob + g] + smooth[ob + g];
+        const double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
         if (v == v) mn = fmin(mn, v);
     }
     mn = wave_min(mn);
@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(256) natac_peak_flags(ChunkTable ct, const int
     for (int u = threadIdx.x; u < 256 + 2 * order; u += 256) {
         int g = x0 - order + u;
         g = g < 0 ? 0 : (g > L - 1 ? L - 1 : g);                 // numpy take(..., mode='clip')
-        double v = norm[ob + g] + smooth[ob + g];
+        double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
         if (v != v) v = fillv;
         ys[u] = v * (1 + jitter[g]);
     }
@@ -1121,7 +1121,7 @@ __global__ void __launch_bounds__(256) natac_peak_flags(ChunkTable ct, const int
     for (int sft = 1; sft <= order && pk; ++sft)
         pk = (y > ys[threadIdx.x + order + sft]) && (y > ys[threadIdx.x + order - sft]);
     if (pk) {
-        double v = norm[ob + g] + smooth[ob + g];
+        double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
         if (v != v) v = fillv;
         pk = (v >= min_signal) && (g >= boundary) && (g < L - boundary);
     }
@@ -1160,7 +1160,7 @@ __global__ void __launch_bounds__(256) natac_peak_reduce(ChunkTable ct, const un
         if (f) {
             const int i = off + __popcll(m & ((1ull << lane) - 1ull));
             if (i < PEAK_MAX) {
-                double v = norm[ob + g] + smooth[ob + g];
+                double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
                 if (v != v) v = fillv;
                 pos[i] = g;
                 sig[i] = v;

@@ -295,6 +295,21 @@ class DeviceBatch(object):
         L.check(self._lib.natac_download_peaks(self._h, n, _ptr(cc), _ptr(cp), _ptr(lr), _ptr(var), _ptr(z)))
         return cc, cp, lr, var, z
 
+    def run_track_peaks(self, track, min_signal=0.0, sep=120, boundary=None, order=1):
+        """utils.call_peaks on one per-base track of every chunk, on the device (natac_run_track_peaks).
+        Returns (chunk, pos) arrays in chunk order."""
+        if boundary is None:
+            boundary = sep // 2
+        maxL = int(self.packed.chunk_len.max())
+        jitter = np.ascontiguousarray(np.random.RandomState(seed=25).uniform(0, 10 ** -12, maxL))
+        n = C.c_int64(0)
+        L.check(self._lib.natac_run_track_peaks(self._h, int(track), float(min_signal), int(sep), int(boundary), int(order),
+                                                _ptr(jitter), maxL, C.byref(n)))
+        n = n.value
+        cc, cp = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        L.check(self._lib.natac_download_peaks(self._h, n, _ptr(cc), _ptr(cp), None, None, None))
+        return cc, cp
+
     def track(self, t):
         """download one per-base track (concatenated over chunks)"""
         dt = np.int32 if t == L.T_INS else np.float64

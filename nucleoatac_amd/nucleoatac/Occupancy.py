@@ -172,8 +172,15 @@ def occ_batch(chunks, params, ctx=None, with_flat=False):
     run = BatchRunner(pk, ctx)
     try:
         res = run.occ()
+        # OccChunk.callPeaks (Occupancy.py:225-231) for every chunk on the device: call_peaks(smoothed_vals, sep, min_occ)
+        from .. import _lib as L
+        pk_chunk, pk_pos = run.batch.run_track_peaks(L.T_OCC, min_signal=params.min_occ, sep=params.sep,
+                                                     boundary=params.sep // 2, order=1)
+        if (run.batch.status() & 2).any():
+            raise Exception("chunk too long for the device peak finder (more than 2048 local maxima)")
     finally:
         run.close()
+    bounds = np.searchsorted(pk_chunk, np.arange(len(chunks) + 1))
     out = []
     for k, ch in enumerate(chunks):
         oc = OccChunk(ch)
@@ -187,7 +194,7 @@ def occ_batch(chunks, params, ctx=None, with_flat=False):
         oc.occ.smoothed_upper = res["smoothed_upper"][k].copy()
         oc.cov = CoverageTrack(ch.chrom, ch.start, ch.end)
         oc.cov.vals = res["cov"][k].copy()
-        oc.callPeaks()
+        oc.callPeaks(peaks=pk_pos[int(bounds[k]):int(bounds[k + 1])])
         out.append(oc)
     if with_flat:
         # smoothed_vals was NaN-filled on the device exactly like call_peaks does in place, so the flat array is what
@@ -206,8 +213,10 @@ class OccChunk(Chunk):
         self.peaks = {}
         self.nfrs = []
 
-    def callPeaks(self):
-        peaks = call_peaks(self.occ.smoothed_vals, sep=self.params.sep, min_signal=self.params.min_occ)
+    def callPeaks(self, peaks=None):
+        """occupancy peaks (Occupancy.py:225-231); `peaks` = positions already found on the device by occ_batch"""
+        if peaks is None:
+            peaks = call_peaks(self.occ.smoothed_vals, sep=self.params.sep, min_signal=self.params.min_occ)
         for peak in peaks:
             tmp = OccPeak(int(peak) + self.start, self)
             if tmp.occ_lower > self.params.min_occ and tmp.reads > 0:

@@ -95,3 +95,25 @@ def test_run_peaks_argument_errors(ctx):
     with pytest.raises(L.NatacError):
         b.run_peaks(order=0)
     b.free()
+
+
+def test_track_peaks_on_occupancy_equal_host_call_peaks(ctx):
+    """OccChunk.callPeaks parameters (sep 120, min_signal 0.1, order 1) on the NaN-filled smoothed occupancy track"""
+    from oracle import natac_oracle as O
+    from nucleoatac_amd.synth import synth_occ_distributions
+    nucp, nfrp = synth_occ_distributions(251)
+    ctx.set_occ_model(nucp, nfrp, step=5, flank=60)
+    pk = make_synthetic_chunks(2000, 1501, 300, seed=33)
+    b = ctx.upload(pk)
+    with pytest.raises(L.NatacError):
+        b.run_track_peaks(L.T_OCC)          # stage has not run
+    b.run_occ()
+    cc, cp = b.run_track_peaks(L.T_OCC, min_signal=0.1, sep=120, boundary=60, order=1)
+    occ = b.split(b.track(L.T_OCC))
+    hc, hp = [], []
+    for k in range(pk.n_chunks):
+        p = O.call_peaks(occ[k].copy(), sep=120, min_signal=0.1)
+        hc += [k] * len(p)
+        hp += [int(x) for x in p]
+    assert len(cc) > 3000 and np.array_equal(cc, hc) and np.array_equal(cp, hp)
+    b.free()

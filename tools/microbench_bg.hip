@@ -184,6 +184,103 @@ float run3(const ChunkTable &ct, const VMatDev &vm, int nc, int L, double *d_a, 
     return best;
 }
 
+// ---- variant 6: explicit 4-deep register prefetch of the product row in the sweep (scalar-loaded template as MODE 0)
+// ---- variant 7: two rows per barrier (two product buffers built, then both swept)
+template <int G, int W, int MODE>
+__global__ void __launch_bounds__(64) bg_variant2(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
+                                                    const double *__restrict__ nuc_cov, const double *__restrict__ raw,
+                                                    double *__restrict__ bg, double *__restrict__ norm) {
+    constexpr int TW = WAVE * G, HW = W / 2, PW = TW + W - 1, NQ = (PW + WAVE - 1) / WAVE, PWP = (PW + 1) & ~1;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, x0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
+    const int EW = PW + A + Bh;
+    double *Et = smem;
+    double *P0 = smem + ((EW + 1) & ~1);
+    double *P1 = P0 + PWP;
+    {
+        const double *b = ct.bias + ct.bias_off[chunk];
+        const int nb = L + ct.bias_left + ct.bias_right;
+        const int j0 = x0 - HW - A + ct.bias_left;
+        for (int u = lane; u < EW; u += WAVE) { const int j = j0 + u; Et[u] = (j >= 0 && j < nb) ? exp(b[j]) : 0.0; }
+    }
+    __syncthreads();
+    double acc[G]; double q[NQ];
+#pragma unroll
+    for (int k = 0; k < G; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) q[k] = 0.0;
+    const int ub = lane * G;
+    auto build = [&](int r, double *__restrict__ Pb) {
+        const int i = vm.lower + r;
+        const int hl = floor_half(i - 1), hr = floor_half(i);
+        const double s = vm.srow[r];
+        const double *el = Et + (A - hl); const double *er = Et + (A + hr);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) { const int u = lane + WAVE * k; if (u < PW) { const double p = (s * el[u]) * er[u]; q[k] += p; Pb[u] = p; } }
+    };
+    auto sweep = [&](int r, const double *__restrict__ Pb) {
+        const double *__restrict__ vr = vm.mat + r * W;
+        const double *pl = Pb + ub;
+        if (MODE == 6) {
+            constexpr int D = 4;
+            double pw[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) pw[d] = pl[d];
+#pragma unroll
+            for (int j = 0; j < G + W - 1; ++j) {
+                const double p = pw[j % D];
+                if (j + D < G + W - 1) pw[j % D] = pl[j + D];
+#pragma unroll
+                for (int k = 0; k < G; ++k) { const int c = j - k; if (c >= 0 && c < W) acc[k] = fma(p, vr[c], acc[k]); }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G + W - 1; ++j) { const double p = pl[j];
+#pragma unroll
+                for (int k = 0; k < G; ++k) { const int c = j - k; if (c >= 0 && c < W) acc[k] = fma(p, vr[c], acc[k]); } }
+        }
+    };
+    if (MODE == 6) {
+        for (int r = 0; r < vm.R; ++r) { build(r, P0); __syncthreads(); sweep(r, P0); __syncthreads(); }
+    } else {
+        int r = 0;
+        for (; r + 1 < vm.R; r += 2) { build(r, P0); build(r + 1, P1); __syncthreads(); sweep(r, P0); sweep(r + 1, P1); __syncthreads(); }
+        if (r < vm.R) { build(r, P0); __syncthreads(); sweep(r, P0); }
+    }
+    const long long ob = ct.out_off[chunk];
+#pragma unroll
+    for (int k = 0; k < G; ++k) { const int g = x0 + ub + k; if (g < L) { bg[ob + g] = acc[k] + q[k % NQ]; norm[ob + g] = acc[k]; } }
+}
+
+template <int G, int MODE>
+float run4(const ChunkTable &ct, const VMatDev &vm, int nc, int L, double *d_a, double *d_b, double *d_o1, double *d_o2, int reps) {
+    const int TW = 64 * G;
+    std::vector<int2> tiles;
+    for (int i = 0; i < nc; ++i) for (int x = 0; x < L; x += TW) tiles.push_back(make_int2(i, x));
+    int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2)));
+    CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
+    const int PW = TW + 120, EW = PW + 249;
+    size_t lds = ((size_t)((EW + 1) & ~1) + 2 * ((PW + 1) & ~1)) * 8;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int it = 0; it < reps + 1; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((bg_variant2<G, 121, MODE>), dim3(tiles.size()), dim3(64), lds, 0, ct, d_t, vm, d_a, d_b, d_o1, d_o2);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0 && ms < best) best = ms;
+    }
+    CK(hipGetLastError());
+    double flop = 2.0 * 146 * 121 * (double)nc * L;
+    printf("G=%2d VARIANT %d tiles=%zu lds=%zu  %.3f ms  %.2f TFLOP/s (useful)\n", G, MODE, tiles.size(), lds, best, flop / best / 1e9);
+    CK(hipFree(d_t));
+    return best;
+}
+
 int main(int argc, char **argv) {
     int nc = argc > 1 ? atoi(argv[1]) : 20000, L = 2120, F = 0;
     const int R = 146, W = 121, lo = 105, up = 251, bl = 246, br = 247;
@@ -205,6 +302,10 @@ int main(int argc, char **argv) {
     ct.nc = nc; ct.chunk_len = d_len; ct.frag_off = d_foff; ct.bias_off = d_boff; ct.bias = d_bias; ct.bias_left = bl; ct.bias_right = br; ct.out_off = d_ooff;
     v.mat = d_vm; v.srow = d_srow; v.lower = lo; v.upper = up; v.w = 60; v.R = R; v.W = W;
     (void)F;
+    run4<9, 6>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
+    run4<17, 6>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
+    run4<9, 7>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
+    run4<17, 7>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
     run<9, 4>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
     run<17, 4>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
     run<13, 4>(ct, v, nc, L, d_a, d_b, d_o1, d_o2, 2);
