@@ -17,7 +17,8 @@ def get_context():
     global _default_ctx
     if _default_ctx is None:
         from .device import Context
-        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+        # one context per process: GPU = LOCAL_RANK (torchrun); NATAC_DEVICE overrides it (e.g. several ranks on one GPU in tests)
+        _default_ctx = Context(int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     return _default_ctx
 
 

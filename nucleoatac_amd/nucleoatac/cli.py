@@ -62,9 +62,31 @@ def nucleoatac_main(args):
         raise SystemExit("usage: nucleoatac {occ,nuc} ...")
 
 
+def _init_distributed():
+    """under torchrun (WORLD_SIZE > 1) the chunk list is sharded over the ranks; torch.distributed (RCCL = backend "nccl",
+    or NATAC_DIST_BACKEND=gloo) only carries the barrier and the gather of small per-chunk results"""
+    import os
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        backend = os.environ.get("NATAC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            import torch
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return dist
+
+
 def main(argv=None):
     args = nucleoatac_parser().parse_args(argv)
-    nucleoatac_main(args)
+    dist = _init_distributed()
+    try:
+        nucleoatac_main(args)
+    finally:
+        if dist is not None and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
