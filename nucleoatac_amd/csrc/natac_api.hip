@@ -92,6 +92,7 @@ struct natac_batch {
     long long n_jitter = 0, pk_cap = 0, pk_n = -1, slot_total = 0;
     int pk_order = -1;
     bool pk_has_stats = false;
+    int nuc_w = -1, nuc_upper = -1;   // V-plot geometry natac_run_nuc ran with (coverage tracks depend on it)
 };
 
 static hipError_t sync_all(natac_ctx *c) {
@@ -538,6 +539,8 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
     b->nuc_done = true;
+    b->nuc_w = c->vw;
+    b->nuc_upper = c->vupper;
     return NATAC_OK;
 }
 
@@ -609,7 +612,7 @@ int natac_run_occ(natac_batch *b) {
         hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream2, ct, b->d_tiles256, om, c->d_win_occ, M,
                            b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_track[NATAC_T_OCC_PREFILL],
                            b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER]);
-        if (b->nuc_done && c->have_vmat && c->flank == c->vw && c->occ_upper == c->vupper)
+        if (b->nuc_done && c->flank == b->nuc_w && c->occ_upper == b->nuc_upper)
             hipLaunchKernelGGL(natac_add_tracks, dim3(4096), dim3(256), 0, c->stream2, b->d_track[NATAC_T_NUC_COV],
                                b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_OCC_COV], b->total_bp);
         else

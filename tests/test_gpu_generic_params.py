@@ -1,0 +1,80 @@
+"""GPU: non-default parameters take the generic kernels (natac_background_generic, natac_occ_mle<0,0>, natac_occ_cov,
+runtime-width smoothing): trimmed V-plot (W = 101, rows 110..240), occupancy with step 3 / flank 45 / upper 200,
+smoothing sd 7, a 65-point alpha grid -- all against the oracle."""
+import numpy as np
+import pytest
+
+from helpers import assert_track, expand_grid, golden
+from nucleoatac_amd import _lib as L
+from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions, synth_size_distribution
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generic_vmat_geometry():
+    from nucleoatac_amd.device import Context
+    from oracle import natac_oracle as O
+    par = golden("params_example")
+    vlo, vup, w = 110, 240, 50
+    vm = np.ascontiguousarray(par["vmat"][vlo - 105:vup - 105, 60 - w:60 + w + 1])
+    sizes = synth_size_distribution(251)[:vup]
+    pk = make_synthetic_chunks(40, 777, 260, seed=17)
+    with Context(0) as c:
+        c.set_vmat(vm, vlo, vup)
+        c.set_sizes(sizes)
+        b = c.upload(pk)
+        b.run_nuc(7)
+        tr = {t: b.split(b.track(t)) for t in (L.T_NUC_COV, L.T_NFR_COV, L.T_RAW, L.T_BACKGROUND, L.T_NORM, L.T_SMOOTH)}
+        cc, cp, lr, var, z = b.run_peaks(min_signal=0, sep=21, boundary=40, order=10)
+        for k in (0, 13, 39):
+            l, n = pk.chunk_frags(k)
+            nt = O.nuc_chunk_tracks(l.astype(np.int64), n.astype(np.int64), 0, 777, pk.chunk_bias(k), -246, vm, vlo, vup, sizes,
+                                    smooth_sd=7)
+            assert_track(tr[L.T_NUC_COV][k], nt["nuc_cov"], "nuc_cov", exact=True)
+            assert_track(tr[L.T_NFR_COV][k], nt["nfr_cov"], "nfr_cov", exact=True)
+            assert_track(tr[L.T_RAW][k], nt["raw"], "raw")
+            assert_track(tr[L.T_BACKGROUND][k], nt["bg"], "bg")
+            assert_track(tr[L.T_NORM][k], nt["norm"], "norm")
+            assert_track(tr[L.T_SMOOTH][k], nt["smoothed"], "smoothed")
+            hp = O.call_peaks((tr[L.T_NORM][k] + tr[L.T_SMOOTH][k]).copy(), min_signal=0, sep=21, boundary=40, order=10)
+            mine = cp[cc == k]
+            assert np.array_equal(mine, hp)
+            for pos, lrv, varv in list(zip(mine, lr[cc == k], var[cc == k]))[:4]:
+                ref_lr = O.get_lr(nt["mat"], nt["mat_start"], nt["bmat"], nt["b0"], nt["b_start"], vm, vlo, vup, int(pos))
+                assert abs(lrv - ref_lr) <= 1e-7 * max(1.0, abs(ref_lr))
+                pr = O.signal_distribution_probs(nt["bmat"], nt["b_start"], vlo, vup, w, int(pos))
+                ref_var = O.calculate_cov_closed(pr, np.ravel(vm), nt["nuc_cov"][pos])
+                assert abs(varv - ref_var) <= 1e-7 * max(1e-12, abs(ref_var))
+        b.free()
+
+
+def test_generic_occupancy_parameters():
+    from nucleoatac_amd.device import Context
+    from oracle import natac_oracle as O
+    upper, flank, step = 200, 45, 3
+    nucp, nfrp = synth_occ_distributions(251)
+    nucp, nfrp = nucp[:upper] / nucp[:upper].sum(), nfrp[:upper] / nfrp[:upper].sum()
+    alphas = np.linspace(0, 1, 65)
+    pk = make_synthetic_chunks(30, 641, 220, seed=23)
+    with Context(0) as c:
+        c.set_occ_model(nucp, nfrp, alphas=alphas, cutoff=3.841458820694124, step=step, flank=flank)   # chi2.ppf(0.95, 1)
+        b = c.upload(pk)
+        b.run_occ()
+        assert not b.status().any()
+        grids = [b.grid(g) for g in (L.G_OCC, L.G_LOWER, L.G_UPPER)]
+        sm = {t: b.split(b.track(t)) for t in (L.T_OCC_PREFILL, L.T_OCC_LOWER, L.T_OCC_UPPER, L.T_OCC_COV)}
+        nk = len(range(1, 641, 3))
+        for k in (0, 11, 29):
+            l, n = pk.chunk_frags(k)
+            oc = O.occ_chunk_tracks(l.astype(np.int64), n.astype(np.int64), 0, 641, pk.chunk_bias(k), -246, nucp, nfrp, upper=upper,
+                                    flank=flank, step=step, cutoff=3.841458820694124, n_alpha=65)
+            for gi, key in enumerate(("occ", "occ_lower", "occ_upper")):
+                assert_track(expand_grid(grids[gi][k * nk:(k + 1) * nk], 641, step), oc[key], key, exact=True)
+            assert_track(sm[L.T_OCC_PREFILL][k], oc["smoothed_vals"], "smoothed")
+            assert_track(sm[L.T_OCC_LOWER][k], oc["smoothed_lower"], "smoothed_lower")
+            assert_track(sm[L.T_OCC_UPPER][k], oc["smoothed_upper"], "smoothed_upper")
+            assert_track(sm[L.T_OCC_COV][k], oc["cov"], "cov", exact=True)
+        b.free()
+        # even step is decremented like the reference (Occupancy.py:190-191)
+        c.set_occ_model(nucp, nfrp, alphas=alphas, cutoff=3.84, step=4, flank=flank)
+        assert c.occ_step == 3
