@@ -1140,7 +1140,6 @@ __global__ void __launch_bounds__(256) natac_peak_reduce(ChunkTable ct, const un
     __shared__ int ord[PEAK_MAX];
     __shared__ unsigned char state[PEAK_MAX];   // 0 free, 1 kept, 2 excluded
     __shared__ int wave_cnt[4];
-    __shared__ int n_sh;
     const int chunk = blockIdx.x;
     const int L = ct.chunk_len[chunk];
     const long long ob = ct.out_off[chunk];
@@ -1192,7 +1191,6 @@ __global__ void __launch_bounds__(256) natac_peak_reduce(ChunkTable ct, const un
         for (int i = 0; i < n; ++i) if (state[i] == 1) dst[m++] = pos[i];
         count[chunk] = m;
         if (overflow) atomicOr(&status[chunk], 2);
-        n_sh = m;
     }
 }
 
