@@ -2,6 +2,7 @@
 // Host-side runtime: contexts, batches of packed chunks resident in HBM, tile tables, launches, profiling.
 #include "../../include/natac.h"
 #include "natac_kernels.hpp"
+#include "natac_fft_bg.hpp"
 #include "natac_writer.hpp"
 #include "natac_bam.hpp"
 
@@ -45,6 +46,9 @@ struct natac_ctx {
     int vlower = 0, vupper = 0, vw = 0, R = 0, W = 0, sizes_upper = 0;
     bool have_vmat = false, have_sizes = false, srow_dirty = true;
     bool vmat_zero = false, srow_zero = false;
+    // FFT background path: twiddles (once) and template spectra (per V-plot)
+    double *d_fft_tw = nullptr, *d_fft_k = nullptr;
+    bool fft_dirty = true, bg_direct = false;
     std::vector<double> h_sizes;
     double *d_nucp = nullptr, *d_nfrp = nullptr, *d_alphas = nullptr;
     int occ_upper = 0, n_alpha = 0, step = 0, halfstep = 0, flank = 0;
@@ -79,7 +83,7 @@ struct natac_batch {
     double *d_bias = nullptr;
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
     int ranges256_w = -1;
-    int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;
+    int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;   // bgG: lanes' output count of the direct kernel, -1 = FFT tiles
     int grid_step = 0, grid_half = 0;
     double *d_track[NATAC_T_COUNT] = {nullptr};
     double *d_grid[3] = {nullptr, nullptr, nullptr};
@@ -228,6 +232,10 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
     c->stream2 = c->stream;
     HIPCHK(hipEventCreate(&c->t0));
     HIPCHK(hipEventCreate(&c->t1));
+    {   // NATAC_BG_DIRECT=1 selects the direct-summation background kernel (validation / A-B timing of the FFT path)
+        const char *e = getenv("NATAC_BG_DIRECT");
+        c->bg_direct = e && e[0] == '1';
+    }
     *out = c;
     return NATAC_OK;
 }
@@ -240,6 +248,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     dev_free(c->d_vmat); dev_free(c->d_srow); dev_free(c->d_sizes);
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
     dev_free(c->d_win_nuc); dev_free(c->d_win_occ);
+    dev_free(c->d_fft_tw); dev_free(c->d_fft_k);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -279,6 +288,7 @@ int natac_set_vmat(natac_ctx *c, const double *mat, int lower, int upper, int w)
     HIPCHK(sync_all(c));
     c->have_vmat = true;
     c->srow_dirty = true;
+    c->fft_dirty = true;
     return NATAC_OK;
 }
 
@@ -333,6 +343,38 @@ static int ensure_srow(natac_ctx *c) {
     c->srow_zero = false;
     for (int r = 0; r < c->R; ++r) if (c->h_sizes[(size_t)c->vlower + r] == 0.0) c->srow_zero = true;
     c->srow_dirty = false;
+    return NATAC_OK;
+}
+
+// FFT background path applies when the valid part of a 512-point tile is still most of it and the product row has no
+// single-cell special case (i == 1, handled by the generic kernel)
+static bool fft_bg_applicable(const natac_ctx *c) {
+    if (c->bg_direct || c->W > 192 || c->vlower < 2) return false;
+    const int EW = natac::FFT_N + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
+    return ((size_t)((EW + 1) & ~1) + 2 * natac::FFT_LA) * sizeof(double) <= 64 * 1024;
+}
+
+static int ensure_fft(natac_ctx *c) {
+    int rc;
+    if (!c->d_fft_tw) {
+        std::vector<double> tw(2 * (size_t)natac::FFT_N);
+        for (int k = 0; k < natac::FFT_N; ++k) {
+            const double a = 2.0 * M_PI * k / natac::FFT_N;
+            tw[2 * k] = std::cos(a);
+            tw[2 * k + 1] = -std::sin(a);
+        }
+        if ((rc = dev_upload(c, &c->d_fft_tw, tw.data(), tw.size()))) return rc;
+        HIPCHK(sync_all(c));
+    }
+    if (!c->fft_dirty) return NATAC_OK;
+    HIPCHK(sync_all(c));
+    dev_free(c->d_fft_k);
+    c->d_fft_k = nullptr;
+    const int npair = (c->R + 1) / 2;
+    if ((rc = dev_alloc(&c->d_fft_k, (size_t)npair * 2 * natac::FFT_N))) return rc;
+    hipLaunchKernelGGL(natac_fft_template, dim3(npair), dim3(64), 0, c->stream, c->d_vmat, c->R, c->W, c->d_fft_tw, c->d_fft_k);
+    HIPCHK(hipGetLastError());
+    c->fft_dirty = false;
     return NATAC_OK;
 }
 
@@ -494,8 +536,16 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     if ((rc = ensure_window(c, &c->d_win_nuc, &c->win_nuc_M, &c->win_nuc_sd, M, smooth_sd))) return rc;
     for (int t : {NATAC_T_NUC_COV, NATAC_T_NFR_COV, NATAC_T_RAW, NATAC_T_BACKGROUND, NATAC_T_NORM, NATAC_T_SMOOTH})
         if ((rc = ensure_track(b, t))) return rc;
-    const bool fast = (c->W == 121 && c->vlower >= 2);
-    if (fast) {
+    const bool use_fft = fft_bg_applicable(c);
+    const bool fast = !use_fft && (c->W == 121 && c->vlower >= 2);
+    if (use_fft) {
+        if ((rc = ensure_fft(c))) return rc;
+        const int TV = FFT_N - c->W + 1;
+        if (b->bgG != -TV) {
+            if ((rc = build_tiles(b, TV, &b->d_tiles_bg, &b->n_tiles_bg))) return rc;
+            b->bgG = -TV;
+        }
+    } else if (fast) {
         const int G = choose_bg_G(b, c->W);
         if (G != b->bgG) {
             if ((rc = build_tiles(b, 64 * G, &b->d_tiles_bg, &b->n_tiles_bg))) return rc;
@@ -516,7 +566,13 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
                        b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_RAW]);
     prof_end(c, ev);
     prof_begin(c, NATAC_K_BACKGROUND, ev);
-    if (fast) {
+    if (use_fft) {
+        const int EW = FFT_N + ((vm.upper - 2) >> 1) + ((vm.upper - 1) >> 1);
+        const size_t lds = ((size_t)((EW + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
+        hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
+                           c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
+                           b->d_track[NATAC_T_NORM]);
+    } else if (fast) {
         switch (b->bgG) {
             case 7: launch_bg<7>(b, ct, vm); break;
             case 9: launch_bg<9>(b, ct, vm); break;

@@ -1,0 +1,294 @@
+// natac_fft_bg.hpp -- dense background correlation through hand-written fp64 FFTs (gfx950).
+//
+// Same quantity as natac_background (natac_kernels.hpp): num[g] = sum_r sum_c B[lower+r, g-w+c] V[r,c], i.e. the sum over
+// V-plot rows of 1-D cross-correlations of the product row P_r with the template row V_r (NucleosomeCalling.py:60-63;
+// the reference's scipy.signal.correlate also picks an FFT for these sizes).  Direct evaluation costs W = 121 FMA per
+// base and row; here
+//   * two rows are packed into one complex signal  z = P_a + i P_b  and the template pair into  k = V_a + i V_b :
+//       sum_c z[g+c] conj(k[c]) = (P_a*V_a + P_b*V_b)[g] + i (...)   -> the real part is the sum of both correlations;
+//   * one wave transforms z with a 512-point radix-8 FFT (8 complex values per lane, three in-register 8-point DFTs, two
+//     LDS transposes with conflict-free layouts), multiplies by conj(K) (K = FFT(k), precomputed with the SAME transform,
+//     so no bit-reversal is ever undone) and ACCUMULATES IN THE FREQUENCY DOMAIN over all row pairs;
+//   * one inverse FFT per tile gives 512 - W + 1 = 392 valid outputs (no wrap-around inside the valid range).
+// Cost per row pair and tile: ~350 fp64 ops per lane instead of 2 x 121 x 6.1 = 1480 for the same outputs (~4x fewer),
+// numerics: forward error ~1e-15 relative to the tile's signal norm (tests: <= 1e-12 vs the direct kernel).
+#pragma once
+#include "natac_kernels.hpp"
+
+namespace natac {
+
+constexpr int FFT_N = 512;
+constexpr int FFT_LA = 576;   // layout A: p + 8 * (p >> 6)
+constexpr int FFT_LB = 520;   // layout B: (p & 7) * 65 + (p >> 3)
+
+// 8-point DFT in registers, natural order in and out.  INV: conjugate twiddles (unnormalised inverse).
+template <bool INV>
+__device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
+    const double h = 0.70710678118654752440;
+    double ar[8], ai[8];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        ar[n] = re[n] + re[n + 4]; ai[n] = im[n] + im[n + 4];
+        ar[n + 4] = re[n] - re[n + 4]; ai[n + 4] = im[n] - im[n + 4];
+    }
+    // even outputs: DFT4 of a0..a3
+    {
+        const double b0r = ar[0] + ar[2], b0i = ai[0] + ai[2], b2r = ar[0] - ar[2], b2i = ai[0] - ai[2];
+        const double b1r = ar[1] + ar[3], b1i = ai[1] + ai[3];
+        const double tr = ar[1] - ar[3], ti = ai[1] - ai[3];
+        const double b3r = INV ? -ti : ti, b3i = INV ? tr : -tr;          // * (-i) forward, * (+i) inverse
+        re[0] = b0r + b1r; im[0] = b0i + b1i; re[4] = b0r - b1r; im[4] = b0i - b1i;
+        re[2] = b2r + b3r; im[2] = b2i + b3i; re[6] = b2r - b3r; im[6] = b2i - b3i;
+    }
+    // odd outputs: DFT4 of a4, a5 W, a6 W^2, a7 W^3  with W = exp(-+ i pi/4)
+    {
+        const double c0r = ar[4], c0i = ai[4];
+        double c1r, c1i, c2r, c2i, c3r, c3i;
+        if (!INV) {
+            c1r = (ar[5] + ai[5]) * h; c1i = (ai[5] - ar[5]) * h;            // (1 - i)/sqrt2
+            c2r = ai[6]; c2i = -ar[6];                                        // -i
+            c3r = (ai[7] - ar[7]) * h; c3i = -(ai[7] + ar[7]) * h;           // (-1 - i)/sqrt2
+        } else {
+            c1r = (ar[5] - ai[5]) * h; c1i = (ai[5] + ar[5]) * h;            // (1 + i)/sqrt2
+            c2r = -ai[6]; c2i = ar[6];                                        // +i
+            c3r = -(ar[7] + ai[7]) * h; c3i = (ar[7] - ai[7]) * h;           // (-1 + i)/sqrt2
+        }
+        const double d0r = c0r + c2r, d0i = c0i + c2i, d2r = c0r - c2r, d2i = c0i - c2i;
+        const double d1r = c1r + c3r, d1i = c1i + c3i;
+        const double tr = c1r - c3r, ti = c1i - c3i;
+        const double d3r = INV ? -ti : ti, d3i = INV ? tr : -tr;
+        re[1] = d0r + d1r; im[1] = d0i + d1i; re[5] = d0r - d1r; im[5] = d0i - d1i;
+        re[3] = d2r + d3r; im[3] = d2i + d3i; re[7] = d2r - d3r; im[7] = d2i - d3i;
+    }
+}
+
+struct FftTwiddles {            // per-lane twiddles, loaded once per kernel
+    double w1r[8], w1i[8];      // W_512^(lane * m)
+    double w2r[8], w2i[8];      // W_64^((lane & 7) * m)
+};
+
+__device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *__restrict__ tw /* [512][2] cos, -sin */, int lane) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = (lane * m) & 511, b = (((lane & 7) * m) * 8) & 511;
+        t.w1r[m] = tw[2 * a]; t.w1i[m] = tw[2 * a + 1];
+        t.w2r[m] = tw[2 * b]; t.w2i[m] = tw[2 * b + 1];
+    }
+}
+
+// forward 512-point FFT of the wave's data (lane n, register j <-> element n + 64 j); result: lane b, register m holds the
+// bin of "stage-3 butterfly b, output m" (a fixed permutation of the frequencies, identical for signal and template).
+// sa / sb: the wave's LDS scratch, FFT_LA and FFT_LB doubles for the real and for the imaginary parts each.
+__device__ __forceinline__ void fft512_fwd(double (&re)[8], double (&im)[8], const FftTwiddles &t, double *sar, double *sai,
+                                           double *sbr, double *sbi, int lane) {
+    dft8<false>(re, im);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 1 (layout A: lane + 72 m)
+        const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])), xi = fma(re[m], t.w1i[m], im[m] * t.w1r[m]);
+        sar[lane + 72 * m] = m ? xr : re[0];
+        sai[lane + 72 * m] = m ? xi : im[0];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int m2 = lane >> 3, n1 = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { re[j] = sar[72 * m2 + n1 + 8 * j]; im[j] = sai[72 * m2 + n1 + 8 * j]; }
+    __builtin_amdgcn_wave_barrier();   // sb* may alias sa*
+    dft8<false>(re, im);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 2 (layout B: element n1 of butterfly 8 m2 + m)
+        const double xr = fma(re[m], t.w2r[m], -(im[m] * t.w2i[m])), xi = fma(re[m], t.w2i[m], im[m] * t.w2r[m]);
+        sbr[n1 * 65 + 8 * m2 + m] = m ? xr : re[0];
+        sbi[n1 * 65 + 8 * m2 + m] = m ? xi : im[0];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { re[n] = sbr[n * 65 + lane]; im[n] = sbi[n * 65 + lane]; }
+    dft8<false>(re, im);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// exact inverse of fft512_fwd up to the factor 512
+__device__ __forceinline__ void fft512_inv(double (&re)[8], double (&im)[8], const FftTwiddles &t, double *sar, double *sai,
+                                           double *sbr, double *sbi, int lane) {
+    dft8<true>(re, im);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) { sbr[n * 65 + lane] = re[n]; sbi[n * 65 + lane] = im[n]; }
+    __builtin_amdgcn_wave_barrier();
+    const int m2 = lane >> 3, n1 = lane & 7;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const double xr = sbr[n1 * 65 + 8 * m2 + m], xi = sbi[n1 * 65 + 8 * m2 + m];
+        re[m] = m ? fma(xr, t.w2r[m], xi * t.w2i[m]) : xr;                 // * conj(W)
+        im[m] = m ? fma(xi, t.w2r[m], -(xr * t.w2i[m])) : xi;
+    }
+    __builtin_amdgcn_wave_barrier();
+    dft8<true>(re, im);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sar[72 * m2 + n1 + 8 * j] = re[j]; sai[72 * m2 + n1 + 8 * j] = im[j]; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const double xr = sar[lane + 72 * m], xi = sai[lane + 72 * m];
+        re[m] = m ? fma(xr, t.w1r[m], xi * t.w1i[m]) : xr;
+        im[m] = m ? fma(xi, t.w1r[m], -(xr * t.w1i[m])) : xi;
+    }
+    dft8<true>(re, im);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// K[pair] = FFT(V_a + i V_b) in the layout fft512_fwd produces; kout[pair][re/im][m][lane].  One wave per pair.
+__global__ void __launch_bounds__(64) natac_fft_template(const double *__restrict__ vmat, int R, int W, const double *__restrict__ tw,
+                                                           double *__restrict__ kout) {
+    __shared__ double sar[FFT_LA], sai[FFT_LA], sbr[FFT_LB], sbi[FFT_LB];
+    const int lane = threadIdx.x, pair = blockIdx.x;
+    const int ra = 2 * pair, rb = 2 * pair + 1;
+    FftTwiddles t;
+    fft_load_twiddles(t, tw, lane);
+    double re[8], im[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int u = lane + 64 * j;
+        re[j] = (u < W) ? vmat[ra * W + u] : 0.0;
+        im[j] = (u < W && rb < R) ? vmat[rb * W + u] : 0.0;
+    }
+    fft512_fwd(re, im, t, sar, sai, sbr, sbi, lane);
+    double *o = kout + (size_t)pair * 2 * FFT_N;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { o[m * 64 + lane] = re[m]; o[FFT_N + m * 64 + lane] = im[m]; }
+}
+
+// background + normalised signal for tiles of TV = 512 - W + 1 bases; one tile per wave, one wave per workgroup.
+// Tiles whose bias window is not well conditioned for an FFT (non-finite or zero values, or a dynamic range > 1e4, where the
+// FFT's error -- relative to the tile's largest product -- could show in the smallest outputs, and where a NaN must stay
+// confined to the bases whose window touches it) are evaluated by direct summation in the same order as natac_background.
+constexpr double FFT_MAX_RANGE = 1e4;
+
+__global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
+                                                             const double *__restrict__ tw, const double *__restrict__ ktab,
+                                                             const double *__restrict__ nuc_cov, const double *__restrict__ raw,
+                                                             double *__restrict__ bg, double *__restrict__ norm) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
+    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
+    const int EW = FFT_N + A + Bh, EWP = (EW + 1) & ~1;
+    double *Et = smem, *sar = Et + EWP, *sai = sar + FFT_LA, *sbr = sar, *sbi = sai;   // layouts A and B are never live together
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, x0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    bool use_fft;
+    {   // Et[u] <-> coordinate x0 - HW - A + u
+        const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
+        const int nb = L + ct.bias_left + ct.bias_right;
+        const int j0 = x0 - HW - A + ct.bias_left;
+        // only the first `need` entries feed bases of this chunk; the rest of the tile is padded with zeros
+        const int need = min(TV, L - x0) + W - 1 + A + Bh;
+        double emax = 0.0, emin = 1e300;
+        bool okl = true;
+        for (int u = lane; u < EW; u += WAVE) {
+            const int j = j0 + u;
+            double e = 0.0;
+            if (u < need) {
+                e = 1.0;
+                if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+                okl = okl && (e > 0.0) && (e < 1e300);   // false for NaN, inf, zero
+                emax = fmax(emax, e); emin = fmin(emin, e);
+            }
+            Et[u] = e;
+        }
+        emax = wave_max(emax); emin = wave_min(emin);
+        use_fft = (__ballot(!okl) == 0ull) && (emax <= emin * FFT_MAX_RANGE);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const long long ob = ct.out_off[chunk];
+    if (!use_fft) {
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) {
+            const int u = lane + 64 * j, g = x0 + u;
+            if (u >= TV || g >= L) continue;
+            double num = 0.0, cv = 0.0;
+#pragma unroll 1
+            for (int r = 0; r < vm.R; ++r) {
+                const int i = vm.lower + r;
+                const double s = vm.srow[r];
+                const double *el = Et + (A - floor_half(i - 1)) + u, *er = Et + (A + floor_half(i)) + u;
+                const double *vr = vm.mat + r * W;
+#pragma unroll 1
+                for (int c = 0; c < W; ++c) {
+                    const double p = (s * el[c]) * er[c];
+                    cv += p;
+                    num = fma(p, vr[c], num);
+                }
+            }
+            const long long o = ob + g;
+            const double bgv = (num * nuc_cov[o]) / cv;
+            bg[o] = bgv;
+            norm[o] = raw[o] - bgv;
+        }
+        return;
+    }
+    FftTwiddles tww;
+    fft_load_twiddles(tww, tw, lane);
+    double accr[8], acci[8], q[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { accr[m] = 0.0; acci[m] = 0.0; q[m] = 0.0; }
+    const int npair = (vm.R + 1) >> 1;
+    for (int pair = 0; pair < npair; ++pair) {
+        const int ra = 2 * pair, rb = ra + 1;
+        const int ia = vm.lower + ra, ib = ia + 1;
+        const double sa = vm.srow[ra], sb = (rb < vm.R) ? vm.srow[rb] : 0.0;
+        const double *ela = Et + (A - floor_half(ia - 1)), *era = Et + (A + floor_half(ia));
+        const double *elb = Et + (A - floor_half(ib - 1)), *erb = Et + (A + floor_half(ib));
+        double re[8], im[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int u = lane + 64 * j;
+            re[j] = (sa * ela[u]) * era[u];
+            im[j] = (sb * elb[u]) * erb[u];
+            q[j] += re[j] + im[j];
+        }
+        fft512_fwd(re, im, tww, sar, sai, sbr, sbi, lane);
+        const double *k = ktab + (size_t)pair * 2 * FFT_N;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
+            const double kr = k[m * 64 + lane], ki = k[FFT_N + m * 64 + lane];
+            accr[m] = fma(re[m], kr, fma(im[m], ki, accr[m]));
+            acci[m] = fma(im[m], kr, fma(-re[m], ki, acci[m]));
+        }
+    }
+    fft512_inv(accr, acci, tww, sar, sai, sbr, sbi, lane);
+    // covB: W-wide box sum of Q (both rows of every pair already added), two levels: T[u] = sum of B consecutive Q,
+    // cov[u] = sum of nb strided T + the remainder  (B = 11, nb = 11 for W = 121: 23 LDS reads per base instead of 121)
+    int B = 1;
+    while ((B + 1) * (B + 1) <= W) ++B;
+    const int nbk = W / B;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sar[lane + 64 * j] = q[j];
+    sar[FFT_N + lane] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int u = lane + 64 * j;
+        double tsum = 0.0;
+        for (int c = 0; c < B; ++c) tsum += sar[u + c];
+        sai[u] = tsum;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int u = lane + 64 * j;
+        const int g = x0 + u;
+        if (u < TV && g < L) {
+            double cv = 0.0;
+            for (int k = 0; k < nbk; ++k) cv += sai[u + B * k];
+            for (int c = B * nbk; c < W; ++c) cv += sar[u + c];
+            const long long o = ob + g;
+            const double num = accr[j] * (1.0 / FFT_N);
+            const double b = (num * nuc_cov[o]) / cv;
+            bg[o] = b;
+            norm[o] = raw[o] - b;
+        }
+    }
+}
+
+}  // namespace natac
