@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256) natac_smooth_same(ChunkTable ct, const in
 //            `0 * log(0) = NaN -> -inf` of the reference is reproduced with the zero-probability flags.
 // ------------------------------------------------------------------------------------------------
 constexpr int OCC_T = 16;
-constexpr int OCC_FMAX = 1024;   // fragments of a tile staged in LDS (larger tiles read them from global memory)
+constexpr int OCC_FMAX = 768;    // fragments of a tile staged in LDS (larger tiles read them from global memory)
 
 struct OccModelDev {
     const double *nuc_probs, *nfr_probs, *alphas;
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
                 const double b = bj[n];
                 const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                 const double a = (nucp[n] * b) / sn, c = (nfrp[n] * b) / sf;
-                ac[2 * pos] = a;
+                ac[2 * pos] = a - c;                 // mixture alpha a + (1 - alpha) c evaluated as fma(alpha, a - c, c)
                 ac[2 * pos + 1] = c;
                 tiny = !(a >= 0x1p-200 && c >= 0x1p-200);
             }
@@ -591,8 +591,8 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const double au = ac[2 * (q + 4 * u + v)], cu = ac[2 * (q + 4 * u + v) + 1];
-                            m0[v] *= al0 * au + be0 * cu;
-                            m1[v] *= al1 * au + be1 * cu;
+                            m0[v] *= fma(al0, au, cu);
+                            m1[v] *= fma(al1, au, cu);
                         }
                     }
 #pragma unroll
@@ -609,8 +609,8 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
                     for (int v = 0; v < 4; ++v) {
                         const double au = ac[2 * (q + v)], cu = ac[2 * (q + v) + 1];
                         int ex0, ex1;
-                        m0[v] = frexp(m0[v] * (al0 * au + be0 * cu), &ex0);
-                        m1[v] = frexp(m1[v] * (al1 * au + be1 * cu), &ex1);
+                        m0[v] = frexp(m0[v] * fma(al0, au, cu), &ex0);
+                        m1[v] = frexp(m1[v] * fma(al1, au, cu), &ex1);
                         e0 += ex0;
                         e1 += ex1;
                     }
@@ -619,8 +619,8 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
             for (; q < cnt; ++q) {                         // tail / unsafe windows: renormalise every multiply
                 const double au = ac[2 * q], cu = ac[2 * q + 1];
                 int ex0, ex1;
-                m0[0] = frexp(m0[0] * (al0 * au + be0 * cu), &ex0);   // static index: keeps the chains in registers
-                m1[0] = frexp(m1[0] * (al1 * au + be1 * cu), &ex1);
+                m0[0] = frexp(m0[0] * fma(al0, au, cu), &ex0);   // static index: keeps the chains in registers
+                m1[0] = frexp(m1[0] * fma(al1, au, cu), &ex1);
                 e0 += ex0;
                 e1 += ex1;
             }
