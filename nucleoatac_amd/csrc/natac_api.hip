@@ -176,7 +176,8 @@ static int choose_bg_G(const natac_batch *b, int W) {
 static void launch_candidates(natac_ctx *c, const ChunkTable &ct, const VMatDev &vm, const int *d_cc, const int *d_cp, long long n,
                               const double *nuc_cov, const double *norm, double *lr, double *var, double *z) {
     const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
-    const size_t lds4 = (size_t)4 * CAND_PER_WAVE * ((EW + 1) & ~1) * sizeof(double);
+    const int ZN = (((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1) + 5) & ~1, ON = (c->W + 1) & ~1;
+    const size_t lds4 = ((size_t)4 * CAND_PER_WAVE * ((EW + 1) & ~1) + ZN + ON) * sizeof(double);
     if (lds4 <= 64 * 1024) {
         const long long per_block = 4 * CAND_PER_WAVE;
         hipLaunchKernelGGL(natac_candidates4, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), lds4, c->stream, ct, vm, d_cc,

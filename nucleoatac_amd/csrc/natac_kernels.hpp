@@ -938,6 +938,23 @@ __global__ void __launch_bounds__(256) natac_candidates(ChunkTable ct, VMatDev v
 // no block-level synchronisation: DPP wave reductions only).  Workgroup = 4 waves = 16 candidates.
 constexpr int CAND_PER_WAVE = 4;
 
+// first index in the sorted array a[lo, hi) with a[idx] >= key, found by the whole wave: 64 evenly spaced probes per step
+// (one coalesced-ish load + a ballot) instead of one dependent load per bisection step.  Every lane returns the result.
+__device__ __forceinline__ int wave_lower_bound(const int *__restrict__ a, int lo, int hi, int key, int lane) {
+    while (hi - lo > WAVE) {
+        const int n = hi - lo, stride = (n + WAVE - 1) / WAVE;
+        const int pi = min((lane + 1) * stride - 1, n - 1);
+        const int cnt = __popcll(__ballot(a[lo + pi] < key));      // probes are sorted: the predicate is a prefix
+        lo = min(lo + cnt * stride, hi);
+        hi = min(lo + stride, hi);
+    }
+    const int i = lo + lane;
+    const int v = (i < hi) ? a[i] : 0x7fffffff;
+    return lo + __popcll(__ballot(v < key));
+}
+
+// LDS: [zeros: A + Bh + 4][ones: W] shared by the workgroup, then [4 waves][CAND_PER_WAVE][EWP] bias windows.
+// Lanes without a template column (c >= W) read the zeros block instead of branching: their products are exactly 0.
 __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
                                                            const int *__restrict__ cand_pos, int ncand,
                                                            const double *__restrict__ nuc_cov, const double *__restrict__ norm,
@@ -946,14 +963,18 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
     const int EW = vm.W + A + Bh, EWP = (EW + 1) & ~1;
+    const int ZN = (A + Bh + 5) & ~1, ON = (vm.W + 1) & ~1;      // idle lanes index the zeros block from 2 (bases run 2 below)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *Et = smem + (size_t)wave * CAND_PER_WAVE * EWP;     // [4][EWP];  Et[q][u] <-> coordinate p_q - w - A + u
+    for (int u = threadIdx.x; u < ZN + ON; u += 256) smem[u] = (u < ZN) ? 0.0 : 1.0;
+    const int et0 = ZN + ON + wave * CAND_PER_WAVE * EWP;          // smem[et0 + q * EWP + u] <-> coordinate p_q - w - A + u
     const int k0 = (blockIdx.x * 4 + wave) * CAND_PER_WAVE;
-    if (k0 >= ncand) return;
+    const bool active = k0 < ncand;                                // wave-uniform
     int chunk[CAND_PER_WAVE], pos[CAND_PER_WAVE];
     bool esmall[CAND_PER_WAVE];
 #pragma unroll
     for (int q = 0; q < CAND_PER_WAVE; ++q) {
+        esmall[q] = false; chunk[q] = 0; pos[q] = 0;
+        if (!active) continue;
         const int k = (k0 + q < ncand) ? k0 + q : k0;          // tail: recompute candidate k0 (result discarded)
         chunk[q] = cand_chunk[k];
         pos[q] = cand_pos[k];
@@ -966,12 +987,13 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
             const int j = j0 + u;
             double e = 1.0;
             if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
-            Et[q * EWP + u] = e;
+            smem[et0 + q * EWP + u] = e;
             emin = fmin(emin, e);
         }
         esmall[q] = !(wave_min(emin) > 0x1p-500);     // no product of two window values can underflow to 0 above this
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (!active) return;
     double sB[CAND_PER_WAVE], sBV[CAND_PER_WAVE], sBV2[CAND_PER_WAVE], sB0V[CAND_PER_WAVE];
     bool zero[CAND_PER_WAVE];
 #pragma unroll
@@ -980,57 +1002,103 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
     // product of two exp(bias) values underflows; the per-cell test runs only in those (wave-uniform) cases
     const bool check_any = vm.has_zero || esmall[0] || esmall[1] || esmall[2] || esmall[3];
     const int c1 = lane, c2 = lane + WAVE;
-    const bool h2 = c2 < vm.W;
-    auto sweep = [&](auto CHECK) {
-    // template values are prefetched four rows ahead (L2 latency >> the ~320 cycles of arithmetic per row)
-    constexpr int PF = 4;
-    double pv1[PF], pv2[PF];
+    const bool h1 = c1 < vm.W, h2 = c2 < vm.W;
+    const int cc1 = h1 ? c1 : 0, cc2 = h2 ? c2 : 0;
+    int o1[CAND_PER_WAVE], o2[CAND_PER_WAVE];                   // per-lane window bases (the zeros block for idle lanes)
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        pv1[u] = (u < vm.R && c1 < vm.W) ? vm.mat[u * vm.W + c1] : 0.0;
-        pv2[u] = (u < vm.R && h2) ? vm.mat[u * vm.W + c2] : 0.0;
-    }
-    for (int rb = 0; rb < vm.R; rb += PF) {
-      double nv1[PF], nv2[PF];
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-          const int rn = rb + PF + u;
-          nv1[u] = (rn < vm.R && c1 < vm.W) ? vm.mat[rn * vm.W + c1] : 0.0;
-          nv2[u] = (rn < vm.R && h2) ? vm.mat[rn * vm.W + c2] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int r = rb + u;
-        if (r >= vm.R) break;
+    for (int q = 0; q < CAND_PER_WAVE; ++q) { o1[q] = h1 ? et0 + q * EWP + c1 : 2; o2[q] = h2 ? et0 + q * EWP + c2 : 2; }
+    const int R = vm.R, W = vm.W;
+    // one template row, any geometry (used for the R % 4 tail rows and for V-plots that include insert size 1)
+    auto row_generic = [&](int r, auto CHECK) {
         const int i = vm.lower + r;
         const int hl = floor_half(i - 1), hr = floor_half(i);
-        const bool single = (hl == -hr);
+        const bool single = (hl == -hr);     // i == 1 (the two ends coincide, chunkmat2d.py:150-151): right factor from the ones block
         const double sr = vm.srow[r];
-        const double v1 = pv1[u], v2 = pv2[u];
+        const double v1 = vm.mat[r * W + cc1], v2 = vm.mat[r * W + cc2];
         const double v1sq = v1 * v1, v2sq = v2 * v2;
         const int ol = A - hl, orr = A + hr;
 #pragma unroll
         for (int q = 0; q < CAND_PER_WAVE; ++q) {
-            const double *e = Et + q * EWP;
-            if (c1 < vm.W) {
-                const double b0 = single ? e[c1 + ol] : e[c1 + ol] * e[c1 + orr];
+            const int r1 = single ? ZN + cc1 : o1[q] + orr, r2 = single ? ZN + cc2 : o2[q] + orr;
+            {
+                const double b0 = smem[o1[q] + ol] * smem[r1];
                 const double bb = sr * b0;
                 sB[q] += bb; sB0V[q] = fma(v1, b0, sB0V[q]); sBV[q] = fma(bb, v1, sBV[q]); sBV2[q] = fma(bb, v1sq, sBV2[q]);
-                if (decltype(CHECK)::value) zero[q] |= (v1 * b0 == 0.0 || bb == 0.0);
+                if (decltype(CHECK)::value) zero[q] |= (h1 && (v1 * b0 == 0.0 || bb == 0.0));
             }
-            if (h2) {
-                const double b0 = single ? e[c2 + ol] : e[c2 + ol] * e[c2 + orr];
+            {
+                const double b0 = smem[o2[q] + ol] * smem[r2];
                 const double bb = sr * b0;
                 sB[q] += bb; sB0V[q] = fma(v2, b0, sB0V[q]); sBV[q] = fma(bb, v2, sBV[q]); sBV2[q] = fma(bb, v2sq, sBV2[q]);
-                if (decltype(CHECK)::value) zero[q] |= (v2 * b0 == 0.0 || bb == 0.0);
+                if (decltype(CHECK)::value) zero[q] |= (h2 && (v2 * b0 == 0.0 || bb == 0.0));
             }
         }
-      }
-#pragma unroll
-      for (int u = 0; u < PF; ++u) { pv1[u] = nv1[u]; pv2[u] = nv2[u]; }
-    }
     };
-    if (check_any) sweep(std::true_type{}); else sweep(std::false_type{});   // one wave-uniform branch, two straight-line bodies
+    // four rows at a time (lower >= 2).  rb % 4 == 0, so the parity of i0 = lower + rb is that of `lower` (PAR) and the
+    // half-lengths inside a block are compile-time offsets from the block's first row: every LDS address is a running
+    // base register plus an immediate.  Template values arrive through two alternating register sets (no copies).
+    auto sweep4 = [&](auto CHECK, auto PARITY) {
+        constexpr int PAR = decltype(PARITY)::value;
+        constexpr int DL[4] = {0, PAR ? 0 : 1, 1, PAR ? 1 : 2};     // hl(i0 + u) - hl(i0)
+        constexpr int DR[4] = {0, PAR ? 1 : 0, 1, PAR ? 2 : 1};     // hr(i0 + u) - hr(i0)
+        int lb1[CAND_PER_WAVE], lb2[CAND_PER_WAVE], rb1[CAND_PER_WAVE], rb2[CAND_PER_WAVE];
+        {
+            const int hl0 = floor_half(vm.lower - 1), hr0 = floor_half(vm.lower);
+#pragma unroll
+            for (int q = 0; q < CAND_PER_WAVE; ++q) {
+                lb1[q] = o1[q] + A - hl0 - 2; lb2[q] = o2[q] + A - hl0 - 2;
+                rb1[q] = o1[q] + A + hr0;     rb2[q] = o2[q] + A + hr0;
+            }
+        }
+        auto loadv = [&](int rb, double (&x1)[4], double (&x2)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int r = min(rb + u, R - 1); x1[u] = vm.mat[r * W + cc1]; x2[u] = vm.mat[r * W + cc2]; }
+        };
+        auto block = [&](int rb, const double (&x1)[4], const double (&x2)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double sr = vm.srow[rb + u];
+                const double v1 = x1[u], v2 = x2[u];
+                const double v1sq = v1 * v1, v2sq = v2 * v2;
+#pragma unroll
+                for (int q = 0; q < CAND_PER_WAVE; ++q) {
+                    {
+                        const double b0 = smem[lb1[q] + (2 - DL[u])] * smem[rb1[q] + DR[u]];
+                        const double bb = sr * b0;
+                        sB[q] += bb; sB0V[q] = fma(v1, b0, sB0V[q]); sBV[q] = fma(bb, v1, sBV[q]); sBV2[q] = fma(bb, v1sq, sBV2[q]);
+                        if (decltype(CHECK)::value) zero[q] |= (h1 && (v1 * b0 == 0.0 || bb == 0.0));
+                    }
+                    {
+                        const double b0 = smem[lb2[q] + (2 - DL[u])] * smem[rb2[q] + DR[u]];
+                        const double bb = sr * b0;
+                        sB[q] += bb; sB0V[q] = fma(v2, b0, sB0V[q]); sBV[q] = fma(bb, v2, sBV[q]); sBV2[q] = fma(bb, v2sq, sBV2[q]);
+                        if (decltype(CHECK)::value) zero[q] |= (h2 && (v2 * b0 == 0.0 || bb == 0.0));
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CAND_PER_WAVE; ++q) { lb1[q] -= 2; lb2[q] -= 2; rb1[q] += 2; rb2[q] += 2; }
+        };
+        double va1[4], va2[4], vb1[4], vb2[4];
+        const int nblk = R / 4;
+        loadv(0, va1, va2);
+        int bk = 0;
+        for (; bk + 2 <= nblk; bk += 2) {
+            loadv(4 * (bk + 1), vb1, vb2);
+            block(4 * bk, va1, va2);
+            loadv(4 * (bk + 2), va1, va2);
+            block(4 * (bk + 1), vb1, vb2);
+        }
+        if (bk < nblk) block(4 * bk, va1, va2);
+        for (int r = 4 * nblk; r < R; ++r) row_generic(r, CHECK);
+    };
+    // wave-uniform dispatch to straight-line bodies
+    if (vm.lower >= 2) {
+        if (vm.lower & 1) { if (check_any) sweep4(std::true_type{}, std::integral_constant<int, 1>{}); else sweep4(std::false_type{}, std::integral_constant<int, 1>{}); }
+        else              { if (check_any) sweep4(std::true_type{}, std::integral_constant<int, 0>{}); else sweep4(std::false_type{}, std::integral_constant<int, 0>{}); }
+    } else {
+        for (int r = 0; r < R; ++r) { if (check_any) row_generic(r, std::true_type{}); else row_generic(r, std::false_type{}); }
+    }
 #pragma unroll
     for (int q = 0; q < CAND_PER_WAVE; ++q) {
         const double tB = wave_sum(sB[q]), tBV = wave_sum(sBV[q]), tBV2 = wave_sum(sBV2[q]), tB0V = wave_sum(sB0V[q]);
@@ -1039,11 +1107,12 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
         const int nfr = (int)(ct.frag_off[chunk[q] + 1] - ct.frag_off[chunk[q]]);
         const int *cen = ct.centre + ct.frag_off[chunk[q]];
         const int *iln = ct.ilen + ct.frag_off[chunk[q]];
-        const int f0 = lower_bound_i32(cen, 0, nfr, p - vm.w);
-        const int f1 = lower_bound_i32(cen, f0, nfr, p + vm.w + 1);
-        const double *e = Et + q * EWP;
+        const int f0 = wave_lower_bound(cen, 0, nfr, p - vm.w, lane);
+        const int f1 = wave_lower_bound(cen, f0, min(nfr, f0 + 4 * WAVE), p + vm.w + 1, lane) ;
+        const int f1x = (f1 == f0 + 4 * WAVE) ? wave_lower_bound(cen, f1, nfr, p + vm.w + 1, lane) : f1;   // very dense windows
+        const double *e = smem + et0 + q * EWP;
         double nl = 0.0, ul = 0.0;
-        for (int f = f0 + lane; f < f1; f += WAVE) {
+        for (int f = f0 + lane; f < f1x; f += WAVE) {
             const int n = iln[f];
             if (n < vm.lower || n >= vm.upper) continue;
             const int r = n - vm.lower, c = cen[f] - p + vm.w;
