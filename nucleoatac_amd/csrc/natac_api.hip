@@ -632,7 +632,7 @@ int natac_run_occ(natac_batch *b) {
             b->d_grid[i] = nullptr;
             if ((rc = dev_alloc(&b->d_grid[i], (size_t)b->total_grid))) return rc;
         }
-        if ((rc = build_tiles(b, OCC_T, &b->d_tiles_occ, &b->n_tiles_occ, true, c->step, c->halfstep))) return rc;
+        if ((rc = build_tiles(b, OCC_T * OCC_NP, &b->d_tiles_occ, &b->n_tiles_occ, true, c->step, c->halfstep))) return rc;
         dev_free(b->d_ranges_occ);
         b->d_ranges_occ = nullptr;
         if ((rc = dev_alloc(&b->d_ranges_occ, (size_t)b->n_tiles_occ))) return rc;
@@ -647,13 +647,18 @@ int natac_run_occ(natac_batch *b) {
     prof_begin(c, NATAC_K_OCC_MLE, ev, c->stream2);
     {
         const int U = c->occ_upper, UP = (U + 1) & ~1;
-        const int span = (OCC_T - 1) * c->step + M;
+        const int span = (OCC_T * OCC_NP - 1) * c->step + M + c->step;
         const int EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
-        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + ((span + 3) & ~1) + 512) * sizeof(double) +
+        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + 512) * sizeof(double) +
                            (size_t)2 * OCC_FMAX * sizeof(int);
+        if ((OCC_T - 1) * c->step + M + c->step + 2 > 512 || lds > 64 * 1024)
+            return fail(NATAC_E_ARG, "occupancy window / step too large for the device tile (step=%d flank=%d upper=%d)", c->step, c->flank, U);
         hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
                            b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
-        if (c->step == 5 && c->flank == 60)
+        if (c->step == 5 && c->flank == 60 && c->n_alpha <= 16 * OCC_RA)
+            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0, 1>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
+                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
+        else if (c->step == 5 && c->flank == 60)
             hipLaunchKernelGGL((natac_occ_mle<5, 60, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
                                b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
         else

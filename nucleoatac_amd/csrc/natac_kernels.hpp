@@ -89,6 +89,38 @@ __device__ __forceinline__ int wave_or(int v) {      // OR of 4-bit flag words: 
         if (__ballot((v & bit) != 0) != 0ull) r |= bit;
     return r;
 }
+// reductions inside each 16-lane row (the first four DPP steps of the wave reductions): every lane of a row ends with
+// the row's result; the four rows of a wave work on four independent problems at once.
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_mov_f64<0xB1>(v);
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0x141>(v);
+    v += dpp_mov_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double row_max(double v) {
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_min_i32(int v) {
+    v = min(v, dpp_mov_i32<0xB1>(v));
+    v = min(v, dpp_mov_i32<0x4E>(v));
+    v = min(v, dpp_mov_i32<0x141>(v));
+    v = min(v, dpp_mov_i32<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ int row_max_i32(int v) {
+    v = max(v, dpp_mov_i32<0xB1>(v));
+    v = max(v, dpp_mov_i32<0x4E>(v));
+    v = max(v, dpp_mov_i32<0x141>(v));
+    v = max(v, dpp_mov_i32<0x140>(v));
+    return v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // fragment centres: c = l + (n-1)//2   (pyatac/fragments.pyx:36)
@@ -378,7 +410,8 @@ __global__ void __launch_bounds__(256) natac_smooth_same(ChunkTable ct, const in
 //            (fragment, alpha) costs a handful of fp64 ops instead of a log(); one log per alpha at the end.
 //            `0 * log(0) = NaN -> -inf` of the reference is reproduced with the zero-probability flags.
 // ------------------------------------------------------------------------------------------------
-constexpr int OCC_T = 16;
+constexpr int OCC_T = 16;    // grid points per pass (one 16-lane row or one wave each in phase 2)
+constexpr int OCC_NP = 4;    // passes per tile
 constexpr int OCC_FMAX = 768;    // fragments of a tile staged in LDS (larger tiles read them from global memory)
 
 struct OccModelDev {
@@ -412,13 +445,174 @@ __global__ void __launch_bounds__(256) natac_occ_tile_ranges(ChunkTable ct, cons
     const int *cen = ct.centre + ct.frag_off[t.x];
     const int gfirst = halfstep + t.y * step;
     const int t0 = lower_bound_i32(cen, 0, nfr, gfirst - flank);
-    const int t1 = lower_bound_i32(cen, t0, nfr, gfirst + (OCC_T - 1) * step + flank + 1);
+    const int t1 = lower_bound_i32(cen, t0, nfr, gfirst + (OCC_T * OCC_NP - 1) * step + flank + 1);
     ranges[i] = make_int2(t0, t1);
 }
 
+// ---- phase 2 of natac_occ_mle, row-parallel form: each 16-lane row of a wave owns one grid point (4 per wave, the 16 of
+// a tile in one pass) and each lane 7 of the <= 112 alphas (a = l + 16 t).  The per-grid-point overheads of the
+// wave-per-grid-point form (normaliser reductions, window search, per-fragment probabilities, the argmax / interval
+// decision) are paid once per four grid points; the multiply chain  L(alpha) = prod_f (c_f + alpha (a_f - c_f))  costs the
+// same lane work as before.  One product chain per alpha (7 independent chains per lane hide the fp64 latency), rescaled
+// by an exact power of two after every 4th factor (every factor when a probability < 2^-200 is present).
+constexpr int OCC_RA = 7;     // alphas per lane in the row-parallel form
+__device__ __forceinline__ void occ_phase2_rows(const ChunkTable &ct, const OccModelDev &om, int chunk, int k0, int nk, int step, int fl,
+                                                int gfirst, int U, int UP, const double *bw, const double *nucp, const double *nfrp,
+                                                double *acl, const int *cs, const int *is, int nt, double *__restrict__ g_occ,
+                                                double *__restrict__ g_lo, double *__restrict__ g_hi, int *__restrict__ status) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
+    const int kk = 4 * wave + row, k = k0 + kk;
+    const bool live = k < nk;                                   // row-uniform
+    const int sh = 16 * row;
+    const double *bj = bw + kk * UP;
+    double al[OCC_RA];
+#pragma unroll
+    for (int t = 0; t < OCC_RA; ++t) { const int a = l + 16 * t; al[t] = (a < om.n_alpha) ? om.alphas[a] : 0.0; }
+    // normalisers of  nuc_probs * bias / sum(...)  (Occupancy.py:108-111) + zero / NaN flags of the quotients
+    double sn = 0.0, sf = 0.0;
+    int lf = 0;   // 1: some pn == 0, 2: some pf == 0, 4: some both == 0, 8: some NaN
+    for (int j = l; j < U; j += 16) {
+        const double b = bj[j];
+        const double pa = nucp[j] * b, pc = nfrp[j] * b;
+        sn += pa;
+        sf += pc;
+        if (pa == 0.0) lf |= 1;
+        if (pc == 0.0) lf |= 2;
+        if (pa == 0.0 && pc == 0.0) lf |= 4;
+        if (pa != pa || pc != pc) lf |= 8;
+    }
+    sn = row_sum(sn);
+    sf = row_sum(sf);
+    int flags = 0;
+#pragma unroll
+    for (int bit = 1; bit <= 8; bit <<= 1)
+        if (((__ballot((lf & bit) != 0) >> sh) & 0xffffull) != 0ull) flags |= bit;
+    if (!(sn > 0.0 && sn < __builtin_inf() && sf > 0.0 && sf < __builtin_inf())) flags |= 8;  // 0/0, x/inf, NaN sums
+    // fragments of the row's window [g-fl, g+fl]: ranks of the two keys in the tile's sorted centre list
+    int f0 = 0, f1 = 0;
+    {
+        const int kmax = gfirst + (4 * wave + 3) * step + fl + 1;
+        for (int base = 0; base < nt; base += WAVE) {
+            const int i = base + lane;
+            const int v = (i < nt) ? cs[i] : 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gr = gfirst + (4 * wave + r) * step;
+                const int c0 = __popcll(__ballot(v < gr - fl)), c1 = __popcll(__ballot(v < gr + fl + 1));
+                if (row == r) { f0 += c0; f1 += c1; }
+            }
+            if (__ballot(v < kmax) != ~0ull) break;             // the rest of the list lies right of every window
+        }
+    }
+    const int cnt_row = f1 - f0;
+    const int maxcnt = max(max(__builtin_amdgcn_readlane(cnt_row, 0), __builtin_amdgcn_readlane(cnt_row, 16)),
+                           max(__builtin_amdgcn_readlane(cnt_row, 32), __builtin_amdgcn_readlane(cnt_row, 48)));
+    double m[OCC_RA];
+    int e[OCC_RA];
+#pragma unroll
+    for (int t = 0; t < OCC_RA; ++t) { m[t] = 1.0; e[t] = 0; }
+    int nins = 0;
+    double *ac = acl + (wave * 4 + row) * 32;                   // 16 x (a - c, c) of the row's current batch
+    for (int b0 = 0; b0 < maxcnt; b0 += 16) {
+        int n = -1;
+        if (b0 + l < cnt_row) n = is[f0 + b0 + l];
+        const bool ok = (n >= 0 && n < U);
+        const unsigned long long bal = __ballot(ok);
+        const unsigned rowmask = (unsigned)(bal >> sh) & 0xffffu;
+        nins += __popc(rowmask);
+        ac[2 * l] = 0.0;                                        // neutral factor (x = 1 for every alpha) in unused slots
+        ac[2 * l + 1] = 1.0;
+        __builtin_amdgcn_wave_barrier();
+        bool tiny = false;
+        if (ok) {                                               // lane-parallel: one fragment per lane, compacted per row
+            const double b = bj[n];
+            const int pos = __popc(rowmask & ((1u << l) - 1u));
+            const double a = (nucp[n] * b) / sn, c = (nfrp[n] * b) / sf;
+            ac[2 * pos] = a - c;                                // mixture alpha a + (1 - alpha) c evaluated as fma(alpha, a - c, c)
+            ac[2 * pos + 1] = c;
+            tiny = !(a >= 0x1p-200 && c >= 0x1p-200);
+        }
+        const bool safe = __ballot(tiny) == 0ull;
+        __builtin_amdgcn_wave_barrier();
+        const int mc = max(max(__popc((unsigned)bal & 0xffffu), __popc((unsigned)(bal >> 16) & 0xffffu)),
+                           max(__popc((unsigned)(bal >> 32) & 0xffffu), __popc((unsigned)(bal >> 48) & 0xffffu)));
+        if (safe) {
+            for (int q = 0; q < mc; q += 4) {                   // slots >= the row's count hold the neutral factor
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double d = ac[2 * (q + v)], c = ac[2 * (q + v) + 1];
+#pragma unroll
+                    for (int t = 0; t < OCC_RA; ++t) m[t] *= fma(al[t], d, c);
+                }
+#pragma unroll
+                for (int t = 0; t < OCC_RA; ++t) { int ex; m[t] = frexp(m[t], &ex); e[t] += ex; }
+            }
+        } else {
+            for (int q = 0; q < mc; ++q) {
+                const double d = ac[2 * q], c = ac[2 * q + 1];
+#pragma unroll
+                for (int t = 0; t < OCC_RA; ++t) { int ex; m[t] = frexp(m[t] * fma(al[t], d, c), &ex); e[t] += ex; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // decision without logarithms (see natac_occ_mle): L = m * 2^e, m in [0.5, 1), 0 stands for log L = -inf
+    const int ENONE = -(1 << 30);
+    int lemax = ENONE;
+#pragma unroll
+    for (int t = 0; t < OCC_RA; ++t) {
+        int ex;
+        m[t] = frexp(m[t], &ex);
+        e[t] += ex;
+        const double be = 1 - al[t];
+        if (flags & (8 | 4)) m[t] = 0.0;
+        if ((flags & 2) && al[t] == 0.0) m[t] = 0.0;
+        if ((flags & 1) && be == 0.0) m[t] = 0.0;
+        if (!(m[t] > 0.0) || l + 16 * t >= om.n_alpha) m[t] = 0.0;      // NaN likelihood -> -inf as well
+        if (!(m[t] > 0.0)) e[t] = ENONE;
+        lemax = max(lemax, e[t]);
+    }
+    const int iemax = row_max_i32(lemax);
+    const bool none = (iemax == ENONE);
+    double lmmax = 0.0;
+#pragma unroll
+    for (int t = 0; t < OCC_RA; ++t) lmmax = fmax(lmmax, e[t] == iemax ? m[t] : 0.0);
+    const double mmax = row_max(lmmax);
+    const double thr = mmax * om.ci_factor;
+    int limax = 0x7fffffff, lilo = 0x7fffffff, lihi = -1;
+#pragma unroll
+    for (int t = OCC_RA - 1; t >= 0; --t) {
+        const int a = l + 16 * t;
+        if (e[t] == iemax && m[t] == mmax) limax = a;
+        const int d = e[t] - iemax;
+        const bool in = m[t] > 0.0 && d > -1100 && ldexp(m[t], d) > thr;
+        if (in) { lilo = a; lihi = max(lihi, a); }
+    }
+    const int imax = row_min_i32(limax), ilo = row_min_i32(lilo), ihi = row_max_i32(lihi);
+    if (live && l == 0) {
+        const long long go = ct.grid_off[chunk] + k;
+        const double qn = __builtin_nan("");
+        if (nins == 0) {                         // sum(new_inserts) > 0 fails: stay NaN (Occupancy.py:143)
+            g_occ[go] = qn; g_lo[go] = qn; g_hi[go] = qn;
+        } else if (none) {
+            // every likelihood is -inf: the reference raises ValueError (min of empty, Occupancy.py:118)
+            g_occ[go] = qn; g_lo[go] = qn; g_hi[go] = qn;
+            atomicOr(&status[chunk], 1);
+        } else {
+            g_occ[go] = om.alphas[imax];
+            g_lo[go] = om.alphas[ilo];
+            g_hi[go] = om.alphas[ihi];
+        }
+    }
+}
+
 // STEP/FLANK > 0: compile-time fast path (defaults 5 / 60, requires (2*FLANK) % STEP == 0); STEP == 0: runtime values.
-template <int STEP, int FLANK, int ABL = 0>   // ABL != 0: ablation variants for tools/microbench_occ.hip only
-__global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *__restrict__ tiles,
+// A tile is OCC_T * OCC_NP consecutive grid points of one chunk, processed in OCC_NP passes of OCC_T: the exp(bias) window
+// and the fragments are staged once per tile, and in the fast path the block sums of the window products slide on from
+// pass to pass in registers (80 new products per insert size and pass instead of 196).
+template <int STEP, int FLANK, int ABL = 0, int ROWS = 0>   // ABL != 0: ablation variants for tools/microbench_occ.hip only;
+                                                          // ROWS: row-parallel phase 2 (n_alpha <= 16 * OCC_RA)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) natac_occ_mle(ChunkTable ct, const int2 *__restrict__ tiles,
                                                        const int2 *__restrict__ ranges, OccModelDev om,
                                                        double *__restrict__ g_occ, double *__restrict__ g_lo,
                                                        double *__restrict__ g_hi, int *__restrict__ status) {
@@ -427,14 +621,14 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
     const int step = STEP ? STEP : om.step;
     const int fl = STEP ? FLANK : om.flank, WIN = 2 * fl + 1;
     const int A = (U - 2) >> 1, Bh = (U - 1) >> 1;
-    const int span = (OCC_T - 1) * step + WIN;        // centre positions covered by the tile
+    const int span = (OCC_T * OCC_NP - 1) * step + WIN + step;   // centre positions covered by the tile (+ the last block in full)
     const int EW = span + A + Bh + 2;
     double *Et = smem;                                 // [EW]
     double *bw = smem + ((EW + 1) & ~1);               // [OCC_T][UP]
     double *nucp = bw + OCC_T * UP;                    // [UP]
     double *nfrp = nucp + UP;                          // [UP]
-    double *ones = nfrp + UP;                          // [span + 2] of 1.0: right factor of the single-cell row j == 1
-    double *acl = ones + ((span + 3) & ~1);            // [4 waves][64 x (pn, pf)]
+    double *acl = nfrp + UP;                           // [4 waves][64 x (pn, pf)] in phase 2
+    double *ones = acl;                                // phase 1: (OCC_T-1)*step + WIN + step + 2 <= 512 ones, the right factor of row j == 1
     int *cen_s = (int *)(acl + 4 * 2 * WAVE);          // [OCC_FMAX]
     int *iln_s = cen_s + OCC_FMAX;                     // [OCC_FMAX]
     const int2 t = tiles[blockIdx.x];
@@ -451,235 +645,254 @@ __global__ void __launch_bounds__(256) natac_occ_mle(ChunkTable ct, const int2 *
     if (staged)
         for (int i = threadIdx.x; i < nt; i += 256) { cen_s[i] = cen[t0 + i]; iln_s[i] = iln[t0 + i]; }
     for (int j = threadIdx.x; j < U; j += 256) { nucp[j] = om.nuc_probs[j]; nfrp[j] = om.nfr_probs[j]; }
-    for (int u = threadIdx.x; u < span + 2; u += 256) ones[u] = 1.0;
     {   // Et[u] <-> coordinate gfirst - fl - A + u
         const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
         const int nb = L + ct.bias_left + ct.bias_right;
         const int j0 = gfirst - fl - A + ct.bias_left;
+        // only the part of the window that the chunk's remaining grid points reach
+        const int need = min(EW, (min(OCC_T * OCC_NP, nk - k0) - 1) * step + WIN + A + Bh + 2);
         for (int u = threadIdx.x; u < EW; u += 256) {
             const int j = j0 + u;
-            double e = 1.0;
-            if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+            double e = 0.0;
+            if (u < need) {
+                e = 1.0;
+                if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+            }
             Et[u] = e;
         }
     }
-    __syncthreads();
-    // ---- phase 1: window sums of B0 for every insert size j (thread j), all OCC_T grid points of the tile
-    {
-        const int j = threadIdx.x;
-        if (ABL == 2) { for (int k = 0; k < OCC_T; ++k) if (j < U) bw[k * UP + j] = 1.0; }
-        else if (j < U) {
-            const int hl = floor_half(j - 1), hr = floor_half(j);
-            const bool single = (hl == -hr);   // j == 1: the two pattern ones coincide (chunkmat2d.py:150-151)
-            // branch-free: the j == 1 row multiplies by a row of ones (exact) instead of selecting per element
-            const double *el = Et + (A - hl);
-            const double *er = single ? ones : Et + (A + hr);
-            if (STEP) {
-                // window k = columns [k*STEP, k*STEP + WIN), WIN = Q*STEP + 1: sum of Q aligned STEP-blocks + the first
-                // element of block k+Q.  Every product is formed once; block sums stay in registers (static indices).
-                constexpr int SS = STEP ? STEP : 1;
-                constexpr int Q = (2 * FLANK) / SS;
-                double blk[OCC_T + Q];
-                double first[OCC_T + Q];
-#pragma unroll
-                for (int m = 0; m < OCC_T + Q; ++m) {
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int d = 0; d < SS; ++d) {
-                        if (m == OCC_T + Q - 1 && d > 0) break;        // last block: only its first element is used
-                        const int u = m * SS + d;
-                        const double p = el[u] * er[u];
-                        if (d == 0) first[m] = p;
-                        sacc += p;
-                    }
-                    blk[m] = sacc;
-                }
-                double T = 0.0;
-#pragma unroll
-                for (int m = 0; m < Q; ++m) T += blk[m];
-#pragma unroll
-                for (int k = 0; k < OCC_T; ++k) {
-                    bw[k * UP + j] = T + first[k + Q];
-                    T = (T - blk[k]) + blk[k + Q];
-                }
-            } else {
-                double S = 0.0;
-                for (int u = 0; u < WIN; ++u) S += el[u] * er[u];
-                bw[j] = S;
-                for (int k = 1; k < OCC_T; ++k) {
-                    const int u0 = (k - 1) * step;
-                    for (int d = 0; d < step; ++d) {
-                        const int ua = u0 + d, ub = u0 + WIN + d;
-                        S -= el[ua] * er[ua];
-                        S += el[ub] * er[ub];
-                    }
-                    bw[k * UP + j] = S;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase 2: one wave per grid point; lanes own alphas a = lane, lane + 64
-    if (ABL == 1) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int *cs = staged ? cen_s : cen + t0;   // window search + gather source (LDS copy, or global for huge tiles)
     const int *is = staged ? iln_s : iln + t0;
+    constexpr int SS = STEP ? STEP : 1;
+    constexpr int Q = STEP ? (2 * FLANK) / SS : 1;
+    double blk[OCC_T + Q];                       // fast path: block sums of thread j's products, carried from pass to pass
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *ac = acl + wave * 2 * WAVE;
     const int a0 = lane, a1 = lane + WAVE;
     const double al0 = (a0 < om.n_alpha) ? om.alphas[a0] : 0.0;
     const double al1 = (a1 < om.n_alpha) ? om.alphas[a1] : 0.0;
     const double be0 = 1 - al0, be1 = 1 - al1;
     int f0 = 0, f1 = 0;
-    for (int kk = wave; kk < OCC_T; kk += 4) {
-        const int k = k0 + kk;
-        if (k >= nk) break;                      // wave-uniform
-        const int g = om.halfstep + k * step;
-        const double *bj = bw + kk * UP;
-        // normalisers of  nuc_probs * bias / sum(...)  (Occupancy.py:108-111) + zero / NaN flags of the quotients:
-        // a quotient is 0 iff its product is 0 (sum finite, > 0) and NaN iff the product or the sum is.
-        double sn = 0.0, sf = 0.0;
-        int flags = 0;   // 1: some pn == 0, 2: some pf == 0, 4: some both == 0, 8: some NaN
-        for (int j = lane; j < U && ABL != 6; j += WAVE) {
-            const double b = bj[j];
-            const double pa = nucp[j] * b, pc = nfrp[j] * b;
-            sn += pa;
-            sf += pc;
-            if (pa == 0.0) flags |= 1;
-            if (pc == 0.0) flags |= 2;
-            if (pa == 0.0 && pc == 0.0) flags |= 4;
-            if (pa != pa || pc != pc) flags |= 8;
-        }
-        if (ABL == 6) { sn = 1.0; sf = 1.0; }
-        sn = wave_sum(sn);
-        sf = wave_sum(sf);
-        flags = wave_or(flags);
-        if (!(sn > 0.0 && sn < __builtin_inf() && sf > 0.0 && sf < __builtin_inf())) flags |= 8;  // 0/0, x/inf, NaN sums
-        // fragments of the window [g-fl, g+fl] (sorted by centre; windows only move right)
-        f0 = advance_while_less(cs, f0, nt, g - fl, lane);
-        f1 = advance_while_less(cs, (f1 > f0 ? f1 : f0), nt, g + fl + 1, lane);
-        // log-likelihood as a running product (mantissa x 2^exponent), 4 independent chains per alpha.  frexp only
-        // rescales by an exact power of two, so renormalising every 4th multiply instead of every multiply leaves the
-        // mantissa bits unchanged as long as nothing underflows: safe when every factor is >= 2^-200 (then the product
-        // of a mantissa in [0.5,1) and 4 factors stays >= 2^-801).  Windows holding a smaller probability take the
-        // renormalise-every-multiply path.
-        double m0[4] = {1.0, 1.0, 1.0, 1.0}, m1[4] = {1.0, 1.0, 1.0, 1.0};
-        int e0 = 0, e1 = 0, nins = 0;
-        for (int base = f0; base < f1 && ABL != 3; base += WAVE) {
-            const int i = base + lane;
-            int n = -1;
-            if (i < f1) n = is[i];
-            const bool ok = (n >= 0 && n < U);
-            const unsigned long long mask = __ballot(ok);
-            const int cnt = __popcll(mask);
-            nins += cnt;
-            bool tiny = false;
-            if (ok) {                            // lane-parallel: one fragment per lane, compacted into LDS
-                const double b = bj[n];
-                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                const double a = (nucp[n] * b) / sn, c = (nfrp[n] * b) / sf;
-                ac[2 * pos] = a - c;                 // mixture alpha a + (1 - alpha) c evaluated as fma(alpha, a - c, c)
-                ac[2 * pos + 1] = c;
-                tiny = !(a >= 0x1p-200 && c >= 0x1p-200);
+    for (int pass = 0; pass < OCC_NP; ++pass) {
+        const int kbase = k0 + pass * OCC_T;
+        if (kbase >= nk) break;                                  // block-uniform
+        const int uoff = pass * OCC_T * step;                    // Et offset of the pass's first window
+        if (pass > 0) __syncthreads();                           // phase 2 of the previous pass is done with bw / acl
+        for (int u = threadIdx.x; u < (OCC_T - 1) * step + WIN + step + 2; u += 256) ones[u] = 1.0;
+        __syncthreads();
+        // ---- phase 1: window sums of B0 for every insert size j (thread j), the OCC_T grid points of the pass
+        {
+            const int j = threadIdx.x;
+            if (ABL == 2) { for (int k = 0; k < OCC_T; ++k) if (j < U) bw[k * UP + j] = 1.0; }
+            else if (j < U) {
+                const int hl = floor_half(j - 1), hr = floor_half(j);
+                const bool single = (hl == -hr);   // j == 1: the two pattern ones coincide (chunkmat2d.py:150-151)
+                // branch-free: the j == 1 row multiplies by a row of ones (exact) instead of selecting per element
+                const double *el = Et + (A - hl) + uoff;
+                const double *er = single ? ones : Et + (A + hr) + uoff;
+                if (STEP) {
+                    // window k = columns [k*STEP, k*STEP + WIN), WIN = Q*STEP + 1: sum of Q aligned STEP-blocks + the first
+                    // element of block k+Q.  Every product is formed once; block sums stay in registers (static indices).
+                    if (pass > 0) {
+#pragma unroll
+                        for (int m = 0; m < Q; ++m) blk[m] = blk[m + OCC_T];
+                    }
+#pragma unroll
+                    for (int m = 0; m < OCC_T + Q; ++m) {
+                        if (m < Q && pass > 0) continue;               // carried over from the previous pass
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int d = 0; d < SS; ++d) {
+                            const int u = m * SS + d;
+                            sacc += (ABL == 7) ? (el[0] + (double)u) * er[0] : el[u] * er[u];
+                        }
+                        blk[m] = sacc;
+                    }
+                    double T = 0.0;
+#pragma unroll
+                    for (int m = 0; m < Q; ++m) T += blk[m];
+#pragma unroll
+                    for (int k = 0; k < OCC_T; ++k) {
+                        // + the first element of block k + Q (formed again: cheaper than 16 more live registers)
+                        bw[k * UP + j] = T + el[(k + Q) * SS] * er[(k + Q) * SS];
+                        T = (T - blk[k]) + blk[k + Q];
+                    }
+                } else {
+                    double S = 0.0;
+                    for (int u = 0; u < WIN; ++u) S += el[u] * er[u];
+                    bw[j] = S;
+                    for (int k = 1; k < OCC_T; ++k) {
+                        const int u0 = (k - 1) * step;
+                        for (int d = 0; d < step; ++d) {
+                            const int ua = u0 + d, ub = u0 + WIN + d;
+                            S -= el[ua] * er[ua];
+                            S += el[ub] * er[ub];
+                        }
+                        bw[k * UP + j] = S;
+                    }
+                }
             }
-            const bool safe = __ballot(tiny) == 0ull;
-            __builtin_amdgcn_wave_barrier();
-            int q = 0;
-            if (safe) {
-                for (; q + 16 <= cnt; q += 16) {           // 16 fragments: 4 multiplies on each of the 8 chains, one renorm
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-#pragma unroll
+        }
+        __syncthreads();
+        // ---- phase 2
+        if (ABL == 1) continue;
+        if (ROWS) {
+            occ_phase2_rows(ct, om, chunk, kbase, nk, step, fl, gfirst + uoff, U, UP, bw, nucp, nfrp, acl, cs, is, nt, g_occ, g_lo, g_hi,
+                            status);
+            continue;
+        }
+        for (int kk = wave; kk < OCC_T; kk += 4) {
+            const int k = kbase + kk;
+            if (k >= nk) break;                      // wave-uniform
+            const int g = om.halfstep + k * step;
+            const double *bj = bw + kk * UP;
+            // normalisers of  nuc_probs * bias / sum(...)  (Occupancy.py:108-111) + zero / NaN flags of the quotients:
+            // a quotient is 0 iff its product is 0 (sum finite, > 0) and NaN iff the product or the sum is.
+            double sn = 0.0, sf = 0.0;
+            int flags = 0;   // 1: some pn == 0, 2: some pf == 0, 4: some both == 0, 8: some NaN
+            for (int j = lane; j < U && ABL != 6; j += WAVE) {
+                const double b = bj[j];
+                const double pa = nucp[j] * b, pc = nfrp[j] * b;
+                sn += pa;
+                sf += pc;
+                if (pa == 0.0) flags |= 1;
+                if (pc == 0.0) flags |= 2;
+                if (pa == 0.0 && pc == 0.0) flags |= 4;
+                if (pa != pa || pc != pc) flags |= 8;
+            }
+            if (ABL == 6) { sn = 1.0; sf = 1.0; }
+            sn = wave_sum(sn);
+            sf = wave_sum(sf);
+            flags = wave_or(flags);
+            if (!(sn > 0.0 && sn < __builtin_inf() && sf > 0.0 && sf < __builtin_inf())) flags |= 8;  // 0/0, x/inf, NaN sums
+            // fragments of the window [g-fl, g+fl] (sorted by centre; windows only move right)
+            f0 = advance_while_less(cs, f0, nt, g - fl, lane);
+            f1 = advance_while_less(cs, (f1 > f0 ? f1 : f0), nt, g + fl + 1, lane);
+            // log-likelihood as a running product (mantissa x 2^exponent), 4 independent chains per alpha.  frexp only
+            // rescales by an exact power of two, so renormalising every 4th multiply instead of every multiply leaves the
+            // mantissa bits unchanged as long as nothing underflows: safe when every factor is >= 2^-200 (then the product
+            // of a mantissa in [0.5,1) and 4 factors stays >= 2^-801).  Windows holding a smaller probability take the
+            // renormalise-every-multiply path.
+            double m0[4] = {1.0, 1.0, 1.0, 1.0}, m1[4] = {1.0, 1.0, 1.0, 1.0};
+            int e0 = 0, e1 = 0, nins = 0;
+            for (int base = f0; base < f1 && ABL != 3; base += WAVE) {
+                const int i = base + lane;
+                int n = -1;
+                if (i < f1) n = is[i];
+                const bool ok = (n >= 0 && n < U);
+                const unsigned long long mask = __ballot(ok);
+                const int cnt = __popcll(mask);
+                nins += cnt;
+                bool tiny = false;
+                if (ok) {                            // lane-parallel: one fragment per lane, compacted into LDS
+                    const double b = bj[n];
+                    const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    const double a = (nucp[n] * b) / sn, c = (nfrp[n] * b) / sf;
+                    ac[2 * pos] = a - c;                 // mixture alpha a + (1 - alpha) c evaluated as fma(alpha, a - c, c)
+                    ac[2 * pos + 1] = c;
+                    tiny = !(a >= 0x1p-200 && c >= 0x1p-200);
+                }
+                const bool safe = __ballot(tiny) == 0ull;
+                __builtin_amdgcn_wave_barrier();
+                int q = 0;
+                if (safe) {
+                    for (; q + 16 <= cnt; q += 16) {           // 16 fragments: 4 multiplies on each of the 8 chains, one renorm
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+    #pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const double au = ac[2 * (q + 4 * u + v)], cu = ac[2 * (q + 4 * u + v) + 1];
+                                m0[v] *= fma(al0, au, cu);
+                                m1[v] *= fma(al1, au, cu);
+                            }
+                        }
+    #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            const double au = ac[2 * (q + 4 * u + v)], cu = ac[2 * (q + 4 * u + v) + 1];
-                            m0[v] *= fma(al0, au, cu);
-                            m1[v] *= fma(al1, au, cu);
+                            int ex0, ex1;
+                            m0[v] = frexp(m0[v], &ex0);
+                            m1[v] = frexp(m1[v], &ex1);
+                            e0 += ex0;
+                            e1 += ex1;
                         }
                     }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        int ex0, ex1;
-                        m0[v] = frexp(m0[v], &ex0);
-                        m1[v] = frexp(m1[v], &ex1);
-                        e0 += ex0;
-                        e1 += ex1;
+                    for (; q + 4 <= cnt; q += 4) {             // 4 fragments: one multiply per chain
+    #pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double au = ac[2 * (q + v)], cu = ac[2 * (q + v) + 1];
+                            int ex0, ex1;
+                            m0[v] = frexp(m0[v] * fma(al0, au, cu), &ex0);
+                            m1[v] = frexp(m1[v] * fma(al1, au, cu), &ex1);
+                            e0 += ex0;
+                            e1 += ex1;
+                        }
                     }
                 }
-                for (; q + 4 <= cnt; q += 4) {             // 4 fragments: one multiply per chain
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const double au = ac[2 * (q + v)], cu = ac[2 * (q + v) + 1];
-                        int ex0, ex1;
-                        m0[v] = frexp(m0[v] * fma(al0, au, cu), &ex0);
-                        m1[v] = frexp(m1[v] * fma(al1, au, cu), &ex1);
-                        e0 += ex0;
-                        e1 += ex1;
-                    }
+                for (; q < cnt; ++q) {                         // tail / unsafe windows: renormalise every multiply
+                    const double au = ac[2 * q], cu = ac[2 * q + 1];
+                    int ex0, ex1;
+                    m0[0] = frexp(m0[0] * fma(al0, au, cu), &ex0);   // static index: keeps the chains in registers
+                    m1[0] = frexp(m1[0] * fma(al1, au, cu), &ex1);
+                    e0 += ex0;
+                    e1 += ex1;
                 }
+                __builtin_amdgcn_wave_barrier();
             }
-            for (; q < cnt; ++q) {                         // tail / unsafe windows: renormalise every multiply
-                const double au = ac[2 * q], cu = ac[2 * q + 1];
-                int ex0, ex1;
-                m0[0] = frexp(m0[0] * fma(al0, au, cu), &ex0);   // static index: keeps the chains in registers
-                m1[0] = frexp(m1[0] * fma(al1, au, cu), &ex1);
-                e0 += ex0;
-                e1 += ex1;
+            double mm0, mm1;
+            {
+                int ex0, ex1, ex2, ex3, ex4, ex5;
+                const double p0 = frexp(m0[0] * m0[1], &ex0), p1 = frexp(m0[2] * m0[3], &ex1);
+                const double r0 = frexp(m1[0] * m1[1], &ex2), r1 = frexp(m1[2] * m1[3], &ex3);
+                mm0 = frexp(p0 * p1, &ex4);
+                mm1 = frexp(r0 * r1, &ex5);
+                e0 += ex0 + ex1 + ex4;
+                e1 += ex2 + ex3 + ex5;
             }
-            __builtin_amdgcn_wave_barrier();
+            const long long go = ct.grid_off[chunk] + k;
+            if (nins == 0) {                         // sum(new_inserts) > 0 fails: stay NaN (Occupancy.py:143)
+                if (lane == 0) { g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan(""); }
+                continue;
+            }
+            if (ABL == 5) { if (lane == 0) g_occ[go] = mm0 + mm1 + e0 + e1; continue; }
+            // Decision without logarithms.  The likelihood of alpha is L = mm * 2^e with mm in [0.5, 1) (0 stands for
+            // log L = -inf).  argmax ll == argmax (e, mm) lexicographically, and the reference's likelihood-ratio test
+            //   2 (max ll - ll) < cutoff   <=>   L > Lmax * exp(-cutoff / 2)
+            // is evaluated as  ldexp(mm, e - emax) > mmax * ci_factor  (ci_factor = exp(-cutoff/2) from the host).
+            // reference: a zero-probability insert size gives log(0)*ins = -inf (ins>0) or NaN (ins==0) -> -inf
+            if (flags & (8 | 4)) { mm0 = 0.0; mm1 = 0.0; }
+            if ((flags & 2) && al0 == 0.0) mm0 = 0.0;
+            if ((flags & 2) && al1 == 0.0) mm1 = 0.0;
+            if ((flags & 1) && be0 == 0.0) mm0 = 0.0;
+            if ((flags & 1) && be1 == 0.0) mm1 = 0.0;
+            if (!(mm0 > 0.0) || a0 >= om.n_alpha) mm0 = 0.0;      // NaN likelihood -> -inf as well
+            if (!(mm1 > 0.0) || a1 >= om.n_alpha) mm1 = 0.0;
+            const double NONE = -1e300;
+            const double ed0 = mm0 > 0.0 ? (double)e0 : NONE, ed1 = mm1 > 0.0 ? (double)e1 : NONE;
+            const double emax = wave_max(fmax(ed0, ed1));
+            if (emax == NONE) {
+                // every likelihood is -inf: the reference raises ValueError (min of empty, Occupancy.py:118)
+                if (lane == 0) { g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan(""); atomicOr(&status[chunk], 1); }
+                continue;
+            }
+            const double mmax = wave_max(fmax(ed0 == emax ? mm0 : 0.0, ed1 == emax ? mm1 : 0.0));
+            const unsigned long long eq0 = __ballot(ed0 == emax && mm0 == mmax);
+            const unsigned long long eq1 = __ballot(ed1 == emax && mm1 == mmax);
+            const int imax = eq0 ? (__ffsll((long long)eq0) - 1) : (WAVE + __ffsll((long long)eq1) - 1);
+            const double thr = mmax * om.ci_factor;
+            const int iemax = (int)emax;
+            const int d0 = e0 - iemax, d1 = e1 - iemax;
+            const bool in0 = mm0 > 0.0 && d0 > -1100 && ldexp(mm0, d0) > thr;
+            const bool in1 = mm1 > 0.0 && d1 > -1100 && ldexp(mm1, d1) > thr;
+            const unsigned long long c0 = __ballot(in0);
+            const unsigned long long c1 = __ballot(in1);
+            if (lane == 0) {
+                const int ilo = c0 ? (__ffsll((long long)c0) - 1) : (WAVE + __ffsll((long long)c1) - 1);
+                const int ihi = c1 ? (WAVE + 63 - __clzll((long long)c1)) : (63 - __clzll((long long)c0));
+                g_occ[go] = om.alphas[imax];
+                g_lo[go] = om.alphas[ilo];
+                g_hi[go] = om.alphas[ihi];
+            }
         }
-        double mm0, mm1;
-        {
-            int ex0, ex1, ex2, ex3, ex4, ex5;
-            const double p0 = frexp(m0[0] * m0[1], &ex0), p1 = frexp(m0[2] * m0[3], &ex1);
-            const double r0 = frexp(m1[0] * m1[1], &ex2), r1 = frexp(m1[2] * m1[3], &ex3);
-            mm0 = frexp(p0 * p1, &ex4);
-            mm1 = frexp(r0 * r1, &ex5);
-            e0 += ex0 + ex1 + ex4;
-            e1 += ex2 + ex3 + ex5;
-        }
-        const long long go = ct.grid_off[chunk] + k;
-        if (nins == 0) {                         // sum(new_inserts) > 0 fails: stay NaN (Occupancy.py:143)
-            if (lane == 0) { g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan(""); }
-            continue;
-        }
-        if (ABL == 5) { if (lane == 0) g_occ[go] = mm0 + mm1 + e0 + e1; continue; }
-        // Decision without logarithms.  The likelihood of alpha is L = mm * 2^e with mm in [0.5, 1) (0 stands for
-        // log L = -inf).  argmax ll == argmax (e, mm) lexicographically, and the reference's likelihood-ratio test
-        //   2 (max ll - ll) < cutoff   <=>   L > Lmax * exp(-cutoff / 2)
-        // is evaluated as  ldexp(mm, e - emax) > mmax * ci_factor  (ci_factor = exp(-cutoff/2) from the host).
-        // reference: a zero-probability insert size gives log(0)*ins = -inf (ins>0) or NaN (ins==0) -> -inf
-        if (flags & (8 | 4)) { mm0 = 0.0; mm1 = 0.0; }
-        if ((flags & 2) && al0 == 0.0) mm0 = 0.0;
-        if ((flags & 2) && al1 == 0.0) mm1 = 0.0;
-        if ((flags & 1) && be0 == 0.0) mm0 = 0.0;
-        if ((flags & 1) && be1 == 0.0) mm1 = 0.0;
-        if (!(mm0 > 0.0) || a0 >= om.n_alpha) mm0 = 0.0;      // NaN likelihood -> -inf as well
-        if (!(mm1 > 0.0) || a1 >= om.n_alpha) mm1 = 0.0;
-        const double NONE = -1e300;
-        const double ed0 = mm0 > 0.0 ? (double)e0 : NONE, ed1 = mm1 > 0.0 ? (double)e1 : NONE;
-        const double emax = wave_max(fmax(ed0, ed1));
-        if (emax == NONE) {
-            // every likelihood is -inf: the reference raises ValueError (min of empty, Occupancy.py:118)
-            if (lane == 0) { g_occ[go] = g_lo[go] = g_hi[go] = __builtin_nan(""); atomicOr(&status[chunk], 1); }
-            continue;
-        }
-        const double mmax = wave_max(fmax(ed0 == emax ? mm0 : 0.0, ed1 == emax ? mm1 : 0.0));
-        const unsigned long long eq0 = __ballot(ed0 == emax && mm0 == mmax);
-        const unsigned long long eq1 = __ballot(ed1 == emax && mm1 == mmax);
-        const int imax = eq0 ? (__ffsll((long long)eq0) - 1) : (WAVE + __ffsll((long long)eq1) - 1);
-        const double thr = mmax * om.ci_factor;
-        const int iemax = (int)emax;
-        const int d0 = e0 - iemax, d1 = e1 - iemax;
-        const bool in0 = mm0 > 0.0 && d0 > -1100 && ldexp(mm0, d0) > thr;
-        const bool in1 = mm1 > 0.0 && d1 > -1100 && ldexp(mm1, d1) > thr;
-        const unsigned long long c0 = __ballot(in0);
-        const unsigned long long c1 = __ballot(in1);
-        if (lane == 0) {
-            const int ilo = c0 ? (__ffsll((long long)c0) - 1) : (WAVE + __ffsll((long long)c1) - 1);
-            const int ihi = c1 ? (WAVE + 63 - __clzll((long long)c1)) : (63 - __clzll((long long)c0));
-            g_occ[go] = om.alphas[imax];
-            g_lo[go] = om.alphas[ilo];
-            g_hi[go] = om.alphas[ihi];
-        }
+
     }
 }
 

@@ -8,19 +8,19 @@
 using namespace natac;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int ABL>
+template <int ABL, int ROWS = 0>
 void run(const ChunkTable &ct, const OccModelDev &om, int2 *d_t, int2 *d_r, int ntiles, double *g0, double *g1, double *g2, int *st, size_t lds, long long bp) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     for (int it = 0; it < 3; ++it) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((natac_occ_mle<5, 60, ABL>), dim3(ntiles), dim3(256), lds, 0, ct, d_t, d_r, om, g0, g1, g2, st);
+        hipLaunchKernelGGL((natac_occ_mle<5, 60, ABL, ROWS>), dim3(ntiles), dim3(256), lds, 0, ct, d_t, d_r, om, g0, g1, g2, st);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (it > 0 && ms < best) best = ms;
     }
     CK(hipGetLastError());
-    printf("ABL=%d  %.3f ms  %.1f Mbp/s\n", ABL, best, bp / best / 1e3);
+    printf("ABL=%d ROWS=%d  %.3f ms  %.1f Mbp/s\n", ABL, ROWS, best, bp / best / 1e3);
 }
 
 int main(int argc, char **argv) {
@@ -51,21 +51,34 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(d_nucp, nucp.data(), U * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_nfrp, nfrp.data(), U * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_al, al.data(), 101 * 8, hipMemcpyHostToDevice));
     ChunkTable ct{}; ct.nc = nc; ct.chunk_len = d_len; ct.frag_off = d_foff; ct.lpos = d_lp; ct.ilen = d_iln; ct.centre = d_cen; ct.bias_off = d_boff; ct.bias = d_bias; ct.bias_left = bl; ct.bias_right = br; ct.out_off = d_ooff; ct.grid_off = d_goff;
     OccModelDev om{}; om.nuc_probs = d_nucp; om.nfr_probs = d_nfrp; om.alphas = d_al; om.upper = U; om.n_alpha = 101; om.step = step; om.halfstep = half; om.flank = fl; om.cutoff = 2.705543454095404;
-    std::vector<int2> tiles; for (int i = 0; i < nc; ++i) for (int k = 0; k < nk; k += OCC_T) tiles.push_back(make_int2(i, k));
+    std::vector<int2> tiles; for (int i = 0; i < nc; ++i) for (int k = 0; k < nk; k += OCC_T * OCC_NP) tiles.push_back(make_int2(i, k));
     int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2))); CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
-    const int UP = (U + 1) & ~1, span = (OCC_T - 1) * step + 2 * fl + 1, EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
-    size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + ((span + 3) & ~1) + 512) * 8 + 2 * OCC_FMAX * 4;
+    const int UP = (U + 1) & ~1, span = (OCC_T * OCC_NP - 1) * step + 2 * fl + 1 + step, EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
+    size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + 512) * 8 + 2 * OCC_FMAX * 4;
     int2 *d_r; CK(hipMalloc(&d_r, tiles.size() * sizeof(int2)));
     { hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventRecord(e0));
       hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((tiles.size() + 255) / 256), dim3(256), 0, 0, ct, d_t, (int)tiles.size(), step, half, fl, d_r);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("tile ranges %.3f ms\n", ms); }
     printf("tiles=%zu lds=%zu grid points=%zu\n", tiles.size(), lds, ng);
     long long bp = (long long)nc * L;
+    std::vector<double> ref(3 * ng), got(3 * ng);
     run<0>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
+    CK(hipMemcpy(ref.data(), g0, ng * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(ref.data() + ng, g1, ng * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ref.data() + 2 * ng, g2, ng * 8, hipMemcpyDeviceToHost));
+    CK(hipMemset(g0, 0, ng * 8)); CK(hipMemset(g1, 0, ng * 8)); CK(hipMemset(g2, 0, ng * 8));
+    run<0, 1>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
+    CK(hipMemcpy(got.data(), g0, ng * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(got.data() + ng, g1, ng * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(got.data() + 2 * ng, g2, ng * 8, hipMemcpyDeviceToHost));
+    size_t bad = 0, nan = 0;
+    for (size_t i = 0; i < 3 * ng; ++i) {
+        const bool n1 = ref[i] != ref[i], n2 = got[i] != got[i];
+        if (n1) ++nan;
+        if (n1 != n2 || (!n1 && ref[i] != got[i])) { if (bad < 5) printf("mismatch at %zu (track %zu, idx %zu): %g vs %g\n", i, i / ng, i % ng, ref[i], got[i]); ++bad; }
+    }
+    printf("rows vs wave-per-point: %zu mismatches of %zu (%zu NaN in ref)\n", bad, 3 * ng, nan);
+    run<7, 1>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
+    run<2, 1>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
     run<1>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
-    run<2>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
     run<3>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
-    run<5>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
-    run<6>(ct, om, d_t, d_r, tiles.size(), g0, g1, g2, d_st, lds, bp);
     return 0;
 }
