@@ -198,6 +198,14 @@ int natac_write_bedgraph(const char *path, int append, int compress, int finish,
                          const int64_t *chunk_start, const int64_t *out_off, const double *vals, int write_zero,
                          int n_threads, int64_t *bytes_written);
 
+/* bgzip: compress a text file into BGZF members of <= 0xff00 input bytes + the EOF marker (the reference's
+ * pysam.tabix_compress, pyatac/utils.py:135-141 / run_nuc.py:204-214). */
+int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads);
+/* tabix: write the .tbi index ("bed" preset: columns 1/2/3, 0-based half-open, '#' comments) of a BGZF-compressed,
+ * position-sorted BED / bedGraph file (the reference's pysam.tabix_index(..., preset="bed"), same call sites).
+ * tbi_path NULL: `path` + ".tbi".  n_records (may be NULL) receives the number of indexed lines. */
+int natac_tabix_index(const char *path, const char *tbi_path, int n_threads, int64_t *n_records);
+
 /* ---- native BAM -> fragment arrays extractor (host side) -------------- */
 /* Decode a BAM once (parallel BGZF inflate) into per-reference arrays of the reads pyatac/fragments.pyx:25 keeps
  * (`is_proper_pair and not is_reverse`): pos = leftmost 0-based coordinate, tlen = |template length|, in file order. */

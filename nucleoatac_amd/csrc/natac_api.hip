@@ -4,6 +4,7 @@
 #include "natac_kernels.hpp"
 #include "natac_fft_bg.hpp"
 #include "natac_writer.hpp"
+#include "natac_tabix.hpp"
 #include "natac_bam.hpp"
 
 #include <algorithm>
@@ -1167,6 +1168,64 @@ int natac_write_bedgraph(const char *path, int append, int compress, int finish,
     if (rc == 2) return fail(NATAC_E_ARG, "write to %s failed", path);
     if (rc == 3) return fail(NATAC_E_NOMEM, "deflate failed");
     return NATAC_OK;
+}
+
+int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads) {
+    if (!src || !dst) return fail(NATAC_E_ARG, "null argument");
+    if (level < 1 || level > 9) return fail(NATAC_E_ARG, "level must be 1..9");
+    std::string text;
+    {
+        FILE *f = std::fopen(src, "rb");
+        if (!f) return fail(NATAC_E_ARG, "cannot open %s", src);
+        std::fseek(f, 0, SEEK_END);
+        const long sz = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        text.resize((size_t)sz);
+        const bool ok = sz == 0 || std::fread(&text[0], 1, (size_t)sz, f) == (size_t)sz;
+        std::fclose(f);
+        if (!ok) return fail(NATAC_E_ARG, "cannot read %s", src);
+    }
+    const size_t BLK = 0xff00, nblk = (text.size() + BLK - 1) / BLK;
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, (nblk + 15) / 16));
+    std::vector<std::string> parts(n_threads);
+    std::vector<int> bad(n_threads, 0);
+    auto work = [&](int t) {   // contiguous block ranges so that the parts concatenate in file order
+        const size_t b0 = nblk * t / n_threads, b1 = nblk * (t + 1) / n_threads;
+        for (size_t b = b0; b < b1; ++b)
+            if (!natac_writer::bgzf_block(parts[t], (const unsigned char *)text.data() + b * BLK, std::min(BLK, text.size() - b * BLK), level)) {
+                bad[t] = 1;
+                return;
+            }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (int b : bad) if (b) return fail(NATAC_E_NOMEM, "deflate failed");
+    FILE *f = std::fopen(dst, "wb");
+    if (!f) return fail(NATAC_E_ARG, "cannot open %s", dst);
+    bool ok = true;
+    for (auto &p : parts) ok = ok && (p.empty() || std::fwrite(p.data(), 1, p.size(), f) == p.size());
+    ok = ok && std::fwrite(natac_writer::BGZF_EOF, 1, 28, f) == 28;
+    if (std::fclose(f) != 0 || !ok) return fail(NATAC_E_ARG, "write to %s failed", dst);
+    return NATAC_OK;
+}
+
+int natac_tabix_index(const char *path, const char *tbi_path, int n_threads, int64_t *n_records) {
+    if (!path) return fail(NATAC_E_ARG, "path is NULL");
+    std::string msg;
+    const int rc = natac_tabix::index_bed(path, tbi_path, n_threads, n_records, &msg);
+    switch (rc) {
+        case 0: return NATAC_OK;
+        case 1: return fail(NATAC_E_ARG, "cannot read %s", path);
+        case 2: return fail(NATAC_E_ARG, "%s is not a BGZF file", path);
+        case 3: return fail(NATAC_E_NOMEM, "inflate / deflate failed on %s", path);
+        case 4: return fail(NATAC_E_ARG, "%s: %s", path, msg.c_str());
+        default: return fail(NATAC_E_ARG, "cannot write the index of %s", path);
+    }
 }
 
 /* ---------------- native BAM extractor ---------------- */

@@ -1,0 +1,212 @@
+// natac_tabix.hpp -- tabix (.tbi) index of a BGZF-compressed, position-sorted BED / bedGraph file (host side).
+//
+// Replaces the reference's pysam.tabix_index(..., preset="bed") calls after every track / peak file it writes
+// (pyatac/utils.py:135-141 `tabix_bedgraph`, nucleoatac/run_occ.py:136-139, run_nuc.py:204-214).  Format: SAM/tabix
+// specification ("The Tabix index file format"): binning index with min_shift 14 / depth 5 + 16-kb linear index over
+// BGZF virtual offsets (compressed block start << 16 | offset inside the inflated block), itself BGZF-compressed.
+#pragma once
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "natac_writer.hpp"
+
+namespace natac_tabix {
+
+struct Block { uint64_t coff; uint32_t csize; uint32_t usize; uint64_t uoff; };
+
+inline int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return ((1 << 15) - 1) / 7 + (int)(beg >> 14);
+    if (beg >> 17 == end >> 17) return ((1 << 12) - 1) / 7 + (int)(beg >> 17);
+    if (beg >> 20 == end >> 20) return ((1 << 9) - 1) / 7 + (int)(beg >> 20);
+    if (beg >> 23 == end >> 23) return ((1 << 6) - 1) / 7 + (int)(beg >> 23);
+    if (beg >> 26 == end >> 26) return ((1 << 3) - 1) / 7 + (int)(beg >> 26);
+    return 0;
+}
+
+struct RefIndex {
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> lin;
+    uint64_t off_beg = 0, off_end = 0, n_rec = 0;
+};
+
+inline void put32(std::string &o, uint32_t v) { for (int i = 0; i < 4; ++i) o.push_back((char)((v >> (8 * i)) & 0xff)); }
+inline void put64(std::string &o, uint64_t v) { for (int i = 0; i < 8; ++i) o.push_back((char)((v >> (8 * i)) & 0xff)); }
+
+// returns 0 ok, 1 cannot open / read, 2 not BGZF, 3 inflate error, 4 unsorted or malformed record, 5 write error
+inline int index_bed(const char *path, const char *tbi_path, int n_threads, int64_t *n_records, std::string *errmsg) {
+    // ---- read the file and walk the BGZF members
+    std::string data;
+    {
+        FILE *f = std::fopen(path, "rb");
+        if (!f) return 1;
+        std::fseek(f, 0, SEEK_END);
+        const long sz = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        data.resize((size_t)sz);
+        if (sz > 0 && std::fread(&data[0], 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); return 1; }
+        std::fclose(f);
+    }
+    std::vector<Block> blocks;
+    const unsigned char *d = (const unsigned char *)data.data();
+    uint64_t p = 0, utotal = 0;
+    while (p < data.size()) {
+        if (p + 18 > data.size() || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8 || !(d[p + 3] & 4)) return 2;
+        const uint32_t xlen = d[p + 10] | (d[p + 11] << 8);
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const uint32_t slen = d[q + 2] | (d[q + 3] << 8);
+            if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2) { bsize = (d[q + 4] | (d[q + 5] << 8)) + 1u; found = true; }
+            q += 4 + slen;
+        }
+        if (!found || p + bsize > data.size()) return 2;
+        const uint32_t isize = d[p + bsize - 4] | (d[p + bsize - 3] << 8) | (d[p + bsize - 2] << 16) | ((uint32_t)d[p + bsize - 1] << 24);
+        blocks.push_back(Block{p, bsize, isize, utotal});
+        utotal += isize;
+        p += bsize;
+    }
+    // ---- inflate all members in parallel into one text buffer
+    std::string text(utotal, '\0');
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    n_threads = std::max(1, std::min<int>(n_threads, (int)std::max<size_t>(1, blocks.size() / 16)));
+    std::vector<int> err(n_threads, 0);
+    auto work = [&](int t) {
+        for (size_t b = t; b < blocks.size(); b += n_threads) {
+            const Block &k = blocks[b];
+            if (k.usize == 0) continue;
+            const uint32_t xlen = d[k.coff + 10] | (d[k.coff + 11] << 8);
+            z_stream zs;
+            std::memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) { err[t] = 3; return; }
+            zs.next_in = (Bytef *)(d + k.coff + 12 + xlen);
+            zs.avail_in = k.csize - 12 - xlen - 8;
+            zs.next_out = (Bytef *)&text[k.uoff];
+            zs.avail_out = k.usize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { err[t] = 3; return; }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        for (int e : err) if (e) return e;
+    }
+    // virtual offset of an uncompressed position (a position at a member's end belongs to the start of the next member)
+    size_t bi = 0;
+    auto voff = [&](uint64_t u) -> uint64_t {
+        while (bi + 1 < blocks.size() && u >= blocks[bi].uoff + blocks[bi].usize) ++bi;
+        return (blocks[bi].coff << 16) | (u - blocks[bi].uoff);
+    };
+    // ---- records: chrom \t beg \t end ...   (0-based half-open: TBX_UCSC)
+    std::vector<std::string> names;
+    std::vector<RefIndex> refs;
+    int cur = -1;
+    uint32_t last_bin = 0xffffffffu;
+    uint64_t save_off = 0, last_off = 0;
+    int64_t last_beg = -1, nrec = 0;
+    auto flush_bin = [&]() {
+        if (cur >= 0 && last_bin != 0xffffffffu && last_off > save_off) refs[cur].bins[last_bin].push_back({save_off, last_off});
+    };
+    uint64_t u = 0;
+    while (u < utotal) {
+        const char *ls = text.data() + u;
+        const char *nl = (const char *)std::memchr(ls, '\n', utotal - u);
+        const uint64_t len = nl ? (uint64_t)(nl - ls) + 1 : utotal - u;
+        if (len > 1 && ls[0] != '#') {
+            const char *t1 = (const char *)std::memchr(ls, '\t', len);
+            const char *t2 = t1 ? (const char *)std::memchr(t1 + 1, '\t', len - (size_t)(t1 + 1 - ls)) : nullptr;
+            if (!t1 || !t2) { if (errmsg) *errmsg = "record without three columns"; return 4; }
+            const int64_t beg = std::strtoll(t1 + 1, nullptr, 10);
+            int64_t end = std::strtoll(t2 + 1, nullptr, 10);
+            if (end <= beg) end = beg + 1;
+            const size_t nlen = (size_t)(t1 - ls);
+            const uint64_t v0 = voff(u);
+            if (cur < 0 || names[cur].size() != nlen || std::memcmp(names[cur].data(), ls, nlen) != 0) {
+                flush_bin();
+                if (cur >= 0) refs[cur].off_end = v0;
+                for (auto &n : names)
+                    if (n.size() == nlen && std::memcmp(n.data(), ls, nlen) == 0) {
+                        if (errmsg) *errmsg = "chromosome blocks not continuous: " + n;
+                        return 4;
+                    }
+                names.emplace_back(ls, nlen);
+                refs.emplace_back();
+                cur = (int)names.size() - 1;
+                refs[cur].off_beg = v0;
+                last_bin = 0xffffffffu;
+                last_beg = -1;
+                save_off = v0;
+            }
+            if (beg < last_beg) { if (errmsg) *errmsg = "unsorted positions on " + names[cur]; return 4; }
+            last_beg = beg;
+            const uint32_t bin = (uint32_t)reg2bin(beg, end);
+            if (bin != last_bin) {
+                flush_bin();
+                save_off = v0;
+                last_bin = bin;
+            }
+            RefIndex &r = refs[cur];
+            const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+            if (r.lin.size() <= w1) r.lin.resize(w1 + 1, ~0ull);
+            for (size_t w = w0; w <= w1; ++w) if (r.lin[w] == ~0ull) r.lin[w] = v0;
+            ++r.n_rec;
+            ++nrec;
+            last_off = voff(u + len);
+        }
+        u += len;
+    }
+    flush_bin();
+    if (cur >= 0) refs[cur].off_end = last_off;
+    // ---- serialise
+    std::string out;
+    out.append("TBI\1", 4);
+    put32(out, (uint32_t)names.size());
+    put32(out, 0x10000u);                 // TBX_UCSC: 0-based half-open coordinates (the "bed" preset)
+    put32(out, 1); put32(out, 2); put32(out, 3);
+    put32(out, (uint32_t)'#');
+    put32(out, 0);
+    uint32_t l_nm = 0;
+    for (auto &n : names) l_nm += (uint32_t)n.size() + 1;
+    put32(out, l_nm);
+    for (auto &n : names) { out.append(n); out.push_back('\0'); }
+    for (auto &r : refs) {
+        for (size_t w = r.lin.size(); w-- > 0;)            // windows without a record inherit the next one's offset
+            if (r.lin[w] == ~0ull) r.lin[w] = (w + 1 < r.lin.size()) ? r.lin[w + 1] : r.off_end;
+        put32(out, (uint32_t)r.bins.size() + 1);
+        for (auto &b : r.bins) {
+            put32(out, b.first);
+            put32(out, (uint32_t)b.second.size());
+            for (auto &c : b.second) { put64(out, c.first); put64(out, c.second); }
+        }
+        put32(out, 37450u);                                 // htslib's pseudo-bin: file range + record counts of the reference
+        put32(out, 2);
+        put64(out, r.off_beg); put64(out, r.off_end);
+        put64(out, r.n_rec); put64(out, 0);
+        put32(out, (uint32_t)r.lin.size());
+        for (uint64_t v : r.lin) put64(out, v);
+    }
+    put64(out, 0);                                          // n_no_coor
+    std::string comp;
+    if (!natac_writer::bgzf_compress(comp, out, 6)) return 3;
+    comp.append((const char *)natac_writer::BGZF_EOF, 28);
+    const std::string tp = tbi_path ? std::string(tbi_path) : std::string(path) + ".tbi";
+    FILE *f = std::fopen(tp.c_str(), "wb");
+    if (!f) return 5;
+    const bool ok = std::fwrite(comp.data(), 1, comp.size(), f) == comp.size();
+    if (std::fclose(f) != 0 || !ok) return 5;
+    if (n_records) *n_records = nrec;
+    return 0;
+}
+
+}  // namespace natac_tabix

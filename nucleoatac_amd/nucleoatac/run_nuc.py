@@ -11,7 +11,7 @@ from ..pyatac.fragmentsizes import FragmentSizes
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
 from ..pyatac.VMat import VMat
 from ..shard import balanced_ranges, env_rank_world
-from ..writer import write_bedgraph
+from ..writer import bgzip_file, tabix_index, write_bedgraph
 from .NucleosomeCalling import NucParameters, nuc_batch
 
 BATCH_CHUNKS = 4096
@@ -105,7 +105,9 @@ def run_nuc(args):
                         with open(base + ".rank%d" % r, "rb") as fi:
                             shutil.copyfileobj(fi, fo)
                         os.remove(base + ".rank%d" % r)
+            # bgzip + tabix of every output like the reference (run_nuc.py:195-201)
             if n.startswith("nucpos"):
-                with open(base, "rb") as fi, gzip.open(base + ".gz", "wb") as fo:
-                    shutil.copyfileobj(fi, fo)
-                os.remove(base)
+                bgzip_file(base, level=COMPRESS_LEVEL)
+                tabix_index(base + ".gz")
+            else:
+                tabix_index(base)

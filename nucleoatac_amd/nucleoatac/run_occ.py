@@ -13,7 +13,7 @@ from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
 from ..shard import balanced_ranges, env_rank_world, gather_in_chunk_order, ordered_sum
-from ..writer import write_bedgraph
+from ..writer import bgzip_file, tabix_index, write_bedgraph
 from .Occupancy import FragmentMixDistribution, OccupancyParameters, occ_batch
 
 BATCH_CHUNKS = 4096   # chunks per GPU batch (the reference maps cores*5 chunks per pool.map round)
@@ -37,12 +37,6 @@ def _occHelperBatch(chunks, params):
         print("Caught exception when processing:\n" + "\n".join(c.asBed() for c in chunks[:3]) + "\n")
         raise
     return out
-
-
-def _compress(path):
-    with open(path, "rb") as fi, gzip.open(path + ".gz", "wb") as fo:
-        shutil.copyfileobj(fi, fo)
-    os.remove(path)
 
 
 def run_occ(args):
@@ -110,6 +104,10 @@ def run_occ(args):
                         with open(base + ".rank%d" % r, "rb") as fi:
                             shutil.copyfileobj(fi, fo)
                         os.remove(base + ".rank%d" % r)
-        _compress(args.out + ".occpeaks.bed")
+        # bgzip + tabix of every output like the reference (run_occ.py:130-136)
+        bgzip_file(args.out + ".occpeaks.bed", level=COMPRESS_LEVEL)
+        tabix_index(args.out + ".occpeaks.bed.gz")
+        for n in names:
+            tabix_index(args.out + "." + n + ".bedgraph.gz")
         nuc_dist = ordered_sum(dists) if dists else np.zeros(args.upper)
         FragmentSizes(0, args.upper, vals=nuc_dist).save(args.out + ".nuc_dist.txt")

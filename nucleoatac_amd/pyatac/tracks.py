@@ -1,5 +1,6 @@
 """Per-base signal tracks (API of the reference's pyatac/tracks.py:16-222)."""
 import gzip
+import os
 
 import numpy as np
 
@@ -68,7 +69,8 @@ class Track(Chunk):
         handle.write("".join(out))
 
     def read_track(self, bedgraph, start=None, end=None, empty=np.nan, flank=None):
-        """read values from a (gzipped) bedGraph file (pyatac/tracks.py:75-87; linear scan instead of tabix)"""
+        """read values from a (gzipped) bedGraph file (pyatac/tracks.py:75-87): through the tabix index when
+        `bedgraph`.tbi exists (pysam.TabixFile.fetch of the reference), else by a linear scan"""
         if start:
             self.start = start
         if end:
@@ -77,6 +79,16 @@ class Track(Chunk):
             self.start -= flank
             self.end += flank
         out = np.ones(self.end - self.start) * empty
+        if bedgraph.endswith(".gz") and os.path.exists(bedgraph + ".tbi"):
+            from ..tabix import TabixFile
+            tb = TabixFile(bedgraph)
+            for line in tb.fetch(self.chrom, max(0, self.start), self.end):
+                f = line.split("\t")
+                s, e = int(f[1]), int(f[2])
+                out[max(s - self.start, 0):min(e - self.start, self.end - self.start)] = float(f[3])
+            tb.close()
+            self.vals = out
+            return
         opener = gzip.open if bedgraph.endswith(".gz") else open
         with opener(bedgraph, "rt") as fh:
             for line in fh:

@@ -1,0 +1,114 @@
+"""Reader for tabix-indexed BGZF BED / bedGraph files (the role of pysam.TabixFile.fetch in pyatac/tracks.py:75-87
+and pyatac/bias.py).  Pure host code: the index is written by natac_tabix_index (csrc/natac_tabix.hpp)."""
+import gzip
+import struct
+import zlib
+
+
+def reg2bins(beg, end):
+    """bins of the 5-level / 16 kb binning scheme that may hold records overlapping [beg, end)"""
+    end -= 1
+    bins = [0]
+    for shift, off in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        bins.extend(range(off + (beg >> shift), off + (end >> shift) + 1))
+    return bins
+
+
+class TabixFile(object):
+    def __init__(self, path, index=None):
+        self.path = path
+        with gzip.open(index or path + ".tbi", "rb") as fh:
+            raw = fh.read()
+        if raw[:4] != b"TBI\x01":
+            raise ValueError("not a tabix index: %s" % (index or path + ".tbi"))
+        n_ref, self.format, self.col_seq, self.col_beg, self.col_end, self.meta, self.skip, l_nm = struct.unpack_from("<8i", raw, 4)
+        p = 36
+        self.contigs = [n.decode() for n in raw[p:p + l_nm].split(b"\0")[:-1]]
+        p += l_nm
+        self.bins, self.lin, self.stats = [], [], []
+        for _ in range(n_ref):
+            (n_bin,) = struct.unpack_from("<i", raw, p)
+            p += 4
+            bins = {}
+            for _b in range(n_bin):
+                b, n_chunk = struct.unpack_from("<Ii", raw, p)
+                p += 8
+                bins[b] = [struct.unpack_from("<QQ", raw, p + 16 * i) for i in range(n_chunk)]
+                p += 16 * n_chunk
+            self.stats.append(bins.pop(37450, None))
+            (n_intv,) = struct.unpack_from("<i", raw, p)
+            p += 4
+            self.lin.append(struct.unpack_from("<%dQ" % n_intv, raw, p))
+            p += 8 * n_intv
+            self.bins.append(bins)
+        self._fh = open(path, "rb")
+
+    def close(self):
+        self._fh.close()
+
+    def _block(self, coff):
+        self._fh.seek(coff)
+        head = self._fh.read(18)
+        if len(head) < 18:
+            return b"", 0
+        xlen = struct.unpack_from("<H", head, 10)[0]
+        extra = head[12:] + self._fh.read(xlen - 6)
+        bsize, q = None, 0
+        while q + 4 <= len(extra):
+            slen = struct.unpack_from("<H", extra, q + 2)[0]
+            if extra[q:q + 2] == b"BC":
+                bsize = struct.unpack_from("<H", extra, q + 4)[0] + 1
+            q += 4 + slen
+        body = self._fh.read(bsize - 12 - xlen)
+        return zlib.decompress(body[:-8], -15), bsize
+
+    def _read(self, v0, v1):
+        """inflated bytes between two virtual offsets"""
+        out = []
+        coff, uoff = v0 >> 16, v0 & 0xffff
+        while coff < (v1 >> 16) or (coff == (v1 >> 16) and uoff < (v1 & 0xffff)):
+            data, bsize = self._block(coff)
+            if bsize == 0:
+                break
+            stop = (v1 & 0xffff) if coff == (v1 >> 16) else len(data)
+            out.append(data[uoff:stop])
+            coff, uoff = coff + bsize, 0
+        return b"".join(out)
+
+    def fetch(self, chrom, start, end):
+        """lines (str, without newline) of records on `chrom` overlapping [start, end)"""
+        if chrom not in self.contigs:
+            return
+        tid = self.contigs.index(chrom)
+        start = max(0, int(start))
+        end = int(end)
+        if end <= start:
+            return
+        lin = self.lin[tid]
+        w = start >> 14
+        min_off = lin[w] if w < len(lin) else (lin[-1] if lin else 0)
+        chunks = []
+        for b in reg2bins(start, end):
+            for c0, c1 in self.bins[tid].get(b, ()):
+                if c1 > min_off:
+                    chunks.append((max(c0, min_off), c1))
+        chunks.sort()
+        merged = []
+        for c0, c1 in chunks:
+            if merged and c0 <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], c1)
+            else:
+                merged.append([c0, c1])
+        for c0, c1 in merged:
+            for line in self._read(c0, c1).split(b"\n"):
+                if not line or line[:1] == b"#":
+                    continue
+                f = line.split(b"\t")
+                if f[self.col_seq - 1].decode() != chrom:
+                    continue
+                b0 = int(f[self.col_beg - 1])
+                e0 = max(int(f[self.col_end - 1]), b0 + 1)
+                if b0 >= end:
+                    return
+                if e0 > start:
+                    yield line.decode()

@@ -23,3 +23,23 @@ def write_bedgraph(path, chroms, chunk_start, out_off, vals, append=False, compr
                                      chunk_start.ctypes.data_as(C.c_void_p), out_off.ctypes.data_as(C.c_void_p),
                                      vals.ctypes.data_as(C.c_void_p), 1 if write_zero else 0, int(n_threads), C.byref(nb)))
     return nb.value
+
+
+def bgzip_file(src, dst=None, level=4, n_threads=0, remove=True):
+    """BGZF-compress a text file (pysam.tabix_compress of the reference); returns the path of the .gz"""
+    import os
+    lib = L.load()
+    dst = dst or (str(src) + ".gz")
+    L.check(lib.natac_bgzip_file(str(src).encode(), str(dst).encode(), int(level), int(n_threads)))
+    if remove:
+        os.remove(src)
+    return dst
+
+
+def tabix_index(path, tbi_path=None, n_threads=0):
+    """write path + '.tbi' ("bed" preset; pysam.tabix_index(path, preset="bed") of the reference); returns #records"""
+    lib = L.load()
+    n = C.c_int64(0)
+    L.check(lib.natac_tabix_index(str(path).encode(), None if tbi_path is None else str(tbi_path).encode(), int(n_threads),
+                                  C.byref(n)))
+    return n.value

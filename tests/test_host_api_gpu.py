@@ -128,7 +128,7 @@ def test_cli_occ_then_nuc(tmp_path):
     out = str(tmp_path / "t")
     main(["occ", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--sizes", sizes])
     for f in ("occ.bedgraph.gz", "occ.lower_bound.bedgraph.gz", "occ.upper_bound.bedgraph.gz", "occpeaks.bed.gz",
-              "nuc_dist.txt", "fragmentsizes.txt"):
+              "nuc_dist.txt", "fragmentsizes.txt", "occ.bedgraph.gz.tbi", "occpeaks.bed.gz.tbi"):
         assert os.path.exists(out + "." + f), f
     vm = str(tmp_path / "v.npz")
     np.savez(vm, vmat=par["vmat"], vlower=par["vlower"], vupper=par["vupper"])
@@ -141,8 +141,21 @@ def test_cli_occ_then_nuc(tmp_path):
         t = Track("chrS", s_, e_)
         t.read_track(out + "." + f + ".bedgraph.gz")
         np.testing.assert_allclose(t.vals, g[key], rtol=1e-5, atol=1e-9)
+    # the same tracks through a linear scan (no index) give the same values as through the tabix index
+    import shutil
+    shutil.copy(out + ".nucleoatac_signal.bedgraph.gz", out + ".noindex.bedgraph.gz")
+    t2 = Track("chrS", s_, e_)
+    t2.read_track(out + ".noindex.bedgraph.gz")
+    t3 = Track("chrS", s_, e_)
+    t3.read_track(out + ".nucleoatac_signal.bedgraph.gz")
+    assert os.path.exists(out + ".nucleoatac_signal.bedgraph.gz.tbi") and os.path.exists(out + ".nucpos.bed.gz.tbi")
+    np.testing.assert_array_equal(t2.vals, t3.vals)
+    from nucleoatac_amd.tabix import TabixFile
+    tb = TabixFile(out + ".nucpos.bed.gz")
     with gzip.open(out + ".nucpos.bed.gz", "rt") as fh:
         rows = [l.split("\t") for l in fh.read().strip().split("\n")]
+    assert [l.split("\t") for l in tb.fetch("chrS", s_, e_)] == [r for r in rows if int(r[1]) < e_ and int(r[2]) > s_]
+    tb.close()
     mine = sorted(int(r[1]) - s_ for r in rows if s_ <= int(r[1]) < e_)
     assert mine == [int(x) for x in g["c2_nucpos"][:, 0]]
     assert all(len(r) == 13 and r[4] != "nan" for r in rows)     # occ read back from the occ track

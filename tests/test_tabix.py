@@ -1,0 +1,130 @@
+"""natac_bgzip_file / natac_tabix_index (csrc/natac_tabix.hpp) + the TabixFile reader: region queries through the index
+must return exactly what a linear scan of the text returns (pysam.tabix_index / TabixFile.fetch of the reference)."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from nucleoatac_amd import _lib as L
+from nucleoatac_amd.tabix import TabixFile, reg2bins
+from nucleoatac_amd.writer import bgzip_file, tabix_index, write_bedgraph
+
+
+def _brute(lines, chrom, start, end):
+    out = []
+    for ln in lines:
+        f = ln.split("\t")
+        if f[0] == chrom and int(f[1]) < end and max(int(f[2]), int(f[1]) + 1) > start:
+            out.append(ln)
+    return out
+
+
+def _random_bed(rng, n_per_chrom, chroms, span):
+    lines = []
+    for c in chroms:
+        pos = np.sort(rng.integers(0, span, n_per_chrom))
+        for p in pos:
+            lines.append("%s\t%d\t%d\t%.3f" % (c, p, p + int(rng.integers(1, 400)), rng.random()))
+    return lines
+
+
+def test_reg2bins_contains_reg2bin():
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        b = int(rng.integers(0, 1 << 29) - 1000)
+        b = max(b, 0)
+        e = b + int(rng.integers(1, 1 << int(rng.integers(1, 27))))
+        e = min(e, 1 << 29)
+        if e <= b:
+            continue
+        # bin of the record itself (same formula as csrc reg2bin)
+        ee = e - 1
+        for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+            if b >> shift == ee >> shift:
+                rb = off + (b >> shift)
+                break
+        else:
+            rb = 0
+        assert rb in reg2bins(b, e)
+
+
+def test_bgzip_and_index_roundtrip(tmp_path):
+    rng = np.random.default_rng(1)
+    lines = ["# a comment line"] + _random_bed(rng, 30000, ["chrI", "chrII", "chrX_random"], 3_000_000)
+    src = tmp_path / "peaks.bed"
+    src.write_text("\n".join(lines) + "\n")
+    gz = bgzip_file(str(src), level=4)
+    assert gz.endswith(".bed.gz") and not os.path.exists(str(src))
+    with gzip.open(gz, "rt") as fh:               # plain gzip readers see the same text
+        assert fh.read().split("\n")[:-1] == lines
+    with open(gz, "rb") as fh:
+        assert fh.read()[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 66, 67, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    n = tabix_index(gz)
+    assert n == len(lines) - 1
+    with gzip.open(gz + ".tbi", "rb") as fh:
+        raw = fh.read()
+    assert raw[:4] == b"TBI\x01"
+    n_ref, fmt, cs, cb, ce, meta, skip, l_nm = struct.unpack_from("<8i", raw, 4)
+    assert (n_ref, fmt, cs, cb, ce, meta, skip) == (3, 0x10000, 1, 2, 3, ord("#"), 0)
+    tb = TabixFile(gz)
+    assert tb.contigs == ["chrI", "chrII", "chrX_random"]
+    assert [int(s[1][0]) for s in tb.stats] == [30000, 30000, 30000]
+    body = lines[1:]
+    for _ in range(300):
+        c = tb.contigs[int(rng.integers(0, 3))]
+        s = int(rng.integers(0, 3_000_000))
+        e = s + int(rng.integers(1, 1 << int(rng.integers(1, 21))))
+        assert list(tb.fetch(c, s, e)) == _brute(body, c, s, e), (c, s, e)
+    assert list(tb.fetch("chrI", 0, 1 << 29)) == [ln for ln in body if ln.startswith("chrI\t")]
+    assert list(tb.fetch("nope", 0, 100)) == []
+    tb.close()
+
+
+def test_index_of_native_bedgraph_writer(tmp_path):
+    """the multi-threaded track writer's BGZF output is indexable, and queries agree with the values written"""
+    rng = np.random.default_rng(2)
+    nc = 40
+    lens = rng.integers(500, 30000, nc)
+    chroms = ["chr1"] * 25 + ["chr2"] * 15
+    starts = np.concatenate([np.cumsum(np.r_[100, lens[:24] + 50]), np.cumsum(np.r_[5000, lens[25:39] + 70])])
+    off = np.r_[0, np.cumsum(lens)]
+    vals = np.round(rng.random(int(off[-1])) * 4) / 4.0          # runs of equal values -> run-length lines
+    path = str(tmp_path / "t.bedgraph.gz")
+    write_bedgraph(path, chroms, starts, off, vals, compress=4)
+    n = tabix_index(path)
+    with gzip.open(path, "rt") as fh:
+        body = fh.read().split("\n")[:-1]
+    assert n == len(body)
+    tb = TabixFile(path)
+    for _ in range(200):
+        i = int(rng.integers(0, nc))
+        s = int(starts[i] + rng.integers(0, lens[i]))
+        e = s + int(rng.integers(1, 3000))
+        got = list(tb.fetch(chroms[i], s, e))
+        assert got == _brute(body, chroms[i], s, e)
+        # and the lines reproduce the written values on the queried bases of this chunk
+        for ln in got:
+            c, b0, e0, v = ln.split("\t")
+            for x in range(max(int(b0), s), min(int(e0), e, int(starts[i] + lens[i]))):
+                if starts[i] <= x:
+                    assert float(v) == vals[off[i] + x - starts[i]]
+    tb.close()
+
+
+def test_index_rejects_unsorted_and_plain_gzip(tmp_path):
+    src = tmp_path / "u.bed"
+    src.write_text("chr1\t500\t600\nchr1\t100\t200\n")
+    gz = bgzip_file(str(src))
+    with pytest.raises(L.NatacError):
+        tabix_index(gz)
+    plain = str(tmp_path / "p.bed.gz")
+    with gzip.open(plain, "wt") as fh:
+        fh.write("chr1\t1\t2\n")
+    with pytest.raises(L.NatacError):
+        tabix_index(plain)
+    split = tmp_path / "s.bed"
+    split.write_text("chr1\t1\t2\nchr2\t1\t2\nchr1\t5\t6\n")
+    with pytest.raises(L.NatacError):
+        tabix_index(bgzip_file(str(split)))
