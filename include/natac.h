@@ -206,6 +206,16 @@ int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads)
  * tbi_path NULL: `path` + ".tbi".  n_records (may be NULL) receives the number of indexed lines. */
 int natac_tabix_index(const char *path, const char *tbi_path, int n_threads, int64_t *n_records);
 
+/* ---- host-side packing of a chunk list (what replaces the per-chunk bamHandle.fetch of pyatac/fragments.pyx:21-36) ---- */
+/* pos[c] / tlen[c]: the forward proper-pair reads of chromosome c (natac_bam_ref_reads), pos ascending.  chrom_id[i] < 0: a
+ * chunk on a chromosome without reads.  Attached to chunk i are the reads with pos in [start - margin - shift, end + margin)
+ * (shift = 4 when atac), as l = pos + shift - start, n = |tlen| - (8 when atac), ordered by centre l + (n-1)//2 (stable).
+ * Call once with lpos == NULL: fills frag_off[0..n_chunks] and first[0..n_chunks) (count pass); allocate
+ * frag_off[n_chunks] entries and call again with lpos / ilen to fill them (multi-threaded). */
+int natac_pack_chunks(int32_t n_chunks, const int64_t *chunk_start, const int64_t *chunk_end, const int32_t *chrom_id, int32_t n_chroms,
+                      const int64_t *const *pos, const int64_t *const *tlen, const int64_t *n_per_chrom, int64_t margin, int atac,
+                      int64_t *frag_off, int64_t *first, int32_t *lpos, int32_t *ilen, int n_threads);
+
 /* ---- native BAM -> fragment arrays extractor (host side) -------------- */
 /* Decode a BAM once (parallel BGZF inflate) into per-reference arrays of the reads pyatac/fragments.pyx:25 keeps
  * (`is_proper_pair and not is_reverse`): pos = leftmost 0-based coordinate, tlen = |template length|, in file order. */

@@ -5,6 +5,7 @@
 #include "natac_fft_bg.hpp"
 #include "natac_writer.hpp"
 #include "natac_tabix.hpp"
+#include "natac_pack.hpp"
 #include "natac_bam.hpp"
 
 #include <algorithm>
@@ -1226,6 +1227,28 @@ int natac_tabix_index(const char *path, const char *tbi_path, int n_threads, int
         case 4: return fail(NATAC_E_ARG, "%s: %s", path, msg.c_str());
         default: return fail(NATAC_E_ARG, "cannot write the index of %s", path);
     }
+}
+
+int natac_pack_chunks(int32_t n_chunks, const int64_t *chunk_start, const int64_t *chunk_end, const int32_t *chrom_id, int32_t n_chroms,
+                      const int64_t *const *pos, const int64_t *const *tlen, const int64_t *n_per_chrom, int64_t margin, int atac,
+                      int64_t *frag_off, int64_t *first, int32_t *lpos, int32_t *ilen, int n_threads) {
+    if (n_chunks < 0 || n_chroms < 0 || margin < 0) return fail(NATAC_E_ARG, "bad sizes");
+    if (n_chunks > 0 && (!chunk_start || !chunk_end || !chrom_id || !frag_off || !first)) return fail(NATAC_E_ARG, "null argument");
+    if (n_chroms > 0 && (!pos || !tlen || !n_per_chrom)) return fail(NATAC_E_ARG, "null argument");
+    for (int32_t i = 0; i < n_chunks; ++i) {
+        if (chrom_id[i] >= n_chroms) return fail(NATAC_E_ARG, "chunk %d: chromosome id %d out of range", i, chrom_id[i]);
+        if (chunk_end[i] < chunk_start[i]) return fail(NATAC_E_ARG, "chunk %d: end < start", i);
+    }
+    const int shift = atac ? 4 : 0, trim = atac ? 8 : 0;
+    if (!lpos || !ilen) {
+        if (!frag_off) return fail(NATAC_E_ARG, "null argument");
+        if (n_chunks == 0) { if (frag_off) frag_off[0] = 0; return NATAC_OK; }
+        natac_pack::count(n_chunks, chunk_start, chunk_end, chrom_id, pos, n_per_chrom, margin, shift, frag_off, first);
+        return NATAC_OK;
+    }
+    if (n_chunks == 0) return NATAC_OK;
+    natac_pack::fill(n_chunks, chunk_start, chrom_id, pos, tlen, frag_off, first, shift, trim, lpos, ilen, n_threads);
+    return NATAC_OK;
 }
 
 /* ---------------- native BAM extractor ---------------- */

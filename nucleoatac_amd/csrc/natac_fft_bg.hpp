@@ -79,56 +79,54 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
 // forward 512-point FFT of the wave's data (lane n, register j <-> element n + 64 j); result: lane b, register m holds the
 // bin of "stage-3 butterfly b, output m" (a fixed permutation of the frequencies, identical for signal and template).
 // sa / sb: the wave's LDS scratch, FFT_LA and FFT_LB doubles for the real and for the imaginary parts each.
-__device__ __forceinline__ void fft512_fwd(double (&re)[8], double (&im)[8], const FftTwiddles &t, double *sar, double *sai,
-                                           double *sbr, double *sbi, int lane) {
+__device__ __forceinline__ void fft512_fwd(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sa, double2 *sb, int lane) {
     dft8<false>(re, im);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 1 (layout A: lane + 72 m)
         const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])), xi = fma(re[m], t.w1i[m], im[m] * t.w1r[m]);
-        sar[lane + 72 * m] = m ? xr : re[0];
-        sai[lane + 72 * m] = m ? xi : im[0];
+        sa[lane + 72 * m] = make_double2(m ? xr : re[0], m ? xi : im[0]);
     }
     __builtin_amdgcn_wave_barrier();
     const int m2 = lane >> 3, n1 = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { re[j] = sar[72 * m2 + n1 + 8 * j]; im[j] = sai[72 * m2 + n1 + 8 * j]; }
+    for (int j = 0; j < 8; ++j) { const double2 v = sa[72 * m2 + n1 + 8 * j]; re[j] = v.x; im[j] = v.y; }
     __builtin_amdgcn_wave_barrier();   // sb* may alias sa*
     dft8<false>(re, im);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 2 (layout B: element n1 of butterfly 8 m2 + m)
         const double xr = fma(re[m], t.w2r[m], -(im[m] * t.w2i[m])), xi = fma(re[m], t.w2i[m], im[m] * t.w2r[m]);
-        sbr[n1 * 65 + 8 * m2 + m] = m ? xr : re[0];
-        sbi[n1 * 65 + 8 * m2 + m] = m ? xi : im[0];
+        sb[n1 * 65 + 8 * m2 + m] = make_double2(m ? xr : re[0], m ? xi : im[0]);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n = 0; n < 8; ++n) { re[n] = sbr[n * 65 + lane]; im[n] = sbi[n * 65 + lane]; }
+    for (int n = 0; n < 8; ++n) { const double2 v = sb[n * 65 + lane]; re[n] = v.x; im[n] = v.y; }
     dft8<false>(re, im);
     __builtin_amdgcn_wave_barrier();
 }
 
 // exact inverse of fft512_fwd up to the factor 512
-__device__ __forceinline__ void fft512_inv(double (&re)[8], double (&im)[8], const FftTwiddles &t, double *sar, double *sai,
-                                           double *sbr, double *sbi, int lane) {
+__device__ __forceinline__ void fft512_inv(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sa, double2 *sb, int lane) {
     dft8<true>(re, im);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) { sbr[n * 65 + lane] = re[n]; sbi[n * 65 + lane] = im[n]; }
+    for (int n = 0; n < 8; ++n) sb[n * 65 + lane] = make_double2(re[n], im[n]);
     __builtin_amdgcn_wave_barrier();
     const int m2 = lane >> 3, n1 = lane & 7;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const double xr = sbr[n1 * 65 + 8 * m2 + m], xi = sbi[n1 * 65 + 8 * m2 + m];
+        const double2 v = sb[n1 * 65 + 8 * m2 + m];
+        const double xr = v.x, xi = v.y;
         re[m] = m ? fma(xr, t.w2r[m], xi * t.w2i[m]) : xr;                 // * conj(W)
         im[m] = m ? fma(xi, t.w2r[m], -(xr * t.w2i[m])) : xi;
     }
     __builtin_amdgcn_wave_barrier();
     dft8<true>(re, im);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sar[72 * m2 + n1 + 8 * j] = re[j]; sai[72 * m2 + n1 + 8 * j] = im[j]; }
+    for (int j = 0; j < 8; ++j) sa[72 * m2 + n1 + 8 * j] = make_double2(re[j], im[j]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const double xr = sar[lane + 72 * m], xi = sai[lane + 72 * m];
+        const double2 v = sa[lane + 72 * m];
+        const double xr = v.x, xi = v.y;
         re[m] = m ? fma(xr, t.w1r[m], xi * t.w1i[m]) : xr;
         im[m] = m ? fma(xi, t.w1r[m], -(xr * t.w1i[m])) : xi;
     }
@@ -139,7 +137,7 @@ __device__ __forceinline__ void fft512_inv(double (&re)[8], double (&im)[8], con
 // K[pair] = FFT(V_a + i V_b) in the layout fft512_fwd produces; kout[pair][re/im][m][lane].  One wave per pair.
 __global__ void __launch_bounds__(64) natac_fft_template(const double *__restrict__ vmat, int R, int W, const double *__restrict__ tw,
                                                            double *__restrict__ kout) {
-    __shared__ double sar[FFT_LA], sai[FFT_LA], sbr[FFT_LB], sbi[FFT_LB];
+    __shared__ double2 sa[FFT_LA], sb[FFT_LB];
     const int lane = threadIdx.x, pair = blockIdx.x;
     const int ra = 2 * pair, rb = 2 * pair + 1;
     FftTwiddles t;
@@ -151,7 +149,7 @@ __global__ void __launch_bounds__(64) natac_fft_template(const double *__restric
         re[j] = (u < W) ? vmat[ra * W + u] : 0.0;
         im[j] = (u < W && rb < R) ? vmat[rb * W + u] : 0.0;
     }
-    fft512_fwd(re, im, t, sar, sai, sbr, sbi, lane);
+    fft512_fwd(re, im, t, sa, sb, lane);
     double *o = kout + (size_t)pair * 2 * FFT_N;
 #pragma unroll
     for (int m = 0; m < 8; ++m) { o[m * 64 + lane] = re[m]; o[FFT_N + m * 64 + lane] = im[m]; }
@@ -172,7 +170,9 @@ __global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const 
     const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
     const int EW = FFT_N + A + Bh, EWP = (EW + 1) & ~1;
-    double *Et = smem, *sar = Et + EWP, *sai = sar + FFT_LA, *sbr = sar, *sbi = sai;   // layouts A and B are never live together
+    double *Et = smem;
+    double2 *ca = (double2 *)(Et + EWP), *cb = ca;     // complex scratch of the transposes; layouts A and B are never live together
+    double *sar = (double *)ca, *sai = sar + FFT_LA;   // the same memory as two real arrays (epilogue)
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, x0 = t.y;
     const int L = ct.chunk_len[chunk];
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const 
             im[j] = (sb * elb[u]) * erb[u];
             q[j] += re[j] + im[j];
         }
-        fft512_fwd(re, im, tww, sar, sai, sbr, sbi, lane);
+        fft512_fwd(re, im, tww, ca, cb, lane);
         const double *k = ktab + (size_t)pair * 2 * FFT_N;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const 
             acci[m] = fma(im[m], kr, fma(-re[m], ki, acci[m]));
         }
     }
-    fft512_inv(accr, acci, tww, sar, sai, sbr, sbi, lane);
+    fft512_inv(accr, acci, tww, ca, cb, lane);
     // covB: W-wide box sum of Q (both rows of every pair already added), two levels: T[u] = sum of B consecutive Q,
     // cov[u] = sum of nb strided T + the remainder  (B = 11, nb = 11 for W = 121: 23 LDS reads per base instead of 121)
     int B = 1;

@@ -19,29 +19,44 @@ def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN)
     """PackedChunks for a list of Chunk objects.  The log-bias slice of every chunk is the PWM score of
     [start-246, end+247) (InsertionBiasTrack.computeBias, as in nucleoatac/Occupancy.py:212-214) or None."""
     st = FragmentStore.open(bam)
-    starts, lens, offs, ls, ns, boffs, bvals, chroms = [], [], [0], [], [], [0], [], []
-    bias_of = _bias_spans(chunks, fasta, chrs, pwm) if fasta is not None else None
-    for ch in chunks:
-        l, n = st.fetch(ch.chrom, ch.start - margin, ch.end + margin, 1 if atac else 0)
-        keep = l >= ch.start - margin
-        l, n = l[keep], n[keep]
-        lr = (l - ch.start).astype(np.int32)
-        o = sort_by_centre(lr, n)
-        ls.append(lr[o])
-        ns.append(n[o].astype(np.int32))
-        offs.append(offs[-1] + len(lr))
-        starts.append(ch.start)
-        lens.append(ch.end - ch.start)
-        chroms.append(ch.chrom)
-        if fasta is not None:
-            vals = bias_of(ch)
-            bvals.append(vals)
-            boffs.append(boffs[-1] + len(vals))
-    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
-    return PackedChunks(chunk_start=np.array(starts, np.int64), chunk_len=np.array(lens, np.int32),
-                        frag_off=np.array(offs, np.int64), frag_lpos=cat(ls, np.int32), frag_ilen=cat(ns, np.int32),
-                        bias_off=np.array(boffs, np.int64) if fasta is not None else None,
-                        bias_log=cat(bvals, np.float64) if fasta is not None else None, chroms=chroms)
+    nc = len(chunks)
+    chroms = [ch.chrom for ch in chunks]
+    starts = np.array([ch.start for ch in chunks], np.int64)
+    ends = np.array([ch.end for ch in chunks], np.int64)
+    offs, lpos, ilen = _pack_fragments(st, chroms, starts, ends, margin, atac)
+    boffs = bias = None
+    if fasta is not None:
+        bias_of = _bias_spans(chunks, fasta, chrs, pwm)
+        bvals = [bias_of(ch) for ch in chunks]
+        boffs = np.zeros(nc + 1, np.int64)
+        np.cumsum([len(v) for v in bvals], out=boffs[1:])
+        bias = np.concatenate(bvals).astype(np.float64) if bvals else np.zeros(0, np.float64)
+    return PackedChunks(chunk_start=starts, chunk_len=(ends - starts).astype(np.int32), frag_off=offs, frag_lpos=lpos,
+                        frag_ilen=ilen, bias_off=boffs, bias_log=bias, chroms=chroms)
+
+
+def _pack_fragments(st, chroms, starts, ends, margin, atac):
+    """CSR fragment arrays of the chunks through natac_pack_chunks (count pass + multi-threaded fill)"""
+    import ctypes as C
+    lib = L.load()
+    nc = len(chroms)
+    refs = st.references
+    idx = {c: i for i, c in enumerate(refs)}
+    cid = np.array([idx.get(c, -1) for c in chroms], np.int32)
+    nref = len(refs)
+    pos_p = (C.c_void_p * max(1, nref))(*[st.pos[c].ctypes.data for c in refs])
+    tl_p = (C.c_void_p * max(1, nref))(*[st.tlen[c].ctypes.data for c in refs])
+    npc = np.array([len(st.pos[c]) for c in refs], np.int64)
+    offs = np.zeros(nc + 1, np.int64)
+    first = np.zeros(max(1, nc), np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    args = (nc, vp(starts), vp(ends), vp(cid), nref, C.cast(pos_p, C.c_void_p), C.cast(tl_p, C.c_void_p), vp(npc), int(margin),
+            1 if atac else 0, vp(offs), vp(first))
+    L.check(lib.natac_pack_chunks(*args, None, None, 0))
+    lpos = np.empty(int(offs[-1]), np.int32)
+    ilen = np.empty(int(offs[-1]), np.int32)
+    L.check(lib.natac_pack_chunks(*args, vp(lpos), vp(ilen), 0))
+    return offs, lpos, ilen
 
 
 def _bias_spans(chunks, fasta, chrs, pwm, max_gap=4096):

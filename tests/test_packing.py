@@ -63,3 +63,36 @@ def test_synthetic_distributions():
     a, b = synth_occ_distributions(251)
     assert abs(s.sum() - 1) < 1e-12 and abs(a.sum() - 1) < 1e-12 and abs(b.sum() - 1) < 1e-12
     assert (a > 0).all() and (b > 0).all()
+
+
+def test_native_pack_matches_per_chunk_fetch():
+    """pipeline.pack (natac_pack_chunks) == the reference-shaped per-chunk fetch + shift + stable centre sort"""
+    from nucleoatac_amd import pipeline
+    from nucleoatac_amd.packing import sort_by_centre
+    from nucleoatac_amd.pyatac.chunk import Chunk
+    from nucleoatac_amd.pyatac.fragments import FragmentStore
+    rng = np.random.default_rng(0)
+    sizes = {"chrA": 600_000, "chrB": 200_000, "chrE": 5000}
+    pos = {c: np.sort(rng.integers(0, sizes[c], n)) for c, n in (("chrA", 60000), ("chrB", 10000), ("chrE", 0))}
+    tl = {c: rng.integers(1, 700, len(pos[c])) * rng.choice([-1, 1], len(pos[c])) for c in pos}
+    st = FragmentStore(list(sizes), list(sizes.values()), pos, tl)
+    chunks = [Chunk("chrA", int(s), int(s) + int(rng.integers(200, 3000))) for s in np.sort(rng.integers(3000, 590_000, 300))]
+    chunks += [Chunk("chrB", int(s), int(s) + 2120) for s in np.sort(rng.integers(3000, 190_000, 100))]
+    chunks += [Chunk("chrE", 100, 900), Chunk("chrZ", 100, 900), Chunk("chrA", 0, 300)]
+    for atac in (True, False):
+        pk = pipeline.pack(chunks, st, atac=atac)
+        offs, ls, ns = [0], [], []
+        for ch in chunks:
+            l, n = st.fetch(ch.chrom, ch.start - pipeline.MARGIN, ch.end + pipeline.MARGIN, 1 if atac else 0)
+            keep = l >= ch.start - pipeline.MARGIN
+            l, n = l[keep], n[keep]
+            lr = (l - ch.start).astype(np.int32)
+            o = sort_by_centre(lr, n)
+            ls.append(lr[o])
+            ns.append(n[o].astype(np.int32))
+            offs.append(offs[-1] + len(lr))
+        assert np.array_equal(pk.frag_off, np.array(offs))
+        assert np.array_equal(pk.frag_lpos, np.concatenate(ls)) and np.array_equal(pk.frag_ilen, np.concatenate(ns))
+        assert pk.chroms == [c.chrom for c in chunks]
+        pk.validate()
+    assert pipeline.pack([], st).n_chunks == 0
