@@ -456,12 +456,16 @@ __global__ void __launch_bounds__(256) natac_occ_tile_ranges(ChunkTable ct, cons
 // same lane work as before.  One product chain per alpha (7 independent chains per lane hide the fp64 latency), rescaled
 // by an exact power of two after every 4th factor (every factor when a probability < 2^-200 is present).
 constexpr int OCC_RA = 7;     // alphas per lane in the row-parallel form
+constexpr int OCC_AC_STRIDE = 34;   // doubles per row list: 16 x 2 + 2, so the four rows' broadcast reads hit different banks
+constexpr int OCC_ACL = 16 * OCC_AC_STRIDE;   // >= 4 waves x 2 x 64 of the wave-per-point form
 __device__ __forceinline__ void occ_phase2_rows(const ChunkTable &ct, const OccModelDev &om, int chunk, int k0, int nk, int step, int fl,
                                                 int gfirst, int U, int UP, const double *bw, const double *nucp, const double *nfrp,
                                                 double *acl, const int *cs, const int *is, int nt, double *__restrict__ g_occ,
                                                 double *__restrict__ g_lo, double *__restrict__ g_hi, int *__restrict__ status) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l = lane & 15;
-    const int kk = 4 * wave + row, k = k0 + kk;
+    // rows of one 32-lane half take grid points 4 apart: their bw rows (stride UP doubles) then sit 128 B apart modulo the
+    // 256-B bank span, so the 16 + 16 lanes of a half read 64 distinct banks
+    const int kk = wave + 4 * row, k = k0 + kk;
     const bool live = k < nk;                                   // row-uniform
     const int sh = 16 * row;
     const double *bj = bw + kk * UP;
@@ -491,13 +495,13 @@ __device__ __forceinline__ void occ_phase2_rows(const ChunkTable &ct, const OccM
     // fragments of the row's window [g-fl, g+fl]: ranks of the two keys in the tile's sorted centre list
     int f0 = 0, f1 = 0;
     {
-        const int kmax = gfirst + (4 * wave + 3) * step + fl + 1;
+        const int kmax = gfirst + (wave + 12) * step + fl + 1;
         for (int base = 0; base < nt; base += WAVE) {
             const int i = base + lane;
             const int v = (i < nt) ? cs[i] : 0x7fffffff;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gr = gfirst + (4 * wave + r) * step;
+                const int gr = gfirst + (wave + 4 * r) * step;
                 const int c0 = __popcll(__ballot(v < gr - fl)), c1 = __popcll(__ballot(v < gr + fl + 1));
                 if (row == r) { f0 += c0; f1 += c1; }
             }
@@ -512,7 +516,7 @@ __device__ __forceinline__ void occ_phase2_rows(const ChunkTable &ct, const OccM
 #pragma unroll
     for (int t = 0; t < OCC_RA; ++t) { m[t] = 1.0; e[t] = 0; }
     int nins = 0;
-    double *ac = acl + (wave * 4 + row) * 32;                   // 16 x (a - c, c) of the row's current batch
+    double *ac = acl + (wave * 4 + row) * OCC_AC_STRIDE;        // 16 x (a - c, c) of the row's current batch
     for (int b0 = 0; b0 < maxcnt; b0 += 16) {
         int n = -1;
         if (b0 + l < cnt_row) n = is[f0 + b0 + l];
@@ -629,7 +633,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     double *nfrp = nucp + UP;                          // [UP]
     double *acl = nfrp + UP;                           // [4 waves][64 x (pn, pf)] in phase 2
     double *ones = acl;                                // phase 1: (OCC_T-1)*step + WIN + step + 2 <= 512 ones, the right factor of row j == 1
-    int *cen_s = (int *)(acl + 4 * 2 * WAVE);          // [OCC_FMAX]
+    int *cen_s = (int *)(acl + OCC_ACL);               // [OCC_FMAX]
     int *iln_s = cen_s + OCC_FMAX;                     // [OCC_FMAX]
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, k0 = t.y;
@@ -1166,7 +1170,7 @@ __device__ __forceinline__ int wave_lower_bound(const int *__restrict__ a, int l
     return lo + __popcll(__ballot(v < key));
 }
 
-// LDS: [zeros: A + Bh + 4][ones: W] shared by the workgroup, then [4 waves][CAND_PER_WAVE][EWP] bias windows.
+// LDS: [zeros: A + Bh + 36][ones: W] shared by the workgroup, then [4 waves][CAND_PER_WAVE][EWP] bias windows.
 // Lanes without a template column (c >= W) read the zeros block instead of branching: their products are exactly 0.
 __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
                                                            const int *__restrict__ cand_pos, int ncand,
@@ -1176,7 +1180,7 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
     const int EW = vm.W + A + Bh, EWP = (EW + 1) & ~1;
-    const int ZN = (A + Bh + 5) & ~1, ON = (vm.W + 1) & ~1;      // idle lanes index the zeros block from 2 (bases run 2 below)
+    const int ZN = (A + Bh + 5 + 32) & ~1, ON = (vm.W + 1) & ~1; // idle lanes index the zeros block from 2..33 (bases run 2 below)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int u = threadIdx.x; u < ZN + ON; u += 256) smem[u] = (u < ZN) ? 0.0 : 1.0;
     const int et0 = ZN + ON + wave * CAND_PER_WAVE * EWP;          // smem[et0 + q * EWP + u] <-> coordinate p_q - w - A + u
@@ -1219,7 +1223,11 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
     const int cc1 = h1 ? c1 : 0, cc2 = h2 ? c2 : 0;
     int o1[CAND_PER_WAVE], o2[CAND_PER_WAVE];                   // per-lane window bases (the zeros block for idle lanes)
 #pragma unroll
-    for (int q = 0; q < CAND_PER_WAVE; ++q) { o1[q] = h1 ? et0 + q * EWP + c1 : 2; o2[q] = h2 ? et0 + q * EWP + c2 : 2; }
+    for (int q = 0; q < CAND_PER_WAVE; ++q) {
+        // an idle lane reads the zeros block at the bank its own column would use: no conflict with the busy lanes
+        o1[q] = h1 ? et0 + q * EWP + c1 : 2 + ((et0 + q * EWP + c1 - 2) & 31);
+        o2[q] = h2 ? et0 + q * EWP + c2 : 2 + ((et0 + q * EWP + c2 - 2) & 31);
+    }
     const int R = vm.R, W = vm.W;
     // one template row, any geometry (used for the R % 4 tail rows and for V-plots that include insert size 1)
     auto row_generic = [&](int r, auto CHECK) {
