@@ -178,7 +178,7 @@ static int choose_bg_G(const natac_batch *b, int W) {
 static void launch_candidates(natac_ctx *c, const ChunkTable &ct, const VMatDev &vm, const int *d_cc, const int *d_cp, long long n,
                               const double *nuc_cov, const double *norm, double *lr, double *var, double *z) {
     const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
-    const int ZN = (((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1) + 5) & ~1, ON = (c->W + 1) & ~1;
+    const int ZN = (((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1) + 5 + 32) & ~1, ON = (c->W + 1) & ~1;
     const size_t lds4 = ((size_t)4 * CAND_PER_WAVE * ((EW + 1) & ~1) + ZN + ON) * sizeof(double);
     if (lds4 <= 64 * 1024) {
         const long long per_block = 4 * CAND_PER_WAVE;
@@ -651,9 +651,9 @@ int natac_run_occ(natac_batch *b) {
         const int U = c->occ_upper, UP = (U + 1) & ~1;
         const int span = (OCC_T * OCC_NP - 1) * c->step + M + c->step;
         const int EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
-        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + 512) * sizeof(double) +
+        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + OCC_ACL) * sizeof(double) +
                            (size_t)2 * OCC_FMAX * sizeof(int);
-        if ((OCC_T - 1) * c->step + M + c->step + 2 > 512 || lds > 64 * 1024)
+        if ((OCC_T - 1) * c->step + M + c->step + 2 > OCC_ACL || lds > 64 * 1024)
             return fail(NATAC_E_ARG, "occupancy window / step too large for the device tile (step=%d flank=%d upper=%d)", c->step, c->flank, U);
         hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
                            b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
