@@ -258,3 +258,74 @@ def test_zero_probability_bins_reproduce_reference_failure():
         g = b.grid(L.G_UPPER)[:len(range(2, 400, 5))]
         assert np.array_equal(np.repeat(g, 5)[:400], oc["occ_upper"], equal_nan=True) and np.nanmax(g) < 1.0
         b.free()
+
+
+def test_background_fft_fallback_tiles_match_oracle(ctx):
+    """bias windows that the FFT background kernel must not transform (NaN, -inf, a huge dynamic range) are evaluated by
+    direct summation inside the kernel: NaNs stay confined to the bases whose window touches them, exactly where the
+    reference's dense correlation has them, and every other base agrees with the oracle."""
+    from oracle import natac_oracle as O
+    par = golden("params_example")
+    sizes = synth_size_distribution(251)
+    rng = np.random.default_rng(11)
+    lens = [1500, 1500, 1500, 1500]
+    fr = []
+    for Lc in lens:
+        n = rng.integers(30, 300, size=700)
+        l = rng.integers(-150, Lc + 100, size=700)
+        o = np.argsort(l + (n - 1) // 2, kind="stable")
+        fr.append((l[o], n[o]))
+    off = np.concatenate(([0], np.cumsum([len(x[0]) for x in fr])))
+    nb = [Lc + 493 for Lc in lens]
+    boff = np.concatenate(([0], np.cumsum(nb)))
+    bias = rng.normal(0, 0.7, size=sum(nb))
+    bias[boff[0] + 246 + 700] = np.nan                     # chunk 0: one NaN in the middle
+    bias[boff[1] + 246 + 300] = -np.inf                    # chunk 1: exp(-inf) = 0
+    bias[boff[2] + 246 + 900:boff[2] + 246 + 1000] += 25.0   # chunk 2: dynamic range e^25 inside one tile
+    pk = PackedChunks(np.arange(len(lens)) * 5000, lens, off, np.concatenate([x[0] for x in fr]),
+                      np.concatenate([x[1] for x in fr]), boff, bias)
+    b = ctx.upload(pk)
+    b.run_nuc(10)
+    bg = b.split(b.track(L.T_BACKGROUND))
+    nm = b.split(b.track(L.T_NORM))
+    for k, Lc in enumerate(lens):
+        l, n = fr[k]
+        with np.errstate(all="ignore"):
+            nt = O.nuc_chunk_tracks(l, n, 0, Lc, pk.chunk_bias(k), -246, par["vmat"], 105, 251, sizes)
+        assert np.array_equal(np.isnan(bg[k]), np.isnan(nt["bg"])), k
+        assert_track(bg[k], nt["bg"], "bg %d" % k)
+        assert_track(nm[k], nt["norm"], "norm %d" % k, atol=1e-8)
+    assert np.isnan(bg[0]).sum() > 0 and np.isnan(bg[0]).sum() < 600 and not np.isnan(bg[3]).any()
+    b.free()
+
+
+def test_background_fft_equals_direct_kernel(ctx):
+    """NATAC_BG_DIRECT=1 (direct summation, the pre-FFT kernel) and the FFT kernel agree to ~1e-13 on a ragged batch"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import golden
+from nucleoatac_amd import _lib as L
+from nucleoatac_amd.device import Context
+from nucleoatac_amd.synth import make_synthetic_chunks, synth_size_distribution
+par = golden("params_example")
+c = Context(0); c.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"])); c.set_sizes(synth_size_distribution(251))
+pk = make_synthetic_chunks(300, 2120, 500, seed=3)
+b = c.upload(pk); b.run_nuc(10)
+np.save(sys.argv[1], np.stack([b.track(L.T_BACKGROUND), b.track(L.T_NORM), b.track(L.T_SMOOTH)]))
+b.free(); c.close()
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("0", "1"):
+            env = dict(os.environ, NATAC_BG_DIRECT=mode)
+            path = os.path.join(td, "m%s.npy" % mode)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+            out.append(np.load(path))
+    for t in range(3):
+        np.testing.assert_allclose(out[0][t], out[1][t], rtol=1e-10, atol=1e-12)
+    assert not np.array_equal(out[0][0], out[1][0])          # really two different kernels
