@@ -220,13 +220,32 @@ def nuc_batch(chunks, params, ctx=None, with_flat=False):
         # of every chunk on the device: nothing round-trips between the signal kernels and the statistics
         cc, cp, lr, var, z = run.batch.run_peaks(min_signal=0, sep=params.redundant_sep,
                                                  boundary=params.nonredundant_sep // 2, order=params.redundant_sep // 2)
-        if (run.batch.status() & 2).any():
-            raise Exception("chunk too long for the device peak finder (more than 2048 local maxima)")
+        # chunks with more local maxima than the device peak finder holds per chunk: utils.call_peaks on the host, the
+        # statistics of those candidates still on the device (natac_run_candidates)
+        host = {}
+        over = np.nonzero(run.batch.status() & 2)[0]
+        if len(over):
+            hc, hp = [], []
+            for k in over:
+                combined = res["norm_signal"][k] + res["smoothed"][k]
+                pos = np.asarray(call_peaks(combined, min_signal=0, sep=params.redundant_sep,
+                                            boundary=params.nonredundant_sep // 2, order=params.redundant_sep // 2), np.int32)
+                hc.append(np.full(len(pos), k, np.int32))
+                hp.append(pos)
+            hc, hp = np.concatenate(hc), np.concatenate(hp)
+            hlr, _hvar, hz = run.batch.run_candidates(hc, hp)
+            hb = np.searchsorted(hc, np.arange(len(out) + 1))
+            for k in over:
+                a, b = int(hb[k]), int(hb[k + 1])
+                host[int(k)] = (hp[a:b], hlr[a:b], hz[a:b])
         bounds = np.searchsorted(cc, np.arange(len(out) + 1))
         for k, nc in enumerate(out):
             a, b = int(bounds[k]), int(bounds[k + 1])
-            nc._cands = cp[a:b]
-            nc.findAllNucs(stats=(lr[a:b], z[a:b]))
+            if k in host:
+                nc._cands, klr, kz = host[k]
+            else:
+                nc._cands, klr, kz = cp[a:b], lr[a:b], z[a:b]
+            nc.findAllNucs(stats=(klr, kz))
             nc.fit()
     finally:
         run.close()

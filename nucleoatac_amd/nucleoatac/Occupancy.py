@@ -176,8 +176,11 @@ def occ_batch(chunks, params, ctx=None, with_flat=False):
         from .. import _lib as L
         pk_chunk, pk_pos = run.batch.run_track_peaks(L.T_OCC, min_signal=params.min_occ, sep=params.sep,
                                                      boundary=params.sep // 2, order=1)
-        if (run.batch.status() & 2).any():
-            raise Exception("chunk too long for the device peak finder (more than 2048 local maxima)")
+        # chunks with more local maxima than the device peak finder holds per chunk: utils.call_peaks on the host
+        host_peaks = {}
+        for k in np.nonzero(run.batch.status() & 2)[0]:
+            host_peaks[int(k)] = call_peaks(res["smoothed_vals"][k].copy(), min_signal=params.min_occ, sep=params.sep,
+                                            boundary=params.sep // 2, order=1)
     finally:
         run.close()
     bounds = np.searchsorted(pk_chunk, np.arange(len(chunks) + 1))
@@ -194,7 +197,7 @@ def occ_batch(chunks, params, ctx=None, with_flat=False):
         oc.occ.smoothed_upper = res["smoothed_upper"][k].copy()
         oc.cov = CoverageTrack(ch.chrom, ch.start, ch.end)
         oc.cov.vals = res["cov"][k].copy()
-        oc.callPeaks(peaks=pk_pos[int(bounds[k]):int(bounds[k + 1])])
+        oc.callPeaks(peaks=host_peaks[k] if k in host_peaks else pk_pos[int(bounds[k]):int(bounds[k + 1])])
         out.append(oc)
     if with_flat:
         # smoothed_vals was NaN-filled on the device exactly like call_peaks does in place, so the flat array is what

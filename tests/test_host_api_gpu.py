@@ -159,3 +159,45 @@ def test_cli_occ_then_nuc(tmp_path):
     mine = sorted(int(r[1]) - s_ for r in rows if s_ <= int(r[1]) < e_)
     assert mine == [int(x) for x in g["c2_nucpos"][:, 0]]
     assert all(len(r) == 13 and r[4] != "nan" for r in rows)     # occ read back from the occ track
+
+
+def test_long_chunk_falls_back_to_host_peak_finder():
+    """a 400-kb chunk holds more local maxima than the device peak finder keeps per chunk (status bit 2): occ_batch /
+    nuc_batch then take utils.call_peaks on the host for that chunk (statistics still on the device) instead of failing,
+    and a short chunk in the same batch keeps the device path"""
+    from helpers import synth_genome
+    from nucleoatac_amd.nucleoatac.NucleosomeCalling import NucParameters, nuc_batch
+    from nucleoatac_amd.nucleoatac.Occupancy import FragmentMixDistribution, OccupancyParameters, occ_batch
+    from nucleoatac_amd.pyatac.chunk import Chunk
+    from nucleoatac_amd.pyatac.fragments import FragmentStore
+    from nucleoatac_amd.pyatac.fragmentsizes import FragmentSizes
+    from nucleoatac_amd.pyatac.utils import call_peaks
+    from nucleoatac_amd.pyatac.VMat import VMat
+    par = golden("params_example")
+    l, n, seq = synth_genome(21, chrom_len=420000)
+    frags = FragmentStore(["chrS"], [len(seq)], {"chrS": l - 4}, {"chrS": n + 8})
+    fd = FragmentMixDistribution(0, 251)
+    fd.fragmentsizes = FragmentSizes(0, 251, vals=par["sizes"])
+    fd.nuc_fit = FragmentSizes(0, 251, vals=par["nuc_probs"])
+    fd.nfr_fit = FragmentSizes(0, 251, vals=par["nfr_probs"])
+    from nucleoatac_amd.pyatac.seq import FastaStore
+    op = OccupancyParameters(fd, 251, FastaStore({"chrS": seq.copy()}), "Human", sep=120, min_occ=0.1, flank=60, bam=frags,
+                             ci=0.9, step=5)
+    op.fasta = None
+    npar = NucParameters(vmat=VMat(par["vmat"], int(par["vlower"]), int(par["vupper"])),
+                         fragmentsizes=FragmentSizes(0, 251, vals=par["sizes"]), bam=frags, fasta=None, pwm="Human",
+                         occ_track=None, sd=10, nonredundant_sep=120, redundant_sep=25, min_z=6, min_lr=0, atac=True)
+    chunks = [Chunk("chrS", 2000, 410000), Chunk("chrS", 412000, 414000)]
+    ocs = occ_batch(chunks, op)
+    for oc in ocs:
+        want = call_peaks(oc.occ.smoothed_vals.copy(), min_signal=op.min_occ, sep=op.sep, boundary=op.sep // 2, order=1)
+        assert sorted(oc.peaks.keys()) == [int(x) for x in want]
+    assert len(ocs[0].peaks) > 800
+    ncs = nuc_batch(chunks, npar)
+    for nc in ncs:
+        combined = nc.norm_signal.vals + nc.smoothed.vals
+        want = call_peaks(combined, min_signal=0, sep=npar.redundant_sep, boundary=npar.nonredundant_sep // 2,
+                          order=npar.redundant_sep // 2)
+        assert [int(x) for x in nc._cands] == [int(x) for x in want]
+        assert set(nc.sorted_nuc_keys) <= set(int(x) for x in want)
+    assert len(ncs[0].sorted_nuc_keys) > 0 and len(ncs[0]._cands) > 2048          # the long chunk really overflowed the device finder
