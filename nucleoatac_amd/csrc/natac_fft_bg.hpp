@@ -156,10 +156,10 @@ __global__ void __launch_bounds__(64) natac_fft_template(const double *__restric
 }
 
 // background + normalised signal for tiles of TV = 512 - W + 1 bases; one tile per wave, one wave per workgroup.
-// Tiles whose bias window is not well conditioned for an FFT (non-finite or zero values, or a dynamic range > 1e4, where the
+// Tiles whose bias window is not well conditioned for an FFT (non-finite or zero values, or a dynamic range > 3e4, where the
 // FFT's error -- relative to the tile's largest product -- could show in the smallest outputs, and where a NaN must stay
 // confined to the bases whose window touches it) are evaluated by direct summation in the same order as natac_background.
-constexpr double FFT_MAX_RANGE = 1e4;
+constexpr double FFT_MAX_RANGE = 3e4;   // real Tn5 PWM log-bias spans <= 8.7 log units genome-wide (e^8.7 = 6e3)
 
 __global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
                                                              const double *__restrict__ tw, const double *__restrict__ ktab,

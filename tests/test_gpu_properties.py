@@ -282,6 +282,7 @@ def test_background_fft_fallback_tiles_match_oracle(ctx):
     bias[boff[0] + 246 + 700] = np.nan                     # chunk 0: one NaN in the middle
     bias[boff[1] + 246 + 300] = -np.inf                    # chunk 1: exp(-inf) = 0
     bias[boff[2] + 246 + 900:boff[2] + 246 + 1000] += 25.0   # chunk 2: dynamic range e^25 inside one tile
+    bias[boff[3]:boff[4]] = rng.uniform(-5.0, 4.9, size=nb[3])   # chunk 3: e^9.9 = 2e4, the widest range still transformed
     pk = PackedChunks(np.arange(len(lens)) * 5000, lens, off, np.concatenate([x[0] for x in fr]),
                       np.concatenate([x[1] for x in fr]), boff, bias)
     b = ctx.upload(pk)
