@@ -88,7 +88,52 @@ class SignalDistribution(object):
 def norm(x, v, w, mean):
     """normal pdf with variance v scaled to height w (NucleosomeCalling.py:92-97)"""
     y = 1.0 / np.sqrt(2 * np.pi * v) * np.exp(-(x - mean) ** 2 / (2 * v))
-    return y * (w / max(y))
+    return y * (w / y.max())
+
+
+def fit_fuzz_one(vals, allnucs, index, nonredundant_sep, smooth_sd):
+    """Nucleosome.getFuzz of the reference (NucleosomeCalling.py:137-194) for the call at chunk-relative position `index`:
+    up to three Gaussians (the call and its neighbours closer than nonredundant_sep) fitted to the smoothed signal with
+    scipy's L-BFGS-B; returns (fuzz, weight, fit_pos).  Clamps vals[left:right] at 0 in place like the reference."""
+    third = nonredundant_sep // 3
+    x = bisect_left(allnucs, index)
+    if x > 0 and index - allnucs[x - 1] < nonredundant_sep:
+        left = allnucs[x - 1]
+        means = (index - allnucs[x - 1], 0)
+    else:
+        left = index - third
+        means = (third,)
+    if x < len(allnucs) - 1 and allnucs[x + 1] - index < nonredundant_sep:
+        right = allnucs[x + 1]
+        means += (allnucs[x + 1] - left,)
+    else:
+        right = index + third + 1
+    sig = vals[left:right]
+    sig[sig < 0] = 0
+    top = max(sig)
+    bounds, guess = (), ()
+    for m in means:
+        bounds += ((2 ** 2, 50 ** 2), (0.001, top * 1.1), (m - 10, m + 10))
+        guess += (smooth_sd ** 2, top * 0.9, m)
+    xs = np.linspace(0, len(sig) - 1, len(sig))
+
+    def err(pars):
+        fit = np.zeros(len(xs))
+        for j in range(len(pars) // 3):
+            fit += norm(xs, pars[3 * j], pars[3 * j + 1], pars[3 * j + 2])
+        return np.sum((fit - sig) ** 2)
+
+    res = optimize.minimize(err, guess, bounds=bounds, method="L-BFGS-B")
+    return np.sqrt(res["x"][0]), res["x"][1], res["x"][2] + left
+
+
+def fit_fuzz_chunk(task):
+    """all calls of one chunk in ascending order (the unit of work of the --cores pool); task = (smoothed values,
+    sorted call positions, nonredundant_sep, smooth_sd)"""
+    vals, keys, nonredundant_sep, smooth_sd = task
+    vals = np.array(vals, dtype=np.float64)
+    keys = np.asarray(keys)
+    return [fit_fuzz_one(vals, keys, int(k), nonredundant_sep, smooth_sd) for k in keys]
 
 
 class Nucleosome(Chunk):
@@ -116,40 +161,8 @@ class Nucleosome(Chunk):
         """sd of a (mixture of up to 3) Gaussian(s) fitted to the smoothed signal around the call
         (NucleosomeCalling.py:137-194; scipy L-BFGS-B on the host)"""
         p = nuctrack.params
-        third = p.nonredundant_sep // 3
-        index = self.start - nuctrack.start
-        allnucs = nuctrack.sorted_nuc_keys
-        x = bisect_left(allnucs, index)
-        if x > 0 and index - allnucs[x - 1] < p.nonredundant_sep:
-            left = allnucs[x - 1]
-            means = (index - allnucs[x - 1], 0)
-        else:
-            left = index - third
-            means = (third,)
-        if x < len(allnucs) - 1 and allnucs[x + 1] - index < p.nonredundant_sep:
-            right = allnucs[x + 1]
-            means += (allnucs[x + 1] - left,)
-        else:
-            right = index + third + 1
-        sig = nuctrack.smoothed.vals[left:right]
-        sig[sig < 0] = 0
-        top = max(sig)
-        bounds, guess = (), ()
-        for m in means:
-            bounds += ((2 ** 2, 50 ** 2), (0.001, top * 1.1), (m - 10, m + 10))
-            guess += (p.smooth_sd ** 2, top * 0.9, m)
-        xs = np.linspace(0, len(sig) - 1, len(sig))
-
-        def err(pars):
-            fit = np.zeros(len(xs))
-            for j in range(len(pars) // 3):
-                fit += norm(xs, pars[3 * j], pars[3 * j + 1], pars[3 * j + 2])
-            return np.sum((fit - sig) ** 2)
-
-        res = optimize.minimize(err, guess, bounds=bounds, method="L-BFGS-B")
-        self.fuzz = np.sqrt(res["x"][0])
-        self.weight = res["x"][1]
-        self.fit_pos = res["x"][2] + left
+        self.fuzz, self.weight, self.fit_pos = fit_fuzz_one(nuctrack.smoothed.vals, nuctrack.sorted_nuc_keys,
+                                                            self.start - nuctrack.start, p.nonredundant_sep, p.smooth_sd)
 
     def asBed(self):
         s = _py2_float_str
@@ -246,7 +259,14 @@ def nuc_batch(chunks, params, ctx=None, with_flat=False):
             else:
                 nc._cands, klr, kz = cp[a:b], lr[a:b], z[a:b]
             nc.findAllNucs(stats=(klr, kz))
-            nc.fit()
+        pool = getattr(params, "pool", None)
+        if pool is None:
+            for nc in out:
+                nc.fit()
+        else:   # the L-BFGS fits are independent per chunk: farm them out like the reference's --cores pool
+            tasks = [(nc.smoothed.vals, nc.sorted_nuc_keys, params.nonredundant_sep, params.smooth_sd) for nc in out]
+            for nc, r in zip(out, pool.map(fit_fuzz_chunk, tasks, chunksize=max(1, len(tasks) // (4 * params.pool_workers)))):
+                nc.fit(results=r)
     finally:
         run.close()
     if with_flat:
@@ -303,12 +323,17 @@ class NucChunk(Chunk):
                                          self.params.nonredundant_sep)
         self.redundant = np.setdiff1d(self.sorted_nuc_keys, self.nonredundant)
 
-    def fit(self):
+    def fit(self, results=None):
+        """fuzziness of every call + the fitted signal (NucleosomeCalling.py:316-324); `results`: fit_fuzz_chunk output
+        computed elsewhere (the --cores pool)"""
         x = np.linspace(0, self.length() - 1, self.length())
         fit = np.zeros(self.length())
-        for k in self.sorted_nuc_keys:
+        for j, k in enumerate(self.sorted_nuc_keys):
             n = self.nuc_collection[int(k)]
-            n.getFuzz(self)
+            if results is None:
+                n.getFuzz(self)
+            else:
+                n.fuzz, n.weight, n.fit_pos = results[j]
             fit += norm(x, n.fuzz ** 2, n.weight, n.fit_pos)
         self.fitted = Track(self.chrom, self.start, self.end, "Fitted Nucleosome Signal")
         self.fitted.assign_track(fit)

@@ -31,7 +31,7 @@ def add_nuc_parser(sub):
     p.add_argument("--pwm", default="Human")
     p.add_argument("--sizes")
     p.add_argument("--occ_track")
-    p.add_argument("--cores", type=int, default=1)
+    p.add_argument("--cores", type=int, default=1, help="host processes for the per-nucleosome fuzziness fits")
     p.add_argument("--write_all", action="store_true", default=False)
     p.add_argument("--not_atac", dest="atac", action="store_false", default=True)
     p.add_argument("--min_z", type=float, default=3)

@@ -56,6 +56,13 @@ def run_nuc(args):
     params = NucParameters(vmat=vmat, fragmentsizes=fragment_dist, bam=args.bam, fasta=args.fasta, pwm=args.pwm,
                            occ_track=args.occ_track, sd=args.sd, nonredundant_sep=args.nuc_sep,
                            redundant_sep=args.redundant_sep, min_z=args.min_z, min_lr=args.min_lr, atac=args.atac)
+    pool = None
+    if getattr(args, "cores", 1) and args.cores > 1:
+        # host pool for the per-nucleosome L-BFGS fits (the reference's --cores); spawn: workers never touch the GPU
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+        pool = ProcessPoolExecutor(max_workers=args.cores, mp_context=multiprocessing.get_context("spawn"))
+        params.pool, params.pool_workers = pool, args.cores
     outputs = ["nucpos", "nucpos.redundant", "nucleoatac_signal", "nucleoatac_signal.smooth"]
     if args.write_all:
         outputs += ["nucleoatac_background", "nucleoatac_raw"]
@@ -92,6 +99,8 @@ def run_nuc(args):
             nuc.removeData()
     for h in handles.values():
         h.close()
+    if pool is not None:
+        pool.shutdown()
     if world > 1:
         import torch.distributed as dist
         if dist.is_initialized():

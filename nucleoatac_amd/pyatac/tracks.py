@@ -8,6 +8,22 @@ from .chunk import Chunk
 from .utils import smooth
 
 
+_TABIX = {}
+
+
+def _tabix(path):
+    """one parsed index per file (NucChunk.getOcc reads three tracks per chunk, NucleosomeCalling.py:284-293)"""
+    from ..tabix import TabixFile
+    key = (path, os.path.getmtime(path + ".tbi"))
+    tb = _TABIX.get(path)
+    if tb is None or tb[0] != key:
+        if tb is not None:
+            tb[1].close()
+        tb = (key, TabixFile(path))
+        _TABIX[path] = tb
+    return tb[1]
+
+
 def _py2_float_str(v):
     """python-2 str(float): 12 significant digits (what the reference's text outputs contain)"""
     if isinstance(v, (float, np.floating)):
@@ -80,13 +96,11 @@ class Track(Chunk):
             self.end += flank
         out = np.ones(self.end - self.start) * empty
         if bedgraph.endswith(".gz") and os.path.exists(bedgraph + ".tbi"):
-            from ..tabix import TabixFile
-            tb = TabixFile(bedgraph)
+            tb = _tabix(bedgraph)
             for line in tb.fetch(self.chrom, max(0, self.start), self.end):
                 f = line.split("\t")
                 s, e = int(f[1]), int(f[2])
                 out[max(s - self.start, 0):min(e - self.start, self.end - self.start)] = float(f[3])
-            tb.close()
             self.vals = out
             return
         opener = gzip.open if bedgraph.endswith(".gz") else open

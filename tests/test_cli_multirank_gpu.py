@@ -62,3 +62,17 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert open(str(tmp_path / "one") + ".nuc_dist.txt").read() == open(str(tmp_path / "two") + ".nuc_dist.txt").read()
     left = [f for f in os.listdir(str(tmp_path)) if ".rank" in f]
     assert not left, left
+
+
+def test_nuc_cores_pool_equals_serial(tmp_path):
+    """--cores N farms the per-nucleosome L-BFGS fits out to spawned host processes: outputs identical to --cores 1"""
+    bed, bam, fa, sizes, vm = _inputs(tmp_path)
+    outs = []
+    for cores in (1, 3):
+        out = str(tmp_path / ("c%d" % cores))
+        cmd = [sys.executable, "-m", "nucleoatac_amd.nucleoatac.cli", "nuc", "--bed", bed, "--bam", bam, "--fasta", fa, "--sizes",
+               sizes, "--out", out, "--vmat", vm, "--cores", str(cores)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(gzip.open(out + ".nucpos.bed.gz", "rt").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 0
