@@ -61,6 +61,9 @@ def run_nuc(args):
         # host pool for the per-nucleosome L-BFGS fits (the reference's --cores); spawn: workers never touch the GPU
         import multiprocessing
         from concurrent.futures import ProcessPoolExecutor
+        # one BLAS / OpenMP thread per worker: N processes x all-core thread pools oversubscribe the host (measured 40x slower)
+        for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            os.environ[var] = "1"
         pool = ProcessPoolExecutor(max_workers=args.cores, mp_context=multiprocessing.get_context("spawn"))
         params.pool, params.pool_workers = pool, args.cores
     outputs = ["nucpos", "nucpos.redundant", "nucleoatac_signal", "nucleoatac_signal.smooth"]

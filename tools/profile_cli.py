@@ -1,5 +1,5 @@
 """Host-side profile of the `occ` / `nuc` drivers on a synthetic genome (development tool).
-usage: python tools/profile_cli.py [chrom_len] [n_chunks]"""
+usage: python tools/profile_cli.py [chrom_len] [n_chunks] [cores]"""
 import cProfile
 import os
 import pstats
@@ -18,6 +18,7 @@ from helpers import golden, synth_genome  # noqa: E402
 def main():
     chrom_len = int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000
     n_chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    cores = sys.argv[3] if len(sys.argv) > 3 else "1"
     from nucleoatac_amd.nucleoatac.cli import main as cli
     from nucleoatac_amd.pyatac.fragments import FragmentStore
     from nucleoatac_amd.pyatac.fragmentsizes import FragmentSizes
@@ -41,7 +42,7 @@ def main():
     np.savez(vm, vmat=par["vmat"], vlower=par["vlower"], vupper=par["vupper"])
     out = os.path.join(td, "o")
     common = ["--bed", bed, "--bam", bam, "--fasta", fa, "--sizes", sizes, "--out", out]
-    for sub in (["occ"] + common, ["nuc"] + common + ["--vmat", vm, "--occ_track", out + ".occ.bedgraph.gz"]):
+    for sub in (["occ"] + common, ["nuc"] + common + ["--vmat", vm, "--occ_track", out + ".occ.bedgraph.gz", "--cores", cores]):
         pr = cProfile.Profile()
         t = time.time()
         pr.enable()
