@@ -96,11 +96,14 @@ class Track(Chunk):
             self.end += flank
         out = np.ones(self.end - self.start) * empty
         if bedgraph.endswith(".gz") and os.path.exists(bedgraph + ".tbi"):
-            tb = _tabix(bedgraph)
-            for line in tb.fetch(self.chrom, max(0, self.start), self.end):
-                f = line.split("\t")
-                s, e = int(f[1]), int(f[2])
-                out[max(s - self.start, 0):min(e - self.start, self.end - self.start)] = float(f[3])
+            b0, e0, v0 = _tabix(bedgraph).fetch_values(self.chrom, max(0, self.start), self.end)
+            n = self.end - self.start
+            a = np.clip(b0 - self.start, 0, n)
+            z = np.clip(e0 - self.start, 0, n)
+            single = (z - a) == 1
+            out[a[single]] = v0[single]                      # one line per base is the common case of a float track
+            for i in np.nonzero(~single)[0]:                 # in file order, like the reference's line loop
+                out[a[i]:z[i]] = v0[i]
             self.vals = out
             return
         opener = gzip.open if bedgraph.endswith(".gz") else open

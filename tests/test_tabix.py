@@ -128,3 +128,30 @@ def test_index_rejects_unsorted_and_plain_gzip(tmp_path):
     split.write_text("chr1\t1\t2\nchr2\t1\t2\nchr1\t5\t6\n")
     with pytest.raises(L.NatacError):
         tabix_index(bgzip_file(str(split)))
+
+
+def test_read_track_through_index_equals_linear_scan(tmp_path):
+    """Track.read_track gives the same values through the tabix index (bulk parse) as through a plain linear scan"""
+    import shutil
+    from nucleoatac_amd.pyatac.tracks import Track
+    rng = np.random.default_rng(4)
+    lens = rng.integers(800, 6000, 12)
+    chroms = ["chr1"] * 7 + ["chr2"] * 5
+    starts = np.concatenate([np.cumsum(np.r_[300, lens[:6] + 200]), np.cumsum(np.r_[900, lens[7:11] + 90])])
+    off = np.r_[0, np.cumsum(lens)]
+    vals = rng.random(int(off[-1]))
+    vals[rng.integers(0, len(vals), 500)] = np.nan                       # NaN runs are not written
+    vals[1000:1400] = 0.25                                               # a multi-base run
+    path = str(tmp_path / "t.bedgraph.gz")
+    write_bedgraph(path, chroms, starts, off, vals, compress=4)
+    noidx = str(tmp_path / "n.bedgraph.gz")
+    shutil.copy(path, noidx)
+    tabix_index(path)
+    for _ in range(40):
+        i = int(rng.integers(0, 12))
+        s = int(starts[i] + rng.integers(-50, lens[i]))
+        e = s + int(rng.integers(1, 2500))
+        a, b = Track(chroms[i], s, e), Track(chroms[i], s, e)
+        a.read_track(path)
+        b.read_track(noidx)
+        assert np.array_equal(a.vals, b.vals, equal_nan=True)
