@@ -115,6 +115,11 @@ class TabixFile(object):
                 if e0 > start:
                     yield line.decode()
 
+    def _before(self, other, name):
+        """chromosome `other` (bytes) precedes `name` in the file's order"""
+        o = other.decode()
+        return o in self.contigs and self.contigs.index(o) < self.contigs.index(name.decode())
+
     def fetch_values(self, chrom, start, end, value_col=4):
         """(beg, end, value) arrays of the records on `chrom` overlapping [start, end) -- the bedGraph case of fetch(),
         parsed in bulk (Track.read_track reads ~one line per base)"""
@@ -143,16 +148,49 @@ class TabixFile(object):
                 merged.append([c0, c1])
         bs, es, vs = [], [], []
         name = chrom.encode()
+        cb, ce, cs = self.col_beg - 1, self.col_end - 1, self.col_seq - 1
+        ncol = max(cb, ce, cs, value_col - 1) + 1
         for c0, c1 in merged:
             lines = [ln for ln in self._read(c0, c1).split(b"\n") if ln and ln[:1] != b"#"]
-            if not lines:
-                continue
-            cols = [ln.split(b"\t") for ln in lines]
-            keep = [c for c in cols if c[self.col_seq - 1] == name]
+            # a chunk holds whole bins (>= 16 kb of records, position-sorted): bisect on the begin column instead of parsing
+            # every line.  bedGraph records do not overlap, so the first overlapping record is at most a few lines before
+            # the first one that begins at or after `start`; the backward scan is bounded and checked.
+            lo, hi = 0, len(lines)
+            while lo < hi:                                   # first line of this chromosome that begins at or after `end`
+                mid = (lo + hi) >> 1
+                f = lines[mid].split(b"\t", ncol)
+                if f[cs] == name and int(f[cb]) < end or f[cs] != name and mid < len(lines) and self._before(f[cs], name):
+                    lo = mid + 1
+                else:
+                    hi = mid
+            stop = lo
+            lo, hi = 0, stop
+            while lo < hi:                                   # first line of this chromosome that begins at or after `start`
+                mid = (lo + hi) >> 1
+                f = lines[mid].split(b"\t", ncol)
+                if f[cs] == name and int(f[cb]) < start or f[cs] != name and self._before(f[cs], name):
+                    lo = mid + 1
+                else:
+                    hi = mid
+            first = lo
+            back = 0
+            while first > 0 and back < 64:
+                f = lines[first - 1].split(b"\t", ncol)
+                if f[cs] != name:
+                    break
+                if max(int(f[ce]), int(f[cb]) + 1) > start:
+                    first -= 1
+                    back = 0
+                else:
+                    back += 1
+                    if back >= 8:
+                        break
+                    first -= 1
+            keep = [c for c in (ln.split(b"\t", ncol) for ln in lines[first:stop]) if c[cs] == name]
             if not keep:
                 continue
-            b0 = np.array([c[self.col_beg - 1] for c in keep]).astype(np.int64)
-            e0 = np.array([c[self.col_end - 1] for c in keep]).astype(np.int64)
+            b0 = np.array([c[cb] for c in keep]).astype(np.int64)
+            e0 = np.array([c[ce] for c in keep]).astype(np.int64)
             v0 = np.array([c[value_col - 1] for c in keep]).astype(np.float64)
             m = (b0 < end) & (np.maximum(e0, b0 + 1) > start)
             bs.append(b0[m]); es.append(e0[m]); vs.append(v0[m])
