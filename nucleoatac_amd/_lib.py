@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnatac_hip.so")
+LIB_PATH = os.environ.get("NATAC_LIB") or os.path.join(_HERE, "libnatac_hip.so")   # NATAC_LIB: A/B builds of the same ABI
 
 # enums of include/natac.h
 T_NUC_COV, T_NFR_COV, T_RAW, T_BACKGROUND, T_NORM, T_SMOOTH = 0, 1, 2, 3, 4, 5

@@ -1203,7 +1203,9 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
         for (int u = lane; u < EW; u += WAVE) {
             const int j = j0 + u;
             double e = 1.0;
+#ifndef NATAC_ABL_CAND_STAGE
             if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+#endif
             smem[et0 + q * EWP + u] = e;
             emin = fmin(emin, e);
         }
@@ -1330,7 +1332,11 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
         const int *iln = ct.ilen + ct.frag_off[chunk[q]];
         const int f0 = wave_lower_bound(cen, 0, nfr, p - vm.w, lane);
         const int f1 = wave_lower_bound(cen, f0, min(nfr, f0 + 4 * WAVE), p + vm.w + 1, lane) ;
+#ifdef NATAC_ABL_CAND_TAIL
+        const int f1x = f0; (void)f1;
+#else
         const int f1x = (f1 == f0 + 4 * WAVE) ? wave_lower_bound(cen, f1, nfr, p + vm.w + 1, lane) : f1;   // very dense windows
+#endif
         const double *e = smem + et0 + q * EWP;
         double nl = 0.0, ul = 0.0;
         for (int f = f0 + lane; f < f1x; f += WAVE) {
