@@ -206,6 +206,15 @@ int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads)
  * tbi_path NULL: `path` + ".tbi".  n_records (may be NULL) receives the number of indexed lines. */
 int natac_tabix_index(const char *path, const char *tbi_path, int n_threads, int64_t *n_records);
 
+/* region reads through the index (pysam.TabixFile.fetch as used by Track.read_track, pyatac/tracks.py:75-87): out[x - start] =
+ * the value column (1-based, 4 for bedGraph) of the records of `chrom` overlapping [start, end); bases without a record keep
+ * `empty`.  One handle per file and thread. */
+typedef struct natac_tbx natac_tbx;
+int natac_tbx_open(const char *path, natac_tbx **out);
+void natac_tbx_close(natac_tbx *t);
+int natac_tbx_read_values(natac_tbx *t, const char *chrom, int64_t start, int64_t end, int value_col, double empty, double *out,
+                          int64_t *n_records);
+
 /* ---- host-side packing of a chunk list (what replaces the per-chunk bamHandle.fetch of pyatac/fragments.pyx:21-36) ---- */
 /* pos[c] / tlen[c]: the forward proper-pair reads of chromosome c (natac_bam_ref_reads), pos ascending.  chrom_id[i] < 0: a
  * chunk on a chromosome without reads.  Attached to chunk i are the reads with pos in [start - margin - shift, end + margin)

@@ -1251,6 +1251,37 @@ int natac_pack_chunks(int32_t n_chunks, const int64_t *chunk_start, const int64_
     return NATAC_OK;
 }
 
+struct natac_tbx { natac_tabix::Reader *impl = nullptr; };
+
+int natac_tbx_open(const char *path, natac_tbx **out) {
+    if (!path || !out) return fail(NATAC_E_ARG, "null argument");
+    *out = nullptr;
+    natac_tabix::Reader *r = nullptr;
+    const int rc = natac_tabix::open_reader(path, &r);
+    if (rc == 1) return fail(NATAC_E_ARG, "cannot open %s (or its .tbi)", path);
+    if (rc) return fail(NATAC_E_ARG, "%s.tbi is not a tabix index", path);
+    natac_tbx *t = new natac_tbx();
+    t->impl = r;
+    *out = t;
+    return NATAC_OK;
+}
+
+void natac_tbx_close(natac_tbx *t) {
+    if (!t) return;
+    natac_tabix::close_reader(t->impl);
+    delete t;
+}
+
+int natac_tbx_read_values(natac_tbx *t, const char *chrom, int64_t start, int64_t end, int value_col, double empty, double *out,
+                          int64_t *n_records) {
+    if (!t || !chrom || (end > start && !out)) return fail(NATAC_E_ARG, "null argument");
+    if (value_col < 1 || value_col > 8) return fail(NATAC_E_ARG, "value_col must be 1..8");
+    const int64_t n = natac_tabix::read_values(t->impl, chrom, start, end, value_col, empty, out);
+    if (n < 0) return fail(NATAC_E_ARG, "read error in the indexed file");
+    if (n_records) *n_records = n;
+    return NATAC_OK;
+}
+
 /* ---------------- native BAM extractor ---------------- */
 
 int natac_bam_open(const char *path, int n_threads, natac_bam **out) {

@@ -210,3 +210,248 @@ inline int index_bed(const char *path, const char *tbi_path, int n_threads, int6
 }
 
 }  // namespace natac_tabix
+
+// ---- reader: values of a tabix-indexed bedGraph over a region (Track.read_track, pyatac/tracks.py:75-87) ----
+namespace natac_tabix {
+
+struct Reader {
+    FILE *f = nullptr;
+    std::vector<std::string> names;
+    std::vector<std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins;
+    std::vector<std::vector<uint64_t>> lin;
+    int col_seq = 1, col_beg = 2, col_end = 3;
+    std::string buf, block;
+};
+
+// inflate a whole BGZF file into memory (the .tbi itself)
+inline int inflate_all(const char *path, std::string &out) {
+    std::string data;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return 1;
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    data.resize((size_t)sz);
+    const bool ok = sz == 0 || std::fread(&data[0], 1, (size_t)sz, f) == (size_t)sz;
+    std::fclose(f);
+    if (!ok) return 1;
+    const unsigned char *d = (const unsigned char *)data.data();
+    uint64_t p = 0;
+    while (p + 18 <= data.size()) {
+        if (d[p] != 0x1f || d[p + 1] != 0x8b) return 2;
+        const uint32_t xlen = d[p + 10] | (d[p + 11] << 8);
+        uint32_t bsize = 0;
+        for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const uint32_t slen = d[q + 2] | (d[q + 3] << 8);
+            if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2) bsize = (d[q + 4] | (d[q + 5] << 8)) + 1u;
+            q += 4 + slen;
+        }
+        if (!bsize || p + bsize > data.size()) return 2;
+        const uint32_t isize = d[p + bsize - 4] | (d[p + bsize - 3] << 8) | (d[p + bsize - 2] << 16) | ((uint32_t)d[p + bsize - 1] << 24);
+        const size_t o = out.size();
+        out.resize(o + isize);
+        if (isize) {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) return 3;
+            zs.next_in = (Bytef *)(d + p + 12 + xlen);
+            zs.avail_in = bsize - 12 - xlen - 8;
+            zs.next_out = (Bytef *)&out[o];
+            zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) return 3;
+        }
+        p += bsize;
+    }
+    return 0;
+}
+
+inline uint32_t rd32(const std::string &s, size_t &p) {
+    uint32_t v = 0;
+    for (int i = 0; i < 4; ++i) v |= (uint32_t)(unsigned char)s[p + i] << (8 * i);
+    p += 4;
+    return v;
+}
+inline uint64_t rd64(const std::string &s, size_t &p) {
+    uint64_t v = 0;
+    for (int i = 0; i < 8; ++i) v |= (uint64_t)(unsigned char)s[p + i] << (8 * i);
+    p += 8;
+    return v;
+}
+
+// 0 ok, 1 cannot open, 2 bad format, 3 inflate error
+inline int open_reader(const char *path, Reader **out) {
+    std::string raw;
+    const int rc = inflate_all((std::string(path) + ".tbi").c_str(), raw);
+    if (rc) return rc;
+    if (raw.size() < 36 || std::memcmp(raw.data(), "TBI\1", 4) != 0) return 2;
+    Reader *r = new Reader();
+    size_t p = 4;
+    const uint32_t n_ref = rd32(raw, p);
+    rd32(raw, p);
+    r->col_seq = (int)rd32(raw, p); r->col_beg = (int)rd32(raw, p); r->col_end = (int)rd32(raw, p);
+    rd32(raw, p); rd32(raw, p);
+    const uint32_t l_nm = rd32(raw, p);
+    if (p + l_nm > raw.size()) { delete r; return 2; }
+    for (size_t q = p; q < p + l_nm;) {
+        const size_t e = raw.find('\0', q);
+        r->names.emplace_back(raw.substr(q, e - q));
+        q = e + 1;
+    }
+    p += l_nm;
+    r->bins.resize(n_ref);
+    r->lin.resize(n_ref);
+    for (uint32_t t = 0; t < n_ref; ++t) {
+        if (p + 4 > raw.size()) { delete r; return 2; }
+        const uint32_t n_bin = rd32(raw, p);
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            const uint32_t bin = rd32(raw, p), n_chunk = rd32(raw, p);
+            if (p + 16ull * n_chunk > raw.size()) { delete r; return 2; }
+            std::vector<std::pair<uint64_t, uint64_t>> cs(n_chunk);
+            for (auto &c : cs) { c.first = rd64(raw, p); c.second = rd64(raw, p); }
+            if (bin != 37450u) r->bins[t][bin] = std::move(cs);
+        }
+        const uint32_t n_intv = rd32(raw, p);
+        if (p + 8ull * n_intv > raw.size()) { delete r; return 2; }
+        r->lin[t].resize(n_intv);
+        for (auto &v : r->lin[t]) v = rd64(raw, p);
+    }
+    r->f = std::fopen(path, "rb");
+    if (!r->f) { delete r; return 1; }
+    *out = r;
+    return 0;
+}
+
+inline void close_reader(Reader *r) {
+    if (!r) return;
+    if (r->f) std::fclose(r->f);
+    delete r;
+}
+
+// inflate the member at compressed offset coff into r->block; returns its compressed size (0 at EOF / error)
+inline uint32_t read_block(Reader *r, uint64_t coff) {
+    unsigned char head[18];
+    if (std::fseek(r->f, (long)coff, SEEK_SET) != 0 || std::fread(head, 1, 18, r->f) != 18) return 0;
+    if (head[0] != 0x1f || head[1] != 0x8b) return 0;
+    const uint32_t xlen = head[10] | (head[11] << 8);
+    r->buf.resize(xlen + 12);
+    std::memcpy(&r->buf[0], head, 18);
+    if (xlen > 6 && std::fread(&r->buf[18], 1, xlen - 6, r->f) != xlen - 6) return 0;
+    uint32_t bsize = 0;
+    const unsigned char *x = (const unsigned char *)r->buf.data() + 12;
+    for (uint32_t q = 0; q + 4 <= xlen;) {
+        const uint32_t slen = x[q + 2] | (x[q + 3] << 8);
+        if (x[q] == 'B' && x[q + 1] == 'C' && slen == 2) bsize = (x[q + 4] | (x[q + 5] << 8)) + 1u;
+        q += 4 + slen;
+    }
+    if (!bsize) return 0;
+    const uint32_t clen = bsize - 12 - xlen;
+    r->buf.resize(clen);
+    if (std::fread(&r->buf[0], 1, clen, r->f) != clen) return 0;
+    const unsigned char *b = (const unsigned char *)r->buf.data();
+    const uint32_t isize = b[clen - 4] | (b[clen - 3] << 8) | (b[clen - 2] << 16) | ((uint32_t)b[clen - 1] << 24);
+    r->block.resize(isize);
+    if (isize) {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) return 0;
+        zs.next_in = (Bytef *)b;
+        zs.avail_in = clen - 8;
+        zs.next_out = (Bytef *)&r->block[0];
+        zs.avail_out = isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END) return 0;
+    }
+    return bsize;
+}
+
+// out[x - start] = value (column value_col) of every record of `chrom` overlapping [start, end), later records overwrite
+// earlier ones like the reference's line loop; bases without a record keep `empty`.  Returns #records used, -1 on IO error.
+inline int64_t read_values(Reader *r, const char *chrom, int64_t start, int64_t end, int value_col, double empty, double *out) {
+    const int64_t n = end - start;
+    for (int64_t i = 0; i < n; ++i) out[i] = empty;
+    int tid = -1;
+    for (size_t i = 0; i < r->names.size(); ++i) if (r->names[i] == chrom) tid = (int)i;
+    if (tid < 0 || n <= 0) return 0;
+    const int64_t qs = std::max<int64_t>(0, start), qe = end;
+    if (qe <= qs) return 0;
+    const auto &lin = r->lin[tid];
+    const size_t w = (size_t)(qs >> 14);
+    const uint64_t min_off = lin.empty() ? 0 : (w < lin.size() ? lin[w] : lin.back());
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    {
+        const int64_t b = qs, e = qe - 1;
+        auto add = [&](uint32_t bin) {
+            auto it = r->bins[tid].find(bin);
+            if (it == r->bins[tid].end()) return;
+            for (auto &c : it->second) if (c.second > min_off) chunks.push_back({std::max(c.first, min_off), c.second});
+        };
+        add(0);
+        const int shifts[5] = {26, 23, 20, 17, 14};
+        const uint32_t offs[5] = {1, 9, 73, 585, 4681};
+        for (int l = 0; l < 5; ++l)
+            for (int64_t k = b >> shifts[l]; k <= (e >> shifts[l]); ++k) add(offs[l] + (uint32_t)k);
+    }
+    std::sort(chunks.begin(), chunks.end());
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    for (auto &c : chunks) {
+        if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second);
+        else merged.push_back(c);
+    }
+    int64_t used = 0;
+    const size_t clen = std::strlen(chrom);
+    std::string line;
+    for (auto &c : merged) {
+        uint64_t coff = c.first >> 16;
+        uint32_t uoff = (uint32_t)(c.first & 0xffff);
+        line.clear();
+        bool done = false;
+        while (!done && (coff < (c.second >> 16) || (coff == (c.second >> 16) && uoff < (c.second & 0xffff)))) {
+            const uint32_t bsize = read_block(r, coff);
+            if (!bsize) return -1;
+            const uint32_t stop = (coff == (c.second >> 16)) ? (uint32_t)(c.second & 0xffff) : (uint32_t)r->block.size();
+            const char *p = r->block.data() + uoff, *pe = r->block.data() + std::min<size_t>(stop, r->block.size());
+            while (p < pe) {
+                const char *nl = (const char *)std::memchr(p, '\n', (size_t)(pe - p));
+                if (!nl) { line.append(p, (size_t)(pe - p)); break; }       // record continues in the next member
+                const char *ls = p;
+                size_t ll = (size_t)(nl - p);
+                if (!line.empty()) { line.append(p, ll); ls = line.data(); ll = line.size(); }
+                if (ll > 0 && ls[0] != '#') {
+                    // columns (1-based): seq, beg, end, value
+                    const char *cp = ls, *le = ls + ll;
+                    const char *fld[8];
+                    int nf = 0;
+                    fld[nf++] = cp;
+                    for (const char *t = cp; t < le && nf < 8; ++t) if (*t == '\t') fld[nf++] = t + 1;
+                    const int need = std::max(std::max(r->col_seq, r->col_end), value_col);
+                    if (nf >= need) {
+                        const char *sq = fld[r->col_seq - 1];
+                        const size_t sl = (size_t)((r->col_seq < nf ? fld[r->col_seq] - 1 : le) - sq);
+                        if (sl == clen && std::memcmp(sq, chrom, clen) == 0) {
+                            const int64_t b0 = std::strtoll(fld[r->col_beg - 1], nullptr, 10);
+                            int64_t e0 = std::strtoll(fld[r->col_end - 1], nullptr, 10);
+                            if (e0 <= b0) e0 = b0 + 1;
+                            if (b0 >= qe) { done = true; break; }
+                            if (e0 > qs) {
+                                const double v = std::strtod(fld[value_col - 1], nullptr);
+                                const int64_t a = std::max(b0, start) - start, z = std::min(e0, end) - start;
+                                for (int64_t i = a; i < z; ++i) out[i] = v;
+                                ++used;
+                            }
+                        }
+                    }
+                }
+                line.clear();
+                p = nl + 1;
+            }
+            coff += bsize;
+            uoff = 0;
+        }
+    }
+    return used;
+}
+
+}  // namespace natac_tabix

@@ -12,14 +12,19 @@ _TABIX = {}
 
 
 def _tabix(path):
-    """one parsed index per file (NucChunk.getOcc reads three tracks per chunk, NucleosomeCalling.py:284-293)"""
-    from ..tabix import TabixFile
+    """one open index per file (NucChunk.getOcc reads three tracks per chunk, NucleosomeCalling.py:284-293): the native
+    reader when libnatac_hip.so is there, else the pure-Python one"""
+    from ..tabix import NativeTabix, TabixFile
     key = (path, os.path.getmtime(path + ".tbi"))
     tb = _TABIX.get(path)
     if tb is None or tb[0] != key:
         if tb is not None:
             tb[1].close()
-        tb = (key, TabixFile(path))
+        try:
+            rd = NativeTabix(path)
+        except ImportError:
+            rd = TabixFile(path)
+        tb = (key, rd)
         _TABIX[path] = tb
     return tb[1]
 
@@ -96,7 +101,11 @@ class Track(Chunk):
             self.end += flank
         out = np.ones(self.end - self.start) * empty
         if bedgraph.endswith(".gz") and os.path.exists(bedgraph + ".tbi"):
-            b0, e0, v0 = _tabix(bedgraph).fetch_values(self.chrom, max(0, self.start), self.end)
+            rd = _tabix(bedgraph)
+            if hasattr(rd, "read_values"):
+                self.vals = rd.read_values(self.chrom, self.start, self.end, empty=empty)
+                return
+            b0, e0, v0 = rd.fetch_values(self.chrom, max(0, self.start), self.end)
             n = self.end - self.start
             a = np.clip(b0 - self.start, 0, n)
             z = np.clip(e0 - self.start, 0, n)

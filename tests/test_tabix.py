@@ -152,6 +152,20 @@ def test_read_track_through_index_equals_linear_scan(tmp_path):
         s = int(starts[i] + rng.integers(-50, lens[i]))
         e = s + int(rng.integers(1, 2500))
         a, b = Track(chroms[i], s, e), Track(chroms[i], s, e)
-        a.read_track(path)
+        a.read_track(path)                                             # native reader (natac_tbx_read_values)
         b.read_track(noidx)
         assert np.array_equal(a.vals, b.vals, equal_nan=True)
+        from nucleoatac_amd.tabix import TabixFile
+        tb = TabixFile(path)                                           # pure-Python reader, bulk parse
+        b0, e0, v0 = tb.fetch_values(chroms[i], max(0, s), e)
+        c = np.full(e - s, np.nan)
+        for x0, x1, v in zip(b0, e0, v0):
+            c[max(x0 - s, 0):min(x1 - s, e - s)] = v
+        tb.close()
+        assert np.array_equal(a.vals, c, equal_nan=True)
+    t = Track("chrNone", 5, 50)
+    t.read_track(path, empty=-1.0)
+    assert (t.vals == -1.0).all()
+    t = Track("chr1", -40, 30)                                           # negative start: bases before 0 stay empty
+    t.read_track(path)
+    assert np.isnan(t.vals).all()
