@@ -60,6 +60,7 @@ struct natac_ctx {
     double *d_win_nuc = nullptr, *d_win_occ = nullptr;
     int win_nuc_M = 0, win_occ_M = 0;
     double win_nuc_sd = -1, win_occ_sd = -1;
+    double win_nuc_sum = 0, win_occ_sum = 0;   // sequential sums of the window values (the all-valid denominator)
     // profiling
     bool profiling = false;
     struct Ev { int k; hipEvent_t a, b; hipStream_t st; };
@@ -381,7 +382,7 @@ static int ensure_fft(natac_ctx *c) {
     return NATAC_OK;
 }
 
-static int ensure_window(natac_ctx *c, double **slot, int *slotM, double *slotsd, int M, double sd) {
+static int ensure_window(natac_ctx *c, double **slot, int *slotM, double *slotsd, int M, double sd, double *slotsum = nullptr) {
     if (*slot && *slotM == M && *slotsd == sd) return NATAC_OK;
     HIPCHK(sync_all(c));
     dev_free(*slot);
@@ -396,6 +397,11 @@ static int ensure_window(natac_ctx *c, double **slot, int *slotM, double *slotsd
     int rc = dev_upload(c, slot, w.data(), (size_t)M);
     if (rc) return rc;
     HIPCHK(sync_all(c));
+    if (slotsum) {
+        double acc = 0.0;
+        for (int i = 0; i < M; ++i) acc = acc + w[i];     // same order as the kernel's fma(w, 1, den) chain
+        *slotsum = acc;
+    }
     *slotM = M;
     *slotsd = sd;
     return NATAC_OK;
@@ -536,7 +542,7 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
                     b->bias_left, b->bias_right);
     for (int i = 0; i < b->nc; ++i)
         if (b->h_len[i] < M) return fail(NATAC_E_ARG, "chunk %d shorter (%d) than the smoothing window (%d)", i, b->h_len[i], M);
-    if ((rc = ensure_window(c, &c->d_win_nuc, &c->win_nuc_M, &c->win_nuc_sd, M, smooth_sd))) return rc;
+    if ((rc = ensure_window(c, &c->d_win_nuc, &c->win_nuc_M, &c->win_nuc_sd, M, smooth_sd, &c->win_nuc_sum))) return rc;
     for (int t : {NATAC_T_NUC_COV, NATAC_T_NFR_COV, NATAC_T_RAW, NATAC_T_BACKGROUND, NATAC_T_NORM, NATAC_T_SMOOTH})
         if ((rc = ensure_track(b, t))) return rc;
     const bool use_fft = fft_bg_applicable(c);
@@ -591,9 +597,9 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     prof_begin(c, NATAC_K_SMOOTH_NUC, ev);
     {
         const int h = (M - 1) / 2;
-        const size_t lds = ((size_t)2 * (256 + 2 * h) + M) * sizeof(double);
+        const size_t lds = ((size_t)2 * (256 + 2 * h)) * sizeof(double);
         hipLaunchKernelGGL((natac_smooth_same<true>), dim3(b->n_tiles256), dim3(256), lds, c->stream, ct, b->d_tiles256,
-                           c->d_win_nuc, M, b->d_track[NATAC_T_NORM], b->d_track[NATAC_T_SMOOTH]);
+                           c->d_win_nuc, M, c->win_nuc_sum, b->d_track[NATAC_T_NORM], b->d_track[NATAC_T_SMOOTH]);
     }
     prof_end(c, ev);
     HIPCHK(hipGetLastError());

@@ -357,17 +357,20 @@ __global__ void __launch_bounds__(256) natac_background_generic(ChunkTable ct, c
 // ------------------------------------------------------------------------------------------------
 template <bool CLAMP>
 __global__ void __launch_bounds__(256) natac_smooth_same(ChunkTable ct, const int2 *__restrict__ tiles,
-                                                           const double *__restrict__ win, int M,
+                                                           const double *__restrict__ win, int M, double win_sum,
                                                            const double *__restrict__ x, double *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int any_gap;
     const int h = (M - 1) / 2;
     double *xs = smem;               // [256 + 2h]  value (NaN -> 0)
     double *ok = smem + 256 + 2 * h; // [256 + 2h]  1 / 0
-    double *wl = ok + 256 + 2 * h;   // [M]
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, x0 = t.y;
     const int L = ct.chunk_len[chunk];
     const long long ob = ct.out_off[chunk];
+    if (threadIdx.x == 0) any_gap = 0;
+    __syncthreads();
+    bool gap = false;
     for (int u = threadIdx.x; u < 256 + 2 * h; u += 256) {
         const int g = x0 - h + u;
         double v = 0.0, o = 0.0;
@@ -377,18 +380,28 @@ __global__ void __launch_bounds__(256) natac_smooth_same(ChunkTable ct, const in
         }
         xs[u] = v;
         ok[u] = o;
+        gap |= (o == 0.0);
     }
-    for (int u = threadIdx.x; u < M; u += 256) wl[u] = win[u];
+    if (gap) any_gap = 1;
     __syncthreads();
     const int g = x0 + threadIdx.x;
     if (g >= L) return;
-    double num = 0.0, den = 0.0;
-    for (int n = 0; n < M; ++n) {
-        // np.convolve(w, x)[t+h] = sum_k w[k] x[t+h-k]
-        const double wv = wl[n];
-        const int u = threadIdx.x + 2 * h - n;
-        num = fma(wv, xs[u], num);
-        den = fma(wv, ok[u], den);
+    // the window values are wave-uniform: scalar loads, SGPR operands of the FMAs (no LDS traffic for them)
+    double num = 0.0, den;
+    if (!any_gap) {
+        // no NaN and no chunk edge under any window of the tile: the denominator is the plain sum of the window, formed on
+        // the host in the same order (fma(w, 1, den) == den + w), so the quotient has the same bits as the general path
+        for (int n = 0; n < M; ++n) num = fma(win[n], xs[threadIdx.x + 2 * h - n], num);
+        den = win_sum;
+    } else {
+        den = 0.0;
+        for (int n = 0; n < M; ++n) {
+            // np.convolve(w, x)[t+h] = sum_k w[k] x[t+h-k]
+            const double wv = win[n];
+            const int u = threadIdx.x + 2 * h - n;
+            num = fma(wv, xs[u], num);
+            den = fma(wv, ok[u], den);
+        }
     }
     y[ob + g] = (den == 0.0) ? __builtin_nan("") : num / den;
 }
