@@ -79,10 +79,10 @@ def _cpu_worker_init():
 def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks):
     """reference execution shape: multiprocessing.Pool(cores-1), chunk per task (run_occ.py:101-123)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    cores = _effective_cores()
     workers = max(1, cores - 1)
     if n_chunks <= 0:
-        n_chunks = min(1024, max(64, 2 * workers))   # ~10-20 s of wall time at ~0.5-2 core-s per chunk
+        n_chunks = min(1024, max(256, 2 * workers))  # ~0.45 core-s per chunk: >= 100 core-s, several seconds of wall time
     n_chunks = min(n_chunks, pk.n_chunks)
     tasks = []
     for k in range(n_chunks):
@@ -99,6 +99,24 @@ def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks):
     return dict(value=bp / dt / 1e6, unit="Mbp/s", cores=workers, kind="port",
                 sample="%d of the workload's chunks (%d bp) through oracle/natac_oracle.py, occ+nuc+ins, "
                        "Pool(%d) one chunk per task, %.1f s" % (n_chunks, bp, workers, dt))
+
+
+def _effective_cores():
+    """CPUs this process can really use: the visible ones capped by the cgroup CPU quota (cpu.max "1600000 100000" = 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def pmc_traffic_bytes(kernel_substr):

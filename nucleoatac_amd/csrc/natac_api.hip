@@ -3,6 +3,7 @@
 #include "../../include/natac.h"
 #include "natac_kernels.hpp"
 #include "natac_fft_bg.hpp"
+#include "natac_cores.hpp"
 #include "natac_writer.hpp"
 #include "natac_tabix.hpp"
 #include "natac_pack.hpp"
@@ -1193,7 +1194,7 @@ int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads)
         if (!ok) return fail(NATAC_E_ARG, "cannot read %s", src);
     }
     const size_t BLK = 0xff00, nblk = (text.size() + BLK - 1) / BLK;
-    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    if (n_threads <= 0) n_threads = natac_cores::default_threads(64);
     n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, (nblk + 15) / 16));
     std::vector<std::string> parts(n_threads);
     std::vector<int> bad(n_threads, 0);

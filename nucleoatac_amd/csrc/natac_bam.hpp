@@ -6,6 +6,7 @@
 // reads; nucleoatac_amd/pyatac/fragments.py slices them per chunk.
 // Format: SAM spec section 4 (BGZF blocks = gzip members with the BC extra field; BAM records little-endian).
 #pragma once
+#include "natac_cores.hpp"
 #include <zlib.h>
 
 #include <algorithm>
@@ -68,7 +69,7 @@ inline Bam *decode(const char *path, int n_threads, std::string &err) {
     if (o != raw.size()) { err = "trailing bytes after the last BGZF block"; return nullptr; }
     std::vector<unsigned char> data(utotal);
     // ---- parallel inflate
-    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    if (n_threads <= 0) n_threads = natac_cores::default_threads(64);
     n_threads = std::max(1, std::min<int>(n_threads, (int)std::max<size_t>(1, blks.size())));
     std::atomic<size_t> next(0);
     std::atomic<int> bad(0);

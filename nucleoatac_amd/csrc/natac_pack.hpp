@@ -5,6 +5,7 @@
 // (l = pos + 4, n = |tlen| - 8 when atac; fragments.pyx:26-34), relative to the chunk start and ordered by centre
 // l + (n - 1) // 2 (stable), which is the order every device kernel expects (nucleoatac_amd/packing.py).
 #pragma once
+#include "natac_cores.hpp"
 #include <algorithm>
 #include <cstdint>
 #include <thread>
@@ -36,7 +37,7 @@ inline void count(int32_t nc, const int64_t *cstart, const int64_t *cend, const 
 
 inline void fill(int32_t nc, const int64_t *cstart, const int32_t *chrom_id, const int64_t *const *pos, const int64_t *const *tlen,
                  const int64_t *frag_off, const int64_t *first, int shift, int trim, int32_t *lpos, int32_t *ilen, int n_threads) {
-    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    if (n_threads <= 0) n_threads = natac_cores::default_threads(64);
     n_threads = std::max(1, std::min(n_threads, std::max(1, nc / 64)));
     auto work = [&](int t) {
         std::vector<std::pair<int32_t, int32_t>> key;      // (centre, rank) -> stable order

@@ -5,6 +5,7 @@
 // specification ("The Tabix index file format"): binning index with min_shift 14 / depth 5 + 16-kb linear index over
 // BGZF virtual offsets (compressed block start << 16 | offset inside the inflated block), itself BGZF-compressed.
 #pragma once
+#include "natac_cores.hpp"
 #include <zlib.h>
 
 #include <cstdint>
@@ -75,7 +76,7 @@ inline int index_bed(const char *path, const char *tbi_path, int n_threads, int6
     }
     // ---- inflate all members in parallel into one text buffer
     std::string text(utotal, '\0');
-    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    if (n_threads <= 0) n_threads = natac_cores::default_threads(64);
     n_threads = std::max(1, std::min<int>(n_threads, (int)std::max<size_t>(1, blocks.size() / 16)));
     std::vector<int> err(n_threads, 0);
     auto work = [&](int t) {

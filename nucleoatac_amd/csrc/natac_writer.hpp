@@ -7,13 +7,18 @@
 // The reference's writer processes manage 0.31 Mbp/s each; the GPU path produces tracks three orders
 // of magnitude faster, so the formatter is the first "next" row of SURVEY.md section 8(f).
 #pragma once
+#include "natac_cores.hpp"
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -21,7 +26,7 @@
 
 namespace natac_writer {
 
-inline char *fmt_py2_float(char *p, double v) {
+inline char *fmt_py2_float_slow(char *p, double v) {
     if (std::isinf(v)) {
         const char *s = v > 0 ? "inf" : "-inf";
         size_t n = std::strlen(s);
@@ -35,6 +40,57 @@ inline char *fmt_py2_float(char *p, double v) {
     for (char *q = b; q < p; ++q)
         if (!((*q >= '0' && *q <= '9') || *q == '-')) { plain = false; break; }
     if (plain) { *p++ = '.'; *p++ = '0'; }
+    return p;
+}
+
+// python-2 str(float) == '%.12g' (+ ".0" for integral text).  Fast exact path for 1e-4 <= |v| < 1e12 (fixed notation in
+// %.12g): |v| = m 2^e exactly, so |v| 10^s = (m 5^s) 2^(e+s) with a 128-bit integer numerator; the 12 significant digits are
+// that quotient rounded half-to-even on the exact remainder -- the same correctly rounded result as printf / to_chars, at a
+// tenth of the cost.  Everything else (0, tiny, huge, inf) takes the to_chars path.
+inline char *fmt_py2_float(char *p, double v) {
+    const double a = std::fabs(v);
+    if (!(a >= 1e-4 && a < 1e12)) return fmt_py2_float_slow(p, v);
+    static const double P10[17] = {1e-4, 1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12};
+    static const uint64_t I5[17] = {1ull, 5ull, 25ull, 125ull, 625ull, 3125ull, 15625ull, 78125ull, 390625ull, 1953125ull, 9765625ull,
+                                    48828125ull, 244140625ull, 1220703125ull, 6103515625ull, 30517578125ull, 152587890625ull};
+    int e10 = -4;
+    while (e10 < 11 && a >= P10[e10 + 5]) ++e10;           // provisional floor(log10 a): the inexact 1e-4..1e-1 are fixed below
+    int ex;
+    const double fr = std::frexp(a, &ex);                   // a = fr 2^ex, fr in [0.5, 1)
+    const uint64_t m = (uint64_t)std::ldexp(fr, 53);        // 53-bit integer mantissa
+    const int e2 = ex - 53;
+    uint64_t D;
+    for (;;) {
+        const int sft = 11 - e10;                           // 0 .. 15 (16 after a downward correction)
+        const unsigned __int128 N = (unsigned __int128)m * I5[sft];
+        const int k = -(e2 + sft);                          // a 10^sft = N / 2^k, k > 0 in this range
+        const unsigned __int128 q = N >> k, rem = N - (q << k), half = (unsigned __int128)1 << (k - 1);
+        D = (uint64_t)q;
+        if (rem > half || (rem == half && (D & 1))) ++D;
+        if (D < 100000000000ull) { --e10; continue; }       // a was just below the (inexact) table entry
+        if (D >= 1000000000000ull) {                         // 999999999999.5+ rounded up to 10^12 (exactly divisible)
+            if (e10 >= 11) return fmt_py2_float_slow(p, v);   // ... and 1e+12 is written in scientific notation
+            D /= 10;
+            ++e10;
+        }
+        break;
+    }
+    char dg[12];
+    for (int i = 11; i >= 0; --i) { dg[i] = (char)('0' + D % 10); D /= 10; }
+    int nd = 12;
+    while (nd > 1 && dg[nd - 1] == '0') --nd;               // %g strips trailing zeros
+    if (std::signbit(v)) *p++ = '-';
+    if (e10 >= 0) {
+        const int ni = e10 + 1;                             // integer digits
+        for (int i = 0; i < ni; ++i) *p++ = (i < nd) ? dg[i] : '0';
+        *p++ = '.';
+        if (nd > ni) { for (int i = ni; i < nd; ++i) *p++ = dg[i]; }
+        else *p++ = '0';                                    // integral text gets ".0"
+    } else {
+        *p++ = '0'; *p++ = '.';
+        for (int i = 0; i < -e10 - 1; ++i) *p++ = '0';
+        for (int i = 0; i < nd; ++i) *p++ = dg[i];
+    }
     return p;
 }
 
@@ -74,21 +130,37 @@ inline void format_chunk(std::string &out, const char *chrom, size_t chrom_len, 
     }
 }
 
-// one BGZF member for <= 0xff00 input bytes (SAM spec section 4.1)
-inline bool bgzf_block(std::string &out, const unsigned char *src, size_t len, int level) {
+// one BGZF member for <= 0xff00 input bytes (SAM spec section 4.1).  A Deflater keeps its z_stream (deflateReset per member:
+// no 268-KB allocate + clear per 64-KB block).
+struct Deflater {
+    z_stream zs;
+    bool ready = false;
+    int level = 0;
+    ~Deflater() { if (ready) deflateEnd(&zs); }
+    bool init(int lvl) {
+        if (ready && lvl == level) return deflateReset(&zs) == Z_OK;
+        if (ready) deflateEnd(&zs);
+        std::memset(&zs, 0, sizeof zs);
+        ready = deflateInit2(&zs, lvl, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+        level = lvl;
+        return ready;
+    }
+};
+
+inline bool bgzf_block(std::string &out, const unsigned char *src, size_t len, int level, Deflater *df = nullptr) {
     unsigned char buf[65536 + 64];
     static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
     std::memcpy(buf, hdr, 16);
-    z_stream zs;
-    std::memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    Deflater local;
+    if (!df) df = &local;
+    if (!df->init(level)) return false;
+    z_stream &zs = df->zs;
     zs.next_in = const_cast<unsigned char *>(src);
     zs.avail_in = (uInt)len;
     zs.next_out = buf + 18;
     zs.avail_out = 65536 - 18 - 8;
     const int rc = deflate(&zs, Z_FINISH);
     const size_t clen = zs.total_out;
-    deflateEnd(&zs);
     if (rc != Z_STREAM_END) return false;
     const size_t total = 18 + clen + 8;
     buf[16] = (unsigned char)((total - 1) & 0xff);
@@ -103,12 +175,15 @@ inline bool bgzf_block(std::string &out, const unsigned char *src, size_t len, i
     return true;
 }
 
-inline bool bgzf_compress(std::string &out, const std::string &text, int level) {
+inline bool bgzf_compress(std::string &out, const char *text, size_t n, int level, Deflater *df = nullptr) {
     const size_t BLK = 0xff00;
-    for (size_t o = 0; o < text.size(); o += BLK)
-        if (!bgzf_block(out, (const unsigned char *)text.data() + o, std::min(BLK, text.size() - o), level)) return false;
+    Deflater local;
+    if (!df) df = &local;
+    for (size_t o = 0; o < n; o += BLK)
+        if (!bgzf_block(out, (const unsigned char *)text + o, std::min(BLK, n - o), level, df)) return false;
     return true;
 }
+inline bool bgzf_compress(std::string &out, const std::string &text, int level) { return bgzf_compress(out, text.data(), text.size(), level); }
 
 static const unsigned char BGZF_EOF[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -116,7 +191,7 @@ static const unsigned char BGZF_EOF[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff
 inline int write_bedgraph(const char *path, bool append, int compress, bool finish, int nc, const char *const *chroms,
                           const int64_t *chunk_start, const int64_t *out_off, const double *vals, bool write_zero, int n_threads,
                           int64_t *bytes_written) {
-    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128u);
+    if (n_threads <= 0) n_threads = natac_cores::default_threads(128);
     n_threads = std::max(1, std::min(n_threads, std::max(1, nc)));
     // contiguous chunk ranges with ~equal numbers of bases
     std::vector<int> cut(n_threads + 1, nc);
@@ -127,44 +202,87 @@ inline int write_bedgraph(const char *path, bool append, int compress, bool fini
         while (i < nc && out_off[i] < target) ++i;
         cut[t] = i;
     }
+    const bool dbg = std::getenv("NATAC_WRITER_DEBUG") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<double> t_fmt(n_threads, 0.0), t_def(n_threads, 0.0);
     std::vector<std::string> parts(n_threads);
     std::vector<int> err(n_threads, 0);
     auto work = [&](int t) {
+        const auto w0 = std::chrono::steady_clock::now();
+        const long long bases = (cut[t] < nc ? out_off[cut[t + 1]] - out_off[cut[t]] : 0);
         std::string text;
-        text.reserve((size_t)1 << 20);
-        std::string &dst = compress ? parts[t] : text;
+        Deflater df;
+        const size_t FLUSH = (size_t)4 << 20;
+        if (compress) {
+            text.reserve(FLUSH + ((size_t)1 << 16));
+            parts[t].reserve((size_t)bases * 14 + 4096);     // ~13 bytes of BGZF per base for float tracks
+        } else {
+            parts[t].reserve((size_t)bases * 40 + 4096);
+        }
+        std::string &fmt = compress ? text : parts[t];
         for (int i = cut[t]; i < cut[t + 1]; ++i) {
-            format_chunk(text, chroms[i], std::strlen(chroms[i]), chunk_start[i], vals + out_off[i], out_off[i + 1] - out_off[i],
+            format_chunk(fmt, chroms[i], std::strlen(chroms[i]), chunk_start[i], vals + out_off[i], out_off[i + 1] - out_off[i],
                          write_zero);
-            if (compress && text.size() >= ((size_t)4 << 20)) {   // bound memory: flush whole 0xff00-byte blocks
+            if (compress && text.size() >= FLUSH) {          // bound memory: flush whole 0xff00-byte blocks
                 const size_t whole = text.size() / 0xff00 * 0xff00;
-                if (!bgzf_compress(dst, text.substr(0, whole), compress)) { err[t] = 3; return; }
+                if (!bgzf_compress(parts[t], text.data(), whole, compress, &df)) { err[t] = 3; return; }
                 text.erase(0, whole);
             }
         }
-        if (compress) {
-            if (!bgzf_compress(dst, text, compress)) err[t] = 3;
-        } else {
-            parts[t].swap(text);
+        if (compress && !bgzf_compress(parts[t], text.data(), text.size(), compress, &df)) err[t] = 3;
+        t_fmt[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (int e : err) if (e) return e;
+    const auto t_mid = std::chrono::steady_clock::now();
+    // every part lands at its own offset: parallel pwrite (a serial fwrite of GBs of text is the bottleneck otherwise)
+    const int fd = ::open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0644);
+    if (fd < 0) return 1;
+    int64_t base = 0;
+    if (append) {
+        const off_t e = ::lseek(fd, 0, SEEK_END);
+        if (e < 0) { ::close(fd); return 2; }
+        base = (int64_t)e;
+    }
+    std::vector<int64_t> at(n_threads + 1, base);
+    for (int t = 0; t < n_threads; ++t) at[t + 1] = at[t] + (int64_t)parts[t].size();
+    std::vector<int> werr(n_threads, 0);
+    auto put = [&](int t) {
+        const char *p = parts[t].data();
+        size_t left = parts[t].size();
+        int64_t o = at[t];
+        while (left) {
+            const ssize_t w = ::pwrite(fd, p, left, (off_t)o);
+            if (w <= 0) { werr[t] = 1; return; }
+            p += w; left -= (size_t)w; o += w;
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-    for (int e : err) if (e) return e;
-    FILE *f = std::fopen(path, append ? "ab" : "wb");
-    if (!f) return 1;
-    int64_t nb = 0;
-    for (auto &p : parts) {
-        if (!p.empty() && std::fwrite(p.data(), 1, p.size(), f) != p.size()) { std::fclose(f); return 2; }
-        nb += (int64_t)p.size();
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) if (!parts[t].empty()) th.emplace_back(put, t);
+        put(0);
+        for (auto &x : th) x.join();
     }
-    if (compress && finish) {
-        if (std::fwrite(BGZF_EOF, 1, 28, f) != 28) { std::fclose(f); return 2; }
+    int64_t nb = at[n_threads] - base;
+    bool ok = true;
+    for (int e : werr) ok = ok && !e;
+    if (ok && compress && finish) {
+        ok = ::pwrite(fd, BGZF_EOF, 28, (off_t)at[n_threads]) == 28;
         nb += 28;
     }
-    if (std::fclose(f) != 0) return 2;
+    if (::close(fd) != 0 || !ok) return 2;
+    if (dbg) {
+        double mx = 0, sm = 0;
+        for (double x : t_fmt) { mx = std::max(mx, x); sm += x; }
+        std::fprintf(stderr, "[natac writer] threads %d: parallel section %.3f s (worker max %.3f avg %.3f), write %.3f s\n", n_threads,
+                     std::chrono::duration<double>(t_mid - t_begin).count(), mx, sm / n_threads,
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_mid).count());
+    }
     if (bytes_written) *bytes_written = nb;
     return 0;
 }
