@@ -101,6 +101,7 @@ struct natac_batch {
     int pk_order = -1;
     bool pk_has_stats = false;
     int nuc_w = -1, nuc_upper = -1;   // V-plot geometry natac_run_nuc ran with (coverage tracks depend on it)
+    double *d_bnum = nullptr, *d_bcov = nullptr;   // per-base sum B V / sum B of the background kernel (candidate statistics)
 };
 
 static hipError_t sync_all(natac_ctx *c) {
@@ -178,14 +179,19 @@ static int choose_bg_G(const natac_batch *b, int W) {
 }
 
 static void launch_candidates(natac_ctx *c, const ChunkTable &ct, const VMatDev &vm, const int *d_cc, const int *d_cp, long long n,
-                              const double *nuc_cov, const double *norm, double *lr, double *var, double *z) {
+                              const double *nuc_cov, const double *norm, const double *bnum, const double *bcov, double *lr,
+                              double *var, double *z) {
     const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
     const int ZN = (((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1) + 5 + 32) & ~1, ON = (c->W + 1) & ~1;
     const size_t lds4 = ((size_t)4 * CAND_PER_WAVE * ((EW + 1) & ~1) + ZN + ON) * sizeof(double);
     if (lds4 <= 64 * 1024) {
         const long long per_block = 4 * CAND_PER_WAVE;
-        hipLaunchKernelGGL(natac_candidates4, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), lds4, c->stream, ct, vm, d_cc,
-                           d_cp, (int)n, nuc_cov, norm, lr, var, z);
+        if (bnum && bcov && !getenv("NATAC_CAND_FULL"))   // NATAC_CAND_FULL=1: all four window sums in the kernel (validation)
+            hipLaunchKernelGGL((natac_candidates4<true>), dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), lds4, c->stream,
+                               ct, vm, d_cc, d_cp, (int)n, nuc_cov, norm, bnum, bcov, lr, var, z);
+        else
+            hipLaunchKernelGGL((natac_candidates4<false>), dim3((unsigned)((n + per_block - 1) / per_block)), dim3(256), lds4, c->stream,
+                               ct, vm, d_cc, d_cp, (int)n, nuc_cov, norm, bnum, bcov, lr, var, z);
     } else {   // very wide templates: one workgroup per candidate
         hipLaunchKernelGGL(natac_candidates, dim3((unsigned)n), dim3(256), (size_t)(EW + 2) * sizeof(double), c->stream, ct, vm, d_cc,
                            d_cp, nuc_cov, norm, lr, var, z);
@@ -201,7 +207,7 @@ static void launch_bg(natac_batch *b, const ChunkTable &ct, const VMatDev &vm) {
     const size_t lds = ((size_t)((EW + 1) & ~1) + PW) * sizeof(double);
     hipLaunchKernelGGL((natac_background<G, W>), dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm,
                        b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                       b->d_track[NATAC_T_NORM]);
+                       b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov);
 }
 
 extern "C" {
@@ -512,6 +518,7 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_cmin); dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_pkflag); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
+    dev_free(b->d_bnum); dev_free(b->d_bcov);
     for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
     delete b;
 }
@@ -546,6 +553,8 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     if ((rc = ensure_window(c, &c->d_win_nuc, &c->win_nuc_M, &c->win_nuc_sd, M, smooth_sd, &c->win_nuc_sum))) return rc;
     for (int t : {NATAC_T_NUC_COV, NATAC_T_NFR_COV, NATAC_T_RAW, NATAC_T_BACKGROUND, NATAC_T_NORM, NATAC_T_SMOOTH})
         if ((rc = ensure_track(b, t))) return rc;
+    if (!b->d_bnum && (rc = dev_alloc(&b->d_bnum, (size_t)b->total_bp))) return rc;
+    if (!b->d_bcov && (rc = dev_alloc(&b->d_bcov, (size_t)b->total_bp))) return rc;
     const bool use_fft = fft_bg_applicable(c);
     const bool fast = !use_fft && (c->W == 121 && c->vlower >= 2);
     if (use_fft) {
@@ -581,7 +590,7 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
         const size_t lds = ((size_t)((EW + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
         hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
                            c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                           b->d_track[NATAC_T_NORM]);
+                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov);
     } else if (fast) {
         switch (b->bgG) {
             case 7: launch_bg<7>(b, ct, vm); break;
@@ -592,7 +601,7 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     } else {
         hipLaunchKernelGGL(natac_background_generic, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, vm,
                            b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                           b->d_track[NATAC_T_NORM]);
+                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov);
     }
     prof_end(c, ev);
     prof_begin(c, NATAC_K_SMOOTH_NUC, ev);
@@ -741,7 +750,8 @@ int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chu
     const VMatDev vm = make_vmat(c);
     natac_ctx::Ev ev;
     prof_begin(c, NATAC_K_CAND, ev);
-    launch_candidates(c, ct, vm, d_cc, d_cp, n_cand, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM], d_out, d_out + n_cand,
+    launch_candidates(c, ct, vm, d_cc, d_cp, n_cand, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, d_out,
+                      d_out + n_cand,
                       d_out + 2 * n_cand);
     prof_end(c, ev);
     hipError_t e = hipGetLastError();
@@ -819,6 +829,7 @@ static int run_peaks_impl(natac_batch *b, const double *sig_a, const double *sig
         if (with_stats) {
             const VMatDev vm = make_vmat(c);
             launch_candidates(c, ct, vm, b->d_pk_chunk, b->d_pk_pos, total, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM],
+                              b->d_bnum, b->d_bcov,
                               b->d_pk_out, b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap);
         }
     }

@@ -164,7 +164,8 @@ constexpr double FFT_MAX_RANGE = 3e4;   // real Tn5 PWM log-bias spans <= 8.7 lo
 __global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
                                                              const double *__restrict__ tw, const double *__restrict__ ktab,
                                                              const double *__restrict__ nuc_cov, const double *__restrict__ raw,
-                                                             double *__restrict__ bg, double *__restrict__ norm) {
+                                                             double *__restrict__ bg, double *__restrict__ norm,
+                                                             double *__restrict__ bnum, double *__restrict__ bcov) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
@@ -224,6 +225,8 @@ __global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const 
             const double bgv = (num * nuc_cov[o]) / cv;
             bg[o] = bgv;
             norm[o] = raw[o] - bgv;
+            bnum[o] = num;
+            bcov[o] = cv;
         }
         return;
     }
@@ -287,6 +290,8 @@ __global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const 
             const double b = (num * nuc_cov[o]) / cv;
             bg[o] = b;
             norm[o] = raw[o] - b;
+            bnum[o] = num;           // sum B V and sum B of the window at this base: reused by the candidate statistics
+            bcov[o] = cv;
         }
     }
 }

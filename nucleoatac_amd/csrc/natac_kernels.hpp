@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(256) natac_add_tracks(const double *__restrict
 template <int G, int W>
 __global__ void __launch_bounds__(64) natac_background(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
                                                          const double *__restrict__ nuc_cov, const double *__restrict__ raw,
-                                                         double *__restrict__ bg, double *__restrict__ norm) {
+                                                         double *__restrict__ bg, double *__restrict__ norm,
+                                                         double *__restrict__ bnum, double *__restrict__ bcov) {
     constexpr int TW = WAVE * G;
     constexpr int HW = W / 2;
     constexpr int PW = TW + W - 1;               // product-row length
@@ -316,6 +317,8 @@ __global__ void __launch_bounds__(64) natac_background(ChunkTable ct, const int2
             const double b = (acc[k] * nuc_cov[o]) / cv;
             bg[o] = b;
             norm[o] = raw[o] - b;
+            bnum[o] = acc[k];        // sum B V and sum B of the window at this base: reused by the candidate statistics
+            bcov[o] = cv;
         }
     }
 }
@@ -324,7 +327,8 @@ __global__ void __launch_bounds__(64) natac_background(ChunkTable ct, const int2
 __global__ void __launch_bounds__(256) natac_background_generic(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
                                                                   const double *__restrict__ nuc_cov,
                                                                   const double *__restrict__ raw, double *__restrict__ bg,
-                                                                  double *__restrict__ norm) {
+                                                                  double *__restrict__ norm, double *__restrict__ bnum,
+                                                                  double *__restrict__ bcov) {
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, g = t.y + threadIdx.x;
     const int L = ct.chunk_len[chunk];
@@ -347,6 +351,8 @@ __global__ void __launch_bounds__(256) natac_background_generic(ChunkTable ct, c
     const double v = (num * nuc_cov[o]) / cov;
     bg[o] = v;
     norm[o] = raw[o] - v;
+    bnum[o] = num;
+    bcov[o] = cov;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1185,9 +1191,13 @@ __device__ __forceinline__ int wave_lower_bound(const int *__restrict__ a, int l
 
 // LDS: [zeros: A + Bh + 36][ones: W] shared by the workgroup, then [4 waves][CAND_PER_WAVE][EWP] bias windows.
 // Lanes without a template column (c >= W) read the zeros block instead of branching: their products are exactly 0.
+// USEBG: sum B and sum B V of a candidate's window are the per-base values the background kernel already formed at that
+// position (bcov / bnum of natac_run_nuc); the sweep then keeps two accumulators per candidate instead of four.
+template <bool USEBG>
 __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
                                                            const int *__restrict__ cand_pos, int ncand,
                                                            const double *__restrict__ nuc_cov, const double *__restrict__ norm,
+                                                           const double *__restrict__ bnum, const double *__restrict__ bcov,
                                                            double *__restrict__ out_lr, double *__restrict__ out_var,
                                                            double *__restrict__ out_z) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1259,13 +1269,15 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
             {
                 const double b0 = smem[o1[q] + ol] * smem[r1];
                 const double bb = sr * b0;
-                sB[q] += bb; sB0V[q] = fma(v1, b0, sB0V[q]); sBV[q] = fma(bb, v1, sBV[q]); sBV2[q] = fma(bb, v1sq, sBV2[q]);
+                if (!USEBG) { sB[q] += bb; sBV[q] = fma(bb, v1, sBV[q]); }
+                        sB0V[q] = fma(v1, b0, sB0V[q]); sBV2[q] = fma(bb, v1sq, sBV2[q]);
                 if (decltype(CHECK)::value) zero[q] |= (h1 && (v1 * b0 == 0.0 || bb == 0.0));
             }
             {
                 const double b0 = smem[o2[q] + ol] * smem[r2];
                 const double bb = sr * b0;
-                sB[q] += bb; sB0V[q] = fma(v2, b0, sB0V[q]); sBV[q] = fma(bb, v2, sBV[q]); sBV2[q] = fma(bb, v2sq, sBV2[q]);
+                if (!USEBG) { sB[q] += bb; sBV[q] = fma(bb, v2, sBV[q]); }
+                        sB0V[q] = fma(v2, b0, sB0V[q]); sBV2[q] = fma(bb, v2sq, sBV2[q]);
                 if (decltype(CHECK)::value) zero[q] |= (h2 && (v2 * b0 == 0.0 || bb == 0.0));
             }
         }
@@ -1301,13 +1313,15 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
                     {
                         const double b0 = smem[lb1[q] + (2 - DL[u])] * smem[rb1[q] + DR[u]];
                         const double bb = sr * b0;
-                        sB[q] += bb; sB0V[q] = fma(v1, b0, sB0V[q]); sBV[q] = fma(bb, v1, sBV[q]); sBV2[q] = fma(bb, v1sq, sBV2[q]);
+                        if (!USEBG) { sB[q] += bb; sBV[q] = fma(bb, v1, sBV[q]); }
+                        sB0V[q] = fma(v1, b0, sB0V[q]); sBV2[q] = fma(bb, v1sq, sBV2[q]);
                         if (decltype(CHECK)::value) zero[q] |= (h1 && (v1 * b0 == 0.0 || bb == 0.0));
                     }
                     {
                         const double b0 = smem[lb2[q] + (2 - DL[u])] * smem[rb2[q] + DR[u]];
                         const double bb = sr * b0;
-                        sB[q] += bb; sB0V[q] = fma(v2, b0, sB0V[q]); sBV[q] = fma(bb, v2, sBV[q]); sBV2[q] = fma(bb, v2sq, sBV2[q]);
+                        if (!USEBG) { sB[q] += bb; sBV[q] = fma(bb, v2, sBV[q]); }
+                        sB0V[q] = fma(v2, b0, sB0V[q]); sBV2[q] = fma(bb, v2sq, sBV2[q]);
                         if (decltype(CHECK)::value) zero[q] |= (h2 && (v2 * b0 == 0.0 || bb == 0.0));
                     }
                 }
@@ -1337,9 +1351,11 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
     }
 #pragma unroll
     for (int q = 0; q < CAND_PER_WAVE; ++q) {
-        const double tB = wave_sum(sB[q]), tBV = wave_sum(sBV[q]), tBV2 = wave_sum(sBV2[q]), tB0V = wave_sum(sB0V[q]);
-        const bool anyzero = __ballot(zero[q]) != 0ull;
         const int p = pos[q];
+        const long long op = ct.out_off[chunk[q]] + p;
+        const double tB = USEBG ? bcov[op] : wave_sum(sB[q]), tBV = USEBG ? bnum[op] : wave_sum(sBV[q]);
+        const double tBV2 = wave_sum(sBV2[q]), tB0V = wave_sum(sB0V[q]);
+        const bool anyzero = __ballot(zero[q]) != 0ull;
         const int nfr = (int)(ct.frag_off[chunk[q] + 1] - ct.frag_off[chunk[q]]);
         const int *cen = ct.centre + ct.frag_off[chunk[q]];
         const int *iln = ct.ilen + ct.frag_off[chunk[q]];

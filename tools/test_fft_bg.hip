@@ -6,6 +6,7 @@
 #include <vector>
 #include <cmath>
 using namespace natac;
+static double *g_x1 = nullptr, *g_x2 = nullptr;   // the kernels' bnum / bcov outputs
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const double *d_tw, const double *d_k, double *d_a, double *d_b,
@@ -22,7 +23,7 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
     const int nt = (int)tiles.size();
     for (int it = 0; it < reps + 1; ++it) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2);
+        hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (it > 0 && ms < best) best = ms;
@@ -50,6 +51,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&d_bias, bias.size() * 8)); CK(hipMalloc(&d_vm, vm.size() * 8)); CK(hipMalloc(&d_srow, R * 8));
     CK(hipMalloc(&d_a, nbp * 8)); CK(hipMalloc(&d_b, nbp * 8)); CK(hipMalloc(&d_o1, nbp * 8)); CK(hipMalloc(&d_o2, nbp * 8));
     CK(hipMalloc(&d_p1, nbp * 8)); CK(hipMalloc(&d_p2, nbp * 8));
+    double *d_x1, *d_x2; CK(hipMalloc(&d_x1, nbp * 8)); CK(hipMalloc(&d_x2, nbp * 8)); g_x1 = d_x1; g_x2 = d_x2;
     CK(hipMemcpy(d_a, ncov.data(), nbp * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_b, raw.data(), nbp * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_len, len.data(), nc * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_foff, foff.data(), (nc + 1) * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_boff, boff.data(), (nc + 1) * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ooff, ooff.data(), (nc + 1) * 8, hipMemcpyHostToDevice));
@@ -78,7 +80,7 @@ int main(int argc, char **argv) {
         float best = 1e30f;
         for (int it = 0; it < 3; ++it) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL((natac_background<G, 121>), dim3(tiles.size()), dim3(64), lds, 0, ct, d_t, v, d_a, d_b, d_p1, d_p2);
+            hipLaunchKernelGGL((natac_background<G, 121>), dim3(tiles.size()), dim3(64), lds, 0, ct, d_t, v, d_a, d_b, d_p1, d_p2, d_x1, d_x2);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (it > 0 && ms < best) best = ms;
