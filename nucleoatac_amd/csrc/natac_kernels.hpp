@@ -1194,7 +1194,7 @@ __device__ __forceinline__ int wave_lower_bound(const int *__restrict__ a, int l
 // USEBG: sum B and sum B V of a candidate's window are the per-base values the background kernel already formed at that
 // position (bcov / bnum of natac_run_nuc); the sweep then keeps two accumulators per candidate instead of four.
 template <bool USEBG>
-__global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) natac_candidates4(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
                                                            const int *__restrict__ cand_pos, int ncand,
                                                            const double *__restrict__ nuc_cov, const double *__restrict__ norm,
                                                            const double *__restrict__ bnum, const double *__restrict__ bcov,
@@ -1331,15 +1331,25 @@ __global__ void __launch_bounds__(256) natac_candidates4(ChunkTable ct, VMatDev 
         };
         double va1[4], va2[4], vb1[4], vb2[4];
         const int nblk = R / 4;
-        loadv(0, va1, va2);
         int bk = 0;
-        for (; bk + 2 <= nblk; bk += 2) {
-            loadv(4 * (bk + 1), vb1, vb2);
-            block(4 * bk, va1, va2);
-            loadv(4 * (bk + 2), va1, va2);
-            block(4 * (bk + 1), vb1, vb2);
+        if (USEBG) {
+            // three waves per SIMD hide the template loads: no second register set
+#pragma unroll 1
+            for (; bk < nblk; ++bk) {
+                loadv(4 * bk, va1, va2);
+                block(4 * bk, va1, va2);
+            }
+            (void)vb1; (void)vb2;
+        } else {
+            loadv(0, va1, va2);
+            for (; bk + 2 <= nblk; bk += 2) {
+                loadv(4 * (bk + 1), vb1, vb2);
+                block(4 * bk, va1, va2);
+                loadv(4 * (bk + 2), va1, va2);
+                block(4 * (bk + 1), vb1, vb2);
+            }
+            if (bk < nblk) block(4 * bk, va1, va2);
         }
-        if (bk < nblk) block(4 * bk, va1, va2);
         for (int r = 4 * nblk; r < R; ++r) row_generic(r, CHECK);
     };
     // wave-uniform dispatch to straight-line bodies
