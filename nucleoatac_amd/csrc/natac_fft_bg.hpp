@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const 
     const int npair = (vm.R + 1) >> 1;
     for (int pair = 0; pair < npair; ++pair) {
         const int ra = 2 * pair, rb = ra + 1;
-        const int ia = vm.lower + ra, ib = ia + 1;
+        const int ia = vm.lower + ra, ib = (rb < vm.R) ? ia + 1 : ia;   // odd R: the missing row reads row a's (valid) window with weight 0
         const double sa = vm.srow[ra], sb = (rb < vm.R) ? vm.srow[rb] : 0.0;
         const double *ela = Et + (A - floor_half(ia - 1)), *era = Et + (A + floor_half(ia));
         const double *elb = Et + (A - floor_half(ib - 1)), *erb = Et + (A + floor_half(ib));

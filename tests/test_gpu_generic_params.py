@@ -11,12 +11,18 @@ from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions,
 pytestmark = pytest.mark.gpu
 
 
-def test_generic_vmat_geometry():
+@pytest.mark.parametrize("vlo,vup,w", [(110, 240, 50), (111, 240, 50), (107, 250, 60), (1, 60, 20)])
+def test_generic_vmat_geometry(vlo, vup, w):
+    """V-plots of other shapes: even / odd lower bound, odd number of rows (the FFT kernel pads a row pair), a width other than
+    121, and a V-plot that includes insert size 1 (single-cell row: generic kernels)"""
     from nucleoatac_amd.device import Context
     from oracle import natac_oracle as O
     par = golden("params_example")
-    vlo, vup, w = 110, 240, 50
-    vm = np.ascontiguousarray(par["vmat"][vlo - 105:vup - 105, 60 - w:60 + w + 1])
+    if vlo >= 105:
+        vm = np.ascontiguousarray(par["vmat"][vlo - 105:vup - 105, 60 - w:60 + w + 1])
+    else:
+        rng = np.random.default_rng(3)
+        vm = rng.random((vup - vlo, 2 * w + 1)) * 0.01 + 1e-4
     sizes = synth_size_distribution(251)[:vup]
     pk = make_synthetic_chunks(40, 777, 260, seed=17)
     with Context(0) as c:
@@ -41,7 +47,10 @@ def test_generic_vmat_geometry():
             assert np.array_equal(mine, hp)
             for pos, lrv, varv in list(zip(mine, lr[cc == k], var[cc == k]))[:4]:
                 ref_lr = O.get_lr(nt["mat"], nt["mat_start"], nt["bmat"], nt["b0"], nt["b_start"], vm, vlo, vup, int(pos))
-                assert abs(lrv - ref_lr) <= 1e-7 * max(1.0, abs(ref_lr))
+                if np.isnan(ref_lr):     # a zero model cell (zero size probability): NaN in the reference as well
+                    assert np.isnan(lrv)
+                else:
+                    assert abs(lrv - ref_lr) <= 1e-7 * max(1.0, abs(ref_lr))
                 pr = O.signal_distribution_probs(nt["bmat"], nt["b_start"], vlo, vup, w, int(pos))
                 ref_var = O.calculate_cov_closed(pr, np.ravel(vm), nt["nuc_cov"][pos])
                 assert abs(varv - ref_var) <= 1e-7 * max(1e-12, abs(ref_var))
