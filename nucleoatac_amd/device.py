@@ -281,15 +281,22 @@ class DeviceBatch(object):
         L.check(self._lib.natac_run_candidates(self._h, n, _ptr(cc), _ptr(cp), _ptr(lr), _ptr(var), _ptr(z)))
         return lr, var, z
 
-    def run_peaks(self, min_signal=0.0, sep=25, boundary=60, order=12):
+    def run_peaks(self, min_signal=0.0, sep=25, boundary=60, order=12, download=True):
         """candidate search + LR / var / z on the device (natac_run_peaks): call_peaks(norm + smoothed, ...) of every chunk
-        as NucChunk.findAllNucs does it (nucleoatac/NucleosomeCalling.py:297-301).  Returns (chunk, pos, lr, var, z)."""
+        as NucChunk.findAllNucs does it (nucleoatac/NucleosomeCalling.py:297-301).  Returns (chunk, pos, lr, var, z), or with
+        download=False only the number of candidates (the arrays stay in HBM for download_peaks)."""
         maxL = int(self.packed.chunk_len.max())
         jitter = np.ascontiguousarray(np.random.RandomState(seed=25).uniform(0, 10 ** -12, maxL))   # utils.py:94-97
         n = C.c_int64(0)
         L.check(self._lib.natac_run_peaks(self._h, float(min_signal), int(sep), int(boundary), int(order), _ptr(jitter), maxL,
                                           C.byref(n)))
         n = n.value
+        if not download:
+            return n
+        return self.download_peaks(n)
+
+    def download_peaks(self, n):
+        """(chunk, pos, lr, var, z) of the last run_peaks"""
         cc, cp = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
         lr, var, z = (np.empty(n, dtype=np.float64) for _ in range(3))
         L.check(self._lib.natac_download_peaks(self._h, n, _ptr(cc), _ptr(cp), _ptr(lr), _ptr(var), _ptr(z)))
