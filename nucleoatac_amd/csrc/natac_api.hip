@@ -667,9 +667,10 @@ int natac_run_occ(natac_batch *b) {
         const int U = c->occ_upper, UP = (U + 1) & ~1;
         const int span = (OCC_T * OCC_NP - 1) * c->step + M + c->step;
         const int EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
-        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + OCC_ACL) * sizeof(double) +
+        const int n_ones = ((OCC_T - 1) * c->step + M + c->step + 3) & ~1;
+        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + OCC_ACL + n_ones) * sizeof(double) +
                            (size_t)2 * OCC_FMAX * sizeof(int);
-        if ((OCC_T - 1) * c->step + M + c->step + 2 > OCC_ACL || lds > 64 * 1024)
+        if (lds > 64 * 1024)
             return fail(NATAC_E_ARG, "occupancy window / step too large for the device tile (step=%d flank=%d upper=%d)", c->step, c->flank, U);
         hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
                            b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);

@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256) natac_smooth_same(ChunkTable ct, const in
 // ------------------------------------------------------------------------------------------------
 constexpr int OCC_T = 16;    // grid points per pass (one 16-lane row or one wave each in phase 2)
 constexpr int OCC_NP = 4;    // passes per tile
-constexpr int OCC_FMAX = 768;    // fragments of a tile staged in LDS (larger tiles read them from global memory)
+constexpr int OCC_FMAX = 512;    // fragments of a tile staged in LDS (larger tiles read them from global memory)
 
 struct OccModelDev {
     const double *nuc_probs, *nfr_probs, *alphas;
@@ -651,8 +651,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     double *nucp = bw + OCC_T * UP;                    // [UP]
     double *nfrp = nucp + UP;                          // [UP]
     double *acl = nfrp + UP;                           // [4 waves][64 x (pn, pf)] in phase 2
-    double *ones = acl;                                // phase 1: (OCC_T-1)*step + WIN + step + 2 <= 512 ones, the right factor of row j == 1
-    int *cen_s = (int *)(acl + OCC_ACL);               // [OCC_FMAX]
+    double *ones = acl + OCC_ACL;                      // [n_ones] of 1.0: the right factor of the single-cell row j == 1
+    const int n_ones = ((OCC_T - 1) * step + WIN + step + 3) & ~1;
+    int *cen_s = (int *)(ones + n_ones);               // [OCC_FMAX]
     int *iln_s = cen_s + OCC_FMAX;                     // [OCC_FMAX]
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, k0 = t.y;
@@ -668,6 +669,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     if (staged)
         for (int i = threadIdx.x; i < nt; i += 256) { cen_s[i] = cen[t0 + i]; iln_s[i] = iln[t0 + i]; }
     for (int j = threadIdx.x; j < U; j += 256) { nucp[j] = om.nuc_probs[j]; nfrp[j] = om.nfr_probs[j]; }
+    for (int u = threadIdx.x; u < n_ones; u += 256) ones[u] = 1.0;
     {   // Et[u] <-> coordinate gfirst - fl - A + u
         const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
         const int nb = L + ct.bias_left + ct.bias_right;
@@ -700,9 +702,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         const int kbase = k0 + pass * OCC_T;
         if (kbase >= nk) break;                                  // block-uniform
         const int uoff = pass * OCC_T * step;                    // Et offset of the pass's first window
-        if (pass > 0) __syncthreads();                           // phase 2 of the previous pass is done with bw / acl
-        for (int u = threadIdx.x; u < (OCC_T - 1) * step + WIN + step + 2; u += 256) ones[u] = 1.0;
-        __syncthreads();
+        __syncthreads();                                         // staging done / phase 2 of the previous pass is done with bw
         // ---- phase 1: window sums of B0 for every insert size j (thread j), the OCC_T grid points of the pass
         {
             const int j = threadIdx.x;

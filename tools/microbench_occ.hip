@@ -54,7 +54,7 @@ int main(int argc, char **argv) {
     std::vector<int2> tiles; for (int i = 0; i < nc; ++i) for (int k = 0; k < nk; k += OCC_T * OCC_NP) tiles.push_back(make_int2(i, k));
     int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2))); CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
     const int UP = (U + 1) & ~1, span = (OCC_T * OCC_NP - 1) * step + 2 * fl + 1 + step, EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
-    size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + OCC_ACL) * 8 + 2 * OCC_FMAX * 4;
+    size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + OCC_ACL + (((OCC_T - 1) * step + 2 * fl + 1 + step + 3) & ~1)) * 8 + 2 * OCC_FMAX * 4;
     int2 *d_r; CK(hipMalloc(&d_r, tiles.size() * sizeof(int2)));
     { hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventRecord(e0));
       hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((tiles.size() + 255) / 256), dim3(256), 0, 0, ct, d_t, (int)tiles.size(), step, half, fl, d_r);
