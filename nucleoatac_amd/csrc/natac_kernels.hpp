@@ -141,6 +141,19 @@ __global__ void natac_frag_centres(const int *__restrict__ lpos, const int *__re
 // only ~F*W entries are non-zero, so one thread per base walks the (centre-sorted) fragments in its window.
 // tile = (chunk, x0): 256 consecutive bases of one chunk.
 // ------------------------------------------------------------------------------------------------
+// number of leading entries of the sorted array a[from, n) that are < key, found 64 at a time with a ballot
+__device__ __forceinline__ int advance_while_less(const int *a, int from, int n, int key, int lane) {
+    int f = from;
+    while (f < n) {
+        const int i = f + lane;
+        const int v = (i < n) ? a[i] : 0x7fffffff;
+        const int cnt = __popcll(__ballot(v < key));
+        f += cnt;
+        if (cnt < WAVE) break;
+    }
+    return f;
+}
+
 constexpr int GATHER_FMAX = 1024;   // fragments of a 256-base tile staged in LDS (denser tiles read global memory)
 
 // fragment range [t0, t1) of every 256-base tile: centres within [x0 - w, x0 + 255 + w]; one thread per tile
@@ -176,23 +189,32 @@ __global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const in
         cen = cen_s;
         iln = iln_s;
     }
-    if (g >= L) return;
-    int f = lower_bound_i32(cen, 0, nt, g - vm.w);
+    // Wave-uniform walk over the fragments that can touch the wave's 64 bases, in list (= centre) order: every lane adds the
+    // template value of its own column, so a step is one coalesced read of (part of) a template row instead of 64 scattered
+    // ones, and the order of the additions per base is the list order as before (bit-identical sums).
+    const int lane = threadIdx.x & 63;
+    const int gw0 = g - lane;                                  // first base of the wave
+    if (gw0 >= L) return;                                      // wave-uniform
+    int f = advance_while_less(cen, 0, nt, gw0 - vm.w, lane);
+    const int fend = advance_while_less(cen, f, nt, gw0 + 63 + vm.w + 1, lane);
     int cnt_nuc = 0, cnt_nfr = 0;
     double acc = 0.0;
-    for (; f < nt; ++f) {
-        const int c = cen[f];
-        if (c > g + vm.w) break;
-        const int n = iln[f];
-        if (n >= vm.lower) {
+    for (; f < fend; ++f) {
+        const int c = cen[f], n = iln[f];                      // broadcast reads
+        const int d = c - g + vm.w;                            // this base's column of the template
+        const bool in = (d >= 0) && (d < vm.W);
+        if (n >= vm.lower) {                                   // wave-uniform branches (n is per fragment)
             if (n < vm.upper) {
-                ++cnt_nuc;
-                acc += vm.mat[(n - vm.lower) * vm.W + (c - g + vm.w)];
+                if (in) {
+                    ++cnt_nuc;
+                    acc += vm.mat[(n - vm.lower) * vm.W + d];
+                }
             }
         } else if (n >= 0) {
-            ++cnt_nfr;
+            if (in) ++cnt_nfr;
         }
     }
+    if (g >= L) return;
     const long long o = ct.out_off[chunk] + g;
     nuc_cov[o] = (double)cnt_nuc;
     nfr_cov[o] = (double)cnt_nfr;
@@ -439,19 +461,6 @@ struct OccModelDev {
     double cutoff;
     double ci_factor;   // exp(-cutoff / 2): likelihood-ratio threshold in the product domain
 };
-
-// number of leading entries of the sorted array a[from, n) that are < key, found 64 at a time with a ballot
-__device__ __forceinline__ int advance_while_less(const int *a, int from, int n, int key, int lane) {
-    int f = from;
-    while (f < n) {
-        const int i = f + lane;
-        const int v = (i < n) ? a[i] : 0x7fffffff;
-        const int cnt = __popcll(__ballot(v < key));
-        f += cnt;
-        if (cnt < WAVE) break;
-    }
-    return f;
-}
 
 // fragment range [t0, t1) of every occupancy tile (centres within the tile's windows); one thread per tile so the
 // dependent binary-search loads are hidden by occupancy instead of stalling a whole MLE workgroup.
