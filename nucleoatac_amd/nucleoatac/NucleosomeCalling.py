@@ -91,6 +91,9 @@ def norm(x, v, w, mean):
     return y * (w / y.max())
 
 
+FAST_FD = True    # batched finite differences in fit_fuzz_one (False: scipy's own numerical gradient)
+
+
 def fit_fuzz_one(vals, allnucs, index, nonredundant_sep, smooth_sd):
     """Nucleosome.getFuzz of the reference (NucleosomeCalling.py:137-194) for the call at chunk-relative position `index`:
     up to three Gaussians (the call and its neighbours closer than nonredundant_sep) fitted to the smoothed signal with
@@ -123,7 +126,44 @@ def fit_fuzz_one(vals, allnucs, index, nonredundant_sep, smooth_sd):
             fit += norm(xs, pars[3 * j], pars[3 * j + 1], pars[3 * j + 2])
         return np.sum((fit - sig) ** 2)
 
-    res = optimize.minimize(err, guess, bounds=bounds, method="L-BFGS-B")
+    if not FAST_FD:
+        res = optimize.minimize(err, guess, bounds=bounds, method="L-BFGS-B")
+        return np.sqrt(res["x"][0]), res["x"][1], res["x"][2] + left
+
+    # The reference lets scipy difference `err` numerically: n + 1 Python calls per gradient.  `grad` forms the SAME 2-point
+    # differences (absolute step 1e-8, flipped at an upper bound: scipy.optimize._numdiff.approx_derivative as L-BFGS-B
+    # calls it) from one batched evaluation of the n shifted parameter vectors; every element goes through the same numpy
+    # operations as in `err`, so the optimiser sees bit-identical values and takes the same path (tests/test_host_logic.py).
+    lb = np.array([b[0] for b in bounds], dtype=np.float64)
+    ub = np.array([b[1] for b in bounds], dtype=np.float64)
+    n = len(guess)
+    idx = np.arange(n)
+
+    def grad(pars):
+        x0 = np.asarray(pars, dtype=np.float64)
+        h = np.full(n, 1e-8)
+        lower_dist, upper_dist = x0 - lb, ub - x0
+        x = x0 + h
+        violated = (x < lb) | (x > ub)
+        fitting = np.abs(h) <= np.maximum(lower_dist, upper_dist)
+        h[violated & fitting] *= -1
+        forward = (upper_dist >= lower_dist) & ~fitting
+        h[forward] = upper_dist[forward]
+        backward = (upper_dist < lower_dist) & ~fitting
+        h[backward] = -lower_dist[backward]
+        X = np.tile(x0, (n, 1))
+        X[idx, idx] = x0 + h
+        dx = X[idx, idx] - x0
+        fit = np.zeros((n, len(xs)))
+        for j in range(n // 3):
+            v, w, mean = X[:, 3 * j][:, None], X[:, 3 * j + 1][:, None], X[:, 3 * j + 2][:, None]
+            y = 1.0 / np.sqrt(2 * np.pi * v) * np.exp(-(xs[None, :] - mean) ** 2 / (2 * v))
+            fit += y * (w / y.max(axis=1)[:, None])
+        r = (fit - sig[None, :]) ** 2
+        f1 = np.array([np.sum(r[i]) for i in range(n)])
+        return (f1 - err(x0)) / dx
+
+    res = optimize.minimize(err, guess, jac=grad, bounds=bounds, method="L-BFGS-B")
     return np.sqrt(res["x"][0]), res["x"][1], res["x"][2] + left
 
 

@@ -157,3 +157,27 @@ def test_cli_defaults_match_reference():
     assert (a.upper, a.flank, a.min_occ, a.nuc_sep, a.confidence_interval, a.step, a.pwm) == (251, 60, 0.1, 120, 0.9, 5, "Human")
     n = nucleoatac_parser().parse_args(["nuc", "--bed", "b", "--bam", "x", "--out", "o", "--vmat", "v"])
     assert (n.min_z, n.min_lr, n.nuc_sep, n.redundant_sep, n.sd, n.atac, n.write_all) == (3, 0, 120, 25, 10, True, False)
+
+
+def test_batched_finite_differences_reproduce_scipys_gradient():
+    """fit_fuzz_one hands L-BFGS-B a gradient that is scipy's own 2-point finite difference, evaluated in one batch: the
+    optimiser must take exactly the same path (bit-identical fuzz / weight / position, also next to a bound)"""
+    from nucleoatac_amd.nucleoatac import NucleosomeCalling as N
+    rng = np.random.default_rng(0)
+    tasks = []
+    for i in range(6):
+        Lc = 1500
+        x = np.arange(Lc)
+        keys = np.sort(rng.choice(np.arange(100, Lc - 100, 35), size=14, replace=False))
+        sd = rng.uniform(2.5, 45, size=len(keys))            # some fits end on the variance bounds (2^2, 50^2)
+        v = sum(rng.uniform(0.5, 2) * np.exp(-0.5 * ((x - k) / s) ** 2) for k, s in zip(keys, sd)) + rng.normal(0, 0.01, Lc)
+        tasks.append((v, keys, 120, 10))
+    res = {}
+    try:
+        for fast in (False, True):
+            N.FAST_FD = fast
+            res[fast] = np.array([r for tk in tasks for r in N.fit_fuzz_chunk(tk)])
+    finally:
+        N.FAST_FD = True
+    assert res[True].shape == (6 * 14, 3)
+    assert np.array_equal(res[False], res[True])
