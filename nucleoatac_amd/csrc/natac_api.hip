@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -57,6 +58,8 @@ struct natac_ctx {
     int occ_upper = 0, n_alpha = 0, step = 0, halfstep = 0, flank = 0;
     double cutoff = 0;
     bool have_occ = false;
+    int occ_zero_flags = 0;          // zero pattern of nuc_probs / nfr_probs (bits as in the MLE kernel)
+    double occ_b_floor = 0;          // see OccModelDev::b_floor
     // gaussian windows (cached by (M, sd))
     double *d_win_nuc = nullptr, *d_win_occ = nullptr;
     int win_nuc_M = 0, win_occ_M = 0;
@@ -335,6 +338,23 @@ int natac_set_occ_model(natac_ctx *c, const double *nuc_probs, const double *nfr
     if ((rc = dev_upload(c, &c->d_nfrp, nfr_probs, (size_t)upper))) return rc;
     if ((rc = dev_upload(c, &c->d_alphas, alphas, (size_t)n_alpha))) return rc;
     HIPCHK(sync_all(c));
+    {
+        int zf = 0;
+        double pmin = 1.0;
+        bool odd = false;   // negative / non-finite probabilities: always take the exact per-element path
+        for (int j = 0; j < upper; ++j) {
+            const double a = nuc_probs[j], f = nfr_probs[j];
+            if (a == 0.0) zf |= 1;
+            if (f == 0.0) zf |= 2;
+            if (a == 0.0 && f == 0.0) zf |= 4;
+            if (!(a >= 0.0) || !(f >= 0.0) || std::isinf(a) || std::isinf(f)) odd = true;
+            if (a > 0.0 && a < pmin) pmin = a;
+            if (f > 0.0 && f < pmin) pmin = f;
+        }
+        c->occ_zero_flags = zf;
+        // p * b >= DBL_MIN needs b >= DBL_MIN / pmin; 2^-1000 leaves room for any positive double pmin >= 2^-22
+        c->occ_b_floor = odd ? std::numeric_limits<double>::infinity() : std::ldexp(1.0, -1000) / pmin;
+    }
     c->occ_upper = upper; c->n_alpha = n_alpha; c->cutoff = cutoff; c->step = step;
     c->halfstep = (step - 1) / 2; c->flank = flank;
     c->have_occ = true;
@@ -432,6 +452,8 @@ static OccModelDev make_occ(natac_ctx *c) {
     o.nuc_probs = c->d_nucp; o.nfr_probs = c->d_nfrp; o.alphas = c->d_alphas; o.upper = c->occ_upper;
     o.n_alpha = c->n_alpha; o.step = c->step; o.halfstep = c->halfstep; o.flank = c->flank; o.cutoff = c->cutoff;
     o.ci_factor = std::exp(-0.5 * c->cutoff);
+    o.zero_flags = c->occ_zero_flags;
+    o.b_floor = c->occ_b_floor;
     return o;
 }
 

@@ -460,6 +460,8 @@ struct OccModelDev {
     int upper, n_alpha, step, halfstep, flank;
     double cutoff;
     double ci_factor;   // exp(-cutoff / 2): likelihood-ratio threshold in the product domain
+    int zero_flags;     // host-known zero pattern of the model: 1 some nuc_prob == 0, 2 some nfr_prob == 0, 4 some both
+    double b_floor;     // window bias sums >= b_floor cannot make a non-zero probability underflow to 0 (else: exact flag loop)
 };
 
 // fragment range [t0, t1) of every occupancy tile (centres within the tile's windows); one thread per tile so the
@@ -500,25 +502,35 @@ __device__ __forceinline__ void occ_phase2_rows(const ChunkTable &ct, const OccM
     double al[OCC_RA];
 #pragma unroll
     for (int t = 0; t < OCC_RA; ++t) { const int a = l + 16 * t; al[t] = (a < om.n_alpha) ? om.alphas[a] : 0.0; }
-    // normalisers of  nuc_probs * bias / sum(...)  (Occupancy.py:108-111) + zero / NaN flags of the quotients
-    double sn = 0.0, sf = 0.0;
-    int lf = 0;   // 1: some pn == 0, 2: some pf == 0, 4: some both == 0, 8: some NaN
+    // normalisers of  nuc_probs * bias / sum(...)  (Occupancy.py:108-111) + zero / NaN flags of the quotients:
+    // 1: some pn == 0, 2: some pf == 0, 4: some both == 0, 8: some NaN.  A product nuc_prob * bias is 0 only if a factor is
+    // (the zero pattern of the model is known on the host) or if it underflows, which needs a bias sum below om.b_floor;
+    // the per-element tests run only for waves that see such a sum.
+    double sn = 0.0, sf = 0.0, bmin = __builtin_inf();
     for (int j = l; j < U; j += 16) {
         const double b = bj[j];
-        const double pa = nucp[j] * b, pc = nfrp[j] * b;
-        sn += pa;
-        sf += pc;
-        if (pa == 0.0) lf |= 1;
-        if (pc == 0.0) lf |= 2;
-        if (pa == 0.0 && pc == 0.0) lf |= 4;
-        if (pa != pa || pc != pc) lf |= 8;
+        sn += nucp[j] * b;
+        sf += nfrp[j] * b;
+        bmin = fmin(bmin, b);
     }
     sn = row_sum(sn);
     sf = row_sum(sf);
-    int flags = 0;
+    int flags = om.zero_flags;
+    if (__ballot(!(bmin >= om.b_floor)) != 0ull) {            // wave-uniform, rare: exact per-element flags
+        int lf = 0;
+        for (int j = l; j < U; j += 16) {
+            const double b = bj[j];
+            const double pa = nucp[j] * b, pc = nfrp[j] * b;
+            if (pa == 0.0) lf |= 1;
+            if (pc == 0.0) lf |= 2;
+            if (pa == 0.0 && pc == 0.0) lf |= 4;
+            if (pa != pa || pc != pc) lf |= 8;
+        }
+        flags = 0;
 #pragma unroll
-    for (int bit = 1; bit <= 8; bit <<= 1)
-        if (((__ballot((lf & bit) != 0) >> sh) & 0xffffull) != 0ull) flags |= bit;
+        for (int bit = 1; bit <= 8; bit <<= 1)
+            if (((__ballot((lf & bit) != 0) >> sh) & 0xffffull) != 0ull) flags |= bit;
+    }
     if (!(sn > 0.0 && sn < __builtin_inf() && sf > 0.0 && sf < __builtin_inf())) flags |= 8;  // 0/0, x/inf, NaN sums
     // fragments of the row's window [g-fl, g+fl]: ranks of the two keys in the tile's sorted centre list
     int f0 = 0, f1 = 0;
@@ -591,15 +603,18 @@ __device__ __forceinline__ void occ_phase2_rows(const ChunkTable &ct, const OccM
     // decision without logarithms (see natac_occ_mle): L = m * 2^e, m in [0.5, 1), 0 stands for log L = -inf
     const int ENONE = -(1 << 30);
     int lemax = ENONE;
+    const bool anyflag = __ballot(flags != 0) != 0ull;
 #pragma unroll
     for (int t = 0; t < OCC_RA; ++t) {
         int ex;
         m[t] = frexp(m[t], &ex);
         e[t] += ex;
-        const double be = 1 - al[t];
-        if (flags & (8 | 4)) m[t] = 0.0;
-        if ((flags & 2) && al[t] == 0.0) m[t] = 0.0;
-        if ((flags & 1) && be == 0.0) m[t] = 0.0;
+        if (anyflag) {                                                     // wave-uniform
+            const double be = 1 - al[t];
+            if (flags & (8 | 4)) m[t] = 0.0;
+            if ((flags & 2) && al[t] == 0.0) m[t] = 0.0;
+            if ((flags & 1) && be == 0.0) m[t] = 0.0;
+        }
         if (!(m[t] > 0.0) || l + 16 * t >= om.n_alpha) m[t] = 0.0;      // NaN likelihood -> -inf as well
         if (!(m[t] > 0.0)) e[t] = ENONE;
         lemax = max(lemax, e[t]);

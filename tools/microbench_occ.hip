@@ -50,7 +50,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(d_cen, cen.data(), cen.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_iln, iln.data(), cen.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_lp, lp.data(), cen.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_nucp, nucp.data(), U * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_nfrp, nfrp.data(), U * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_al, al.data(), 101 * 8, hipMemcpyHostToDevice));
     ChunkTable ct{}; ct.nc = nc; ct.chunk_len = d_len; ct.frag_off = d_foff; ct.lpos = d_lp; ct.ilen = d_iln; ct.centre = d_cen; ct.bias_off = d_boff; ct.bias = d_bias; ct.bias_left = bl; ct.bias_right = br; ct.out_off = d_ooff; ct.grid_off = d_goff;
-    OccModelDev om{}; om.nuc_probs = d_nucp; om.nfr_probs = d_nfrp; om.alphas = d_al; om.upper = U; om.n_alpha = 101; om.step = step; om.halfstep = half; om.flank = fl; om.cutoff = 2.705543454095404;
+    OccModelDev om{}; om.nuc_probs = d_nucp; om.nfr_probs = d_nfrp; om.alphas = d_al; om.upper = U; om.n_alpha = 101; om.step = step; om.halfstep = half; om.flank = fl; om.cutoff = 2.705543454095404; om.zero_flags = 0; om.b_floor = 1e-290;
     std::vector<int2> tiles; for (int i = 0; i < nc; ++i) for (int k = 0; k < nk; k += OCC_T * OCC_NP) tiles.push_back(make_int2(i, k));
     int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2))); CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
     const int UP = (U + 1) & ~1, span = (OCC_T * OCC_NP - 1) * step + 2 * fl + 1 + step, EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
