@@ -161,7 +161,9 @@ __global__ void __launch_bounds__(64) natac_fft_template(const double *__restric
 // confined to the bases whose window touches it) are evaluated by direct summation in the same order as natac_background.
 constexpr double FFT_MAX_RANGE = 3e4;   // real Tn5 PWM log-bias spans <= 8.7 log units genome-wide (e^8.7 = 6e3)
 
-__global__ void __launch_bounds__(64) natac_background_fft(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
+// two waves per SIMD on purpose: a third one (reachable with the stage-2 twiddles in LDS, 145 VGPRs) only adds LDS contention
+// (measured 11.4 vs 8.7 ms per 20 k chunks)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) natac_background_fft(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
                                                              const double *__restrict__ tw, const double *__restrict__ ktab,
                                                              const double *__restrict__ nuc_cov, const double *__restrict__ raw,
                                                              double *__restrict__ bg, double *__restrict__ norm,
