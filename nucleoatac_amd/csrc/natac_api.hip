@@ -50,6 +50,7 @@ struct natac_ctx {
     int vlower = 0, vupper = 0, vw = 0, R = 0, W = 0, sizes_upper = 0;
     bool have_vmat = false, have_sizes = false, srow_dirty = true;
     bool vmat_zero = false, srow_zero = false;
+    long long model_gen = 0;         // bumped by natac_set_vmat / natac_set_sizes
     // FFT background path: twiddles (once) and template spectra (per V-plot)
     double *d_fft_tw = nullptr, *d_fft_k = nullptr;
     bool fft_dirty = true, bg_direct = false;
@@ -105,6 +106,7 @@ struct natac_batch {
     bool pk_has_stats = false;
     int nuc_w = -1, nuc_upper = -1;   // V-plot geometry natac_run_nuc ran with (coverage tracks depend on it)
     double *d_bnum = nullptr, *d_bcov = nullptr;   // per-base sum B V / sum B of the background kernel (candidate statistics)
+    long long nuc_gen = -1;                        // model generation natac_run_nuc ran with
 };
 
 static hipError_t sync_all(natac_ctx *c) {
@@ -303,6 +305,7 @@ int natac_set_vmat(natac_ctx *c, const double *mat, int lower, int upper, int w)
     c->have_vmat = true;
     c->srow_dirty = true;
     c->fft_dirty = true;
+    ++c->model_gen;
     return NATAC_OK;
 }
 
@@ -319,6 +322,7 @@ int natac_set_sizes(natac_ctx *c, const double *sizes, int upper) {
     c->sizes_upper = upper;
     c->have_sizes = true;
     c->srow_dirty = true;
+    ++c->model_gen;
     return NATAC_OK;
 }
 
@@ -636,6 +640,7 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
     b->nuc_done = true;
+    b->nuc_gen = c->model_gen;
     b->nuc_w = c->vw;
     b->nuc_upper = c->vupper;
     return NATAC_OK;
@@ -773,7 +778,8 @@ int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chu
     const VMatDev vm = make_vmat(c);
     natac_ctx::Ev ev;
     prof_begin(c, NATAC_K_CAND, ev);
-    launch_candidates(c, ct, vm, d_cc, d_cp, n_cand, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, d_out,
+    launch_candidates(c, ct, vm, d_cc, d_cp, n_cand, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM],
+                      b->nuc_gen == c->model_gen ? b->d_bnum : nullptr, b->nuc_gen == c->model_gen ? b->d_bcov : nullptr, d_out,
                       d_out + n_cand,
                       d_out + 2 * n_cand);
     prof_end(c, ev);
@@ -852,7 +858,7 @@ static int run_peaks_impl(natac_batch *b, const double *sig_a, const double *sig
         if (with_stats) {
             const VMatDev vm = make_vmat(c);
             launch_candidates(c, ct, vm, b->d_pk_chunk, b->d_pk_pos, total, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM],
-                              b->d_bnum, b->d_bcov,
+                              b->nuc_gen == c->model_gen ? b->d_bnum : nullptr, b->nuc_gen == c->model_gen ? b->d_bcov : nullptr,
                               b->d_pk_out, b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap);
         }
     }
