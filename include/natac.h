@@ -76,7 +76,8 @@ enum {
     NATAC_K_OCC_FILL = 5,
     NATAC_K_INS = 6,
     NATAC_K_CAND = 7,
-    NATAC_K_COUNT = 8
+    NATAC_K_SIZE_HIST = 8,   /* insert-size histogram of natac_fragment_sizes */
+    NATAC_K_COUNT = 9
 };
 
 typedef struct natac_ctx natac_ctx;

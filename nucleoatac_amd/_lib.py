@@ -13,9 +13,9 @@ LIB_PATH = os.environ.get("NATAC_LIB") or os.path.join(_HERE, "libnatac_hip.so")
 T_NUC_COV, T_NFR_COV, T_RAW, T_BACKGROUND, T_NORM, T_SMOOTH = 0, 1, 2, 3, 4, 5
 T_OCC, T_OCC_LOWER, T_OCC_UPPER, T_OCC_COV, T_INS, T_OCC_PREFILL = 6, 7, 8, 9, 10, 11
 G_OCC, G_LOWER, G_UPPER = 0, 1, 2
-K_FRAG_GATHER, K_BACKGROUND, K_SMOOTH_NUC, K_OCC_MLE, K_OCC_SMOOTH, K_OCC_FILL, K_INS, K_CAND = range(8)
+K_FRAG_GATHER, K_BACKGROUND, K_SMOOTH_NUC, K_OCC_MLE, K_OCC_SMOOTH, K_OCC_FILL, K_INS, K_CAND, K_SIZE_HIST = range(9)
 KERNEL_NAMES = ["frag_gather", "background", "smooth_nuc", "occ_mle", "occ_smooth", "occ_fill", "insertions",
-                "candidates"]
+                "candidates", "size_hist"]
 
 _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
 _pp = C.POINTER(C.c_void_p)

@@ -1021,28 +1021,42 @@ int natac_fragment_sizes(natac_ctx *c, int64_t nf, const int64_t *l, const int32
                          const int64_t *ce, int lower, int upper, double *sizes) {
     if (!c || !sizes || (nf > 0 && (!l || !n)) || (nchunks > 0 && (!cs || !ce))) return fail(NATAC_E_ARG, "null argument");
     if (upper <= lower) return fail(NATAC_E_ARG, "upper <= lower");
+    if (nf < 0 || nchunks < 0) return fail(NATAC_E_ARG, "negative size");
     const int nb = upper - lower;
-    if (nb > 16384) return fail(NATAC_E_ARG, "size range too wide");
+    if (nb > (1 << 20)) return fail(NATAC_E_ARG, "size range too wide");
     HIPCHK(hipSetDevice(c->device));
+    // chunk starts and ends sorted independently: #{cs <= x} - #{ce <= x} chunks contain x (see natac_size_hist);
+    // an inverted interval (end < start) contains nothing, like the reference's `center >= start and center < end`
+    std::vector<long long> hs((size_t)nchunks), he((size_t)nchunks);
+    for (int k = 0; k < nchunks; ++k) { hs[k] = cs[k]; he[k] = std::max<long long>(ce[k], cs[k]); }
+    std::sort(hs.begin(), hs.end());
+    std::sort(he.begin(), he.end());
     long long *d_l = nullptr, *d_cs = nullptr, *d_ce = nullptr; int *d_n = nullptr; unsigned long long *d_h = nullptr;
     int rc;
     if ((rc = dev_upload(c, &d_l, (const long long *)l, (size_t)nf))) return rc;
     if ((rc = dev_upload(c, &d_n, n, (size_t)nf))) { dev_free(d_l); return rc; }
-    if ((rc = dev_upload(c, &d_cs, (const long long *)cs, (size_t)nchunks))) { dev_free(d_l); dev_free(d_n); return rc; }
-    if ((rc = dev_upload(c, &d_ce, (const long long *)ce, (size_t)nchunks))) { dev_free(d_l); dev_free(d_n); dev_free(d_cs); return rc; }
+    if ((rc = dev_upload(c, &d_cs, hs.data(), (size_t)nchunks))) { dev_free(d_l); dev_free(d_n); return rc; }
+    if ((rc = dev_upload(c, &d_ce, he.data(), (size_t)nchunks))) { dev_free(d_l); dev_free(d_n); dev_free(d_cs); return rc; }
     if ((rc = dev_alloc(&d_h, (size_t)nb))) { dev_free(d_l); dev_free(d_n); dev_free(d_cs); dev_free(d_ce); return rc; }
     std::vector<unsigned long long> h((size_t)nb, 0);
     hipError_t e = hipMemsetAsync(d_h, 0, (size_t)nb * sizeof(unsigned long long), c->stream);
+    natac_ctx::Ev ev;
+    prof_begin(c, NATAC_K_SIZE_HIST, ev);
     if (e == hipSuccess && nf > 0 && nchunks > 0) {
-        int blocks = (int)std::min<long long>((nf + 255) / 256, 1024);
-        hipLaunchKernelGGL(natac_size_hist, dim3(blocks), dim3(256), (size_t)nb * sizeof(unsigned), c->stream, d_l, d_n, (long long)nf,
-                           d_cs, d_ce, (int)nchunks, lower, upper, d_h);
+        const long long nseg = (nf + SIZE_SEG - 1) / SIZE_SEG;
+        const int blocks = (int)std::min<long long>(nseg, 8192);
+        const int use_lds = nb <= 8192 ? 1 : 0;
+        const size_t lds = (size_t)2 * SIZE_STAGE * sizeof(long long) + (use_lds ? (size_t)nb * sizeof(unsigned) : 0);
+        hipLaunchKernelGGL(natac_size_hist, dim3(blocks), dim3(256), lds, c->stream, d_l, d_n, (long long)nf, d_cs, d_ce, (int)nchunks,
+                           lower, upper, use_lds, d_h);
         e = hipGetLastError();
     }
+    prof_end(c, ev);
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_h, (size_t)nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     dev_free(d_l); dev_free(d_n); dev_free(d_cs); dev_free(d_ce); dev_free(d_h);
     if (e != hipSuccess) return fail(NATAC_E_HIP, "fragment_sizes: %s", hipGetErrorString(e));
+    prof_collect(c);
     for (int i = 0; i < nb; ++i) sizes[i] = (double)h[i];
     return NATAC_OK;
 }

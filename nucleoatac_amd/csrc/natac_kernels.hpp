@@ -1624,28 +1624,98 @@ __global__ void natac_i32_to_f64(const int *__restrict__ a, double *__restrict__
 }
 
 // getFragmentSizesFromChunkList, pyatac/fragments.pyx:123-145: a fragment counts once per chunk containing its
-// centre.  Chunks sorted by start; per-workgroup LDS histogram, then one global atomic per bin.
+// centre c (chunks may overlap before ChunkList.merge: the reference loops the chunks and re-fetches).  With the chunk
+// starts and the chunk ends sorted INDEPENDENTLY (host),  #{k: cs[k] <= c < ce[k]} = #{cs <= c} - #{ce <= c}  for any set of
+// intervals with cs[k] <= ce[k], so a fragment costs two searches instead of a scan over all chunks.  A workgroup takes
+// SIZE_SEG consecutive fragments; reads come position-sorted from the BAM, so their centres span a few chunks only: the
+// slices of cs / ce that can matter for the segment (found by four bisections per segment) are staged in LDS and searched
+// there; segments that span more than SIZE_STAGE chunk bounds search global memory.  Per-workgroup LDS histogram, one
+// global atomic per non-empty bin at the end (lh == nullptr: bins too many for LDS, global atomics directly).
+constexpr int SIZE_SEG = 2048;     // fragments per segment (8 per thread)
+constexpr int SIZE_STAGE = 1024;   // staged chunk starts / ends per segment
+
+__device__ __forceinline__ int upper_bound_i64(const long long *a, int lo, int hi, long long key) {
+    // number of entries <= key in the sorted array a[0, hi), searching from lo
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(256) natac_size_hist(const long long *__restrict__ l, const int *__restrict__ n,
                                                          long long nf, const long long *__restrict__ cs,
                                                          const long long *__restrict__ ce, int nchunks, int lower, int upper,
-                                                         unsigned long long *__restrict__ hist) {
-    extern __shared__ unsigned int lh[];
+                                                         int use_lds_hist, unsigned long long *__restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char size_smem[];
+    __shared__ long long seg_min, seg_max;
+    __shared__ int bnd[4];                                  // cntS(cmin - 1), cntS(cmax), cntE(cmin - 1), cntE(cmax)
+    long long *ss = (long long *)size_smem;                 // [SIZE_STAGE] staged chunk starts
+    long long *es = ss + SIZE_STAGE;                        // [SIZE_STAGE] staged chunk ends
+    unsigned int *lh = (unsigned int *)(es + SIZE_STAGE);   // [upper - lower]
     const int nb = upper - lower;
-    for (int b = threadIdx.x; b < nb; b += 256) lh[b] = 0;
-    __syncthreads();
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < nf; i += stride) {
-        const int ilen = n[i];
-        if (ilen < lower || ilen >= upper) continue;
-        const long long c = l[i] + floor_half(ilen - 1);
-        unsigned int cnt = 0;
-        for (int k = 0; k < nchunks; ++k) cnt += (c >= cs[k] && c < ce[k]);
-        if (cnt) atomicAdd(&lh[ilen - lower], cnt);
+    if (use_lds_hist) for (int b = threadIdx.x; b < nb; b += 256) lh[b] = 0;
+    const long long nseg = (nf + SIZE_SEG - 1) / SIZE_SEG;
+    for (long long seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        if (threadIdx.x == 0) { seg_min = 0x7fffffffffffffffLL; seg_max = -0x7fffffffffffffffLL - 1; }
+        __syncthreads();
+        long long c[SIZE_SEG / 256];
+        int il[SIZE_SEG / 256];
+        long long mn = 0x7fffffffffffffffLL, mx = -0x7fffffffffffffffLL - 1;
+#pragma unroll
+        for (int q = 0; q < SIZE_SEG / 256; ++q) {
+            const long long i = seg * SIZE_SEG + q * 256 + threadIdx.x;
+            il[q] = -1;
+            c[q] = 0;
+            if (i < nf) {
+                const int ilen = n[i];
+                if (ilen >= lower && ilen < upper) {
+                    il[q] = ilen;
+                    c[q] = l[i] + floor_half(ilen - 1);
+                    mn = c[q] < mn ? c[q] : mn;
+                    mx = c[q] > mx ? c[q] : mx;
+                }
+            }
+        }
+        if (mn <= mx) { atomicMin(&seg_min, mn); atomicMax(&seg_max, mx); }
+        __syncthreads();
+        const long long cmin = seg_min, cmax = seg_max;
+        if (cmin > cmax) continue;                          // no countable fragment in the segment (block-uniform)
+        if (threadIdx.x < 4) {
+            const long long *arr = (threadIdx.x < 2) ? cs : ce;
+            bnd[threadIdx.x] = upper_bound_i64(arr, 0, nchunks, (threadIdx.x & 1) ? cmax : cmin - 1);
+        }
+        __syncthreads();
+        const int s0 = bnd[0], s1 = bnd[1], e0 = bnd[2], e1 = bnd[3];
+        const bool staged = (s1 - s0 <= SIZE_STAGE) && (e1 - e0 <= SIZE_STAGE);
+        if (staged) {
+            for (int k = threadIdx.x; k < s1 - s0; k += 256) ss[k] = cs[s0 + k];
+            for (int k = threadIdx.x; k < e1 - e0; k += 256) es[k] = ce[e0 + k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SIZE_SEG / 256; ++q) {
+            if (il[q] < 0) continue;
+            int a, b;
+            if (staged) {
+                a = s0 + upper_bound_i64(ss, 0, s1 - s0, c[q]);
+                b = e0 + upper_bound_i64(es, 0, e1 - e0, c[q]);
+            } else {
+                a = upper_bound_i64(cs, s0, s1, c[q]);
+                b = upper_bound_i64(ce, e0, e1, c[q]);
+            }
+            const int cnt = a - b;                          // chunks with cs <= c < ce
+            if (cnt > 0) {
+                if (use_lds_hist) atomicAdd(&lh[il[q] - lower], (unsigned)cnt);
+                else atomicAdd(&hist[il[q] - lower], (unsigned long long)cnt);
+            }
+        }
+        __syncthreads();                                    // ss / es / seg_min are rewritten by the next segment
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nb; b += 256)
-        if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+    if (use_lds_hist)
+        for (int b = threadIdx.x; b < nb; b += 256)
+            if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
 }
 
 // calculateCov, nucleoatac/multinomial_cov.pyx:20-31.

@@ -363,6 +363,46 @@ def case_ins_edge():
          mat_nonzero=np.array(np.nonzero(mat.mat)).T, getins=ins2.vals, getins_start=ins2.start)
 
 
+# ----------------------------------------------------------------------------------------
+# case H: insert-size histogram (a3): getFragmentSizesFromChunkList / getAllFragmentSizes
+# (pyatac/fragments.pyx:101-145) + FragmentSizes.calculateSizes (pyatac/fragmentsizes.py:22-27)
+# on overlapping, adjacent, nested, empty and chromosome-start chunks
+# ----------------------------------------------------------------------------------------
+def case_sizes():
+    from pyatac.fragments import getAllFragmentSizes, getFragmentSizesFromChunkList
+    bam, fa, L, N, seq = make_synth_genome(21, holes=[(9000, 9600)])
+    sets = {
+        "disjoint": [(1000, 1803), (4800, 5500), (8000, 8900)],
+        "overlap": [(1000, 1803), (1500, 2300), (1700, 1750), (2299, 2600)],       # overlapping + nested + 1-bp overlap
+        "adjacent": [(4000, 4500), (4500, 5000), (5000, 5001)],                  # touching chunks, a single-base chunk
+        "empty": [(9100, 9500), (13990, 14000)],                                 # fragment-free hole, chromosome end
+        "chromstart": [(0, 900), (100, 200)],                                    # max(0, start - upper) clamp (fragments.pyx:130)
+        "unsorted": [(8000, 8900), (1000, 1803), (1500, 2300)],                  # the reference loops chunks in list order
+    }
+    out = dict(l=L, n=N, chrom_len=14000)
+    for lo, up, atac in ((0, 251, 1), (30, 251, 1), (0, 2000, 1), (105, 251, 0)):
+        tag = "%d_%d_%d" % (lo, up, atac)
+        # the stored fragments are (l, n) with ATAC shift applied; for atac=0 the reference sees pos = l-4, |tlen| = n+8
+        lx, nx = (L, N) if atac else (L - 4, N + 8)
+        alls = getAllFragmentSizes(bam, lo, up, atac=atac)
+        check("sizes getAllFragmentSizes [%s]" % tag, alls,
+              O.fragment_sizes_from_chunks(lx, nx, [-(1 << 40)], [1 << 40], lo, up), exact=True)
+        out["all_" + tag] = alls
+        for name, ivs in sets.items():
+            chunks = ChunkList(*[Chunk("chrS", s, e) for s, e in ivs])
+            ref = getFragmentSizesFromChunkList(chunks, bam, lo, up, atac=atac)
+            got = O.fragment_sizes_from_chunks(lx, nx, [s for s, _ in ivs], [e for _, e in ivs], lo, up)
+            check("sizes getFragmentSizesFromChunkList %s [%s]" % (name, tag), ref, got, exact=True)
+            fs = FragmentSizes(lo, up, atac=bool(atac))
+            fs.calculateSizes(bam, chunks=chunks)
+            check("sizes calculateSizes %s [%s]" % (name, tag), fs.vals, O.normalise_sizes(got), exact=True)
+            out["%s_%s" % (name, tag)] = ref
+            out["%s_%s_norm" % (name, tag)] = fs.vals
+            out["%s_chunks" % name] = np.array(ivs, dtype=np.int64)
+    assert out["empty_0_251_1"].sum() == 0 and out["overlap_0_251_1"].sum() > out["disjoint_0_251_1"].sum() * 0.3
+    save("sizes_hist", **out)
+
+
 if __name__ == "__main__":
     vmat, fd, pwm = case_params()
     case_chunks("chunks_basic", 11, [(1000, 1803), (4800, 5500), (8000, 9203)], vmat, fd, pwm)
@@ -371,6 +411,7 @@ if __name__ == "__main__":
     case_cov_var()
     case_toy_occ()
     case_ins_edge()
+    case_sizes()
     print("\n".join(REPORT))
     print("oracle pinned against the reference on %d checks" % len(REPORT))
     with open(os.path.join(HERE, "PIN_REPORT.txt"), "w") as f:

@@ -136,3 +136,21 @@ def test_smooth_matches_numpy_semantics():
     x[:] = np.nan
     assert np.isnan(O.smooth(x, 61, window="gaussian", sd=10, mode="same")).all()
     assert O.smooth(np.ones(10), 4, mode="valid", norm=False).shape == (6,)  # even window is bumped to 5
+
+
+def test_fragment_size_histogram_matches_reference():
+    """a3: getFragmentSizesFromChunkList / getAllFragmentSizes / calculateSizes (pyatac/fragments.pyx:101-145,
+    fragmentsizes.py:22-27) on overlapping, nested, adjacent, empty, chromosome-start and unsorted chunk lists"""
+    g = golden("sizes_hist")
+    n_checked = 0
+    for lo, up, atac in ((0, 251, 1), (30, 251, 1), (0, 2000, 1), (105, 251, 0)):
+        tag = "%d_%d_%d" % (lo, up, atac)
+        l, n = (g["l"], g["n"]) if atac else (g["l"] - 4, g["n"] + 8)
+        assert np.array_equal(O.fragment_sizes_from_chunks(l, n, [-(1 << 40)], [1 << 40], lo, up), g["all_" + tag])
+        for name in ("disjoint", "overlap", "adjacent", "empty", "chromstart", "unsorted"):
+            iv = g[name + "_chunks"]
+            got = O.fragment_sizes_from_chunks(l, n, iv[:, 0], iv[:, 1], lo, up)
+            assert np.array_equal(got, g["%s_%s" % (name, tag)]), (name, tag)
+            assert np.array_equal(O.normalise_sizes(got), g["%s_%s_norm" % (name, tag)])
+            n_checked += 1
+    assert n_checked == 24 and g["overlap_0_251_1"].sum() > 0 and g["empty_0_251_1"].sum() == 0
