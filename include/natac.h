@@ -191,7 +191,10 @@ int natac_calculate_occupancy(natac_ctx *ctx, const double *inserts, const doubl
 
 /* ---- native track writer (host side, multi-threaded) ------------- */
 /* Track.write_track, pyatac/tracks.py:37-74, for n_chunks tracks at once (chunk i: chroms[i], chunk_start[i], values
- * vals[out_off[i] .. out_off[i+1]) ), run-length bedGraph text with python-2 float formatting, NaN runs skipped.
+ * vals[out_off[i] .. out_off[i+1]) ), run-length bedGraph text with python-2 float formatting, NaN runs skipped, and -- as in the
+ * reference, whose loop overwrites prev_value with the NaN before flushing (tracks.py:56-66) -- a run of values directly followed
+ * by a NaN is NOT written.  write_zero: bit 0 = write runs of 0 (the reference's write_zero), bit 1 = also keep runs that precede a
+ * NaN (deviation from the reference, off by default).
  * compress: 0 = plain text, 1..9 = BGZF at that deflate level (bgzip-compatible; run_occ.py:130-136).  append != 0
  * appends to `path`; finish != 0 terminates a BGZF file with the EOF marker block.  n_threads <= 0: automatic.
  * No GPU involved; usable on the arrays natac_batch_download returns. */

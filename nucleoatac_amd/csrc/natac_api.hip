@@ -1225,7 +1225,7 @@ int natac_write_bedgraph(const char *path, int append, int compress, int finish,
         if (out_off[i + 1] < out_off[i]) return fail(NATAC_E_ARG, "out_off must be non-decreasing");
     }
     const int rc = natac_writer::write_bedgraph(path, append != 0, compress, finish != 0, n_chunks, chroms, chunk_start, out_off, vals,
-                                                write_zero != 0, n_threads, bytes_written);
+                                                (write_zero & 1) != 0, n_threads, bytes_written, (write_zero & 2) != 0);
     if (rc == 1) return fail(NATAC_E_ARG, "cannot open %s", path);
     if (rc == 2) return fail(NATAC_E_ARG, "write to %s failed", path);
     if (rc == 3) return fail(NATAC_E_NOMEM, "deflate failed");

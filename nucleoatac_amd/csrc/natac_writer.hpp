@@ -2,7 +2,8 @@
 // (pyatac/tracks.py:37-74) + the bgzip step of run_occ.py:130-136 / run_nuc.py:189-200.
 //
 // Text format per run of equal values:  chrom \t start \t end \t value \n  with python-2 `str(float)` formatting
-// (12 significant digits, ".0" appended to integral values), NaN runs skipped, zero runs skipped when !write_zero.
+// (12 significant digits, ".0" appended to integral values), NaN runs skipped, zero runs skipped when !write_zero,
+// value runs directly followed by a NaN dropped like the reference does.
 // Output is plain text or BGZF (blocked gzip, <= 64 KiB members with the 'BC' extra field -- what bgzip / tabix read).
 // The reference's writer processes manage 0.31 Mbp/s each; the GPU path produces tracks three orders
 // of magnitude faster, so the formatter is the first "next" row of SURVEY.md section 8(f).
@@ -100,8 +101,11 @@ inline char *fmt_i64(char *p, long long v) {
 }
 
 // run-length text of one chunk appended to `out`
+// Reference rule kept on purpose (pyatac/tracks.py:56-66): `prev_value` is overwritten by a NaN BEFORE the open run is
+// flushed, so a run of values that is immediately followed by a NaN is never written (for [1, 1, nan, 2, 2] only the last
+// run appears).  keep_before_nan = true writes those runs too (deviation, off by default).
 inline void format_chunk(std::string &out, const char *chrom, size_t chrom_len, long long start, const double *vals, long long n,
-                         bool write_zero) {
+                         bool write_zero, bool keep_before_nan = false) {
     char line[160];
     long long a = 0;
     while (a < n) {
@@ -113,7 +117,8 @@ inline void format_chunk(std::string &out, const char *chrom, size_t chrom_len, 
             continue;
         }
         while (b < n && vals[b] == v) ++b;
-        if (v != 0.0 || write_zero) {
+        const bool dropped = !keep_before_nan && b < n && vals[b] != vals[b];
+        if ((v != 0.0 || write_zero) && !dropped) {
             char *p = line;
             std::memcpy(p, chrom, chrom_len);
             p += chrom_len;
@@ -190,7 +195,7 @@ static const unsigned char BGZF_EOF[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff
 // returns 0 ok, 1 cannot open, 2 write error, 3 deflate error
 inline int write_bedgraph(const char *path, bool append, int compress, bool finish, int nc, const char *const *chroms,
                           const int64_t *chunk_start, const int64_t *out_off, const double *vals, bool write_zero, int n_threads,
-                          int64_t *bytes_written) {
+                          int64_t *bytes_written, bool keep_before_nan = false) {
     if (n_threads <= 0) n_threads = natac_cores::default_threads(128);
     n_threads = std::max(1, std::min(n_threads, std::max(1, nc)));
     // contiguous chunk ranges with ~equal numbers of bases
@@ -222,7 +227,7 @@ inline int write_bedgraph(const char *path, bool append, int compress, bool fini
         std::string &fmt = compress ? text : parts[t];
         for (int i = cut[t]; i < cut[t + 1]; ++i) {
             format_chunk(fmt, chroms[i], std::strlen(chroms[i]), chunk_start[i], vals + out_off[i], out_off[i + 1] - out_off[i],
-                         write_zero);
+                         write_zero, keep_before_nan);
             if (compress && text.size() >= FLUSH) {          // bound memory: flush whole 0xff00-byte blocks
                 const size_t whole = text.size() / 0xff00 * 0xff00;
                 if (!bgzf_compress(parts[t], text.data(), whole, compress, &df)) { err[t] = 3; return; }

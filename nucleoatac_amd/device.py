@@ -176,9 +176,13 @@ class Context(object):
         """InsertionBiasTrack.computeBias (pyatac/bias.py:85-92): log-bias of every position of `sequence`."""
         seq = np.frombuffer(sequence.encode("ascii") if isinstance(sequence, str) else bytes(sequence), dtype=np.uint8)
         logp = _f64(np.log(np.asarray(pwm_mat, dtype=np.float64)))
-        nucs = np.frombuffer("".join(nucleotides).encode("ascii"), dtype=np.uint8)
-        if len(nucs) != logp.shape[0]:
+        lens = set(len(x) for x in nucleotides)
+        if len(lens) != 1:     # the reference's seq_to_mat check (pyatac/seq.py:39-41)
             raise Exception("Usage Error! Nucleotides must all be of same length! No mixing single nucleotides with dinucleotides, etc")
+        if lens != {1}:
+            raise NotImplementedError("k-mer PWMs (words of %d letters) are not supported by natac_pwm_bias: single-"
+                                      "nucleotide PWMs only (every PWM shipped with the reference is one)" % lens.pop())
+        nucs = np.frombuffer("".join(nucleotides).encode("ascii"), dtype=np.uint8)
         out = np.empty(len(seq) - logp.shape[1] + 1, dtype=np.float64)
         L.check(self._lib.natac_pwm_bias(self._h, _ptr(seq), len(seq), _ptr(logp), _ptr(nucs), logp.shape[0],
                                          logp.shape[1], _ptr(out)))

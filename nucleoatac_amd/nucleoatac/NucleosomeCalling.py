@@ -251,7 +251,7 @@ def nuc_batch(chunks, params, ctx=None, with_flat=False):
         chrs = read_chrom_sizes_from_fasta(params.fasta)
     else:
         chrs = params.chrs
-    pk = pack(chunks, params.bam, params.fasta, chrs, params.pwm, atac=params.atac)
+    pk = pack(chunks, params.bam, params.fasta, chrs, params.pwm, atac=params.atac, window=params.window, upper=params.upper)
     run = BatchRunner(pk, ctx)
     out = []
     try:

@@ -168,7 +168,8 @@ def occ_batch(chunks, params, ctx=None, with_flat=False):
     (with_flat: also the concatenated per-base arrays + offsets, for the native track writer)"""
     ctx = ctx or get_context()
     params.occ_calc_params.install(ctx, step=params.step, flank=params.flank)
-    pk = pack(chunks, params.bam, params.fasta, params.chrs, params.pwm if params.fasta is not None else None)
+    pk = pack(chunks, params.bam, params.fasta, params.chrs, params.pwm if params.fasta is not None else None,
+              window=params.window, upper=params.upper)
     run = BatchRunner(pk, ctx)
     try:
         res = run.occ()

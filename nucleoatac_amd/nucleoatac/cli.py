@@ -65,17 +65,8 @@ def nucleoatac_main(args):
 def _init_distributed():
     """under torchrun (WORLD_SIZE > 1) the chunk list is sharded over the ranks; torch.distributed (RCCL = backend "nccl",
     or NATAC_DIST_BACKEND=gloo) only carries the barrier and the gather of small per-chunk results"""
-    import os
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
-        return None
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        backend = os.environ.get("NATAC_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            import torch
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend=backend)
-    return dist
+    from ..shard import ensure_distributed
+    return ensure_distributed()[0]
 
 
 def main(argv=None):

@@ -10,7 +10,7 @@ from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
 from ..pyatac.VMat import VMat
-from ..shard import balanced_ranges, env_rank_world
+from ..shard import balanced_ranges, barrier, ensure_distributed, env_rank_world
 from ..writer import bgzip_file, tabix_index, write_bedgraph
 from .NucleosomeCalling import NucParameters, nuc_batch
 
@@ -69,6 +69,7 @@ def run_nuc(args):
     outputs = ["nucpos", "nucpos.redundant", "nucleoatac_signal", "nucleoatac_signal.smooth"]
     if args.write_all:
         outputs += ["nucleoatac_background", "nucleoatac_raw"]
+    ensure_distributed()
     rank, world, _ = env_rank_world()
     lo, hi = balanced_ranges([c.length() for c in chunks], np.arange(len(chunks) + 1), world)[rank]
     mine = chunks[lo:hi]
@@ -104,10 +105,7 @@ def run_nuc(args):
         h.close()
     if pool is not None:
         pool.shutdown()
-    if world > 1:
-        import torch.distributed as dist
-        if dist.is_initialized():
-            dist.barrier()
+    barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
     if rank == 0:
         for n in outputs:
             base = args.out + "." + n + (".bed" if n.startswith("nucpos") else ".bedgraph.gz")

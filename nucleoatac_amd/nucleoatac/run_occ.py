@@ -12,7 +12,7 @@ from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
-from ..shard import balanced_ranges, env_rank_world, gather_in_chunk_order, ordered_sum
+from ..shard import balanced_ranges, barrier, ensure_distributed, env_rank_world, gather_in_chunk_order, ordered_sum
 from ..writer import bgzip_file, tabix_index, write_bedgraph
 from .Occupancy import FragmentMixDistribution, OccupancyParameters, occ_batch
 
@@ -53,6 +53,7 @@ def run_occ(args):
     else:
         fragment_dist.getFragmentSizes(args.bam, chunks)
     fragment_dist.modelNFR()
+    ensure_distributed()
     rank, world, _ = env_rank_world()
     if rank == 0:
         fragment_dist.fragmentsizes.save(args.out + ".fragmentsizes.txt")
@@ -91,10 +92,7 @@ def run_occ(args):
             oc.removeData()
     peaks_handle.close()
     dists = gather_in_chunk_order(dists, dst=0)
-    if world > 1:
-        import torch.distributed as dist
-        if dist.is_initialized():
-            dist.barrier()
+    barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
     if rank == 0:
         if world > 1:   # BGZF members / text lines concatenate: rank order == chunk order
             for n in list(names) + ["occpeaks"]:

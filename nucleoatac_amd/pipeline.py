@@ -15,9 +15,20 @@ from .pyatac.fragments import FragmentStore
 MARGIN = 2000 + 126
 
 
-def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN):
+def bias_window(window, upper):
+    """(left, right) extent of the reference's bias track around a chunk: [start - window - upper//2, end + window +
+    upper//2 + 1) with window = 2*flank+1 (occ, Occupancy.py:184, 212-213) or the V-plot width (nuc,
+    NucleosomeCalling.py:214, 246-247); never below the packing default 246 / 247 so that occ and nuc batches of the
+    default parameters share one layout."""
+    ext = int(window) + int(upper) // 2
+    return max(BIAS_LEFT, ext), max(BIAS_RIGHT, ext + 1)
+
+
+def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN, window=None, upper=None):
     """PackedChunks for a list of Chunk objects.  The log-bias slice of every chunk is the PWM score of
-    [start-246, end+247) (InsertionBiasTrack.computeBias, as in nucleoatac/Occupancy.py:212-214) or None."""
+    [start-246, end+247) (InsertionBiasTrack.computeBias, as in nucleoatac/Occupancy.py:212-214) or None; `window` /
+    `upper` (OccupancyParameters.window / NucParameters.window and .upper) widen it for non-default parameters."""
+    bl, br = bias_window(window, upper) if window is not None and upper is not None else (BIAS_LEFT, BIAS_RIGHT)
     st = FragmentStore.open(bam)
     nc = len(chunks)
     chroms = [ch.chrom for ch in chunks]
@@ -26,13 +37,13 @@ def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN)
     offs, lpos, ilen = _pack_fragments(st, chroms, starts, ends, margin, atac)
     boffs = bias = None
     if fasta is not None:
-        bias_of = _bias_spans(chunks, fasta, chrs, pwm)
+        bias_of = _bias_spans(chunks, fasta, chrs, pwm, bias_left=bl, bias_right=br)
         bvals = [bias_of(ch) for ch in chunks]
         boffs = np.zeros(nc + 1, np.int64)
         np.cumsum([len(v) for v in bvals], out=boffs[1:])
         bias = np.concatenate(bvals).astype(np.float64) if bvals else np.zeros(0, np.float64)
     return PackedChunks(chunk_start=starts, chunk_len=(ends - starts).astype(np.int32), frag_off=offs, frag_lpos=lpos,
-                        frag_ilen=ilen, bias_off=boffs, bias_log=bias, chroms=chroms)
+                        frag_ilen=ilen, bias_off=boffs, bias_log=bias, chroms=chroms, bias_left=bl, bias_right=br)
 
 
 def _pack_fragments(st, chroms, starts, ends, margin, atac):
@@ -59,13 +70,13 @@ def _pack_fragments(st, chroms, starts, ends, margin, atac):
     return offs, lpos, ilen
 
 
-def _bias_spans(chunks, fasta, chrs, pwm, max_gap=4096):
+def _bias_spans(chunks, fasta, chrs, pwm, max_gap=4096, bias_left=BIAS_LEFT, bias_right=BIAS_RIGHT):
     """PWM log-bias for [start-246, end+247) of every chunk (InsertionBiasTrack.computeBias, pyatac/bias.py:85-92).
     Windows of nearby chunks are merged into spans that are scored with ONE natac_pwm_bias launch each and then sliced,
     instead of one sequence fetch + launch per chunk as in the reference (Occupancy.py:212-214)."""
     by_chrom = {}
     for ch in chunks:
-        by_chrom.setdefault(ch.chrom, []).append((ch.start - BIAS_LEFT, ch.end + BIAS_RIGHT))
+        by_chrom.setdefault(ch.chrom, []).append((ch.start - bias_left, ch.end + bias_right))
     spans = {}
     for chrom, iv in by_chrom.items():
         iv.sort()
@@ -86,7 +97,7 @@ def _bias_spans(chunks, fasta, chrs, pwm, max_gap=4096):
         spans[chrom] = (np.array([t[0] for t in tracks]), tracks)
 
     def lookup(ch):
-        a, b = ch.start - BIAS_LEFT, ch.end + BIAS_RIGHT
+        a, b = ch.start - bias_left, ch.end + bias_right
         s0, tracks = spans[ch.chrom]
         t = tracks[int(np.searchsorted(s0, a, "right")) - 1]
         if a < t[0] or b > t[1]:

@@ -61,8 +61,10 @@ class Track(Chunk):
             raise Exception("The values being assigned to track do not span the start to end of the track")
         self.vals = vals
 
-    def write_track(self, handle, start=None, end=None, vals=None, write_zero=True):
-        """run-length bedGraph text, NaN runs skipped (pyatac/tracks.py:37-74)"""
+    def write_track(self, handle, start=None, end=None, vals=None, write_zero=True, keep_runs_before_nan=False):
+        """run-length bedGraph text, NaN runs skipped (pyatac/tracks.py:37-74).  Like the reference, whose loop overwrites
+        `prev_value` with a NaN before flushing the open run (tracks.py:56-66), a run of values that is directly followed
+        by a NaN is NOT written; keep_runs_before_nan=True writes those runs too (deviation)."""
         if start is None:
             start = self.start
         if end is None:
@@ -85,6 +87,8 @@ class Track(Chunk):
         for a, b in zip(starts, ends):
             v = vals[a]
             if nan[a] or (v == 0 and not write_zero):
+                continue
+            if b < n and nan[b] and not keep_runs_before_nan:
                 continue
             out.append("%s\t%d\t%d\t%s\n" % (self.chrom, start + a, start + b, _py2_float_str(float(v))))
         handle.write("".join(out))

@@ -33,6 +33,34 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def ensure_distributed():
+    """Under torchrun (WORLD_SIZE > 1) make sure the process group exists before any rank-dependent work: run_occ /
+    run_nuc called through the API (not cli.main) would otherwise skip the barrier and the gather silently and rank 0
+    would merge part files that other ranks are still writing.  Backend: RCCL ("nccl") or NATAC_DIST_BACKEND=gloo.
+    Returns (dist module or None, True if this call created the group)."""
+    rank, world, local = env_rank_world()
+    if world <= 1:
+        return None, False
+    import torch.distributed as dist
+    if dist.is_initialized():
+        if dist.get_world_size() != world:
+            raise RuntimeError("WORLD_SIZE=%d but the torch.distributed group has %d ranks" % (world, dist.get_world_size()))
+        return dist, False
+    backend = os.environ.get("NATAC_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(local)
+    dist.init_process_group(backend=backend)
+    return dist, True
+
+
+def barrier():
+    """all ranks reach this point (no-op on one rank; raises if WORLD_SIZE > 1 without a process group)"""
+    dist, _ = ensure_distributed()
+    if dist is not None:
+        dist.barrier()
+
+
 def my_shard(packed, rank=None, world=None, kappa=4.0):
     """(lo, hi, PackedChunks subset) of this rank"""
     if rank is None or world is None:
@@ -48,7 +76,11 @@ def gather_in_chunk_order(local_items, dst=0):
         import torch.distributed as dist
     except Exception:  # pragma: no cover
         dist = None
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_available() or not dist.is_initialized():
+        if env_rank_world()[1] > 1:
+            raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call shard.ensure_distributed() first")
+        return list(local_items)
+    if dist.get_world_size() == 1:
         return list(local_items)
     world, rank = dist.get_world_size(), dist.get_rank()
     bucket = [None] * world if rank == dst else None

@@ -7,8 +7,9 @@ from . import _lib as L
 
 
 def write_bedgraph(path, chroms, chunk_start, out_off, vals, append=False, compress=0, finish=True, write_zero=True,
-                   n_threads=0):
-    """run-length bedGraph text (Track.write_track semantics, pyatac/tracks.py:37-74) for many chunks at once.
+                   n_threads=0, keep_runs_before_nan=False):
+    """run-length bedGraph text (Track.write_track semantics, pyatac/tracks.py:37-74, including its rule that a run of
+    values directly followed by a NaN is not written) for many chunks at once.
     compress: 0 plain text, 1..9 BGZF at that deflate level.  Returns the number of bytes written."""
     lib = L.load()
     nc = len(chroms)
@@ -21,7 +22,7 @@ def write_bedgraph(path, chroms, chunk_start, out_off, vals, append=False, compr
     nb = C.c_int64(0)
     L.check(lib.natac_write_bedgraph(str(path).encode(), 1 if append else 0, int(compress), 1 if finish else 0, nc, names,
                                      chunk_start.ctypes.data_as(C.c_void_p), out_off.ctypes.data_as(C.c_void_p),
-                                     vals.ctypes.data_as(C.c_void_p), 1 if write_zero else 0, int(n_threads), C.byref(nb)))
+                                     vals.ctypes.data_as(C.c_void_p), (1 if write_zero else 0) | (2 if keep_runs_before_nan else 0), int(n_threads), C.byref(nb)))
     return nb.value
 
 

@@ -403,6 +403,35 @@ def case_sizes():
     save("sizes_hist", **out)
 
 
+# ----------------------------------------------------------------------------------------
+# case J: Track.write_track run-length / NaN rule (pyatac/tracks.py:37-74): the rows the REFERENCE writes
+# ----------------------------------------------------------------------------------------
+def case_write_track():
+    import io
+    from pyatac.tracks import Track
+    rng = np.random.default_rng(9)
+    nan = np.nan
+    cases = [np.array([1, 1, nan, 2, 2, nan]), np.array([1, 1, nan, 2, 2]), np.array([nan, nan, 3, 3, 0, 0, nan, 0, 0]),
+             np.array([0, 0, 1.5, 1.5, nan, nan, 1 / 3.0, 1 / 3.0, 0, 0]), np.array([nan, nan, nan]), np.array([5.0]),
+             np.array([0.0, nan, 0.0]), np.array([2.0, nan, 2.0, 2.0, 4.0])]
+    big = np.round(rng.normal(size=600), 1)
+    big[rng.random(600) < 0.2] = nan
+    big[100:140] = 0.0
+    cases.append(big)
+    out = dict(n_cases=len(cases))
+    for k, v in enumerate(cases):
+        for wz in (1, 0):
+            h = io.StringIO()
+            Track("chrS", 100, 100 + len(v), vals=v.copy()).write_track(h, write_zero=bool(wz))
+            rows = [l.split("\t") for l in h.getvalue().split("\n") if l]
+            arr = np.array([[int(r[1]), int(r[2]), float(r[3])] for r in rows], dtype=np.float64).reshape(-1, 3)
+            out["rows_%d_wz%d" % (k, wz)] = arr
+        out["vals_%d" % k] = v
+    assert len(out["rows_0_wz1"]) == 0 and len(out["rows_1_wz1"]) == 1      # the run before a NaN is never flushed
+    REPORT.append("%-44s %s n=%d" % ("write_track rows (reference's NaN/run rule)", "stored", len(cases)))
+    save("write_track_rows", **out)
+
+
 if __name__ == "__main__":
     vmat, fd, pwm = case_params()
     case_chunks("chunks_basic", 11, [(1000, 1803), (4800, 5500), (8000, 9203)], vmat, fd, pwm)
@@ -412,6 +441,7 @@ if __name__ == "__main__":
     case_toy_occ()
     case_ins_edge()
     case_sizes()
+    case_write_track()
     print("\n".join(REPORT))
     print("oracle pinned against the reference on %d checks" % len(REPORT))
     with open(os.path.join(HERE, "PIN_REPORT.txt"), "w") as f:

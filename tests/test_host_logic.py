@@ -75,14 +75,18 @@ def test_chunk_slop_strand_and_center():
 
 
 def test_track_write_bedgraph_format():
-    """run-length text with python-2 float formatting, NaN runs skipped (pyatac/tracks.py:37-74)"""
+    """run-length text with python-2 float formatting, NaN runs skipped, and the reference's rule that a run directly
+    followed by a NaN is never flushed (pyatac/tracks.py:56-66; rows pinned by tests/golden/write_track_rows.npz)"""
     t = Track("chr1", 10, 20, vals=np.array([0, 0, 1.5, 1.5, np.nan, np.nan, 1 / 3.0, 1 / 3.0, 0, 0]))
     h = io.StringIO()
     t.write_track(h)
-    assert h.getvalue() == "chr1\t10\t12\t0.0\nchr1\t12\t14\t1.5\nchr1\t16\t18\t0.333333333333\nchr1\t18\t20\t0.0\n"
+    assert h.getvalue() == "chr1\t10\t12\t0.0\nchr1\t16\t18\t0.333333333333\nchr1\t18\t20\t0.0\n"
     h = io.StringIO()
     t.write_track(h, write_zero=False)
-    assert h.getvalue() == "chr1\t12\t14\t1.5\nchr1\t16\t18\t0.333333333333\n"
+    assert h.getvalue() == "chr1\t16\t18\t0.333333333333\n"
+    h = io.StringIO()
+    t.write_track(h, keep_runs_before_nan=True)
+    assert h.getvalue() == "chr1\t10\t12\t0.0\nchr1\t12\t14\t1.5\nchr1\t16\t18\t0.333333333333\nchr1\t18\t20\t0.0\n"
     with pytest.raises(Exception):
         t.write_track(io.StringIO(), vals=np.zeros(3))
     with pytest.raises(Exception):
