@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--chunk-len", type=int, default=2120)
     ap.add_argument("--frags-per-chunk", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU baseline's optimised-mode sample (0 = 2000)")
+    ap.add_argument("--cpu-literal-chunks", type=int, default=0, help="chunks in the literal-mode sample (0 = auto)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--share-device", action="store_true",
@@ -54,17 +55,38 @@ def parse():
 
 
 def _cpu_chunk(args):
-    """one chunk through the CPU oracle in the reference's execution shape (dense per-chunk numpy/scipy)."""
+    """one chunk through the CPU oracle in the reference's execution shape: what _occHelper + _nucHelper do per chunk
+    (nucleoatac/run_occ.py:23-39, run_nuc.py:22-39): OccChunk.process (grid MLE, smoothing, coverage, callPeaks) and
+    NucChunk.process up to findAllNucs (tracks, call_peaks, getLR for nuc_cov > min_reads, calculateCov / z for
+    lr > min_lr, NucleosomeCalling.py:294-315) + the insertion track.  literal: dense scipy.signal.correlate and the O(N^2)
+    calculateCov pair sum like the reference; otherwise per-row correlations and the closed-form variance."""
     from scipy import signal
     from oracle import natac_oracle as O
-    (l, n, L, bias, bl, vmat, vlo, vup, sizes, nucp, nfrp) = args
+    (l, n, L, bias, bl, vmat, vlo, vup, sizes, nucp, nfrp, literal) = args
     l = l.astype(np.int64)
     n = n.astype(np.int64)
-    dense = lambda sub, vm: signal.correlate(sub, vm, mode="valid")[0]   # what the reference calls (NucleosomeCalling.py:34)
-    nt = O.nuc_chunk_tracks(l, n, 0, L, bias, -bl, vmat, vlo, vup, sizes, dense_correlate=dense)
+    kw = {}
+    if literal:
+        kw["dense_correlate"] = lambda sub, vm: signal.correlate(sub, vm, mode="valid")[0]   # NucleosomeCalling.py:34
+    nt = O.nuc_chunk_tracks(l, n, 0, L, bias, -bl, vmat, vlo, vup, sizes, **kw)
+    comb = nt["norm"] + nt["smoothed"]
+    cands = O.call_peaks(comb.copy(), min_signal=0, sep=25, boundary=60, order=12)
+    w = vmat.shape[1] // 2
+    nz = 0
+    acc = 0.0
+    for p in cands:
+        p = int(p)
+        if nt["nuc_cov"][p] > 1:                                           # min_reads = 1 (NucleosomeCalling.py:210, 304)
+            lr = O.get_lr(nt["mat"], nt["mat_start"], nt["bmat"], nt["b0"], nt["b_start"], vmat, vlo, vup, p)
+            if lr > 0:                                                     # min_lr = 0 (:306)
+                pr = O.signal_distribution_probs(nt["bmat"], nt["b_start"], vlo, vup, w, p)
+                z, _ = O.z_score(nt["norm"][p], nt["nuc_cov"][p], pr, vmat, literal=literal)
+                acc += z
+                nz += 1
     oc = O.occ_chunk_tracks(l, n, 0, L, bias, -bl, nucp, nfrp)
+    O.call_peaks(oc["smoothed_vals"], sep=120, min_signal=0.1)              # OccChunk.callPeaks (Occupancy.py:225-231)
     O.get_insertions(l, n, 0, L)
-    return float(np.nansum(nt["norm"]) + np.nansum(oc["smoothed_vals"]))
+    return (float(np.nansum(nt["norm"]) + np.nansum(oc["smoothed_vals"]) + acc), len(cands), nz)
 
 
 def _cpu_worker_init():
@@ -76,29 +98,50 @@ def _cpu_worker_init():
         pass
 
 
-def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks):
-    """reference execution shape: multiprocessing.Pool(cores-1), chunk per task (run_occ.py:101-123)."""
-    import multiprocessing as mp
-    cores = _effective_cores()
-    workers = max(1, cores - 1)
-    if n_chunks <= 0:
-        n_chunks = min(1024, max(256, 2 * workers))  # ~0.45 core-s per chunk: >= 100 core-s, several seconds of wall time
-    n_chunks = min(n_chunks, pk.n_chunks)
+def _cpu_mode(pool, workers, cores, pk, par, sizes, nucp, nfrp, n_chunks, literal):
+    """time n_chunks chunks in the reference's shape: `chunks.split(items = cores*5)` rounds, one pool.map per round
+    (run_occ.py:101-123, run_nuc.py:164-188)"""
     tasks = []
     for k in range(n_chunks):
         l, n = pk.chunk_frags(k)
         tasks.append((l, n, int(pk.chunk_len[k]), pk.chunk_bias(k), pk.bias_left, par["vmat"], int(par["vlower"]),
-                      int(par["vupper"]), sizes, nucp, nfrp))
+                      int(par["vupper"]), sizes, nucp, nfrp, literal))
     bp = int(pk.chunk_len[:n_chunks].sum())
+    per_round = cores * 5
+    ncand = nz = 0
+    t0 = time.time()
+    for r0 in range(0, n_chunks, per_round):
+        for _, c, z in pool.map(_cpu_chunk, tasks[r0:r0 + per_round]):
+            ncand += c
+            nz += z
+    dt = time.time() - t0
+    return dict(value=round(bp / dt / 1e6, 5), unit="Mbp/s", chunks=n_chunks, bp=bp, seconds=round(dt, 1),
+                candidates=ncand, z_scores=nz, rounds_of=per_round)
+
+
+def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks, n_literal):
+    """the CPU restatement run in the reference's execution shape -- multiprocessing.Pool(cores-1),
+    chunks.split(cores*5) rounds -- on the host cores of this box, on a bounded sample of the same chunks.
+    "literal" = dense correlate + O(N^2) calculateCov as the reference executes them (the reported `value`);
+    "optimised" = per-row correlations + closed-form variance."""
+    import multiprocessing as mp
+    cores = _effective_cores()
+    workers = max(1, cores - 1)
+    n_chunks = min(n_chunks if n_chunks > 0 else 2000, pk.n_chunks)
+    n_literal = min(n_literal if n_literal > 0 else max(5 * cores, 160), pk.n_chunks)
     ctx = mp.get_context("fork")
     with ctx.Pool(workers, initializer=_cpu_worker_init) as pool:
-        pool.map(_cpu_chunk, tasks[:workers])      # warm the workers (imports)
-        t0 = time.time()
-        pool.map(_cpu_chunk, tasks)
-        dt = time.time() - t0
-    return dict(value=bp / dt / 1e6, unit="Mbp/s", cores=workers, kind="port",
-                sample="%d of the workload's chunks (%d bp) through oracle/natac_oracle.py, occ+nuc+ins, "
-                       "Pool(%d) one chunk per task, %.1f s" % (n_chunks, bp, workers, dt))
+        pool.map(_cpu_chunk, [(pk.chunk_frags(0)[0], pk.chunk_frags(0)[1], int(pk.chunk_len[0]), pk.chunk_bias(0), pk.bias_left,
+                               par["vmat"], int(par["vlower"]), int(par["vupper"]), sizes, nucp, nfrp, False)] * workers)  # warm-up (imports)
+        opt = _cpu_mode(pool, workers, cores, pk, par, sizes, nucp, nfrp, n_chunks, False)
+        lit = _cpu_mode(pool, workers, cores, pk, par, sizes, nucp, nfrp, n_literal, True)
+    return dict(value=lit["value"], unit="Mbp/s", cores=workers, kind="port",
+                sample="literal mode (scipy dense correlate + O(N^2) calculateCov, as the reference runs): %d of the workload's "
+                       "chunks, %d bp, %.1f s; optimised mode (per-row correlate, closed-form variance): %d chunks, %d bp, %.1f s; "
+                       "oracle/natac_oracle.py: occ (MLE + smoothing + peaks) + nuc (tracks + call_peaks + LR + z) + ins per chunk, "
+                       "Pool(%d) in rounds of cores*5 = %d chunks" % (lit["chunks"], lit["bp"], lit["seconds"], opt["chunks"],
+                                                                      opt["bp"], opt["seconds"], workers, cores * 5),
+                literal=lit, optimised=opt, host_cores_visible=len(os.sched_getaffinity(0)), cores_by_cgroup_quota=cores)
 
 
 def _effective_cores():
@@ -171,7 +214,7 @@ def main():
     # CPU baseline first (rank 0, N=1 only): it forks worker processes, so run it before the HIP context exists
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(pk, par, sizes, nucp, nfrp, a.cpu_chunks)
+        cpu = cpu_baseline(pk, par, sizes, nucp, nfrp, a.cpu_chunks, a.cpu_literal_chunks)
 
     ctx = Context(local_rank)
     ctx.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))

@@ -330,3 +330,83 @@ b.free(); c.close()
     for t in range(3):
         np.testing.assert_allclose(out[0][t], out[1][t], rtol=1e-10, atol=1e-12)
     assert not np.array_equal(out[0][0], out[1][0])          # really two different kernels
+
+
+def _spawn_pool():
+    """oracle workers in spawned processes (this process already holds a HIP context: no fork)"""
+    import multiprocessing as mp
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except (OSError, ValueError):
+        pass
+    return mp.get_context("spawn").Pool(max(1, min(n, 32) - 1))
+
+
+def test_full_size_occupancy_grid_exact_on_2000_chunks(full):
+    """the MLE decision at scale: the raw occupancy grid (alpha indices: vals / lower_bound / upper_bound, Occupancy.py:104-146)
+    of 2,000 random chunks of the configs[2] batch (848,000 grid points) against the oracle's literal log-likelihood
+    arithmetic, EXACTLY.  The kernel decides in the product domain (frexp-renormalised likelihood products), so this
+    measures how often a near-tie in argmax / the likelihood-ratio test flips an index: it must be zero."""
+    import scale_workers as W
+    pk, b = full
+    nucp, nfrp = synth_occ_distributions(251)
+    rng = np.random.default_rng(2024)
+    ks = np.sort(rng.choice(pk.n_chunks, size=2000, replace=False))
+    tasks = []
+    for k in ks:
+        l, n = pk.chunk_frags(int(k))
+        tasks.append((l, n, int(pk.chunk_len[k]), pk.chunk_bias(int(k)), pk.bias_left, nucp, nfrp))
+    with _spawn_pool() as pool:
+        ref = pool.map(W.occ_grid_worker, tasks, chunksize=8)
+    grids = [b.grid(g) for g in (L.G_OCC, L.G_LOWER, L.G_UPPER)]
+    nk = len(range(2, 2120, 5))
+    flips = [0, 0, 0]
+    npts = 0
+    for k, r in zip(ks, ref):
+        a = int(k) * nk
+        for w in range(3):
+            got, want = grids[w][a:a + nk], r[w]
+            assert got.shape == want.shape
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (int(k), w)
+            m = ~np.isnan(want)
+            flips[w] += int(np.sum(got[m] != want[m]))
+        npts += nk
+    print("occupancy grid at scale: %d grid points of %d chunks; flipped alpha indices occ/lower/upper = %s" % (npts, len(ks), flips))
+    assert flips == [0, 0, 0]
+
+
+def test_full_size_candidates_match_oracle_on_200_chunks(full):
+    """candidate statistics at scale: every candidate the device finds in 200 random chunks of the configs[2] batch gets the
+    oracle's lr / var / z (rtol 1e-5), and the oracle's call_peaks candidates above the FFT noise floor are all found"""
+    import scale_workers as W
+    pk, b = full
+    par = golden("params_example")
+    sizes = synth_size_distribution(251)
+    cc, cp, lr, var, z = b.run_peaks(min_signal=0, sep=25, boundary=60, order=12)
+    assert len(cc) > 1500000
+    rng = np.random.default_rng(77)
+    ks = np.sort(rng.choice(pk.n_chunks, size=200, replace=False))
+    first = np.searchsorted(cc, ks, "left")
+    last = np.searchsorted(cc, ks, "right")
+    tasks = []
+    for k, a, e in zip(ks, first, last):
+        l, n = pk.chunk_frags(int(k))
+        tasks.append((l, n, int(pk.chunk_len[k]), pk.chunk_bias(int(k)), pk.bias_left, par["vmat"], 105, 251, sizes, cp[a:e].copy()))
+    with _spawn_pool() as pool:
+        res = pool.map(W.cand_worker, tasks, chunksize=2)
+    ncand = nz = 0
+    for (ref_c, ref_sig, st), a, e in zip(res, first, last):
+        mine = set(int(x) for x in cp[a:e])
+        assert set(int(x) for x in ref_c[ref_sig > 1e-9]) <= mine
+        assert_track(lr[a:e], st[:, 0], "lr", rtol=1e-5, atol=1e-7)
+        ok = st[:, 3] > 0
+        assert_track(var[a:e][ok], st[ok, 1], "var", rtol=1e-5, atol=1e-12)
+        assert_track(z[a:e][ok], st[ok, 2], "z", rtol=1e-5, atol=1e-7)
+        ncand += e - a
+        nz += int(ok.sum())
+    print("candidates at scale: %d candidates of 200 chunks compared (lr), %d with reads (var, z)" % (ncand, nz))
+    assert ncand > 3000
