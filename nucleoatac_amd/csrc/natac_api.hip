@@ -3,6 +3,7 @@
 #include "../../include/natac.h"
 #include "natac_kernels.hpp"
 #include "natac_fft_bg.hpp"
+#include "natac_occ_fast.hpp"
 #include "natac_cores.hpp"
 #include "natac_writer.hpp"
 #include "natac_tabix.hpp"
@@ -60,6 +61,10 @@ struct natac_ctx {
     double cutoff = 0;
     bool have_occ = false;
     int occ_zero_flags = 0;          // zero pattern of nuc_probs / nfr_probs (bits as in the MLE kernel)
+    // fast occupancy path (natac_occ_fast.hpp): model tables + eligibility
+    double *d_occ_q4 = nullptr, *d_occ_rho = nullptr;
+    int occ_nm = 0;
+    bool occ_fast_ok = false, occ_force_general = false;
     double occ_b_floor = 0;          // see OccModelDev::b_floor
     // gaussian windows (cached by (M, sd))
     double *d_win_nuc = nullptr, *d_win_occ = nullptr;
@@ -93,6 +98,13 @@ struct natac_batch {
     int ranges256_w = -1;
     int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;   // bgG: lanes' output count of the direct kernel, -1 = FFT tiles
     int grid_step = 0, grid_half = 0;
+    // fast occupancy path: per-block sums of g_n / g_f, their tile table and the list of tiles left to natac_occ_mle
+    long long *d_blk_off = nullptr;
+    long long total_blocks = 0;
+    double *d_gsum = nullptr;
+    int2 *d_tiles_gs = nullptr;
+    int n_tiles_gs = 0, gs_Q = -1;
+    int *d_defer = nullptr;          // [0] = count, [1 ..] = tile indices
     double *d_track[NATAC_T_COUNT] = {nullptr};
     double *d_grid[3] = {nullptr, nullptr, nullptr};
     bool nuc_done = false, occ_done = false, ins_done = false;
@@ -251,6 +263,8 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
     {   // NATAC_BG_DIRECT=1 selects the direct-summation background kernel (validation / A-B timing of the FFT path)
         const char *e = getenv("NATAC_BG_DIRECT");
         c->bg_direct = e && e[0] == '1';
+        e = getenv("NATAC_OCC_GENERAL");   // NATAC_OCC_GENERAL=1: every tile through natac_occ_mle (validation / A-B timing)
+        c->occ_force_general = e && e[0] == '1';
     }
     *out = c;
     return NATAC_OK;
@@ -265,6 +279,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
     dev_free(c->d_win_nuc); dev_free(c->d_win_occ);
     dev_free(c->d_fft_tw); dev_free(c->d_fft_k);
+    dev_free(c->d_occ_q4); dev_free(c->d_occ_rho);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -361,6 +376,38 @@ int natac_set_occ_model(natac_ctx *c, const double *nuc_probs, const double *nfr
     }
     c->occ_upper = upper; c->n_alpha = n_alpha; c->cutoff = cutoff; c->step = step;
     c->halfstep = (step - 1) / 2; c->flank = flank;
+    {   // fast path (natac_occ_fast.hpp): 101 increasing alphas in [0, 1], strictly positive finite nfr probabilities, window =
+        // whole number of steps + 1, and a probability range that keeps four likelihood factors inside the fp64 range
+        dev_free(c->d_occ_q4); dev_free(c->d_occ_rho);
+        c->d_occ_q4 = c->d_occ_rho = nullptr;
+        bool ok = n_alpha == OD_NA && step == 5 && (2 * flank) % step == 0 && flank >= step;
+        for (int a = 0; ok && a < n_alpha; ++a) ok = alphas[a] >= 0.0 && alphas[a] <= 1.0 && (a == 0 || alphas[a] > alphas[a - 1]);
+        double rmin = std::numeric_limits<double>::infinity(), rmax = 0.0, pmin = 1.0;
+        bool anynuc = false;
+        std::vector<double> rho((size_t)upper, 0.0);
+        for (int j = 0; ok && j < upper; ++j) {
+            const double a = nuc_probs[j], f = nfr_probs[j];
+            ok = f > 0.0 && std::isfinite(f) && a >= 0.0 && std::isfinite(a);
+            if (!ok) break;
+            rho[j] = a / f;
+            ok = std::isfinite(rho[j]);
+            if (a > 0.0) { anynuc = true; rmin = std::min(rmin, rho[j]); rmax = std::max(rmax, rho[j]); pmin = std::min(pmin, a); }
+            pmin = std::min(pmin, f);
+        }
+        ok = ok && anynuc && rmax <= rmin * std::ldexp(1.0, 200) && pmin >= std::ldexp(1.0, -200);
+        c->occ_fast_ok = ok;
+        if (ok) {
+            c->occ_nm = (upper + 1) / 2;
+            std::vector<double> q4((size_t)4 * c->occ_nm, 0.0);
+            for (int j = 0; j < upper; ++j) {
+                q4[(size_t)4 * (j >> 1) + (j & 1)] = nuc_probs[j];
+                q4[(size_t)4 * (j >> 1) + 2 + (j & 1)] = nfr_probs[j];
+            }
+            if ((rc = dev_upload(c, &c->d_occ_q4, q4.data(), q4.size()))) return rc;
+            if ((rc = dev_upload(c, &c->d_occ_rho, rho.data(), rho.size()))) return rc;
+            HIPCHK(sync_all(c));
+        }
+    }
     c->have_occ = true;
     return NATAC_OK;
 }
@@ -545,6 +592,7 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
     dev_free(b->d_bnum); dev_free(b->d_bcov);
+    dev_free(b->d_blk_off); dev_free(b->d_gsum); dev_free(b->d_tiles_gs); dev_free(b->d_defer);
     for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
     delete b;
 }
@@ -689,6 +737,30 @@ int natac_run_occ(natac_batch *b) {
     const ChunkTable ct = make_table(b);
     const OccModelDev om = make_occ(c);
     natac_ctx::Ev ev;
+    const bool fast = c->occ_fast_ok && !c->occ_force_general;
+    if (fast) {   // per-block sum buffers + tile table of natac_occ_gsum (geometry: step / flank of the model)
+        const int Q = 2 * c->flank / c->step;
+        if (b->gs_Q != Q || !b->d_gsum) {
+            HIPCHK(sync_all(c));
+            std::vector<long long> bo((size_t)b->nc + 1);
+            std::vector<int2> tiles;
+            for (int i = 0; i <= b->nc; ++i) bo[i] = b->h_grid_off[i] + (long long)Q * i;
+            for (int i = 0; i < b->nc; ++i) {
+                const int nblk = (int)(b->h_grid_off[i + 1] - b->h_grid_off[i]) + Q;
+                for (int x = 0; x < nblk; x += GS_BLOCKS) tiles.push_back(make_int2(i, x));
+            }
+            b->total_blocks = bo[b->nc];
+            dev_free(b->d_blk_off); dev_free(b->d_gsum); dev_free(b->d_tiles_gs); dev_free(b->d_defer);
+            b->d_blk_off = nullptr; b->d_gsum = nullptr; b->d_tiles_gs = nullptr; b->d_defer = nullptr;
+            if ((rc = dev_upload(c, &b->d_blk_off, bo.data(), bo.size()))) return rc;
+            if ((rc = dev_upload(c, &b->d_tiles_gs, tiles.data(), tiles.size()))) return rc;
+            HIPCHK(sync_all(c));
+            b->n_tiles_gs = (int)tiles.size();
+            if ((rc = dev_alloc(&b->d_gsum, (size_t)4 * b->total_blocks))) return rc;
+            if ((rc = dev_alloc(&b->d_defer, (size_t)b->n_tiles_occ + 1))) return rc;
+            b->gs_Q = Q;
+        }
+    }
     prof_begin(c, NATAC_K_OCC_MLE, ev, c->stream2);
     {
         const int U = c->occ_upper, UP = (U + 1) & ~1;
@@ -701,15 +773,38 @@ int natac_run_occ(natac_batch *b) {
             return fail(NATAC_E_ARG, "occupancy window / step too large for the device tile (step=%d flank=%d upper=%d)", c->step, c->flank, U);
         hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
                            b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
+        const int *d_list = nullptr, *d_count = nullptr;
+        unsigned grid_general = (unsigned)b->n_tiles_occ;
+        if (fast) {
+            OccFastDev of;
+            of.q4 = c->d_occ_q4; of.rho = c->d_occ_rho; of.alphas = c->d_alphas; of.nm = c->occ_nm; of.upper = U; of.step = c->step;
+            of.halfstep = c->halfstep; of.flank = c->flank; of.Q = b->gs_Q; of.flags = c->occ_zero_flags & 1;
+            of.ci_factor = om.ci_factor; of.e_lo = std::ldexp(1.0, -150); of.e_hi = std::ldexp(1.0, 150);
+            const int R = of.nm - 1;
+            const size_t lds_gs = ((size_t)((GS_BLOCKS * 5 + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
+            const int NGP = (64 + of.Q + 1) & ~1;
+            const size_t lds_od = (size_t)4 * ((OD_FM + 4) + 4 * NGP + OD_FM / 2) * sizeof(double);
+            if (lds_gs > 64 * 1024 || lds_od > 64 * 1024)
+                return fail(NATAC_E_ARG, "occupancy window too large for the device tile (flank=%d upper=%d)", c->flank, U);
+            HIPCHK(hipMemsetAsync(b->d_defer, 0, sizeof(int), c->stream2));
+            hipLaunchKernelGGL((natac_occ_gsum<5>), dim3(b->n_tiles_gs), dim3(256), lds_gs, c->stream2, ct, b->d_tiles_gs, of, b->d_blk_off,
+                               b->total_blocks, b->d_gsum);
+            hipLaunchKernelGGL((natac_occ_decide<5>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream2, ct, b->d_tiles_occ,
+                               b->n_tiles_occ, b->d_ranges_occ, of, b->d_blk_off, b->total_blocks, b->d_gsum, b->d_grid[0], b->d_grid[1],
+                               b->d_grid[2], b->d_defer, b->d_defer + 1);
+            d_count = b->d_defer;
+            d_list = b->d_defer + 1;
+            grid_general = (unsigned)std::min(b->n_tiles_occ, 2048);   // walks the deferred list (normally empty)
+        }
         if (c->step == 5 && c->flank == 60 && c->n_alpha <= 16 * OCC_RA)
-            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0, 1>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
-                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
+            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0, 1>), dim3(grid_general), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
+                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status, d_list, d_count);
         else if (c->step == 5 && c->flank == 60)
-            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
-                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
+            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0>), dim3(grid_general), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
+                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status, d_list, d_count);
         else
-            hipLaunchKernelGGL((natac_occ_mle<0, 0, 0>), dim3(b->n_tiles_occ), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
-                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status);
+            hipLaunchKernelGGL((natac_occ_mle<0, 0, 0>), dim3(grid_general), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
+                               b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status, d_list, d_count);
     }
     prof_end(c, ev);
     prof_begin(c, NATAC_K_OCC_SMOOTH, ev, c->stream2);

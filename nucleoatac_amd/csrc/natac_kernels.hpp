@@ -659,11 +659,18 @@ __device__ __forceinline__ void occ_phase2_rows(const ChunkTable &ct, const OccM
 // pass to pass in registers (80 new products per insert size and pass instead of 196).
 template <int STEP, int FLANK, int ABL = 0, int ROWS = 0>   // ABL != 0: ablation variants for tools/microbench_occ.hip only;
                                                           // ROWS: row-parallel phase 2 (n_alpha <= 16 * OCC_RA)
+// tile_list != nullptr: the workgroups walk the first *tile_count entries of tile_list (tiles deferred by the fast path,
+// natac_occ_fast.hpp) instead of taking tile blockIdx.x.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) natac_occ_mle(ChunkTable ct, const int2 *__restrict__ tiles,
                                                        const int2 *__restrict__ ranges, OccModelDev om,
                                                        double *__restrict__ g_occ, double *__restrict__ g_lo,
-                                                       double *__restrict__ g_hi, int *__restrict__ status) {
+                                                       double *__restrict__ g_hi, int *__restrict__ status,
+                                                       const int *__restrict__ tile_list, const int *__restrict__ tile_count) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n_listed = tile_list ? *tile_count : 0;
+  for (int tile_it = blockIdx.x; tile_list ? tile_it < n_listed : tile_it == (int)blockIdx.x; tile_it += gridDim.x) {
+    const int tile_id = tile_list ? tile_list[tile_it] : tile_it;
+    __syncthreads();                                   // LDS of the previous tile is free
     const int U = om.upper, UP = (U + 1) & ~1;
     const int step = STEP ? STEP : om.step;
     const int fl = STEP ? FLANK : om.flank, WIN = 2 * fl + 1;
@@ -679,7 +686,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int n_ones = ((OCC_T - 1) * step + WIN + step + 3) & ~1;
     int *cen_s = (int *)(ones + n_ones);               // [OCC_FMAX]
     int *iln_s = cen_s + OCC_FMAX;                     // [OCC_FMAX]
-    const int2 t = tiles[blockIdx.x];
+    const int2 t = tiles[tile_id];
     const int chunk = t.x, k0 = t.y;
     const int L = ct.chunk_len[chunk];
     const int nk = (L - om.halfstep + step - 1) / step;         // len(range(halfstep, L, step))
@@ -687,7 +694,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int *cen = ct.centre + ct.frag_off[chunk];
     const int *iln = ct.ilen + ct.frag_off[chunk];
     // ---- phase 0: stage the tile's fragments, the model and exp(bias) in LDS
-    const int2 tr = ranges[blockIdx.x];
+    const int2 tr = ranges[tile_id];
     const int t0 = tr.x, nt = tr.y - tr.x;
     const bool staged = nt <= OCC_FMAX;
     if (staged)
@@ -941,6 +948,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
 
     }
+    if (!tile_list) break;
+  }
 }
 
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }

@@ -14,7 +14,7 @@ void run(const ChunkTable &ct, const OccModelDev &om, int2 *d_t, int2 *d_r, int 
     float best = 1e30f;
     for (int it = 0; it < 3; ++it) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((natac_occ_mle<5, 60, ABL, ROWS>), dim3(ntiles), dim3(256), lds, 0, ct, d_t, d_r, om, g0, g1, g2, st);
+        hipLaunchKernelGGL((natac_occ_mle<5, 60, ABL, ROWS>), dim3(ntiles), dim3(256), lds, 0, ct, d_t, d_r, om, g0, g1, g2, st, nullptr, nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (it > 0 && ms < best) best = ms;
