@@ -1,5 +1,5 @@
-"""`nucleoatac occ | nuc` command line with the reference's flag names and defaults (nucleoatac/cli.py:92-264).
-Only the sub-commands on the accelerated path exist here."""
+"""`nucleoatac run | occ | vprocess | nuc | merge | nfr` command line with the reference's flag names and defaults
+(nucleoatac/cli.py:7-330)."""
 import argparse
 import sys
 
@@ -41,12 +41,72 @@ def add_nuc_parser(sub):
     p.add_argument("--sd", type=int, default=10)
 
 
+def add_vprocess_parser(sub):
+    p = sub.add_parser("vprocess", help="Make processed vplot to use for nucleosome calling")
+    p.add_argument("--out", required=True)
+    p.add_argument("--sizes", help="Insert distribution file")
+    p.add_argument("--vplot", default=None, help="VMat file. Default is the Vplot from S. cer. shipped with the package")
+    p.add_argument("--lower", type=int, default=105)
+    p.add_argument("--upper", type=int, default=251)
+    p.add_argument("--flank", type=int, default=60)
+    p.add_argument("--smooth", type=float, default=0.75)
+    p.add_argument("--plot_extra", action="store_true", default=False)
+
+
+def add_merge_parser(sub):
+    p = sub.add_parser("merge", help="Merge occ and nuc calls")
+    p.add_argument("--occpeaks", required=True, help="Output from occ utility")
+    p.add_argument("--nucpos", required=True, help="Output from nuc utility")
+    p.add_argument("--out", help="output file basename")
+    p.add_argument("--sep", default=120, help="minimum separation between call")
+    p.add_argument("--min_occ", default=0.1, help="minimum lower bound occupancy of nucleosomes to be considered")
+
+
+def add_nfr_parser(sub):
+    p = sub.add_parser("nfr", help="Call NFRs")
+    p.add_argument("--bed", required=True)
+    p.add_argument("--occ_track", required=True, help="bgzip compressed, tabix-indexed bedgraph file with occupancy track")
+    p.add_argument("--calls", required=True, help="bed file with nucleosome center calls")
+    p.add_argument("--ins_track", help="insertion track; generated from --bam if not included")
+    p.add_argument("--bam")
+    p.add_argument("--fasta")
+    p.add_argument("--pwm", default="Human")
+    p.add_argument("--out")
+    p.add_argument("--cores", type=int, default=1)
+    p.add_argument("--max_occ", type=float, default=0.1)
+    p.add_argument("--max_occ_upper", type=float, default=0.25)
+
+
+def add_run_parser(sub):
+    p = sub.add_parser("run", help="Main nucleoatac utility -- occupancy determination & calling nuc positions")
+    p.add_argument("--bed", required=True)
+    p.add_argument("--bam", required=True)
+    p.add_argument("--out", required=True)
+    p.add_argument("--fasta", required=True)
+    p.add_argument("--pwm", default="Human")
+    p.add_argument("--cores", type=int, default=1)
+    p.add_argument("--write_all", action="store_true", default=False)
+
+
 def nucleoatac_parser():
-    parser = argparse.ArgumentParser(prog="nucleoatac", description="NucleoATAC occ + nuc on AMD MI355X")
+    parser = argparse.ArgumentParser(prog="nucleoatac", description="NucleoATAC on AMD MI355X")
     sub = parser.add_subparsers(dest="call")
+    add_run_parser(sub)
     add_occ_parser(sub)
+    add_vprocess_parser(sub)
     add_nuc_parser(sub)
+    add_merge_parser(sub)
+    add_nfr_parser(sub)
     return parser
+
+
+def _rank0_only(fn, args):
+    """vprocess / merge / nfr are single-process steps: under torchrun rank 0 runs them, the others wait"""
+    from ..shard import barrier, env_rank_world
+    rank = env_rank_world()[0]
+    if rank == 0:
+        fn(args)
+    barrier()
 
 
 def nucleoatac_main(args):
@@ -54,12 +114,59 @@ def nucleoatac_main(args):
         from .run_occ import run_occ
         print("---------Computing Occupancy and Nucleosomal Insert Distribution------")
         run_occ(args)
+    elif args.call == "vprocess":
+        from .run_vprocess import run_vprocess
+        print("---------Processing VPlot---------------------------------------------")
+        _rank0_only(run_vprocess, args)
     elif args.call == "nuc":
         from .run_nuc import run_nuc
         print("---------Obtaining nucleosome signal and calling positions-------------")
         run_nuc(args)
+    elif args.call == "merge":
+        from .merge import run_merge
+        print("---------Merging------------------------------------------------------")
+        _rank0_only(run_merge, args)
+    elif args.call == "nfr":
+        from .run_nfr import run_nfr
+        print("---------Calling NFR positions----------------------------------------")
+        _rank0_only(run_nfr, args)
+    elif args.call == "run":
+        # the five steps chained through their output files exactly as the reference does (cli.py:34-64)
+        parser = nucleoatac_parser()
+        occ_args = parser.parse_args(["occ", "--bed", args.bed, "--bam", args.bam, "--fasta", args.fasta, "--pwm", args.pwm,
+                                      "--out", args.out, "--cores", str(args.cores)])
+        vprocess_args = parser.parse_args(["vprocess", "--sizes", args.out + ".nuc_dist.txt", "--out", args.out])
+        nuc_list = ["nuc", "--bed", args.bed, "--bam", args.bam, "--out", args.out, "--cores", str(args.cores), "--occ_track",
+                    args.out + ".occ.bedgraph.gz", "--vmat", args.out + ".VMat", "--fasta", args.fasta, "--pwm", args.pwm,
+                    "--sizes", args.out + ".fragmentsizes.txt"]
+        if args.write_all:
+            nuc_list.append("--write_all")
+        nuc_args = parser.parse_args(nuc_list)
+        merge_args = parser.parse_args(["merge", "--occpeaks", args.out + ".occpeaks.bed.gz", "--nucpos", args.out + ".nucpos.bed.gz",
+                                        "--out", args.out])
+        nfr_args = parser.parse_args(["nfr", "--bed", args.bed, "--occ_track", args.out + ".occ.bedgraph.gz", "--calls",
+                                      args.out + ".nucmap_combined.bed.gz", "--out", args.out, "--fasta", args.fasta, "--pwm",
+                                      args.pwm, "--bam", args.bam])
+        from .merge import run_merge
+        from .run_nfr import run_nfr
+        from .run_nuc import run_nuc
+        from .run_occ import run_occ
+        from .run_vprocess import run_vprocess
+        from ..shard import barrier
+        print("---------Step1: Computing Occupancy and Nucleosomal Insert Distribution---------")
+        run_occ(occ_args)
+        barrier()
+        print("---------Step2: Processing Vplot------------------------------------------------")
+        _rank0_only(run_vprocess, vprocess_args)
+        print("---------Step3: Obtaining nucleosome signal and calling positions---------------")
+        run_nuc(nuc_args)
+        barrier()
+        print("---------Step4: Making combined nucleosome position map ------------------------")
+        _rank0_only(run_merge, merge_args)
+        print("---------Step5: Calling NFR positions-------------------------------------------")
+        _rank0_only(run_nfr, nfr_args)
     else:
-        raise SystemExit("usage: nucleoatac {occ,nuc} ...")
+        raise SystemExit("usage: nucleoatac {run,occ,vprocess,nuc,merge,nfr} ...")
 
 
 def _init_distributed():

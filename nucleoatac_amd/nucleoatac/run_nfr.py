@@ -1,0 +1,87 @@
+"""`nucleoatac nfr` (reference: nucleoatac/run_nfr.py:71-130): NFR positions between the combined nucleosome calls, plus the
+insertion track of the regions when none is given.  The reference's pool.map over chunks becomes one GPU batch per
+BATCH_CHUNKS chunks for the insertion counts (natac_run_ins) and one native multi-threaded writer call per batch."""
+import os
+
+import numpy as np
+
+from ..pyatac.bias import PWM
+from ..pyatac.chunk import ChunkList
+from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
+from ..writer import bgzip_file, tabix_index, write_bedgraph
+from .NFRCalling import NFRChunk, NFRParameters
+
+BATCH_CHUNKS = 4096
+COMPRESS_LEVEL = 4
+
+
+def _nfrHelper(arg):
+    """(nfrs, ins) or nfrs for one chunk -- the reference's helper (run_nfr.py:21-39)"""
+    chunk, params = arg
+    nfr = NFRChunk(chunk)
+    nfr.process(params)
+    out = (nfr.nfrs, nfr.ins) if params.ins_track is None else nfr.nfrs
+    return out
+
+
+def _batch_insertions(chunks, bam):
+    """InsertionTrack.calculateInsertions (lower 0, upper 2000, tracks.py:164-168) of every chunk in one GPU batch"""
+    from .. import _lib as L
+    from .. import get_context
+    from ..pipeline import pack
+    pk = pack(chunks, bam)
+    b = get_context().upload(pk)
+    try:
+        b.run_ins(0, 2000)
+        flat = b.track(L.T_INS).astype(np.float64)
+    finally:
+        b.free()
+    return pk.out_off, flat
+
+
+def run_nfr(args):
+    if args.bam is None and args.ins_track is None:
+        raise Exception("Must supply either bam file or insertion track")
+    if not args.out:
+        args.out = ".".join(os.path.basename(args.calls).split(".")[0:-3])
+    if args.fasta is not None:
+        chrs_fasta = read_chrom_sizes_from_fasta(args.fasta)
+        pwm = PWM.open(args.pwm)
+        chunks = ChunkList.read(args.bed, chromDict=chrs_fasta, min_offset=max(pwm.up, pwm.down))
+    else:
+        chunks = ChunkList.read(args.bed)
+    if args.bam is not None:
+        chunks.checkChroms(read_chrom_sizes_from_bam(args.bam), chrom_source="BAM file")
+    chunks.merge()
+    params = NFRParameters(args.occ_track, args.calls, args.ins_track, args.bam, max_occ=args.max_occ,
+                           max_occ_upper=args.max_occ_upper, fasta=args.fasta, pwm=args.pwm)
+    make_ins = params.ins_track is None
+    ins_path = args.out + ".ins.bedgraph.gz"
+    nb = max(1, (len(chunks) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
+    with open(args.out + ".nfrpos.bed", "w") as nfr_handle:
+        for bi in range(nb):
+            part = chunks[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
+            if not part:
+                if make_ins:
+                    write_bedgraph(ins_path, [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL, finish=True)
+                break
+            off = flat = None
+            if make_ins:
+                off, flat = _batch_insertions(part, args.bam)
+            for k, ch in enumerate(part):
+                nfr = NFRChunk(ch)
+                try:
+                    nfr.process(params, ins_vals=None if flat is None else flat[int(off[k]):int(off[k + 1])])
+                except Exception:
+                    print("Caught exception when processing:\n" + ch.asBed() + "\n")
+                    raise
+                for pos in nfr.nfrs:
+                    pos.write(nfr_handle)
+                nfr.removeData()
+            if make_ins:      # Track.write_track of every chunk's insertion track (run_nfr.py:55-67) through the native writer
+                write_bedgraph(ins_path, [c.chrom for c in part], [c.start for c in part], off, flat, append=bi > 0,
+                               compress=COMPRESS_LEVEL, finish=(bi == nb - 1))
+    bgzip_file(args.out + ".nfrpos.bed", level=COMPRESS_LEVEL)       # pysam.tabix_compress + tabix_index (run_nfr.py:121-128)
+    tabix_index(args.out + ".nfrpos.bed.gz")
+    if make_ins:
+        tabix_index(ins_path)
