@@ -432,6 +432,67 @@ def case_write_track():
     save("write_track_rows", **out)
 
 
+# ----------------------------------------------------------------------------------------
+# case K: BASELINE configs[1] -- the REFERENCE's own `nucleoatac run` (cli.py:34-64: occ -> vprocess -> nuc -> merge -> nfr,
+# its drivers, pools and writers) on the "synthetic sacCer3": example/example.bed regions, chromosome names / lengths of
+# example/sacCer3.fa.fai, seeded synthetic genome + fragments (the example's BAM / FASTA are not in the repository)
+# ----------------------------------------------------------------------------------------
+def case_run_saccer3():
+    import gzip
+    import shutil
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import read_bed3, synth_saccer3
+    from nucleoatac.cli import nucleoatac_main, nucleoatac_parser
+    work = os.path.join(TMP, "run_saccer3")
+    shutil.rmtree(work, ignore_errors=True)
+    os.makedirs(work)
+    bed = os.path.join(SCRATCH, "src", "example", "example.bed")
+    regions = read_bed3(bed)
+    bam, fa = synth_saccer3(work, regions, seed=3)
+    out = os.path.join(work, "ref")
+    args = nucleoatac_parser().parse_args(["run", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--write_all"])
+    nucleoatac_main(args)
+
+    def rows(name, cols):
+        txt = gzip.open(out + "." + name, "rt").read().strip()
+        r = [l.split("\t") for l in txt.split("\n")] if txt else []
+        return np.array([[float(x[c]) for c in cols] for x in r], dtype=np.float64).reshape(-1, len(cols)), [x[0] for x in r]
+
+    def track(name, chrom, s, e):
+        from pyatac.tracks import Track
+        t = Track(chrom, s, e)
+        t.read_track(out + "." + name + ".bedgraph.gz")
+        return t.vals
+
+    from pyatac.fragmentsizes import FragmentSizes
+    res = dict(regions_chrom=np.array([r[0] for r in regions]), regions=np.array([[r[1], r[2]] for r in regions]))
+    res["fragmentsizes"] = FragmentSizes.open(out + ".fragmentsizes.txt").get()
+    res["nuc_dist"] = FragmentSizes.open(out + ".nuc_dist.txt").get()
+    vm = V.VMat.open(out + ".VMat")
+    res["vmat"], res["vlower"], res["vupper"] = vm.mat, vm.lower, vm.upper
+    for name, cols in (("occpeaks.bed.gz", range(1, 7)), ("nucpos.bed.gz", range(1, 13)), ("nucpos.redundant.bed.gz", range(1, 13)),
+                       ("nucmap_combined.bed.gz", range(1, 7)), ("nfrpos.bed.gz", range(1, 7))):
+        key = name.replace(".bed.gz", "").replace(".", "_")
+        res[key], chroms = rows(name, list(cols))
+        res[key + "_chrom"] = np.array(chroms)
+    res["nucmap_source"] = np.array([l.split("\t")[7] for l in gzip.open(out + ".nucmap_combined.bed.gz", "rt").read().strip().split("\n")])
+    # per-base tracks of four of the slopped + merged regions (every track file of the run)
+    slop = [(c, s - 60, e + 60) for c, s, e in regions]
+    for i in (0, 3, 8, 18):
+        c, s, e = slop[i]
+        for t in ("occ", "occ.lower_bound", "occ.upper_bound", "nucleoatac_signal", "nucleoatac_signal.smooth",
+                  "nucleoatac_raw", "nucleoatac_background"):
+            res["track_%d_%s" % (i, t.replace(".", "_"))] = track(t, c, s, e)
+        res["track_%d_ins" % i] = track("ins", regions[i][0], regions[i][1], regions[i][2])
+    res["track_ids"] = np.array([0, 3, 8, 18])
+    n_occ, n_nuc, n_nfr = len(res["occpeaks"]), len(res["nucpos"]), len(res["nfrpos"])
+    assert n_occ > 50 and n_nuc > 50 and n_nfr > 5, (n_occ, n_nuc, n_nfr)
+    REPORT.append("%-44s %s occpeaks=%d nucpos=%d redundant=%d combined=%d nfr=%d" % (
+        "reference `nucleoatac run` on synthetic sacCer3", "stored", n_occ, n_nuc, len(res["nucpos_redundant"]),
+        len(res["nucmap_combined"]), n_nfr))
+    save("run_saccer3", **res)
+
+
 if __name__ == "__main__":
     vmat, fd, pwm = case_params()
     case_chunks("chunks_basic", 11, [(1000, 1803), (4800, 5500), (8000, 9203)], vmat, fd, pwm)
@@ -442,6 +503,7 @@ if __name__ == "__main__":
     case_ins_edge()
     case_sizes()
     case_write_track()
+    case_run_saccer3()
     print("\n".join(REPORT))
     print("oracle pinned against the reference on %d checks" % len(REPORT))
     with open(os.path.join(HERE, "PIN_REPORT.txt"), "w") as f:

@@ -93,3 +93,56 @@ def synth_stores(seed, holes=()):
     l, n, seq = synth_genome(seed, holes=holes)
     frags = FragmentStore(["chrS"], [len(seq)], {"chrS": l - 4}, {"chrS": n + 8})
     return frags, FastaStore({"chrS": seq.copy()})
+
+
+# ---- BASELINE configs[0] / configs[1]: the "synthetic sacCer3"  -------------------------------------
+SACCER3_FAI = [("chrI", 230218), ("chrII", 813184), ("chrIII", 316620), ("chrIV", 1531933), ("chrV", 576874),
+               ("chrVI", 270161), ("chrVII", 1090940), ("chrVIII", 562643), ("chrIX", 439888), ("chrX", 745751),
+               ("chrXI", 666816), ("chrXII", 1078177), ("chrXIII", 924431), ("chrXIV", 784333), ("chrXV", 1091291),
+               ("chrXVI", 948066), ("chrM", 85779)]      # example/sacCer3.fa.fai of the reference (names, lengths)
+
+
+def synth_saccer3(out_dir, bed_regions, seed=3, density=2.5):
+    """Stand-in for the reference's absent example.bam + sacCer3.fa: chromosome names / lengths of its sacCer3.fa.fai, a
+    seeded random genome, and paired-end fragments (phased nucleosome-like centres, NucleoATAC-like size mixture) around
+    the given BED regions.  Writes <out_dir>/sacCer3.bam.npz and sacCer3.fa.npz (the .npz "alignment" / "fasta" formats that
+    both nucleoatac_amd and the scratch reference's pysam stand-in read) and returns their paths.  Used by
+    tests/golden/make_golden.py (to run the REFERENCE's `nucleoatac run`) and by the GPU test that runs ours."""
+    from nucleoatac_amd.synth import synth_centres, synth_sizes
+    rng = np.random.default_rng(seed)
+    names = [n for n, _ in SACCER3_FAI]
+    lens = dict(SACCER3_FAI)
+    fa = dict(chrom_names=np.array(names), chrom_lengths=np.array([lens[n] for n in names]))
+    for n in names:
+        s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=lens[n])
+        s[rng.integers(0, lens[n], size=max(1, lens[n] // 20000))] = ord("N")
+        fa["seq_" + n] = s
+    pos = {n: [] for n in names}
+    tl = {n: [] for n in names}
+    for chrom, s, e in bed_regions:
+        a, b = max(0, s - 1500), min(lens[chrom], e + 1500)
+        nf = int((b - a) * density)
+        n = synth_sizes(rng, nf).astype(np.int64)
+        c = synth_centres(rng, nf, b - a) + a
+        # a nucleosome-free stretch in the middle of every region: only sub-nucleosomal fragments there (what `nfr` finds)
+        mid = (s + e) // 2
+        free = (c >= mid - 200) & (c < mid + 200)
+        n[free] = np.clip(np.rint(30.0 + rng.gamma(2.5, 12.0, size=int(free.sum()))), 20, 100).astype(np.int64)
+        l = c - (n - 1) // 2
+        ok = (l - 4 >= 0) & (l + n + 4 < lens[chrom])
+        pos[chrom].append(l[ok] - 4)
+        tl[chrom].append(n[ok] + 8)
+    bam = dict(chrom_names=np.array(names), chrom_lengths=np.array([lens[n] for n in names]))
+    for n in names:
+        p = np.concatenate(pos[n]) if pos[n] else np.zeros(0, np.int64)
+        t = np.concatenate(tl[n]) if tl[n] else np.zeros(0, np.int64)
+        o = np.argsort(p, kind="stable")
+        bam["pos_" + n], bam["tlen_" + n] = p[o], t[o]
+    bam_path, fa_path = os.path.join(out_dir, "sacCer3.bam.npz"), os.path.join(out_dir, "sacCer3.fa.npz")
+    np.savez(bam_path, **bam)
+    np.savez(fa_path, **fa)
+    return bam_path, fa_path
+
+
+def read_bed3(path):
+    return [(f[0], int(f[1]), int(f[2])) for f in (l.split() for l in open(path) if l.strip())]
