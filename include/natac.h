@@ -142,6 +142,16 @@ int natac_download_peaks(natac_batch *b, int64_t n_cand, int32_t *cand_chunk, in
  * boundary = sep/2, order = 1).  Fetch positions with natac_download_peaks (lr / var / z may be NULL). */
 int natac_run_track_peaks(natac_batch *b, int track, double min_signal, int sep, int boundary, int order,
                           const double *jitter, int64_t n_jitter, int64_t *n_peaks);
+/* OccChunk.callPeaks + OccChunk.getNucDist for every chunk on the device (nucleoatac/Occupancy.py:225-240; needs natac_run_occ):
+ * call_peaks(smoothed_vals, sep, min_signal = min_occ) as natac_run_track_peaks(NATAC_T_OCC, ...) does it, then per peak the
+ * OccPeak values (occ, lower, upper, reads = cov) and keep = (lower > min_occ && reads > 0), and per chunk
+ * nuc_dist[upper] = sum over its kept peaks of the window's insert-size histogram / its total, in peak order.  `jitter` as in
+ * natac_run_peaks.  *n_peaks = number of call_peaks peaks (kept or not). */
+int natac_run_occ_peaks(natac_batch *b, double min_occ, int sep, const double *jitter, int64_t n_jitter, int64_t *n_peaks);
+int natac_download_occ_peaks(natac_batch *b, int64_t n_peaks, int32_t *chunk, int32_t *pos, double *occ, double *lower,
+                             double *upper, double *reads, int32_t *keep);
+/* float64[n_chunks x upper] (upper of natac_set_occ_model), row i = OccChunk.getNucDist() of chunk i */
+int natac_download_nuc_dist(natac_batch *b, double *dst, size_t dst_bytes);
 /* copy one per-base track to host (float64[total_bp], or int32[total_bp] for NATAC_T_INS). Synchronises. */
 int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes);
 /* copy one per-grid-point array to host (float64[total_grid]). */

@@ -42,6 +42,9 @@ SIGNATURES = {
     "natac_run_peaks": (C.c_int, [_vp, _f64, C.c_int, C.c_int, C.c_int, _vp, _i64, C.POINTER(_i64)]),
     "natac_download_peaks": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "natac_run_track_peaks": (C.c_int, [_vp, C.c_int, _f64, C.c_int, C.c_int, C.c_int, _vp, _i64, C.POINTER(_i64)]),
+    "natac_run_occ_peaks": (C.c_int, [_vp, _f64, C.c_int, _vp, _i64, C.POINTER(_i64)]),
+    "natac_download_occ_peaks": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "natac_download_nuc_dist": (C.c_int, [_vp, _vp, _sz]),
     "natac_batch_download": (C.c_int, [_vp, C.c_int, _vp, _sz]),
     "natac_batch_download_grid": (C.c_int, [_vp, C.c_int, _vp, _sz]),
     "natac_batch_status": (C.c_int, [_vp, _vp, _sz]),

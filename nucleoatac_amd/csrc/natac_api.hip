@@ -105,6 +105,11 @@ struct natac_batch {
     int2 *d_tiles_gs = nullptr;
     int n_tiles_gs = 0, gs_Q = -1;
     int *d_defer = nullptr;          // [0] = count, [1 ..] = tile indices
+    // occupancy peaks (natac_run_occ_peaks): OccPeak values + keep flags of the last search, per-chunk nuc_dist
+    double *d_opk_vals = nullptr, *d_nuc_dist = nullptr;
+    int *d_opk_keep = nullptr;
+    long long opk_cap = 0, opk_n = -1;
+    int nd_upper = 0;
     double *d_track[NATAC_T_COUNT] = {nullptr};
     double *d_grid[3] = {nullptr, nullptr, nullptr};
     bool nuc_done = false, occ_done = false, ins_done = false;
@@ -593,6 +598,7 @@ void natac_batch_free(natac_batch *b) {
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
     dev_free(b->d_bnum); dev_free(b->d_bcov);
     dev_free(b->d_blk_off); dev_free(b->d_gsum); dev_free(b->d_tiles_gs); dev_free(b->d_defer);
+    dev_free(b->d_opk_vals); dev_free(b->d_nuc_dist); dev_free(b->d_opk_keep);
     for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
     delete b;
 }
@@ -980,6 +986,81 @@ int natac_run_track_peaks(natac_batch *b, int track, double min_signal, int sep,
     int rc = track_ready(b, track);
     if (rc) return rc;
     return run_peaks_impl(b, b->d_track[track], nullptr, false, min_signal, sep, boundary, order, jitter, n_jitter, n_peaks);
+}
+
+int natac_run_occ_peaks(natac_batch *b, double min_occ, int sep, const double *jitter, int64_t n_jitter, int64_t *n_peaks) {
+    if (!b || !n_peaks) return fail(NATAC_E_ARG, "null argument");
+    if (!b->occ_done) return fail(NATAC_E_STATE, "natac_run_occ must run before natac_run_occ_peaks");
+    natac_ctx *c = b->ctx;
+    const int U = c->occ_upper;
+    if (U > 1024) return fail(NATAC_E_ARG, "upper > 1024");
+    // OccChunk.callPeaks: call_peaks(smoothed_vals, sep, min_signal = min_occ), boundary = sep / 2, order = 1 (Occupancy.py:227)
+    int rc = run_peaks_impl(b, b->d_track[NATAC_T_OCC], nullptr, false, min_occ, sep, sep / 2, 1, jitter, n_jitter, n_peaks);
+    if (rc) return rc;
+    const long long n = *n_peaks;
+    if (n > b->opk_cap) {
+        HIPCHK(sync_all(c));
+        dev_free(b->d_opk_vals); dev_free(b->d_opk_keep);
+        b->d_opk_vals = nullptr; b->d_opk_keep = nullptr;
+        b->opk_cap = n + n / 4 + 16;
+        if ((rc = dev_alloc(&b->d_opk_vals, (size_t)4 * b->opk_cap))) return rc;
+        if ((rc = dev_alloc(&b->d_opk_keep, (size_t)b->opk_cap))) return rc;
+    }
+    if (!b->d_opk_vals) {
+        b->opk_cap = 16;
+        if ((rc = dev_alloc(&b->d_opk_vals, (size_t)4 * b->opk_cap))) return rc;
+        if ((rc = dev_alloc(&b->d_opk_keep, (size_t)b->opk_cap))) return rc;
+    }
+    if (!b->d_nuc_dist || b->nd_upper != U) {
+        HIPCHK(sync_all(c));
+        dev_free(b->d_nuc_dist);
+        b->d_nuc_dist = nullptr;
+        if ((rc = dev_alloc(&b->d_nuc_dist, (size_t)b->nc * U))) return rc;
+        b->nd_upper = U;
+    }
+    const ChunkTable ct = make_table(b);
+    natac_ctx::Ev ev;
+    prof_begin(c, NATAC_K_CAND, ev);
+    hipLaunchKernelGGL(natac_occ_peak_dist, dim3(b->nc), dim3(256), (size_t)U * sizeof(int), c->stream, ct, b->d_pk_offs, b->d_pk_pos,
+                       b->d_track[NATAC_T_OCC], b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER],
+                       b->d_track[NATAC_T_OCC_COV], min_occ, c->flank, U, b->opk_cap, b->d_opk_vals, b->d_opk_keep, b->d_nuc_dist);
+    prof_end(c, ev);
+    HIPCHK(hipGetLastError());
+    b->opk_n = n;
+    return NATAC_OK;
+}
+
+int natac_download_occ_peaks(natac_batch *b, int64_t n, int32_t *chunk, int32_t *pos, double *occ, double *lower, double *upper,
+                             double *reads, int32_t *keep) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    if (b->opk_n < 0 || b->opk_n != b->pk_n) return fail(NATAC_E_STATE, "natac_run_occ_peaks has not run (or another peak search ran since)");
+    if (n != b->opk_n) return fail(NATAC_E_ARG, "expected %lld peaks, got buffers for %lld", b->opk_n, (long long)n);
+    if (n == 0) return NATAC_OK;
+    if (!chunk || !pos || !occ || !lower || !upper || !reads || !keep) return fail(NATAC_E_ARG, "null argument");
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nb = (size_t)n * sizeof(double);
+    HIPCHK(hipMemcpyAsync(chunk, b->d_pk_chunk, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pos, b->d_pk_pos, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(occ, b->d_opk_vals, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(lower, b->d_opk_vals + b->opk_cap, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(upper, b->d_opk_vals + 2 * b->opk_cap, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(reads, b->d_opk_vals + 3 * b->opk_cap, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(keep, b->d_opk_keep, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return NATAC_OK;
+}
+
+int natac_download_nuc_dist(natac_batch *b, double *dst, size_t dst_bytes) {
+    if (!b || !dst) return fail(NATAC_E_ARG, "null argument");
+    if (b->opk_n < 0 || !b->d_nuc_dist) return fail(NATAC_E_STATE, "natac_run_occ_peaks has not run");
+    const size_t need = (size_t)b->nc * b->nd_upper * sizeof(double);
+    if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, nuc_dist needs %zu", dst_bytes, need);
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, b->d_nuc_dist, need, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return NATAC_OK;
 }
 
 int natac_download_peaks(natac_batch *b, int64_t n, int32_t *cand_chunk, int32_t *cand_pos, double *lr, double *var, double *z) {

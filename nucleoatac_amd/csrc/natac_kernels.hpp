@@ -1597,6 +1597,65 @@ __global__ void __launch_bounds__(256) natac_compact_candidates(int nc, const in
 }
 
 // ------------------------------------------------------------------------------------------------
+// K9  OccChunk.callPeaks filter + OccChunk.getNucDist on the device (nucleoatac/Occupancy.py:225-240).
+// One workgroup per chunk walks the chunk's occupancy peaks (ascending, as call_peaks returns them): a peak is kept if
+// smoothed_lower[pos] > min_occ and cov[pos] > 0 (:229-230); every kept peak adds its window's insert-size histogram
+// (fragments centred within +-flank, sizes [0, upper)) divided by its total to the chunk's nuc_dist, in peak order like
+// the reference's `nuc_dist += sub_sum` (:236-239).  out_vals[4][n] = occ, lower, upper, reads of every peak (OccPeak).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) natac_occ_peak_dist(ChunkTable ct, const long long *__restrict__ pk_offs,
+                                                             const int *__restrict__ pk_pos, const double *__restrict__ occ,
+                                                             const double *__restrict__ lower, const double *__restrict__ upper_t,
+                                                             const double *__restrict__ cov, double min_occ, int flank, int U,
+                                                             long long cap, double *__restrict__ out_vals,
+                                                             int *__restrict__ keep, double *__restrict__ nuc_dist) {
+    extern __shared__ int hist_s[];                 // [U]
+    __shared__ int total_s;
+    const int chunk = blockIdx.x;
+    const long long ob = ct.out_off[chunk];
+    const int nfr = (int)(ct.frag_off[chunk + 1] - ct.frag_off[chunk]);
+    const int *cen = ct.centre + ct.frag_off[chunk];
+    const int *iln = ct.ilen + ct.frag_off[chunk];
+    const int nj = (U + 255) / 256;                 // insert sizes per thread (1 for upper <= 256)
+    double nd[4] = {0.0, 0.0, 0.0, 0.0};            // thread t owns sizes t, t + 256, ... (U <= 1024)
+    for (long long k = pk_offs[chunk]; k < pk_offs[chunk + 1]; ++k) {
+        const int p = pk_pos[k];
+        const double lo = lower[ob + p], rd = cov[ob + p];
+        const bool kp = lo > min_occ && rd > 0;      // block-uniform
+        if (threadIdx.x == 0) {
+            out_vals[k] = occ[ob + p];
+            out_vals[cap + k] = lo;
+            out_vals[2 * cap + k] = upper_t[ob + p];
+            out_vals[3 * cap + k] = rd;
+            keep[k] = kp ? 1 : 0;
+        }
+        if (!kp) continue;
+        for (int j = threadIdx.x; j < U; j += 256) hist_s[j] = 0;
+        if (threadIdx.x == 0) total_s = 0;
+        __syncthreads();
+        const int f0 = lower_bound_i32(cen, 0, nfr, p - flank);
+        const int f1 = lower_bound_i32(cen, f0, nfr, p + flank + 1);
+        int mine = 0;
+        for (int f = f0 + threadIdx.x; f < f1; f += 256) {
+            const int n = iln[f];
+            if (n >= 0 && n < U) { atomicAdd(&hist_s[n], 1); ++mine; }
+        }
+        if (mine) atomicAdd(&total_s, mine);
+        __syncthreads();
+        const double tot = (double)total_s;
+        for (int q = 0; q < nj && q < 4; ++q) {
+            const int j = threadIdx.x + 256 * q;
+            if (j < U) nd[q] = nd[q] + (double)hist_s[j] / tot;
+        }
+        __syncthreads();
+    }
+    for (int q = 0; q < nj && q < 4; ++q) {
+        const int j = threadIdx.x + 256 * q;
+        if (j < U) nuc_dist[(long long)chunk * U + j] = nd[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // drop-in kernels for the Cython functions (single region, absolute coordinates)
 // ------------------------------------------------------------------------------------------------
 // makeFragmentMat, pyatac/fragments.pyx:17-40 (mat pre-zeroed; float64 atomics are exact for integer counts)

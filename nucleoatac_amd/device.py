@@ -98,6 +98,7 @@ class Context(object):
                                               _ptr(alphas), alphas.shape[0], float(cutoff), int(step), int(flank)))
         step = int(step)
         self.occ_step = step - 1 if step % 2 == 0 else step
+        self.occ_upper = nuc_probs.shape[0]
 
     # ---- Cython-function drop-ins ------------------------------------------------------------
     def make_fragment_mat(self, l, n, start, end, lower, upper):
@@ -320,6 +321,22 @@ class DeviceBatch(object):
         cc, cp = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
         L.check(self._lib.natac_download_peaks(self._h, n, _ptr(cc), _ptr(cp), None, None, None))
         return cc, cp
+
+    def run_occ_peaks(self, min_occ=0.1, sep=120):
+        """OccChunk.callPeaks + getNucDist of every chunk on the device (natac_run_occ_peaks).  Returns
+        (chunk, pos, occ, lower, upper, reads, keep) of every call_peaks peak and nuc_dist[n_chunks, upper]."""
+        maxL = int(self.packed.chunk_len.max())
+        jitter = np.ascontiguousarray(np.random.RandomState(seed=25).uniform(0, 10 ** -12, maxL))
+        n = C.c_int64(0)
+        L.check(self._lib.natac_run_occ_peaks(self._h, float(min_occ), int(sep), _ptr(jitter), maxL, C.byref(n)))
+        n = n.value
+        cc, cp, keep = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+        occ, lo, up, rd = (np.empty(n, np.float64) for _ in range(4))
+        L.check(self._lib.natac_download_occ_peaks(self._h, n, _ptr(cc), _ptr(cp), _ptr(occ), _ptr(lo), _ptr(up), _ptr(rd), _ptr(keep)))
+        upper = self.ctx.occ_upper
+        nd = np.empty((self.packed.n_chunks, upper), dtype=np.float64)
+        L.check(self._lib.natac_download_nuc_dist(self._h, _ptr(nd), nd.nbytes))
+        return cc, cp, occ, lo, up, rd, keep, nd
 
     def track(self, t):
         """download one per-base track (concatenated over chunks)"""

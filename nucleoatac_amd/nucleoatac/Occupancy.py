@@ -132,6 +132,14 @@ class OccPeak(Chunk):
         self.occ_upper = chunk.occ.smoothed_upper[i]
         self.reads = chunk.cov.get(pos=pos)
 
+    @staticmethod
+    def from_values(chrom, pos, occ, occ_lower, occ_upper, reads):
+        """an OccPeak whose values were gathered on the device (natac_run_occ_peaks)"""
+        p = OccPeak.__new__(OccPeak)
+        p.chrom, p.start, p.end, p.strand = chrom, pos, pos + 1, "*"
+        p.occ, p.occ_lower, p.occ_upper, p.reads = float(occ), float(occ_lower), float(occ_upper), float(reads)
+        return p
+
     def asBed(self):
         from ..pyatac.tracks import _py2_float_str as s
         return "\t".join([str(self.chrom), str(self.start), str(self.end), s(self.occ), s(self.occ_lower),
@@ -173,10 +181,9 @@ def occ_batch(chunks, params, ctx=None, with_flat=False):
     run = BatchRunner(pk, ctx)
     try:
         res = run.occ()
-        # OccChunk.callPeaks (Occupancy.py:225-231) for every chunk on the device: call_peaks(smoothed_vals, sep, min_occ)
-        from .. import _lib as L
-        pk_chunk, pk_pos = run.batch.run_track_peaks(L.T_OCC, min_signal=params.min_occ, sep=params.sep,
-                                                     boundary=params.sep // 2, order=1)
+        # OccChunk.callPeaks + getNucDist (Occupancy.py:225-240) for every chunk on the device: peak search, OccPeak values,
+        # the occ_lower > min_occ / reads > 0 filter and the per-chunk nucleosomal size distribution
+        pk_chunk, pk_pos, p_occ, p_lo, p_up, p_rd, p_keep, nuc_dist = run.batch.run_occ_peaks(min_occ=params.min_occ, sep=params.sep)
         # chunks with more local maxima than the device peak finder holds per chunk: utils.call_peaks on the host
         host_peaks = {}
         for k in np.nonzero(run.batch.status() & 2)[0]:
@@ -198,7 +205,14 @@ def occ_batch(chunks, params, ctx=None, with_flat=False):
         oc.occ.smoothed_upper = res["smoothed_upper"][k].copy()
         oc.cov = CoverageTrack(ch.chrom, ch.start, ch.end)
         oc.cov.vals = res["cov"][k].copy()
-        oc.callPeaks(peaks=host_peaks[k] if k in host_peaks else pk_pos[int(bounds[k]):int(bounds[k + 1])])
+        if k in host_peaks:
+            oc.callPeaks(peaks=host_peaks[k])          # nuc_dist of these chunks: host histogram in getNucDist
+        else:
+            a, e = int(bounds[k]), int(bounds[k + 1])
+            for i in range(a, e):
+                if p_keep[i]:
+                    oc.peaks[int(pk_pos[i])] = OccPeak.from_values(ch.chrom, int(pk_pos[i]) + ch.start, p_occ[i], p_lo[i], p_up[i], p_rd[i])
+            oc._nuc_dist = nuc_dist[k].copy()
         out.append(oc)
     if with_flat:
         # smoothed_vals was NaN-filled on the device exactly like call_peaks does in place, so the flat array is what
@@ -227,7 +241,10 @@ class OccChunk(Chunk):
                 self.peaks[int(peak)] = tmp
 
     def getNucDist(self):
-        """insert-size distribution around the called peaks (Occupancy.py:232-240)"""
+        """insert-size distribution around the called peaks (Occupancy.py:232-240): computed on the device with the peaks
+        (natac_run_occ_peaks); the host histogram remains for chunks whose peaks were found on the host"""
+        if getattr(self, "_nuc_dist", None) is not None:
+            return self._nuc_dist
         nuc_dist = np.zeros(self.params.upper)
         for peak in self.peaks.keys():
             h = window_size_hist(self._pk, self._k, self.peaks[peak].start - self.start, self.params.flank, self.params.upper)
