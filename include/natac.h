@@ -240,7 +240,8 @@ int natac_pack_chunks(int32_t n_chunks, const int64_t *chunk_start, const int64_
                       int64_t *frag_off, int64_t *first, int32_t *lpos, int32_t *ilen, int n_threads);
 
 /* ---- native BAM -> fragment arrays extractor (host side) -------------- */
-/* Decode a BAM once (parallel BGZF inflate) into per-reference arrays of the reads pyatac/fragments.pyx:25 keeps
+/* Decode a BAM once (streaming: bounded windows of compressed data, parallel BGZF inflate per window, records may straddle
+ * windows; peak memory is independent of the file size) into per-reference arrays of the reads pyatac/fragments.pyx:25 keeps
  * (`is_proper_pair and not is_reverse`): pos = leftmost 0-based coordinate, tlen = |template length|, in file order. */
 typedef struct natac_bam natac_bam;
 int natac_bam_open(const char *path, int n_threads, natac_bam **out);

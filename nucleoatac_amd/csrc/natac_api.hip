@@ -1525,7 +1525,9 @@ int natac_bam_open(const char *path, int n_threads, natac_bam **out) {
     if (!path || !out) return fail(NATAC_E_ARG, "null argument");
     *out = nullptr;
     std::string err;
-    natac_bamio::Bam *impl = natac_bamio::decode(path, n_threads, err);
+    size_t window = (size_t)48 << 20;                 // compressed bytes per streaming window; NATAC_BAM_WINDOW overrides (tests)
+    if (const char *e = getenv("NATAC_BAM_WINDOW")) { const long long v = atoll(e); if (v > 0) window = (size_t)v; }
+    natac_bamio::Bam *impl = natac_bamio::decode(path, n_threads, err, window);
     if (!impl) return fail(NATAC_E_ARG, "%s: %s", path, err.c_str());
     natac_bam *h = new natac_bam();
     h->impl = impl;

@@ -36,102 +36,157 @@ inline uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_
 inline int32_t rdi32(const unsigned char *p) { return (int32_t)rd32(p); }
 inline uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-// returns nullptr + error text on failure
-inline Bam *decode(const char *path, int n_threads, std::string &err) {
+// Streaming decode with bounded memory: the file is read in windows of ~batch_bytes of compressed data; the complete BGZF
+// blocks of a window are inflated in parallel into one buffer that is prefixed with the unparsed remainder of the
+// previous window (a BAM record -- or the header -- may straddle any number of blocks), the records are walked, and only
+// the two numbers per kept read stay.  Peak memory = one compressed window + its inflated form (+ the output arrays),
+// independent of the file size.  returns nullptr + error text on failure.
+inline Bam *decode(const char *path, int n_threads, std::string &err, size_t batch_bytes = (size_t)48 << 20) {
     FILE *f = std::fopen(path, "rb");
     if (!f) { err = std::string("cannot open ") + path; return nullptr; }
-    std::fseek(f, 0, SEEK_END);
-    const long fsz = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    std::vector<unsigned char> raw((size_t)std::max(0L, fsz));
-    if (fsz > 0 && std::fread(raw.data(), 1, raw.size(), f) != raw.size()) { std::fclose(f); err = "short read"; return nullptr; }
-    std::fclose(f);
-    // ---- BGZF block table
-    struct Blk { size_t off, csize; uint32_t isize; size_t uoff; };
-    std::vector<Blk> blks;
-    size_t o = 0, utotal = 0;
-    while (o + 18 <= raw.size()) {
-        const unsigned char *h = raw.data() + o;
-        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF file (bad block header)"; return nullptr; }
-        const unsigned xlen = rd16(h + 10);
-        size_t bsize = 0;
-        for (size_t x = 12; x + 4 <= 12 + (size_t)xlen;) {
-            const unsigned slen = rd16(h + x + 2);
-            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(h + x + 4) + 1;
-            x += 4 + slen;
-        }
-        if (!bsize || o + bsize > raw.size()) { err = "truncated BGZF block"; return nullptr; }
-        const uint32_t isize = rd32(h + bsize - 4);
-        blks.push_back({o + 12 + xlen, bsize - 12 - xlen - 8, isize, utotal});
-        utotal += isize;
-        o += bsize;
-    }
-    if (o != raw.size()) { err = "trailing bytes after the last BGZF block"; return nullptr; }
-    std::vector<unsigned char> data(utotal);
-    // ---- parallel inflate
     if (n_threads <= 0) n_threads = natac_cores::default_threads(64);
-    n_threads = std::max(1, std::min<int>(n_threads, (int)std::max<size_t>(1, blks.size())));
-    std::atomic<size_t> next(0);
-    std::atomic<int> bad(0);
-    auto work = [&]() {
-        z_stream zs;
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= blks.size()) break;
-            const Blk &b = blks[i];
-            if (b.isize == 0) continue;
-            std::memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
-            zs.next_in = raw.data() + b.off;
-            zs.avail_in = (uInt)b.csize;
-            zs.next_out = data.data() + b.uoff;
-            zs.avail_out = b.isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.total_out != b.isize) { bad = 1; return; }
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
-    work();
-    for (auto &x : th) x.join();
-    if (bad) { err = "inflate failed (corrupt BGZF block)"; return nullptr; }
-    raw.clear();
-    raw.shrink_to_fit();
-    // ---- BAM header
-    const unsigned char *p = data.data();
-    const size_t n = data.size();
-    if (n < 12 || std::memcmp(p, "BAM\1", 4) != 0) { err = "not a BAM file (bad magic)"; return nullptr; }
-    size_t q = 8 + (size_t)rdi32(p + 4);
-    if (q + 4 > n) { err = "truncated BAM header"; return nullptr; }
-    const int32_t n_ref = rdi32(p + q);
-    q += 4;
+    batch_bytes = std::max<size_t>(batch_bytes, (size_t)4096);           // + 64 KiB below: always room for one maximal BGZF block
+    struct Blk { size_t off, csize; uint32_t isize; size_t uoff; };
+    std::vector<unsigned char> raw, data;
+    std::vector<Blk> blks;
+    size_t raw_len = 0;            // valid bytes in raw (starts with the leftover of the previous window)
+    size_t pend = 0;               // unparsed bytes at the front of data
+    bool eof = false, header_done = false, any_block = false;
+    int32_t n_ref = 0;
     Bam *bam = new Bam();
-    bam->refs.resize((size_t)std::max(0, n_ref));
-    for (int32_t r = 0; r < n_ref; ++r) {
-        if (q + 4 > n) { err = "truncated reference list"; delete bam; return nullptr; }
-        const int32_t ln = rdi32(p + q);
-        if (ln < 1 || q + 8 + (size_t)ln > n) { err = "truncated reference list"; delete bam; return nullptr; }
-        bam->refs[r].name.assign((const char *)p + q + 4, (size_t)ln - 1);
-        bam->refs[r].length = rdi32(p + q + 4 + ln);
-        q += 8 + (size_t)ln;
-    }
-    // ---- records: keep FLAG & 0x2 (proper pair) and not FLAG & 0x10 (reverse strand)
-    while (q + 4 <= n) {
-        const int32_t bs = rdi32(p + q);
-        if (bs < 32 || q + 4 + (size_t)bs > n) { err = "truncated alignment record"; delete bam; return nullptr; }
-        const unsigned char *rec = p + q + 4;
-        const int32_t ref_id = rdi32(rec), pos = rdi32(rec + 4);
-        const uint16_t flag = rd16(rec + 14);
-        const int32_t tlen = rdi32(rec + 28);
-        ++bam->n_records;
-        if (ref_id >= 0 && ref_id < n_ref && (flag & 0x2) && !(flag & 0x10)) {
-            bam->refs[ref_id].pos.push_back(pos);
-            bam->refs[ref_id].tlen.push_back(tlen < 0 ? -(int64_t)tlen : (int64_t)tlen);
-            ++bam->n_kept;
+    auto fail = [&](const char *msg) -> Bam * { err = msg; delete bam; std::fclose(f); return nullptr; };
+    raw.resize(batch_bytes + ((size_t)1 << 16));
+    while (!eof || raw_len > 0) {
+        // ---- refill the compressed window
+        if (!eof) {
+            const size_t want = raw.size() - raw_len;
+            const size_t got = std::fread(raw.data() + raw_len, 1, want, f);
+            raw_len += got;
+            if (got < want) eof = true;
         }
-        q += 4 + (size_t)bs;
+        // ---- complete BGZF blocks of the window
+        blks.clear();
+        size_t o = 0, utotal = pend;
+        while (o + 18 <= raw_len) {
+            const unsigned char *h = raw.data() + o;
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail("not a BGZF file (bad block header)");
+            const unsigned xlen = rd16(h + 10);
+            if (o + 12 + xlen > raw_len) break;
+            size_t bsize = 0;
+            for (size_t x = 12; x + 4 <= 12 + (size_t)xlen;) {
+                const unsigned slen = rd16(h + x + 2);
+                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(h + x + 4) + 1;
+                x += 4 + slen;
+            }
+            if (!bsize || bsize < 12 + (size_t)xlen + 8) return fail("truncated BGZF block");
+            if (o + bsize > raw_len) break;                       // the rest of this block comes with the next window
+            const uint32_t isize = rd32(h + bsize - 4);
+            blks.push_back({o + 12 + xlen, bsize - 12 - xlen - 8, isize, utotal});
+            utotal += isize;
+            o += bsize;
+            any_block = true;
+        }
+        if (blks.empty()) {
+            if (eof) {
+                if (raw_len > 0) return fail(any_block ? "trailing bytes after the last BGZF block" : "not a BGZF file (bad block header)");
+                break;
+            }
+            return fail("BGZF block larger than the read window");
+        }
+        if (data.size() < utotal) data.resize(utotal);               // pend bytes at the front are kept by resize
+        // ---- parallel inflate of the window's blocks
+        {
+            const int nt = std::max(1, std::min<int>(n_threads, (int)blks.size()));
+            std::atomic<size_t> next(0);
+            std::atomic<int> bad(0);
+            auto work = [&]() {
+                z_stream zs;
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= blks.size()) break;
+                    const Blk &bk = blks[i];
+                    if (bk.isize == 0) continue;
+                    std::memset(&zs, 0, sizeof zs);
+                    if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+                    zs.next_in = raw.data() + bk.off;
+                    zs.avail_in = (uInt)bk.csize;
+                    zs.next_out = data.data() + bk.uoff;
+                    zs.avail_out = bk.isize;
+                    const int rc = inflate(&zs, Z_FINISH);
+                    inflateEnd(&zs);
+                    if (rc != Z_STREAM_END || zs.total_out != bk.isize) { bad = 1; return; }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(work);
+            work();
+            for (auto &x : th) x.join();
+            if (bad) return fail("inflate failed (corrupt BGZF block)");
+        }
+        std::memmove(raw.data(), raw.data() + o, raw_len - o);      // leftover compressed bytes (a partial block)
+        raw_len -= o;
+        // ---- walk the uncompressed bytes [0, utotal)
+        const unsigned char *p = data.data();
+        const size_t n = utotal;
+        size_t q = 0;
+        if (!header_done) {
+            // the header is parsed in one go once it is complete (it may span several windows)
+            bool complete = false;
+            do {
+                if (n < 12) break;
+                if (std::memcmp(p, "BAM\1", 4) != 0) return fail("not a BAM file (bad magic)");
+                size_t hq = 8 + (size_t)(uint32_t)rdi32(p + 4);
+                if (hq + 4 > n) break;
+                n_ref = rdi32(p + hq);
+                hq += 4;
+                if (n_ref < 0) return fail("truncated reference list");
+                std::vector<Ref> refs((size_t)n_ref);
+                bool ok = true;
+                for (int32_t r = 0; r < n_ref; ++r) {
+                    if (hq + 4 > n) { ok = false; break; }
+                    const int32_t ln = rdi32(p + hq);
+                    if (ln < 1) return fail("truncated reference list");
+                    if (hq + 8 + (size_t)ln > n) { ok = false; break; }
+                    refs[r].name.assign((const char *)p + hq + 4, (size_t)ln - 1);
+                    refs[r].length = rdi32(p + hq + 4 + ln);
+                    hq += 8 + (size_t)ln;
+                }
+                if (!ok) break;
+                bam->refs.swap(refs);
+                q = hq;
+                complete = true;
+            } while (false);
+            if (!complete) {
+                if (eof && raw_len == 0) return fail(n < 12 ? "not a BAM file (bad magic)" : "truncated BAM header");
+                pend = n;                                             // wait for more data
+                continue;
+            }
+            header_done = true;
+        }
+        // ---- records: keep FLAG & 0x2 (proper pair) and not FLAG & 0x10 (reverse strand)
+        while (q + 4 <= n) {
+            const int32_t bs = rdi32(p + q);
+            if (bs < 32) return fail("truncated alignment record");
+            if (q + 4 + (size_t)bs > n) break;                        // continues in the next window
+            const unsigned char *rec = p + q + 4;
+            const int32_t ref_id = rdi32(rec), pos = rdi32(rec + 4);
+            const uint16_t flag = rd16(rec + 14);
+            const int32_t tlen = rdi32(rec + 28);
+            ++bam->n_records;
+            if (ref_id >= 0 && ref_id < n_ref && (flag & 0x2) && !(flag & 0x10)) {
+                bam->refs[ref_id].pos.push_back(pos);
+                bam->refs[ref_id].tlen.push_back(tlen < 0 ? -(int64_t)tlen : (int64_t)tlen);
+                ++bam->n_kept;
+            }
+            q += 4 + (size_t)bs;
+        }
+        pend = n - q;
+        std::memmove(data.data(), data.data() + q, pend);
+        if (eof && raw_len == 0) break;
     }
+    std::fclose(f);
+    if (!header_done) { err = any_block ? "truncated BAM header" : "not a BGZF file (bad block header)"; delete bam; return nullptr; }
+    if (pend != 0) { err = "truncated alignment record"; delete bam; return nullptr; }
     return bam;
 }
 

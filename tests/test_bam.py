@@ -87,3 +87,39 @@ def test_corrupt_inputs_fail_loudly(tmp_path):
         FragmentStore.from_bam(p)
     with pytest.raises(NatacError):
         FragmentStore.from_bam(str(tmp_path / "missing.bam"))
+
+
+@pytest.mark.parametrize("window", ["4096", "20000", "1000000"])
+def test_streaming_windows_give_identical_arrays(tmp_path, monkeypatch, window):
+    """the streaming decoder with tiny compressed windows (records, the header and BGZF blocks straddle window borders)
+    equals the pure-Python whole-file decoder"""
+    rng = np.random.default_rng(4)
+    refs = [("chr%d" % i, 100000 + i) for i in range(40)]                      # a header longer than one 3000-byte block
+    recs = []
+    for ref_id in (0, 7, 39):
+        for p in np.sort(rng.integers(0, 90000, size=3000)):
+            flag = int(rng.choice([0x63, 0x53, 0x93, 0xa3]))
+            recs.append((ref_id, int(p), flag, int(rng.integers(30, 700)) * (1 if not (flag & 0x10) else -1)))
+    path = str(tmp_path / "w.bam")
+    _write_bam(path, refs, recs)
+    monkeypatch.setenv("NATAC_BAM_WINDOW", window)
+    nat = FragmentStore.from_bam(path)
+    py = FragmentStore.from_bam_python(path)
+    assert nat.references == py.references and nat.lengths == py.lengths
+    for c in nat.references:
+        assert np.array_equal(nat.pos[c], py.pos[c]) and np.array_equal(nat.tlen[c], py.tlen[c]), c
+    assert sum(len(nat.pos[c]) for c in nat.references) > 3000
+
+
+def test_streaming_rejects_truncated_files(tmp_path, monkeypatch):
+    from nucleoatac_amd import _lib as L
+    refs = [("chrA", 5000)]
+    path = str(tmp_path / "t.bam")
+    _write_bam(path, refs, [(0, 10 * i, 0x63, 200) for i in range(2000)])
+    raw = open(path, "rb").read()
+    monkeypatch.setenv("NATAC_BAM_WINDOW", "4096")
+    for cut in (len(raw) - 40, len(raw) // 2, 30):
+        bad = str(tmp_path / ("cut%d.bam" % cut))
+        open(bad, "wb").write(raw[:cut])
+        with pytest.raises(L.NatacError):
+            FragmentStore.from_bam(bad)
