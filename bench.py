@@ -1,13 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- Mbp/s through the occ + nuc signal pipeline on N MI355X (BASELINE.json metric).
 
-One "step" = one pass of the whole hot path over one batch of synthetic chunks that is already
-resident in HBM: nuc tracks (coverage, raw, background, norm, smooth) + occupancy tracks (grid MLE,
-smoothing, cov, NaN fill) + per-base insertion counts + device-side candidate search (call_peaks) with per-candidate
-LR / variance / z.
-Workload at N=1 = BASELINE.json configs[2]: synthetic 100k windows x 2 kb (2,120 bp after the +-60
-slop), 50 M fragments, default VMat (146 x 121).  With N > 1 every rank owns its own shard of the
-same shape (chunk list sharded across GPUs, no data-path collective): weak scaling.
+One "step" = one pass of the whole hot path over the rank's synthetic chunks, inputs already resident in HBM:
+nuc tracks (coverage, raw, background, norm, smooth) + occupancy tracks (grid MLE, smoothing, cov, NaN fill) + per-base
+insertion counts + device-side candidate search (call_peaks) with per-candidate LR / variance / z.
+
+Workloads (--workload):
+  cfg3 (default)  BASELINE.json configs[2]: 100k windows x 2 kb (2,120 bp after the +-60 slop), 50 M fragments, default
+                  VMat (146 x 121).  With N > 1 every rank owns its own shard of the same shape (weak scaling).
+  cfg3-heavy      the same windows with Poisson fragment counts and 1 % of the chunks 10x denser (heavy-tailed load).
+  cfg4            BASELINE.json configs[3]: ~300k tiles x 10 kb (10,120 bp), ~200 M fragments, the chunk list sharded across
+                  the N ranks by sum(L) + kappa sum(F) (nucleoatac_amd/shard.py): STRONG scaling, total work fixed.  Every
+                  rank draws the same cheap per-chunk count vector, balances, and generates only its own shard in
+                  counter-seeded blocks; a shard is processed in sub-batches whose outputs are recycled
+                  (natac_batch_release_outputs) when they do not all fit in HBM.
+
+Also reported (rank 0, N = 1): the host-to-host rate -- packed inputs in (pinned) host memory -> per-base tracks back in
+(pinned) host memory, sub-batches pipelined over three contexts so that uploads, kernels and downloads overlap -- and the CPU
+baseline (the oracle in the reference's Pool.map shape on the box's host cores).
 
 Launch: python bench.py --gpus 1            (default)
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
@@ -17,6 +27,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -24,16 +35,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_BYTES_PER_BP = 79.8          # SURVEY.md section 8(d), config 3 (compulsory HBM traffic of the whole path)
+ALG_BYTES_PER_BP = {"cfg3": 79.8, "cfg3-heavy": 79.8, "cfg4": 76.9}   # 76 L + 8 F + 3,944 B per chunk
 FLOP_PER_BP_BG = 2 * 146 * 121   # fp64 flop per base of the background correlation evaluated directly (R x W FMA)
 # executed by the FFT kernel: 73 row pairs x 364 flop per lane (172 add + 72 mul + 60 fma) x 64 lanes per 392-base tile
 FLOP_PER_BP_BG_FFT = 73 * 364 * 64 / 392.0
 KERNEL_LABEL = {"background": "natac_background_fft (dense bias x VMat correlation, fp64 FFT)",
-                "occ_mle": "natac_occ_mle<5,60,0,1> (occupancy grid MLE)",
+                "occ_mle": "natac_occ_gsum + natac_occ_decide (occupancy grid MLE)",
                 "candidates": "natac_candidates4 + peak search (LR / variance / z of the candidates)"}
-KERNEL_SYMBOL = {"background": "natac_background_fft", "occ_mle": "natac_occ_mle", "candidates": "natac_candidates4"}
+KERNEL_SYMBOL = {"background": "natac_background_fft", "occ_mle": "natac_occ_", "candidates": "natac_candidates4"}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+H2H_TRACKS = ("T_NORM", "T_SMOOTH", "T_OCC", "T_OCC_LOWER", "T_OCC_UPPER")   # what `nucleoatac run` writes by default
 
 
 def parse():
@@ -41,12 +53,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunks", type=int, default=100000, help="chunks per GPU")
-    ap.add_argument("--chunk-len", type=int, default=2120)
-    ap.add_argument("--frags-per-chunk", type=int, default=500)
+    ap.add_argument("--workload", choices=["cfg3", "cfg3-heavy", "cfg4"], default="cfg3")
+    ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU (cfg3: 100000) / in total (cfg4: 300000)")
+    ap.add_argument("--chunk-len", type=int, default=0)
+    ap.add_argument("--frags-per-chunk", type=int, default=0)
+    ap.add_argument("--sub-chunks", type=int, default=20000, help="cfg4: chunks per sub-batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU baseline's optimised-mode sample (0 = 2000)")
     ap.add_argument("--cpu-literal-chunks", type=int, default=0, help="chunks in the literal-mode sample (0 = auto)")
+    ap.add_argument("--no-h2h", action="store_true", help="skip the pipelined host-to-host measurement")
+    ap.add_argument("--h2h-sub", type=int, default=10000, help="chunks per pipelined sub-batch")
+    ap.add_argument("--h2h-threads", type=int, default=3, help="contexts (host threads) of the host-to-host pipeline")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--share-device", action="store_true",
@@ -54,6 +71,7 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_chunk(args):
     """one chunk through the CPU oracle in the reference's execution shape: what _occHelper + _nucHelper do per chunk
     (nucleoatac/run_occ.py:23-39, run_nuc.py:22-39): OccChunk.process (grid MLE, smoothing, coverage, callPeaks) and
@@ -98,7 +116,7 @@ def _cpu_worker_init():
         pass
 
 
-def _cpu_mode(pool, workers, cores, pk, par, sizes, nucp, nfrp, n_chunks, literal):
+def _cpu_mode(pool, cores, pk, par, sizes, nucp, nfrp, n_chunks, literal):
     """time n_chunks chunks in the reference's shape: `chunks.split(items = cores*5)` rounds, one pool.map per round
     (run_occ.py:101-123, run_nuc.py:164-188)"""
     tasks = []
@@ -132,9 +150,9 @@ def cpu_baseline(pk, par, sizes, nucp, nfrp, n_chunks, n_literal):
     ctx = mp.get_context("fork")
     with ctx.Pool(workers, initializer=_cpu_worker_init) as pool:
         pool.map(_cpu_chunk, [(pk.chunk_frags(0)[0], pk.chunk_frags(0)[1], int(pk.chunk_len[0]), pk.chunk_bias(0), pk.bias_left,
-                               par["vmat"], int(par["vlower"]), int(par["vupper"]), sizes, nucp, nfrp, False)] * workers)  # warm-up (imports)
-        opt = _cpu_mode(pool, workers, cores, pk, par, sizes, nucp, nfrp, n_chunks, False)
-        lit = _cpu_mode(pool, workers, cores, pk, par, sizes, nucp, nfrp, n_literal, True)
+                               par["vmat"], int(par["vlower"]), int(par["vupper"]), sizes, nucp, nfrp, False)] * workers)  # warm-up
+        opt = _cpu_mode(pool, cores, pk, par, sizes, nucp, nfrp, n_chunks, False)
+        lit = _cpu_mode(pool, cores, pk, par, sizes, nucp, nfrp, n_literal, True)
     return dict(value=lit["value"], unit="Mbp/s", cores=workers, kind="port",
                 sample="literal mode (scipy dense correlate + O(N^2) calculateCov, as the reference runs): %d of the workload's "
                        "chunks, %d bp, %.1f s; optimised mode (per-row correlate, closed-form variance): %d chunks, %d bp, %.1f s; "
@@ -163,9 +181,10 @@ def _effective_cores():
 
 
 def pmc_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*/pmc_summary.csv):
-    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE under-counts streaming reads 2x on gfx950
-    (MI355X_MICROARCH.md, HBM section).  None when no profile is committed."""
+    """HBM bytes per step of the kernels whose name contains `kernel_substr`, from the newest committed rocprofv3 PMC summary
+    (profiles/*/pmc_summary.csv): (FETCH_SIZE + WRITE_SIZE) x 1024.  FETCH_SIZE is NOT doubled: the guide's x2 correction
+    is calibrated for 16-byte-per-lane streaming reads only; these kernels read 8 bytes per lane (uncalibrated, so the raw
+    counter is reported).  None when no profile is committed."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.csv")))
@@ -176,14 +195,177 @@ def pmc_traffic_bytes(kernel_substr):
         for row in csv.reader(l for l in fh if not l.startswith("#")):
             if len(row) == 4 and kernel_substr in row[0]:
                 if row[1] == "FETCH_SIZE":
-                    f = float(row[2]) / float(row[3])
+                    f = (f or 0.0) + float(row[2]) / float(row[3])
                 if row[1] == "WRITE_SIZE":
-                    w = float(row[2]) / float(row[3])
+                    w = (w or 0.0) + float(row[2]) / float(row[3])
     if f is None or w is None:
         return None
-    return (2.0 * f + w) * 1024.0
+    return (f + w) * 1024.0
 
 
+# ------------------------------------------------------------------------------------------------ workloads
+def make_workload(a, rank, world):
+    """list of PackedChunks sub-batches of this rank + description"""
+    from nucleoatac_amd.shard import balanced_ranges
+    from nucleoatac_amd.synth import fragment_counts, make_synthetic_chunks
+    if a.workload in ("cfg3", "cfg3-heavy"):
+        nc = a.chunks or 100000
+        L = a.chunk_len or 2120
+        F = a.frags_per_chunk or 500
+        if a.workload == "cfg3":
+            pk = make_synthetic_chunks(nc, L, F, seed=a.seed + 1000 * rank)
+            desc = "configs[2]: synthetic %d windows x 2 kb (L=%d after slop), %d fragments, default VMat 146x121, 1 GPU-shard per rank"
+        else:
+            counts = fragment_counts(nc, F, seed=a.seed + 1000 * rank, hot_frac=0.01, hot_mult=10)
+            pk = make_synthetic_chunks(nc, L, F, seed=a.seed + 1000 * rank, counts=counts)
+            desc = ("configs[2] windows with heavy-tailed load: %d windows (L=%d), Poisson(500) fragments per chunk, 1 %% of the "
+                    "chunks 10x denser, %d fragments, default VMat 146x121, 1 GPU-shard per rank")
+        return [pk], desc % (nc, L, pk.n_frags), dict(scaling="weak", imbalance=None, total_chunks=nc * world)
+    # cfg4: strong scaling
+    nc = a.chunks or 300000
+    L = a.chunk_len or 10120
+    F = a.frags_per_chunk or 667
+    counts = fragment_counts(nc, F, seed=a.seed + 2)            # every rank: the same vector
+    ranges = balanced_ranges(np.full(nc, L), np.concatenate(([0], np.cumsum(counts))), world)
+    lo, hi = ranges[rank]
+    BLOCK = 2000                                                # counter-seeded generation blocks
+    subs = []
+    for s0 in range(lo, hi, a.sub_chunks):
+        s1 = min(hi, s0 + a.sub_chunks)
+        parts = []
+        for b0 in range((s0 // BLOCK) * BLOCK, s1, BLOCK):
+            b1 = min(nc, b0 + BLOCK)
+            blk = make_synthetic_chunks(b1 - b0, L, F, seed=[a.seed + 2, b0 // BLOCK], counts=counts[b0:b1], first_chunk=b0)
+            x0, x1 = max(s0, b0) - b0, min(s1, b1) - b0
+            parts.append(blk.subset(x0, x1) if (x0, x1) != (0, b1 - b0) else blk)
+        subs.append(_concat(parts))
+    per_rank = [(int((r1 - r0) * L), int(counts[r0:r1].sum())) for r0, r1 in ranges]
+    bp = np.array([p[0] for p in per_rank], dtype=np.float64)
+    fr = np.array([p[1] for p in per_rank], dtype=np.float64)
+    imb = dict(bp_max_over_mean=round(float(bp.max() / bp.mean()), 4), fragments_max_over_mean=round(float(fr.max() / fr.mean()), 4),
+               bp_per_rank=[int(x) for x in bp], fragments_per_rank=[int(x) for x in fr])
+    desc = ("configs[3]: %d tiles x 10 kb (L=%d), %d fragments (Poisson(%d) per tile), chunk list sharded across %d rank(s) by "
+            "sum(L) + 4 sum(F), sub-batches of <= %d chunks" % (nc, L, int(counts.sum()), F, world, a.sub_chunks))
+    return subs, desc, dict(scaling="strong", imbalance=imb, total_chunks=nc)
+
+
+def _concat(parts):
+    from nucleoatac_amd.packing import PackedChunks
+    if len(parts) == 1:
+        return parts[0]
+    offs = [np.zeros(1, np.int64)]
+    boffs = [np.zeros(1, np.int64)]
+    fo = bo = 0
+    for p in parts:
+        offs.append(p.frag_off[1:] + fo)
+        boffs.append(p.bias_off[1:] + bo)
+        fo += int(p.frag_off[-1])
+        bo += int(p.bias_off[-1])
+    return PackedChunks(chunk_start=np.concatenate([p.chunk_start for p in parts]),
+                        chunk_len=np.concatenate([p.chunk_len for p in parts]), frag_off=np.concatenate(offs),
+                        frag_lpos=np.concatenate([p.frag_lpos for p in parts]), frag_ilen=np.concatenate([p.frag_ilen for p in parts]),
+                        bias_off=np.concatenate(boffs), bias_log=np.concatenate([p.bias_log for p in parts]))
+
+
+def setup_ctx(device, par, sizes, nucp, nfrp):
+    from nucleoatac_amd.device import Context
+    ctx = Context(device)
+    ctx.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
+    ctx.set_sizes(sizes)
+    ctx.set_occ_model(nucp, nfrp, step=5, flank=60)
+    return ctx
+
+
+def run_stages(batch):
+    batch.run_nuc(10)
+    batch.run_occ()
+    batch.run_ins(0, 2000)
+    # candidate search (call_peaks, sep 25 / order 12 / boundary 60 as NucChunk.findAllNucs) + LR / var / z, on the device;
+    # like the per-base tracks, the candidate arrays stay resident in HBM inside the timed region
+    return batch.run_peaks(min_signal=0, sep=25, boundary=60, order=12, download=False)
+
+
+# ------------------------------------------------------------------------------------------------ host-to-host pipeline
+def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_threads):
+    """SURVEY.md section 8(d)'s boundary: packed inputs in host memory -> per-base tracks back in host memory.  The chunk list is
+    cut into sub-batches; `n_threads` host threads, each with its own natac context (stream) on the same GPU, take them in
+    turn: upload (from pinned memory), all stages, download of the five default output tracks + the candidate arrays into
+    pinned memory.  The contexts' uploads, kernels and downloads overlap on the device; no hipMalloc / hipFree happens in
+    the steady state (the library's block pool).  One untimed pass (allocations) precedes `steps` timed ones."""
+    from nucleoatac_amd import _lib as L
+    from nucleoatac_amd.device import pinned_copy, pinned_empty
+    from nucleoatac_amd.packing import PackedChunks
+    nsub = max(1, (pk.n_chunks + sub_chunks - 1) // sub_chunks)
+    subs = []
+    for i in range(nsub):
+        s = pk.subset(i * sub_chunks, min(pk.n_chunks, (i + 1) * sub_chunks))
+        subs.append(PackedChunks(chunk_start=s.chunk_start, chunk_len=s.chunk_len, frag_off=s.frag_off,
+                                 frag_lpos=pinned_copy(s.frag_lpos), frag_ilen=pinned_copy(s.frag_ilen), bias_off=s.bias_off,
+                                 bias_log=pinned_copy(s.bias_log)))
+    tracks = [getattr(L, t) for t in H2H_TRACKS]
+    max_bp = max(s.total_bp for s in subs)
+    state = dict(err=None)
+    gate = threading.Barrier(n_threads + 1)
+    acct = [[0, 0] for _ in range(n_threads)]
+
+    def worker(tid):
+        try:
+            ctx = setup_ctx(device, par, sizes, nucp, nfrp)
+            outs = [pinned_empty(max_bp, np.float64) for _ in tracks]
+
+            def one(k, count):
+                s = subs[k]
+                b = ctx.upload(s)
+                n = run_stages(b)
+                for t, o in zip(tracks, outs):
+                    b.track(t, out=o[:s.total_bp])
+                cand = b.download_peaks(n)
+                b.free()
+                assert len(cand[0]) == n
+                if count:
+                    acct[tid][0] += len(tracks) * 8 * s.total_bp + n * 32
+                    acct[tid][1] += s.frag_lpos.nbytes + s.frag_ilen.nbytes + s.bias_log.nbytes
+
+            for k in range(tid, nsub, n_threads):            # untimed pass: allocations, pool warm-up
+                one(k, False)
+            ctx.sync()
+            gate.wait()                                      # all contexts warm: the clock starts
+            for _ in range(steps):
+                for k in range(tid, nsub, n_threads):
+                    one(k, True)
+            ctx.sync()
+            gate.wait()                                      # all done: the clock stops
+            ctx.close()
+        except Exception as e:      # pragma: no cover
+            state["err"] = e
+            gate.abort()
+            raise
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(n_threads)]
+    for t in th:
+        t.start()
+    try:
+        gate.wait()
+        t0 = time.perf_counter()
+        gate.wait()
+        dt = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        dt = float("nan")
+    for t in th:
+        t.join()
+    if state["err"] is not None:
+        raise state["err"]
+    down = sum(x[0] for x in acct)
+    up = sum(x[1] for x in acct)
+    return dict(host_to_host_mbp_s=round(pk.total_bp * steps / dt / 1e6, 2), seconds=round(dt, 3), steps=steps,
+                sub_batches=nsub, chunks_per_sub_batch=sub_chunks, contexts=n_threads,
+                tracks_downloaded=list(H2H_TRACKS) + ["candidates (chunk, pos, lr, var, z)"],
+                gb_down_per_step=round(down / steps / 1e9, 3), gb_up_per_step=round(up / steps / 1e9, 3),
+                pcie_gbs_down=round(down / dt / 1e9, 2), pcie_gbs_up=round(up / dt / 1e9, 2),
+                note="pinned host buffers both ways; uploads, kernels and downloads of different sub-batches overlap")
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -202,38 +384,39 @@ def main():
             dist.init_process_group(backend=a.dist_backend)
 
     from nucleoatac_amd import _lib as L
-    from nucleoatac_amd.device import Context
-    from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions, synth_size_distribution
+    from nucleoatac_amd.synth import synth_occ_distributions, synth_size_distribution
 
     par = np.load(os.path.join(ROOT, "tests", "golden", "params_example.npz"))
     sizes = synth_size_distribution(251)
     nucp, nfrp = synth_occ_distributions(251)
     t_gen = time.time()
-    pk = make_synthetic_chunks(a.chunks, a.chunk_len, a.frags_per_chunk, seed=a.seed + 1000 * rank)
+    subs, desc, info = make_workload(a, rank, world)
     t_gen = time.time() - t_gen
+    my_bp = sum(s.total_bp for s in subs)
+    my_frags = sum(s.n_frags for s in subs)
     # CPU baseline first (rank 0, N=1 only): it forks worker processes, so run it before the HIP context exists
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(pk, par, sizes, nucp, nfrp, a.cpu_chunks, a.cpu_literal_chunks)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and subs:
+        cpu = cpu_baseline(subs[0], par, sizes, nucp, nfrp, a.cpu_chunks, a.cpu_literal_chunks)
 
-    ctx = Context(local_rank)
-    ctx.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
-    ctx.set_sizes(sizes)
-    ctx.set_occ_model(nucp, nfrp, step=5, flank=60)
+    ctx = setup_ctx(local_rank, par, sizes, nucp, nfrp)
     t_up = time.time()
-    batch = ctx.upload(pk)
+    batches = [ctx.upload(s) for s in subs]
     ctx.sync()
     t_up = time.time() - t_up
-
+    # outputs of every sub-batch stay resident if they fit (~175 B per base incl. internal arrays); else they are recycled
+    mem = ctx.device_info()["mem_bytes"]
+    recycle = len(batches) > 1 and my_bp * 175.0 > 0.8 * mem
     n_cand = [0]
+    last_n = [0] * len(batches)
 
     def step():
-        batch.run_nuc(10)
-        batch.run_occ()
-        batch.run_ins(0, 2000)
-        # candidate search (call_peaks, sep 25 / order 12 / boundary 60 as NucChunk.findAllNucs) + LR / var / z, on the device
-        # like the per-base tracks, the candidate arrays stay resident in HBM inside the timed region
-        n_cand[0] = batch.run_peaks(min_signal=0, sep=25, boundary=60, order=12, download=False)
+        n_cand[0] = 0
+        for i, b in enumerate(batches):
+            last_n[i] = run_stages(b)
+            n_cand[0] += last_n[i]
+            if recycle:
+                b.release_outputs()
 
     on_gpu = dist is not None and a.dist_backend == "nccl"
 
@@ -259,64 +442,87 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
+    total_bp, total_frags, total_cand = my_bp, my_frags, n_cand[0]
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dev = "cuda" if on_gpu else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tot = torch.tensor([my_bp, my_frags, n_cand[0]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bp, total_frags, total_cand = (int(x) for x in tot.tolist())
     prof = ctx.profile()
-    total_bp = pk.total_bp * world
     ms_per_step = dt / a.steps * 1e3
     value = total_bp * a.steps / dt / 1e6
 
-    # PCIe-inclusive figure (never `value`): one upload + one download of the per-base tracks that the writers consume
-    t_dn = time.time()
-    for t in (L.T_NORM, L.T_SMOOTH, L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER):
-        batch.track(t)
-    cand = batch.download_peaks(n_cand[0])
-    t_dn = time.time() - t_dn
-    assert len(cand[0]) == n_cand[0] and np.isfinite(cand[4][:1000]).any()
+    # PCIe-inclusive figure of a resident batch (never `value`): one upload + one download of the per-base tracks that the
+    # writers consume, pageable memory, no overlap -- the pipelined host-to-host rate follows below
+    t_dn = None
+    if not recycle and batches:
+        t_dn = time.time()
+        for t in (L.T_NORM, L.T_SMOOTH, L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER):
+            batches[0].track(t)
+        cand = batches[0].download_peaks(last_n[0])
+        t_dn = time.time() - t_dn
+        assert np.isfinite(cand[4][:1000]).any()
+    for b in batches:
+        b.free()
+    h2h = None
+    if rank == 0 and world == 1 and not a.no_h2h and a.workload != "cfg4":
+        ctx.close()
+        ctx = None
+        h2h = host_to_host(subs[0], local_rank, par, sizes, nucp, nfrp, a.steps, a.h2h_sub, a.h2h_threads)
 
     if rank == 0:
         # roofline of the dominant kernel class of this run (largest HIP-event time on the launch stream)
         dom = max(("background", "occ_mle", "candidates"), key=lambda k: prof[k][0])
         dom_ms, dom_n = prof[dom]
         dom_avg_s = (dom_ms / max(1, dom_n)) / 1e3
-        traffic = pmc_traffic_bytes(KERNEL_SYMBOL[dom])
-        alg_bytes = ALG_BYTES_PER_BP * pk.total_bp
+        launches_per_step = max(1, len(batches))
+        bp_per_launch = my_bp / launches_per_step
+        traffic = pmc_traffic_bytes(KERNEL_SYMBOL[dom]) if a.workload == "cfg3" else None
+        alg_bytes = ALG_BYTES_PER_BP[a.workload] * bp_per_launch
         achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         bg_ms, bg_n = prof["background"]
         bg_avg_s = (bg_ms / max(1, bg_n)) / 1e3
-        direct_tflops = FLOP_PER_BP_BG * pk.total_bp / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
-        fft_tflops = FLOP_PER_BP_BG_FFT * pk.total_bp / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
+        direct_tflops = FLOP_PER_BP_BG * bp_per_launch / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
+        fft_tflops = FLOP_PER_BP_BG_FFT * bp_per_launch / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
+        step_gbs = ALG_BYTES_PER_BP[a.workload] * my_bp / (dt / a.steps) / 1e9
         out = {
             "metric": "Mbp/s through occ+nuc signal pipeline", "value": round(value, 3), "unit": "Mbp/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2]: synthetic %d windows x 2 kb (L=%d after slop), %d fragments, default VMat "
-                                   "146x121, 1 GPU-shard per rank" % (a.chunks, a.chunk_len, pk.n_frags),
-                       "chunks_per_gpu": a.chunks, "chunk_len": a.chunk_len, "fragments_per_gpu": pk.n_frags,
-                       "candidates_per_gpu": int(n_cand[0]), "sharding": "chunk list split across ranks, no collective"},
+            "higher_is_better": True, "scaling": info["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "chunks_total": info["total_chunks"], "chunks_this_rank": int(sum(s.n_chunks for s in subs)),
+                       "bp_total": total_bp, "fragments_total": total_frags, "candidates_per_step": total_cand,
+                       "sub_batches_this_rank": len(subs), "outputs_recycled": bool(recycle),
+                       "sharding": "chunk list split across ranks, no collective", "shard_imbalance": info["imbalance"]},
             "roofline": {"bound": "hbm", "kernel": KERNEL_LABEL[dom],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(dom_avg_s * 1e3, 3), "launches": int(dom_n),
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "the path is fp64-VALU / LDS bound, not HBM bound (SURVEY 8d: ~5e4 flop/base against 79.8 B/base); "
+                         "whole_step": {"algorithmic_gb": round(ALG_BYTES_PER_BP[a.workload] * my_bp / 1e9, 3),
+                                        "achieved_gbs": round(step_gbs, 2), "frac": round(step_gbs / HBM_PEAK_GBS, 5)},
+                         "note": "the path is fp64-VALU / LDS bound, not HBM bound (SURVEY 8d: ~5e4 flop/base against ~80 B/base); "
                                  "background_fp64 gives the arithmetic rate of the background kernel",
                          "background_fp64": {"avg_launch_ms": round(bg_avg_s * 1e3, 3),
                                              "direct_equivalent_tflops": round(direct_tflops, 2),
                                              "executed_tflops": round(fft_tflops, 2), "peak": FP64_PEAK_TFLOPS,
                                              "unit": "TFLOP/s", "frac_executed": round(fft_tflops / FP64_PEAK_TFLOPS, 4)}},
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
-            "host": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2), "download_5_tracks_and_candidates_s": round(t_dn, 2),
-                     "pcie_inclusive_mbp_s": round(pk.total_bp / (dt / a.steps + t_up + t_dn) / 1e6, 2)},
+            "host": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2),
+                     "download_5_tracks_and_candidates_s": None if t_dn is None else round(t_dn, 2),
+                     "pcie_inclusive_mbp_s_no_overlap": None if t_dn is None else round(
+                         subs[0].total_bp / (dt / a.steps / max(1, len(subs)) + t_up / max(1, len(subs)) + t_dn) / 1e6, 2)},
         }
+        if h2h is not None:
+            out["host_to_host"] = h2h
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    batch.free()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -111,6 +111,10 @@ int natac_batch_create(natac_ctx *ctx, int32_t n_chunks, const int32_t *chunk_le
                        const double *bias_log, int32_t bias_left, int32_t bias_right, natac_batch **out);
 void natac_batch_free(natac_batch *b);
 int natac_batch_info(natac_batch *b, int64_t *total_bp, int64_t *total_grid, int64_t *n_frags);
+/* Drop every output of the batch (per-base tracks, grid arrays, candidate / peak arrays) but keep its packed inputs resident:
+ * for workloads whose outputs do not fit in HBM all at once (BASELINE configs[3] on one GPU: 3 Gbp x ~160 B/bp); the blocks go
+ * back to the library's pool and are reused by the next batch's stages. */
+int natac_batch_release_outputs(natac_batch *b);
 
 /* NucChunk.process up to smoothSignal (NucleosomeCalling.py:328-334): fills NUC_COV, NFR_COV, RAW,
  * BACKGROUND, NORM, SMOOTH.  smooth_sd = NucParameters.smooth_sd (cli default 10).  Asynchronous. */
@@ -249,6 +253,15 @@ void natac_bam_close(natac_bam *bam);
 int natac_bam_counts(natac_bam *bam, int32_t *n_refs, int64_t *n_records, int64_t *n_kept);
 int natac_bam_ref_info(natac_bam *bam, int32_t ref, char *name, size_t name_len, int64_t *length, int64_t *n_reads);
 int natac_bam_ref_reads(natac_bam *bam, int32_t ref, int64_t *pos, int64_t *tlen, int64_t n);
+
+/* ---- pinned host memory + device memory pool ---------------------------------------------------------- */
+/* Page-locked host buffers (hipHostMalloc): uploads from / downloads into them run at full PCIe rate and asynchronously to
+ * the host.  Any caller-owned host pointer of this ABI may be pinned or pageable; results are identical. */
+int natac_host_alloc(size_t bytes, void **out);
+int natac_host_free(void *p);
+/* The library keeps freed device blocks in a per-device cache (hipMalloc / hipFree synchronise the device, which would
+ * stall other contexts' overlapping copies); this returns every cached block to the driver. */
+int natac_pool_trim(void);
 
 /* ---- profiling (HIP events on the context's stream) ------------------------------------ */
 int natac_profile_enable(natac_ctx *ctx, int on);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "natac_batch_create": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _pp]),
     "natac_batch_free": (None, [_vp]),
     "natac_batch_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "natac_batch_release_outputs": (C.c_int, [_vp]),
     "natac_run_nuc": (C.c_int, [_vp, _f64]),
     "natac_run_occ": (C.c_int, [_vp]),
     "natac_run_ins": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -71,6 +72,9 @@ SIGNATURES = {
     "natac_bam_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
     "natac_bam_ref_info": (C.c_int, [_vp, _i32, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(_i64)]),
     "natac_bam_ref_reads": (C.c_int, [_vp, _i32, _vp, _vp, _i64]),
+    "natac_host_alloc": (C.c_int, [_sz, _pp]),
+    "natac_host_free": (C.c_int, [_vp]),
+    "natac_pool_trim": (C.c_int, []),
     "natac_profile_enable": (C.c_int, [_vp, C.c_int]),
     "natac_profile_get": (C.c_int, [_vp, C.c_int, C.POINTER(_f64), C.POINTER(_i64)]),
     "natac_profile_reset": (C.c_int, [_vp]),

@@ -162,11 +162,71 @@ static void prof_collect(natac_ctx *c) {
     c->pending.clear();
 }
 
+// Device memory goes through a small caching pool (per device, shared by the contexts of a process, thread-safe): a freed block
+// is kept and handed to the next request of (nearly) the same size.  Batches of similar shape follow each other in every
+// driver (run_occ / run_nuc / bench), and hipMalloc / hipFree synchronise the whole device -- which would also stall the
+// streams of OTHER contexts that overlap their copies with this one's kernels.  Every use of a block is ordered on its
+// context's stream and a batch is only freed after that stream has drained (natac_batch_free), so reuse is safe.
+// NATAC_POOL=0 disables the cache; natac_pool_trim() returns the cached blocks to the driver.
+#include <mutex>
+#include <map>
+#include <unordered_map>
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks[16];          // per device
+    std::unordered_map<void *, std::pair<int, size_t>> live;  // ptr -> (device, bytes)
+    bool enabled = true;
+    DevPool() { const char *e = getenv("NATAC_POOL"); enabled = !(e && e[0] == '0'); }
+    void trim_locked(int dev) {
+        for (auto &kv : free_blocks[dev]) (void)hipFree(kv.second);
+        free_blocks[dev].clear();
+    }
+};
+static DevPool g_pool;
+
+static hipError_t pool_alloc(void **p, size_t bytes) {
+    *p = nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (g_pool.enabled) {
+        auto it = g_pool.free_blocks[dev].lower_bound(bytes);
+        if (it != g_pool.free_blocks[dev].end() && it->first <= bytes + bytes / 8 + 4096) {
+            *p = it->second;
+            g_pool.live[*p] = {dev, it->first};
+            g_pool.free_blocks[dev].erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && !g_pool.free_blocks[dev].empty()) {      // give the cached blocks back and retry
+        (void)hipGetLastError();
+        g_pool.trim_locked(dev);
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) g_pool.live[*p] = {dev, bytes};
+    return e;
+}
+
+static void dev_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.live.find(p);
+    if (it == g_pool.live.end()) { (void)hipFree(p); return; }
+    const int dev = it->second.first;
+    const size_t bytes = it->second.second;
+    g_pool.live.erase(it);
+    if (g_pool.enabled) g_pool.free_blocks[dev].insert({bytes, p});
+    else (void)hipFree(p);
+}
+
 template <class T>
 static int dev_alloc(T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
-    HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+    HIPCHK(pool_alloc((void **)p, n * sizeof(T)));
     return NATAC_OK;
 }
 template <class T>
@@ -175,9 +235,6 @@ static int dev_upload(natac_ctx *c, T **p, const T *src, size_t n) {
     if (rc) return rc;
     if (n) HIPCHK(hipMemcpyAsync(*p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     return NATAC_OK;
-}
-static void dev_free(void *p) {
-    if (p) (void)hipFree(p);
 }
 
 // pick the per-lane output count G of the background kernel: minimise idle lanes (sum of tile widths) with a small
@@ -603,6 +660,24 @@ void natac_batch_free(natac_batch *b) {
     delete b;
 }
 
+int natac_batch_release_outputs(natac_batch *b) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_all(c));
+    prof_collect(c);
+    for (int i = 0; i < NATAC_T_COUNT; ++i) { dev_free(b->d_track[i]); b->d_track[i] = nullptr; }
+    for (int i = 0; i < 3; ++i) { dev_free(b->d_grid[i]); b->d_grid[i] = nullptr; }
+    dev_free(b->d_bnum); dev_free(b->d_bcov); dev_free(b->d_gsum); dev_free(b->d_pkflag); dev_free(b->d_pk_out);
+    dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos); dev_free(b->d_opk_vals); dev_free(b->d_opk_keep); dev_free(b->d_nuc_dist);
+    b->d_bnum = b->d_bcov = b->d_gsum = b->d_pk_out = b->d_opk_vals = b->d_nuc_dist = nullptr;
+    b->d_pkflag = nullptr;
+    b->d_pk_chunk = b->d_pk_pos = b->d_opk_keep = nullptr;
+    b->pk_cap = 0; b->pk_n = -1; b->opk_cap = 0; b->opk_n = -1;
+    b->nuc_done = b->occ_done = b->ins_done = false;
+    return NATAC_OK;     // offset / tile tables stay: the next natac_run_* only re-allocates the arrays
+}
+
 int natac_batch_info(natac_batch *b, int64_t *total_bp, int64_t *total_grid, int64_t *n_frags) {
     if (!b) return fail(NATAC_E_ARG, "batch is NULL");
     if (total_bp) *total_bp = b->total_bp;
@@ -738,6 +813,8 @@ int natac_run_occ(natac_batch *b) {
         b->grid_step = c->step;
         b->grid_half = c->halfstep;
     }
+    for (int i = 0; i < 3; ++i)      // released by natac_batch_release_outputs
+        if (!b->d_grid[i] && (rc = dev_alloc(&b->d_grid[i], (size_t)b->total_grid))) return rc;
     for (int t : {NATAC_T_OCC, NATAC_T_OCC_LOWER, NATAC_T_OCC_UPPER, NATAC_T_OCC_COV, NATAC_T_OCC_PREFILL})
         if ((rc = ensure_track(b, t))) return rc;
     const ChunkTable ct = make_table(b);
@@ -746,7 +823,7 @@ int natac_run_occ(natac_batch *b) {
     const bool fast = c->occ_fast_ok && !c->occ_force_general;
     if (fast) {   // per-block sum buffers + tile table of natac_occ_gsum (geometry: step / flank of the model)
         const int Q = 2 * c->flank / c->step;
-        if (b->gs_Q != Q || !b->d_gsum) {
+        if (b->gs_Q != Q) {
             HIPCHK(sync_all(c));
             std::vector<long long> bo((size_t)b->nc + 1);
             std::vector<int2> tiles;
@@ -762,10 +839,10 @@ int natac_run_occ(natac_batch *b) {
             if ((rc = dev_upload(c, &b->d_tiles_gs, tiles.data(), tiles.size()))) return rc;
             HIPCHK(sync_all(c));
             b->n_tiles_gs = (int)tiles.size();
-            if ((rc = dev_alloc(&b->d_gsum, (size_t)4 * b->total_blocks))) return rc;
             if ((rc = dev_alloc(&b->d_defer, (size_t)b->n_tiles_occ + 1))) return rc;
             b->gs_Q = Q;
         }
+        if (!b->d_gsum && (rc = dev_alloc(&b->d_gsum, (size_t)4 * b->total_blocks))) return rc;
     }
     prof_begin(c, NATAC_K_OCC_MLE, ev, c->stream2);
     {
@@ -1567,6 +1644,36 @@ int natac_bam_ref_reads(natac_bam *bam, int32_t ref, int64_t *pos, int64_t *tlen
         std::memcpy(pos, r.pos.data(), (size_t)n * sizeof(int64_t));
         std::memcpy(tlen, r.tlen.data(), (size_t)n * sizeof(int64_t));
     }
+    return NATAC_OK;
+}
+
+/* ---------------- pinned host memory + pool control ---------------- */
+
+int natac_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(NATAC_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (bytes == 0) bytes = 1;
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return NATAC_OK;
+}
+
+int natac_host_free(void *p) {
+    if (!p) return NATAC_OK;
+    HIPCHK(hipHostFree(p));
+    return NATAC_OK;
+}
+
+int natac_pool_trim(void) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < 16; ++d) {
+        if (g_pool.free_blocks[d].empty()) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        g_pool.trim_locked(d);
+    }
+    (void)hipSetDevice(cur);
     return NATAC_OK;
 }
 

@@ -20,6 +20,58 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+class _PinnedOwner(object):
+    """keeps a hipHostMalloc block alive for the numpy arrays that view it"""
+
+    def __init__(self, nbytes):
+        self._lib = L.load()
+        p = C.c_void_p()
+        L.check(self._lib.natac_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.natac_host_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory (natac_host_alloc): PCIe transfers to / from it run at full rate"""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if not np.isscalar(shape) else int(shape)
+    owner = _PinnedOwner(max(1, n * dt.itemsize))
+    buf = (C.c_char * owner.nbytes).from_address(owner.ptr)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    return _attach_owner(arr, owner)
+
+
+class _PinnedArray(np.ndarray):
+    """ndarray subclass that carries the owner of its pinned memory"""
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
+def _attach_owner(arr, owner):
+    out = arr.view(_PinnedArray)
+    out._owner = owner
+    return out
+
+
+def pinned_copy(a):
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
+def pool_trim():
+    L.check(L.load().natac_pool_trim())
+
+
 class Context(object):
     """one HIP device + stream (natac_ctx)"""
 
@@ -267,6 +319,10 @@ class DeviceBatch(object):
         except Exception:
             pass
 
+    def release_outputs(self):
+        """free every output array of the batch, keep the packed inputs in HBM (natac_batch_release_outputs)"""
+        L.check(self._lib.natac_batch_release_outputs(self._h))
+
     def run_nuc(self, smooth_sd=10):
         L.check(self._lib.natac_run_nuc(self._h, float(smooth_sd)))
 
@@ -338,10 +394,13 @@ class DeviceBatch(object):
         L.check(self._lib.natac_download_nuc_dist(self._h, _ptr(nd), nd.nbytes))
         return cc, cp, occ, lo, up, rd, keep, nd
 
-    def track(self, t):
-        """download one per-base track (concatenated over chunks)"""
+    def track(self, t, out=None):
+        """download one per-base track (concatenated over chunks); `out`: destination array (e.g. pinned_empty)"""
         dt = np.int32 if t == L.T_INS else np.float64
-        out = np.empty(self.total_bp, dtype=dt)
+        if out is None:
+            out = np.empty(self.total_bp, dtype=dt)
+        elif out.dtype != dt or out.size != self.total_bp or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a contiguous %s array of %d elements" % (dt.__name__, self.total_bp))
         L.check(self._lib.natac_batch_download(self._h, int(t), _ptr(out), out.nbytes))
         return out
 

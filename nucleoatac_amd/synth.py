@@ -35,17 +35,33 @@ def synth_centres(rng, n, span, period=190, band=20, enrich=5.0):
     return np.where(in_band, bc, bg).astype(np.int64)
 
 
+def fragment_counts(n_chunks, frags_per_chunk, seed=0, poisson=True, hot_frac=0.0, hot_mult=10):
+    """per-chunk fragment counts of a synthetic chunk set: Poisson around frags_per_chunk, with a fraction `hot_frac` of the
+    chunks `hot_mult` times denser (the heavy tail of real ATAC peak sets).  Cheap (one number per chunk), so every rank of a
+    sharded run can draw the same vector and balance the chunk list before generating only its own shard."""
+    rng = np.random.default_rng([int(seed), 0x636e74])
+    lam = np.full(int(n_chunks), float(frags_per_chunk))
+    if hot_frac > 0:
+        lam[rng.random(int(n_chunks)) < hot_frac] *= hot_mult
+    return (rng.poisson(lam) if poisson else np.rint(lam)).astype(np.int64)
+
+
 def make_synthetic_chunks(n_chunks, chunk_len, frags_per_chunk, seed=0, with_bias=True, flank=126,
-                          genome_gap=1000, poisson=False):
+                          genome_gap=1000, poisson=False, counts=None, first_chunk=0):
     """PackedChunks with `n_chunks` chunks of length `chunk_len` (length AFTER slop+merge).
 
     frags_per_chunk fragments are attached to every chunk (Poisson-distributed when
-    poisson=True -- heavy-ish tail for load-balance tests).
+    poisson=True -- heavy-ish tail for load-balance tests); `counts` gives the per-chunk numbers explicitly.
+    `first_chunk` offsets the chunk start coordinates (a block of a larger, sharded chunk list).
     """
     rng = np.random.default_rng(seed)
     nc = int(n_chunks)
     L = int(chunk_len)
-    if poisson:
+    if counts is not None:
+        per = np.asarray(counts, dtype=np.int64)
+        assert per.shape == (nc,)
+        poisson = True
+    elif poisson:
         per = rng.poisson(frags_per_chunk, size=nc).astype(np.int64)
     else:
         per = np.full(nc, int(frags_per_chunk), dtype=np.int64)
@@ -64,7 +80,7 @@ def make_synthetic_chunks(n_chunks, chunk_len, frags_per_chunk, seed=0, with_bia
         F = int(frags_per_chunk)
         order = (np.argsort(c.reshape(nc, F), axis=1, kind="stable") + (np.arange(nc, dtype=np.int64) * F)[:, None]).ravel()
     lpos, n = lpos[order], n[order]
-    chunk_start = (np.arange(nc, dtype=np.int64) * (L + genome_gap)) + 10000
+    chunk_start = ((np.arange(nc, dtype=np.int64) + int(first_chunk)) * (L + genome_gap)) + 10000
     bias_off = bias_log = None
     if with_bias:
         per_b = L + BIAS_LEFT + BIAS_RIGHT

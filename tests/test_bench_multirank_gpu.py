@@ -27,8 +27,8 @@ def test_two_ranks_share_device():
 
 
 def test_single_rank_default_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chunks", "3000", "--cpu-chunks", "16"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chunks", "3000", "--cpu-chunks", "32",
+                          "--cpu-literal-chunks", "16", "--h2h-sub", "1000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -37,3 +37,28 @@ def test_single_rank_default_contract():
     assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["higher_is_better"] is True
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
+    assert d["cpu_baseline"]["literal"]["chunks"] == 16 and d["cpu_baseline"]["optimised"]["chunks"] == 32
+    h = d["host_to_host"]            # pipelined host -> host rate: pinned buffers, 3 contexts, sub-batches of 1000 chunks
+    assert h["host_to_host_mbp_s"] > 0 and h["sub_batches"] == 3 and h["contexts"] == 3 and h["gb_down_per_step"] > 0
+
+
+def test_cfg4_strong_scaling_two_ranks_share_device():
+    """--workload cfg4 (BASELINE configs[3] shape, scaled down): the chunk list is sharded by balanced_ranges, every rank
+    generates only its shard, sub-batches, one JSON line with the per-rank imbalance; the sharded total equals 1 rank's"""
+    common = ["--workload", "cfg4", "--chunks", "1500", "--sub-chunks", "400", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-device"] + common
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d2 = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][-1])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d1 = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert d2["scaling"] == "strong" and d1["scaling"] == "strong" and d2["n_gpus"] == 2
+    c1, c2 = d1["config"], d2["config"]
+    assert c1["bp_total"] == c2["bp_total"] == 1500 * 10120 and c1["fragments_total"] == c2["fragments_total"]
+    assert c1["candidates_per_step"] == c2["candidates_per_step"]          # same chunks, same results, however they are sharded
+    imb = c2["shard_imbalance"]
+    assert len(imb["bp_per_rank"]) == 2 and sum(imb["bp_per_rank"]) == c2["bp_total"] and imb["bp_max_over_mean"] < 1.05
+    assert c1["sub_batches_this_rank"] == 4 and c2["sub_batches_this_rank"] == 2
