@@ -39,27 +39,15 @@ class _PinnedOwner(object):
 
 
 def pinned_empty(shape, dtype=np.float64):
-    """numpy array in page-locked host memory (natac_host_alloc): PCIe transfers to / from it run at full rate"""
+    """numpy array in page-locked host memory (natac_host_alloc): PCIe transfers to / from it run at full rate.  The block
+    is released when the last array viewing it dies: numpy collapses `.base` chains to the buffer exporter, so the owner is
+    attached to that exporter (the ctypes array), not to an ndarray subclass."""
     dt = np.dtype(dtype)
     n = int(np.prod(shape)) if not np.isscalar(shape) else int(shape)
     owner = _PinnedOwner(max(1, n * dt.itemsize))
     buf = (C.c_char * owner.nbytes).from_address(owner.ptr)
-    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
-    return _attach_owner(arr, owner)
-
-
-class _PinnedArray(np.ndarray):
-    """ndarray subclass that carries the owner of its pinned memory"""
-    _owner = None
-
-    def __array_finalize__(self, obj):
-        self._owner = getattr(obj, "_owner", None)
-
-
-def _attach_owner(arr, owner):
-    out = arr.view(_PinnedArray)
-    out._owner = owner
-    return out
+    buf._natac_owner = owner
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
 
 
 def pinned_copy(a):
