@@ -64,7 +64,7 @@ struct natac_ctx {
     // fast occupancy path (natac_occ_fast.hpp): model tables + eligibility
     double *d_occ_q4 = nullptr, *d_occ_rho = nullptr;
     int occ_nm = 0;
-    bool occ_fast_ok = false, occ_force_general = false;
+    bool occ_fast_ok = false, occ_force_general = false, occ_rn16 = false;
     double occ_b_floor = 0;          // see OccModelDev::b_floor
     // gaussian windows (cached by (M, sd))
     double *d_win_nuc = nullptr, *d_win_occ = nullptr;
@@ -93,7 +93,7 @@ struct natac_batch {
     std::vector<long long> h_out_off, h_grid_off;
     int *d_len = nullptr, *d_lpos = nullptr, *d_ilen = nullptr, *d_centre = nullptr, *d_status = nullptr;
     long long *d_frag_off = nullptr, *d_bias_off = nullptr, *d_out_off = nullptr, *d_grid_off = nullptr;
-    double *d_bias = nullptr;
+    double *d_bias = nullptr, *d_ebias = nullptr;
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
     int ranges256_w = -1;
     int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;   // bgG: lanes' output count of the direct kernel, -1 = FFT tiles
@@ -112,7 +112,7 @@ struct natac_batch {
     int nd_upper = 0;
     double *d_track[NATAC_T_COUNT] = {nullptr};
     double *d_grid[3] = {nullptr, nullptr, nullptr};
-    bool nuc_done = false, occ_done = false, ins_done = false;
+    bool nuc_done = false, occ_done = false, ins_done = false, cov_from_nuc = false, ebias_fresh = false;
     // device-side candidate search
     double *d_cmin = nullptr, *d_jitter = nullptr, *d_pk_out = nullptr;
     unsigned char *d_pkflag = nullptr;
@@ -458,6 +458,14 @@ int natac_set_occ_model(natac_ctx *c, const double *nuc_probs, const double *nfr
         }
         ok = ok && anynuc && rmax <= rmin * std::ldexp(1.0, 200) && pmin >= std::ldexp(1.0, -200);
         c->occ_fast_ok = ok;
+        // a likelihood factor 1 + alpha (rho kappa - 1) lies in [1 - alpha, 1 + rmax / rmin] with 1 - alpha >= the grid's
+        // smallest positive value (or exactly 0 at alpha = 1): 16 of them between two renormalisations stay far inside the
+        // fp64 range when rmax / rmin < 2^50 and that smallest step is > 2^-50
+        {
+            double amin = 1.0;
+            for (int a = 0; ok && a < n_alpha; ++a) if (1 - alphas[a] > 0) amin = std::min(amin, 1 - alphas[a]);
+            c->occ_rn16 = ok && rmax <= rmin * std::ldexp(1.0, 50) && amin >= std::ldexp(1.0, -50);
+        }
         if (ok) {
             c->occ_nm = (upper + 1) / 2;
             std::vector<double> q4((size_t)4 * c->occ_nm, 0.0);
@@ -547,10 +555,23 @@ static int ensure_window(natac_ctx *c, double **slot, int *slotM, double *slotsd
     return NATAC_OK;
 }
 
+// E = exp(bias) of the batch on `st`: part of the work of the stage that needs it.  natac_run_nuc always computes it;
+// natac_run_occ reuses the array natac_run_nuc left since the last natac_run_occ (once per nuc + occ pass), else computes it.
+static int run_exp_bias(natac_batch *b, hipStream_t st, bool from_occ) {
+    if (!b->d_bias) return NATAC_OK;
+    if (from_occ && b->ebias_fresh) { b->ebias_fresh = false; return NATAC_OK; }
+    b->ebias_fresh = !from_occ;
+    int rc;
+    if (!b->d_ebias && (rc = dev_alloc(&b->d_ebias, (size_t)b->nb))) return rc;
+    const int blocks = (int)std::min<long long>((b->nb + 255) / 256, 16384);
+    hipLaunchKernelGGL(natac_exp_bias, dim3(blocks), dim3(256), 0, st, b->d_bias, b->d_ebias, b->nb);
+    return NATAC_OK;
+}
+
 static ChunkTable make_table(natac_batch *b) {
     ChunkTable t;
     t.nc = b->nc; t.chunk_len = b->d_len; t.frag_off = b->d_frag_off; t.lpos = b->d_lpos; t.ilen = b->d_ilen;
-    t.centre = b->d_centre; t.bias_off = b->d_bias_off; t.bias = b->d_bias; t.bias_left = b->bias_left;
+    t.centre = b->d_centre; t.bias_off = b->d_bias_off; t.bias = b->d_bias; t.ebias = b->d_ebias; t.bias_left = b->bias_left;
     t.bias_right = b->bias_right; t.out_off = b->d_out_off; t.grid_off = b->d_grid_off;
     return t;
 }
@@ -649,6 +670,7 @@ void natac_batch_free(natac_batch *b) {
     prof_collect(b->ctx);
     dev_free(b->d_len); dev_free(b->d_lpos); dev_free(b->d_ilen); dev_free(b->d_centre); dev_free(b->d_status);
     dev_free(b->d_frag_off); dev_free(b->d_bias_off); dev_free(b->d_out_off); dev_free(b->d_grid_off); dev_free(b->d_bias);
+    dev_free(b->d_ebias);
     dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
     dev_free(b->d_cmin); dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_pkflag); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
@@ -674,7 +696,7 @@ int natac_batch_release_outputs(natac_batch *b) {
     b->d_pkflag = nullptr;
     b->d_pk_chunk = b->d_pk_pos = b->d_opk_keep = nullptr;
     b->pk_cap = 0; b->pk_n = -1; b->opk_cap = 0; b->opk_n = -1;
-    b->nuc_done = b->occ_done = b->ins_done = false;
+    b->nuc_done = b->occ_done = b->ins_done = b->cov_from_nuc = false;
     return NATAC_OK;     // offset / tile tables stay: the next natac_run_* only re-allocates the arrays
 }
 
@@ -726,6 +748,7 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
             b->bgG = G;
         }
     }
+    if (!b->d_ebias && b->d_bias && (rc = dev_alloc(&b->d_ebias, (size_t)b->nb))) return rc;
     const ChunkTable ct = make_table(b);
     const VMatDev vm = make_vmat(c);
     natac_ctx::Ev ev;
@@ -736,10 +759,16 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
                            b->n_tiles256, c->vw, b->d_ranges256);
         b->ranges256_w = c->vw;
     }
+    // OccChunk.getCov = nuc_cov + nfr_cov when the occupancy model's window / size range are the V-plot's: written here too
+    const bool cov_too = c->have_occ && c->flank == c->vw && c->occ_upper == c->vupper;
+    if (cov_too && (rc = ensure_track(b, NATAC_T_OCC_COV))) return rc;
     hipLaunchKernelGGL(natac_frag_gather, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, b->d_ranges256, vm,
-                       b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_RAW]);
+                       b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_RAW],
+                       cov_too ? b->d_track[NATAC_T_OCC_COV] : nullptr);
+    b->cov_from_nuc = cov_too;
     prof_end(c, ev);
     prof_begin(c, NATAC_K_BACKGROUND, ev);
+    if ((rc = run_exp_bias(b, c->stream, false))) return rc;
     if (use_fft) {
         const int EW = FFT_N + ((vm.upper - 2) >> 1) + ((vm.upper - 1) >> 1);
         const size_t lds = ((size_t)((EW + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
@@ -817,6 +846,7 @@ int natac_run_occ(natac_batch *b) {
         if (!b->d_grid[i] && (rc = dev_alloc(&b->d_grid[i], (size_t)b->total_grid))) return rc;
     for (int t : {NATAC_T_OCC, NATAC_T_OCC_LOWER, NATAC_T_OCC_UPPER, NATAC_T_OCC_COV, NATAC_T_OCC_PREFILL})
         if ((rc = ensure_track(b, t))) return rc;
+    if (!b->d_ebias && b->d_bias && (rc = dev_alloc(&b->d_ebias, (size_t)b->nb))) return rc;
     const ChunkTable ct = make_table(b);
     const OccModelDev om = make_occ(c);
     natac_ctx::Ev ev;
@@ -870,11 +900,17 @@ int natac_run_occ(natac_batch *b) {
             if (lds_gs > 64 * 1024 || lds_od > 64 * 1024)
                 return fail(NATAC_E_ARG, "occupancy window too large for the device tile (flank=%d upper=%d)", c->flank, U);
             HIPCHK(hipMemsetAsync(b->d_defer, 0, sizeof(int), c->stream2));
+            if ((rc = run_exp_bias(b, c->stream2, true))) return rc;
             hipLaunchKernelGGL((natac_occ_gsum<5>), dim3(b->n_tiles_gs), dim3(256), lds_gs, c->stream2, ct, b->d_tiles_gs, of, b->d_blk_off,
                                b->total_blocks, b->d_gsum);
-            hipLaunchKernelGGL((natac_occ_decide<5>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream2, ct, b->d_tiles_occ,
-                               b->n_tiles_occ, b->d_ranges_occ, of, b->d_blk_off, b->total_blocks, b->d_gsum, b->d_grid[0], b->d_grid[1],
-                               b->d_grid[2], b->d_defer, b->d_defer + 1);
+            if (c->occ_rn16)
+                hipLaunchKernelGGL((natac_occ_decide<5, 16>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream2, ct,
+                                   b->d_tiles_occ, b->n_tiles_occ, b->d_ranges_occ, of, b->d_blk_off, b->total_blocks, b->d_gsum,
+                                   b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_defer, b->d_defer + 1);
+            else
+                hipLaunchKernelGGL((natac_occ_decide<5, 4>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream2, ct,
+                                   b->d_tiles_occ, b->n_tiles_occ, b->d_ranges_occ, of, b->d_blk_off, b->total_blocks, b->d_gsum,
+                                   b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_defer, b->d_defer + 1);
             d_count = b->d_defer;
             d_list = b->d_defer + 1;
             grid_general = (unsigned)std::min(b->n_tiles_occ, 2048);   // walks the deferred list (normally empty)
@@ -898,7 +934,9 @@ int natac_run_occ(natac_batch *b) {
         hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream2, ct, b->d_tiles256, om, c->d_win_occ, M,
                            b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_track[NATAC_T_OCC_PREFILL],
                            b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER]);
-        if (b->nuc_done && c->flank == b->nuc_w && c->occ_upper == b->nuc_upper)
+        if (b->nuc_done && b->cov_from_nuc && c->flank == b->nuc_w && c->occ_upper == b->nuc_upper) {
+            // natac_frag_gather of natac_run_nuc already wrote OCC_COV = nuc_cov + nfr_cov for this geometry
+        } else if (b->nuc_done && c->flank == b->nuc_w && c->occ_upper == b->nuc_upper)
             hipLaunchKernelGGL(natac_add_tracks, dim3(4096), dim3(256), 0, c->stream2, b->d_track[NATAC_T_NUC_COV],
                                b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_OCC_COV], b->total_bp);
         else

@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int L = ct.chunk_len[chunk];
     bool use_fft;
     {   // Et[u] <-> coordinate x0 - HW - A + u
-        const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
+        const double *b = ct.bias ? ct.ebias + ct.bias_off[chunk] : nullptr;       // exp(bias), natac_exp_bias
         const int nb = L + ct.bias_left + ct.bias_right;
         const int j0 = x0 - HW - A + ct.bias_left;
         // only the first `need` entries feed bases of this chunk; the rest of the tile is padded with zeros
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             double e = 0.0;
             if (u < need) {
                 e = 1.0;
-                if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+                if (b) e = (j >= 0 && j < nb) ? b[j] : 0.0;
                 okl = okl && (e > 0.0) && (e < 1e300);   // false for NaN, inf, zero
                 emax = fmax(emax, e); emin = fmin(emin, e);
             }

@@ -24,6 +24,7 @@ struct ChunkTable {
     const int *centre;          // [nf]  lpos + floor((ilen-1)/2), non-decreasing inside a chunk
     const long long *bias_off;  // [nc+1] or null
     const double *bias;         // log-bias or null
+    const double *ebias;        // exp(bias), same layout (natac_exp_bias; filled by natac_run_nuc / natac_run_occ), or null
     int bias_left, bias_right;
     const long long *out_off;   // [nc+1]
     const long long *grid_off;  // [nc+1]
@@ -132,6 +133,14 @@ __global__ void natac_frag_centres(const int *__restrict__ lpos, const int *__re
     for (; i < nf; i += stride) centre[i] = lpos[i] + floor_half(ilen[i] - 1);
 }
 
+// E = exp(log-bias) of the whole batch, once per stage: the background, occupancy and candidate kernels all stage windows of
+// it (a ~40-instruction exp per element otherwise repeated in every tile's halo)
+__global__ void __launch_bounds__(256) natac_exp_bias(const double *__restrict__ b, double *__restrict__ e, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < n; i += stride) e[i] = exp(b[i]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K0  sparse V-plot gather: nuc_cov, nfr_cov, raw signal.
 //   nuc_cov[g] = #{frag: vlower <= n < vupper, |c-g| <= w}          tracks.py:209-222 via NucleosomeCalling.py:257-260
@@ -169,10 +178,12 @@ __global__ void __launch_bounds__(256) natac_tile_ranges256(ChunkTable ct, const
     ranges[i] = make_int2(t0, t1);
 }
 
+// occ_cov != nullptr: also writes nuc_cov + nfr_cov (OccChunk.getCov, Occupancy.py:221-224, when the occupancy window and size
+// range coincide with the V-plot's: exact integers).
 __global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const int2 *__restrict__ tiles,
                                                            const int2 *__restrict__ ranges, VMatDev vm,
                                                            double *__restrict__ nuc_cov, double *__restrict__ nfr_cov,
-                                                           double *__restrict__ raw) {
+                                                           double *__restrict__ raw, double *__restrict__ occ_cov) {
     __shared__ int cen_s[GATHER_FMAX];
     __shared__ int iln_s[GATHER_FMAX];
     const int2 t = tiles[blockIdx.x];
@@ -191,7 +202,9 @@ __global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const in
     }
     // Wave-uniform walk over the fragments that can touch the wave's 64 bases, in list (= centre) order: every lane adds the
     // template value of its own column, so a step is one coalesced read of (part of) a template row instead of 64 scattered
-    // ones, and the order of the additions per base is the list order as before (bit-identical sums).
+    // ones, and the order of the additions per base is the list order as before (bit-identical sums).  Only nucleosome-sized
+    // fragments load a template row: the kernel is bound by those L2 reads (a branch-free variant that loaded a clamped row
+    // for every fragment was 30 % slower).
     const int lane = threadIdx.x & 63;
     const int gw0 = g - lane;                                  // first base of the wave
     if (gw0 >= L) return;                                      // wave-uniform
@@ -219,6 +232,7 @@ __global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const in
     nuc_cov[o] = (double)cnt_nuc;
     nfr_cov[o] = (double)cnt_nfr;
     raw[o] = acc;
+    if (occ_cov) occ_cov[o] = (double)(cnt_nuc + cnt_nfr);
 }
 
 // occ coverage when the occupancy window / size range coincide with the V-plot's: cov = nuc_cov + nfr_cov (exact integers)
@@ -1252,7 +1266,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         chunk[q] = cand_chunk[k];
         pos[q] = cand_pos[k];
         const int L = ct.chunk_len[chunk[q]];
-        const double *b = ct.bias ? ct.bias + ct.bias_off[chunk[q]] : nullptr;
+        const double *b = ct.bias ? ct.ebias + ct.bias_off[chunk[q]] : nullptr;     // exp(bias), natac_exp_bias
         const int nb = L + ct.bias_left + ct.bias_right;
         const int j0 = pos[q] - vm.w - A + ct.bias_left;
         double emin = __builtin_inf();
@@ -1260,7 +1274,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             const int j = j0 + u;
             double e = 1.0;
 #ifndef NATAC_ABL_CAND_STAGE
-            if (b) e = (j >= 0 && j < nb) ? exp(b[j]) : 0.0;
+            if (b) e = (j >= 0 && j < nb) ? b[j] : 0.0;
 #endif
             smem[et0 + q * EWP + u] = e;
             emin = fmin(emin, e);

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) natac_occ_gsum(ChunkTable ct, const int2 
     if (threadIdx.x == 0) bad_s = 0;
     __syncthreads();
     {
-        const double *b = ct.bias ? ct.bias + ct.bias_off[chunk] : nullptr;
+        const double *b = ct.bias ? ct.ebias + ct.bias_off[chunk] : nullptr;       // exp(bias), natac_exp_bias
         const int nbias = L + ct.bias_left + ct.bias_right;
         const int need = nb_here * STEP + 2 * R;              // entries [GS_MG, GS_MG + need) feed blocks of this chunk
         bool bad = false;
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) natac_occ_gsum(ChunkTable ct, const int2 
             double e = 1.0;
             if (u >= GS_MG && u < GS_MG + need && b) {
                 const int j = xt0 + u + ct.bias_left;
-                e = (j >= 0 && j < nbias) ? exp(b[j]) : 0.0;
+                e = (j >= 0 && j < nbias) ? b[j] : 0.0;
                 bad |= !(e >= om.e_lo && e <= om.e_hi);       // NaN, inf, 0, tiny, huge
             }
             Et[u] = e;
@@ -164,7 +164,8 @@ __device__ __forceinline__ bool lik_gt(double m1, int e1, double m2, int e2) {  
 // K likelihoods per lane: L_k = prod_i (1 + al[k] t_i) over the lane's window fragments [f0, f0 + cnt); every lane of the
 // wave runs `trips` (multiple of 4) iterations, fragments past its own window contribute the factor 1.
 // GLOBAL: the tile's fragments are read from global memory (cen / iln not compacted: invalid sizes give the factor 1).
-template <int K, bool GLOBAL>
+// RN: factors between two frexp renormalisations (4 or 16; the host picks 16 when 16 factors cannot leave the fp64 range)
+template <int K, bool GLOBAL, int RN>
 __device__ __forceinline__ void occ_eval(const double (&al)[K], double kappa, int f0, int cnt, int trips, const double *rho_s,
                                          const int *iln_g, const double *rho_g, int U, int flags, double (&m)[K], int (&e)[K]) {
 #pragma unroll
@@ -186,6 +187,12 @@ __device__ __forceinline__ void occ_eval(const double (&al)[K], double kappa, in
 #pragma unroll
             for (int k = 0; k < K; ++k) m[k] *= fma(al[k], t, 1.0);
         }
+        if (RN == 4 || ((i >> 2) & (RN / 4 - 1)) == RN / 4 - 1) {      // wave-uniform
+#pragma unroll
+            for (int k = 0; k < K; ++k) { int ex; m[k] = frexp(m[k], &ex); e[k] += ex; }
+        }
+    }
+    if (RN != 4) {
 #pragma unroll
         for (int k = 0; k < K; ++k) { int ex; m[k] = frexp(m[k], &ex); e[k] += ex; }
     }
@@ -200,7 +207,7 @@ __device__ __forceinline__ void occ_eval(const double (&al)[K], double kappa, in
 // One wave = one tile of 64 consecutive grid points of one chunk (the tile table of natac_occ_mle), one lane per grid
 // point; a workgroup holds 4 independent waves.  sums[0..3] = the natac_occ_gsum arrays.  Tiles that cannot be decided
 // here (non-finite / non-positive normalisers: poisoned blocks) are appended to `defer` for natac_occ_mle.
-template <int STEP>
+template <int STEP, int RN>
 __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int2 *__restrict__ tiles, int ntiles,
                                                           const int2 *__restrict__ ranges, OccFastDev om,
                                                           const long long *__restrict__ blk_off, long long total_blocks,
@@ -290,16 +297,16 @@ __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int
     trips = (trips + 3) & ~3;
     const double *al_g = om.alphas;
     auto eval11 = [&](const double (&al)[11], double (&m)[11], int (&e)[11]) {
-        if (staged) occ_eval<11, false>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
-        else occ_eval<11, true>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
+        if (staged) occ_eval<11, false, RN>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
+        else occ_eval<11, true, RN>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
     };
     auto eval8 = [&](const double (&al)[8], double (&m)[8], int (&e)[8]) {
-        if (staged) occ_eval<8, false>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
-        else occ_eval<8, true>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
+        if (staged) occ_eval<8, false, RN>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
+        else occ_eval<8, true, RN>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
     };
     auto eval2 = [&](const double (&al)[2], double (&m)[2], int (&e)[2]) {
-        if (staged) occ_eval<2, false>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
-        else occ_eval<2, true>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
+        if (staged) occ_eval<2, false, RN>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
+        else occ_eval<2, true, RN>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
     };
     // ---- round A: the coarse grid 0, 10, ..., 100
     double cm[11];
