@@ -1,0 +1,201 @@
+// natac_cand.hpp -- per-candidate statistics (Nucleosome.getLR / getZScore, NucleosomeCalling.py:110-127), paired-row form.
+//
+// Same quantities as natac_candidates4 (natac_kernels.hpp): for candidate position p and the V-plot window around it
+//   S_B0V = sum_{r,c} V[r,c] B0[r,x_c],   S_BV2 = sum_{r,c} s_r V[r,c]^2 B0[r,x_c],   B0[i,x] = E[x-(i-1)//2] E[x+i//2]
+// (S_B and S_BV are the per-base values the background kernel left at p), then lr from the window's fragments, var, z.
+// Consecutive insert sizes share one exp(bias) factor and consecutive PAIRS of sizes the other one:
+//   i = 2m+1, 2m+2:   B0 = L_m R_m,  L_m R_{m+1}        (L_m[x] = E[x-m], R_m[x] = E[x+m])
+//   i = 2m,   2m+1:   B0 = L_{m-1} R_m,  L_m R_m
+// so a row pair costs  shared * (v_a * other_a + v_b * other_b)  = 3 flops per output and column instead of 4, and 2 LDS
+// reads per column instead of 4 (the carried factor stays in registers).  The per-fragment likelihood terms of the four
+// candidates of a wave are evaluated together, one 16-lane row per candidate (row-wide 16-ary window search, two
+// fragments per lane, DPP row sums).  V-plots or size distributions with exact zeros, and windows whose exp(bias) values
+// could make a product underflow, take the exact per-cell zero test of natac_candidates4 (launched instead by the host / by
+// the wave-uniform fallback below).
+#pragma once
+#include "natac_kernels.hpp"
+
+namespace natac {
+
+// first index in a[lo, hi) with a[idx] >= key, searched by one 16-lane row (every lane of the row returns it); the four
+// rows of a wave search four different ranges at once.  l = lane & 15, sh = 16 * (lane >> 4).
+__device__ __forceinline__ int row_lower_bound(const int *__restrict__ a, int lo, int hi, int key, int l, int sh) {
+    // all rows iterate until every row is done (ballots are wave-wide)
+    while (__ballot(hi - lo > 16) != 0ull) {
+        const int n = hi - lo;
+        const bool big = n > 16;
+        const int stride = big ? (n + 15) / 16 : 1;
+        const int pi = min((l + 1) * stride - 1, max(n - 1, 0));
+        const bool less = big && a[lo + pi] < key;
+        const int cnt = __popc((unsigned)(__ballot(less) >> sh) & 0xffffu);
+        if (big) {
+            lo = min(lo + cnt * stride, hi);
+            hi = min(lo + stride, hi);
+        }
+    }
+    const int i = lo + l;
+    const bool less = (i < hi) && a[i] < key;
+    return lo + __popc((unsigned)(__ballot(less) >> sh) & 0xffffu);
+}
+
+constexpr int CANDP_STRIDE = 376;   // doubles per candidate window in LDS (compile-time: every LDS address of the sweep is a
+                                    // running base register + an immediate); V-plots with W + upper - 2 > 376 use natac_candidates4
+
+// LODD: parity of vm.lower.  Requires vm.lower >= 2, R even, EW <= CANDP_STRIDE, bnum / bcov of the current model (host-checked).
+template <bool LODD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) natac_candidates_paired(
+    ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk, const int *__restrict__ cand_pos, int ncand,
+    const double *__restrict__ nuc_cov, const double *__restrict__ norm, const double *__restrict__ bnum,
+    const double *__restrict__ bcov, double *__restrict__ out_lr, double *__restrict__ out_var, double *__restrict__ out_z) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int Q = CAND_PER_WAVE;
+    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
+    const int W = vm.W, R = vm.R;
+    const int EW = W + A + Bh;
+    constexpr int EWP = CANDP_STRIDE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *Ew = smem + wave * Q * EWP;                       // Ew[q * EWP + u] <-> coordinate p_q - w - A + u
+    const int k0 = (blockIdx.x * 4 + wave) * Q;
+    if (k0 >= ncand) return;                                   // wave-uniform; no block-level synchronisation below
+    int chunk[Q], pos[Q];
+    bool esmall = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int k = (k0 + q < ncand) ? k0 + q : k0;          // tail: recompute candidate k0 (result discarded)
+        chunk[q] = cand_chunk[k];
+        pos[q] = cand_pos[k];
+        const int L = ct.chunk_len[chunk[q]];
+        const double *b = ct.bias ? ct.ebias + ct.bias_off[chunk[q]] : nullptr;     // exp(bias), natac_exp_bias
+        const int nb = L + ct.bias_left + ct.bias_right;
+        const int j0 = pos[q] - vm.w - A + ct.bias_left;
+        double emin = __builtin_inf();
+        for (int u = lane; u < EW; u += WAVE) {
+            const int j = j0 + u;
+            double e = 1.0;
+            if (b) e = (j >= 0 && j < nb) ? b[j] : 0.0;
+            Ew[q * EWP + u] = e;
+            emin = fmin(emin, e);
+        }
+        esmall |= !(wave_min(emin) > 0x1p-500);                // no product of two window values can underflow to 0 above this
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- sweep: lanes own template columns c1 = lane, c2 = lane + 64 (idle second columns: clamped address, zero template)
+    const int c1 = lane, c2 = min(lane + WAVE, W - 1);
+    const bool h2 = lane + WAVE < W;
+    double a1[Q][2], a2[Q][2];                                 // S_B0V / S_BV2 partial sums per candidate and column
+    double carry[Q][2];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { a1[q][0] = a1[q][1] = a2[q][0] = a2[q][1] = 0.0; }
+    // pair k: rows 2k, 2k+1, insert sizes i = lower + 2k, i + 1
+    const int m0 = LODD ? (vm.lower - 1) >> 1 : vm.lower >> 1;   // m of the first pair
+    {   // carried factor of the first pair: LODD: R_m0 (index c + A + m0);  else: L_{m0-1} (index c + A - m0 + 1)
+        const int off = LODD ? A + m0 : A - m0 + 1;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { carry[q][0] = Ew[q * EWP + c1 + off]; carry[q][1] = Ew[q * EWP + c2 + off]; }
+    }
+    const double *__restrict__ vmat = vm.mat;
+    const int npair = R >> 1;
+    // running LDS pointers of the two columns: shared factor (moves by -1 / +1 per pair) and new other factor (+1 / -1)
+    const double *psh1 = Ew + c1 + (LODD ? A - m0 : A + m0), *psh2 = Ew + c2 + (LODD ? A - m0 : A + m0);
+    const double *pnw1 = Ew + c1 + (LODD ? A + m0 + 1 : A - m0), *pnw2 = Ew + c2 + (LODD ? A + m0 + 1 : A - m0);
+    constexpr int DSH = LODD ? -1 : 1, DNW = LODD ? 1 : -1;
+    // one pair: row a multiplies the carried factor `cin`, row b the newly read one, which is handed on in `cout`
+    auto pair_step = [&](int k, const double (&cin)[Q][2], double (&cout)[Q][2]) {
+        const double sa = vm.srow[2 * k], sb = vm.srow[2 * k + 1];
+        const double va0 = vmat[2 * k * W + c1], va1 = h2 ? vmat[2 * k * W + c2] : 0.0;
+        const double vb0 = vmat[(2 * k + 1) * W + c1], vb1 = h2 ? vmat[(2 * k + 1) * W + c2] : 0.0;
+        const double wa0 = sa * (va0 * va0), wa1 = sa * (va1 * va1);     // weights of S_BV2: s_r v^2
+        const double wb0 = sb * (vb0 * vb0), wb1 = sb * (vb1 * vb1);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const double s0 = psh1[q * EWP], s1 = psh2[q * EWP];
+            const double n0 = pnw1[q * EWP], n1 = pnw2[q * EWP];
+            a1[q][0] = fma(s0, fma(vb0, n0, va0 * cin[q][0]), a1[q][0]);
+            a1[q][1] = fma(s1, fma(vb1, n1, va1 * cin[q][1]), a1[q][1]);
+            a2[q][0] = fma(s0, fma(wb0, n0, wa0 * cin[q][0]), a2[q][0]);
+            a2[q][1] = fma(s1, fma(wb1, n1, wa1 * cin[q][1]), a2[q][1]);
+            cout[q][0] = n0;
+            cout[q][1] = n1;
+        }
+        psh1 += DSH; psh2 += DSH; pnw1 += DNW; pnw2 += DNW;
+    };
+    double carry2[Q][2];
+    int k = 0;
+    for (; k + 2 <= npair; k += 2) {                          // two pairs per trip: the carried factor ping-pongs, no copies
+        pair_step(k, carry, carry2);
+        pair_step(k + 1, carry2, carry);
+    }
+    if (k < npair) pair_step(k, carry, carry2);
+    // ---- exact zero-cell test, only for windows whose exp(bias) values are small enough for a product to underflow
+    // (the host launches natac_candidates4 instead when the template / size distribution hold exact zeros)
+    bool zero[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) zero[q] = false;
+    if (esmall) {                                              // wave-uniform, rare
+        for (int r = 0; r < R; ++r) {
+            const int i = vm.lower + r;
+            const int hl = floor_half(i - 1), hr = floor_half(i);
+            const double sr = vm.srow[r];
+            const double v1 = vmat[r * W + c1], v2 = vmat[r * W + c2];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const double *e = Ew + q * EWP;
+                const double b1 = e[c1 + A - hl] * e[c1 + A + hr], b2 = e[c2 + A - hl] * e[c2 + A + hr];
+                zero[q] |= (v1 * b1 == 0.0 || sr * b1 == 0.0) || (h2 && (v2 * b2 == 0.0 || sr * b2 == 0.0));
+            }
+        }
+    }
+    double tBV2[Q], tB0V[Q];
+    bool anyzero[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        tB0V[q] = wave_sum(a1[q][0] + a1[q][1]);
+        tBV2[q] = wave_sum(a2[q][0] + a2[q][1]);
+        anyzero[q] = __ballot(zero[q]) != 0ull;
+    }
+    // ---- likelihood terms: row `row` of the wave handles candidate `row`
+    const int row = lane >> 4, l = lane & 15, sh = 16 * row;
+    int mych = chunk[0], myp = pos[0];
+    double myB0V = tB0V[0], myBV2 = tBV2[0];
+    bool myzero = anyzero[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q)
+        if (row == q) { mych = chunk[q]; myp = pos[q]; myB0V = tB0V[q]; myBV2 = tBV2[q]; myzero = anyzero[q]; }
+    const long long op = ct.out_off[mych] + myp;
+    const double tB = bcov[op], tBV = bnum[op];
+    const int nfr = (int)(ct.frag_off[mych + 1] - ct.frag_off[mych]);
+    const int *cen = ct.centre + ct.frag_off[mych];
+    const int *iln = ct.ilen + ct.frag_off[mych];
+    const int f0 = row_lower_bound(cen, 0, nfr, myp - vm.w, l, sh);
+    const int f1 = row_lower_bound(cen, f0, nfr, myp + vm.w + 1, l, sh);
+    const double *e = Ew + row * EWP;
+    double nl = 0.0, ul = 0.0;
+    int fmax = f1 - f0;                                         // rows iterate together: longest window of the wave
+    fmax = max(max(__builtin_amdgcn_readlane(fmax, 0), __builtin_amdgcn_readlane(fmax, 16)),
+               max(__builtin_amdgcn_readlane(fmax, 32), __builtin_amdgcn_readlane(fmax, 48)));
+    for (int base = 0; base < fmax; base += 16) {
+        const int f = f0 + base + l;
+        if (f < f1) {
+            const int n = iln[f];
+            if (n >= vm.lower && n < vm.upper) {
+                const int r = n - vm.lower, c = cen[f] - myp + vm.w;
+                const int hl = floor_half(n - 1), hr = floor_half(n);
+                const double b0 = (hl == -hr) ? e[c + A] : e[c + A - hl] * e[c + A + hr];
+                nl += log((vmat[r * W + c] * b0) / myB0V);
+                ul += log((vm.srow[r] * b0) / tB);
+            }
+        }
+    }
+    nl = row_sum(nl);
+    ul = row_sum(ul);
+    if (l == 0 && k0 + row < ncand) {
+        const double m1 = tBV / tB;
+        const int reads = (int)nuc_cov[op];
+        const double var = (double)reads * (myBV2 / tB - m1 * m1);
+        out_lr[k0 + row] = myzero ? __builtin_nan("") : (nl - ul);
+        out_var[k0 + row] = var;
+        out_z[k0 + row] = norm[op] / sqrt(var);
+    }
+}
+
+}  // namespace natac
