@@ -203,8 +203,9 @@ __global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const in
     // Wave-uniform walk over the fragments that can touch the wave's 64 bases, in list (= centre) order: every lane adds the
     // template value of its own column, so a step is one coalesced read of (part of) a template row instead of 64 scattered
     // ones, and the order of the additions per base is the list order as before (bit-identical sums).  Only nucleosome-sized
-    // fragments load a template row: the kernel is bound by those L2 reads (a branch-free variant that loaded a clamped row
-    // for every fragment was 30 % slower).
+    // fragments load a template row: the kernel is bound by those L2 reads (measured: a branch-free variant that loaded a
+    // clamped row for every fragment was 30 % slower; persistent workgroups with the whole template in LDS, 138 of the CU's
+    // 160 KiB, were 35-120 % slower -- 8-16 waves per CU cannot hide the per-segment chain of dependent index loads).
     const int lane = threadIdx.x & 63;
     const int gw0 = g - lane;                                  // first base of the wave
     if (gw0 >= L) return;                                      // wave-uniform
