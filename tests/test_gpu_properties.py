@@ -410,3 +410,51 @@ def test_full_size_candidates_match_oracle_on_200_chunks(full):
         nz += int(ok.sum())
     print("candidates at scale: %d candidates of 200 chunks compared (lr), %d with reads (var, z)" % (ncand, nz))
     assert ncand > 3000
+
+
+def test_fast_occupancy_defers_ill_conditioned_tiles_to_the_general_kernel(ctx):
+    """exp(bias) values outside 2^+-150 (or non-finite) make natac_occ_gsum poison its blocks; natac_occ_decide then hands the
+    tiles that touch them to the general kernel natac_occ_mle through the device-side list.  The result must equal a run
+    that uses the general kernel for every tile (NATAC_OCC_GENERAL=1) bit for bit -- grid values, smoothed tracks, status
+    words -- and the oracle where the reference's arithmetic is defined."""
+    import os
+    from nucleoatac_amd.device import Context
+    from oracle import natac_oracle as O
+    pk = make_synthetic_chunks(6, 2120, 500, seed=21)
+    bias = pk.bias_log.copy()
+    per = 2120 + pk.bias_left + pk.bias_right
+    bias[2 * per + 900:2 * per + 905] = -400.0            # exp() = 1e-174: tiny but finite (ill-conditioned, defined)
+    bias[3 * per + 1500] = 300.0                           # exp() = 2e130: huge
+    bias[4 * per + 700] = np.nan                           # the reference's likelihood is undefined around this base
+    bad = PackedChunks(pk.chunk_start, pk.chunk_len, pk.frag_off, pk.frag_lpos, pk.frag_ilen, pk.bias_off, bias)
+    nucp, nfrp = synth_occ_distributions(251)
+
+    def run(c):
+        b = c.upload(bad)
+        b.run_occ()
+        out = ([b.grid(w) for w in (L.G_OCC, L.G_LOWER, L.G_UPPER)], [b.track(t) for t in (L.T_OCC_PREFILL, L.T_OCC_LOWER, L.T_OCC_UPPER)],
+               b.status())
+        b.free()
+        return out
+
+    fast = run(ctx)
+    os.environ["NATAC_OCC_GENERAL"] = "1"
+    try:
+        par = golden("params_example")
+        g = Context(0)
+        g.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
+        g.set_sizes(synth_size_distribution(251))
+        g.set_occ_model(nucp, nfrp, step=5, flank=60)
+        general = run(g)
+        g.close()
+    finally:
+        del os.environ["NATAC_OCC_GENERAL"]
+    for a, b in zip(fast[0] + fast[1], general[0] + general[1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(fast[2], general[2]) and fast[2][4] & 1 and not fast[2][[0, 1, 5]].any()
+    nk = len(range(2, 2120, 5))
+    for k in (0, 2, 3, 5):                                 # chunk 4 makes the reference raise ValueError (Occupancy.py:118)
+        l, n = bad.chunk_frags(k)
+        oc = O.occ_chunk_tracks(l.astype(np.int64), n.astype(np.int64), 0, 2120, bad.chunk_bias(k), -bad.bias_left, nucp, nfrp)
+        for w, key in enumerate(("occ", "occ_lower", "occ_upper")):
+            assert np.array_equal(fast[0][w][k * nk:(k + 1) * nk], oc[key][2::5], equal_nan=True), (k, key)
