@@ -908,7 +908,7 @@ int natac_run_occ(natac_batch *b) {
             OccFastDev of;
             of.q4 = c->d_occ_q4; of.rho = c->d_occ_rho; of.alphas = c->d_alphas; of.nm = c->occ_nm; of.upper = U; of.step = c->step;
             of.halfstep = c->halfstep; of.flank = c->flank; of.Q = b->gs_Q; of.flags = c->occ_zero_flags & 1;
-            of.ci_factor = om.ci_factor; of.e_lo = std::ldexp(1.0, -150); of.e_hi = std::ldexp(1.0, 150);
+            of.ci_factor = om.ci_factor; of.e_lo = std::ldexp(1.0, -190); of.e_hi = std::ldexp(1.0, 190);
             const int R = of.nm - 1;
             const size_t lds_gs = ((size_t)((GS_BLOCKS * 5 + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
             const int NGP = (64 + of.Q + 1) & ~1;

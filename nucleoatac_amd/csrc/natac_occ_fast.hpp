@@ -40,7 +40,9 @@ struct OccFastDev {
     int upper, step, halfstep, flank, Q;
     int flags;              // bit 0: some nuc_prob == 0 (alpha with 1 - alpha == 0 is excluded, Occupancy.py:112-114)
     double ci_factor;       // exp(-cutoff / 2)
-    double e_lo, e_hi;      // exp(bias) values outside [e_lo, e_hi] (or NaN) send a tile to the general kernel
+    double e_lo, e_hi;      // exp(bias) values outside [e_lo, e_hi] = 2^-+190 (or NaN) send a tile to the general kernel: inside, no
+                            // probability nuc_probs[j] b[j] / sn of the reference can under- or overflow (b ratio >= 2^-760 / 121,
+                            // model probabilities >= 2^-200), so its zero pattern is the model's and the ratio form is equivalent
 };
 
 // ---- per-block sums of g_n, g_f --------------------------------------------------------------------------------
