@@ -1,8 +1,9 @@
 """Nucleosome-free regions between neighbouring nucleosome calls (API of the reference's nucleoatac/NFRCalling.py).
 
-The per-base inputs come from the accelerated path: the insertion track of every chunk is natac_run_ins on one batch, the
-bias track is the PWM kernel (InsertionBiasTrack.computeBias), the occupancy tracks are read back through the native
-tabix reader.  The interval logic itself (a handful of means per chunk) is host code like the reference's."""
+The per-base inputs come from the accelerated path: the insertion track of every chunk is natac_run_ins on one batch
+(run_nfr.py hands the slice in), the bias track is the PWM kernel behind InsertionBiasTrack.computeBias, the occupancy tracks
+are read back through the native tabix reader.  What is left here is interval bookkeeping: the gaps between consecutive
+dyads, four statistics per gap, two thresholds."""
 import numpy as np
 
 from ..pyatac.bias import PWM, InsertionBiasTrack
@@ -11,98 +12,109 @@ from ..pyatac.tracks import InsertionTrack, Track, _py2_float_str
 from ..pyatac.utils import read_chrom_sizes_from_fasta
 from ..tabix import TabixFile
 
+DYAD_LEFT, DYAD_RIGHT = 73, 72      # an NFR starts 73 bp right of a dyad and ends 72 bp left of the next (NFRCalling.py:103-104)
+
+
+def gap_statistics(nfrtrack, left, right):
+    """(mean occupancy, min upper bound, mean insertions, mean bias) over [left, right) -- NFRCalling.py:23-26.  The
+    reference needs --fasta for the last one (its bias track has no values otherwise and NFR() raises); here it is nan."""
+    occ = float(np.mean(nfrtrack.occ.get(left, right)))
+    min_upper = float(np.min(nfrtrack.occ_upper.get(left, right)))
+    ins = float(np.mean(nfrtrack.ins.get(left, right)))
+    bias = float(np.mean(nfrtrack.bias.get(left, right, log=False))) if nfrtrack.bias.vals is not None else float("nan")
+    return occ, min_upper, ins, bias
+
 
 class NFR(Chunk):
-    """one NFR (NFRCalling.py:16-32): mean occupancy, min of the upper bound, insertion and bias densities"""
+    """one nucleosome-free region with its four statistics (NFRCalling.py:16-32)"""
 
     def __init__(self, left, right, nfrtrack):
-        self.chrom = nfrtrack.chrom
-        self.start = left
-        self.end = right
-        self.strand = "*"
-        self.occ = np.mean(nfrtrack.occ.get(left, right))
-        self.min_upper = np.min(nfrtrack.occ_upper.get(left, right))
-        self.ins_density = np.mean(nfrtrack.ins.get(left, right))
-        # the reference needs --fasta here (its bias track has no values otherwise and NFR() raises); without one the
-        # column is written as nan
-        self.bias_density = np.mean(nfrtrack.bias.get(left, right, log=False)) if nfrtrack.bias.vals is not None else np.nan
+        self.chrom, self.start, self.end, self.strand = nfrtrack.chrom, left, right, "*"
+        self.occ, self.min_upper, self.ins_density, self.bias_density = gap_statistics(nfrtrack, left, right)
+
+    def passes(self, params):
+        """depleted of nucleosomes: NaN statistics fail both comparisons, as in the reference (NFRCalling.py:108)"""
+        return self.min_upper < params.max_occ_upper and self.occ < params.max_occ
 
     def asBed(self):
-        return "\t".join([str(self.chrom), str(self.start), str(self.end)] +
-                         [_py2_float_str(float(x)) for x in (self.occ, self.min_upper, self.ins_density, self.bias_density)])
+        cols = [self.chrom, self.start, self.end]
+        cols += [_py2_float_str(v) for v in (self.occ, self.min_upper, self.ins_density, self.bias_density)]
+        return "\t".join(str(c) for c in cols)
 
     def write(self, handle):
         handle.write(self.asBed() + "\n")
 
 
 class NFRParameters(object):
-    """NFRCalling.py:35-48"""
+    """run-level settings of `nucleoatac nfr` (NFRCalling.py:35-48)"""
 
     def __init__(self, occ_track, calls, ins_track=None, bam=None, max_occ=0.25, max_occ_upper=0.25, fasta=None, pwm=None):
-        self.bam = bam
-        self.ins_track = ins_track
-        self.occ_track = occ_track
-        self.calls = calls
-        self.max_occ = max_occ
-        self.max_occ_upper = max_occ_upper
+        self.occ_track, self.calls, self.ins_track, self.bam = occ_track, calls, ins_track, bam
+        self.max_occ, self.max_occ_upper = max_occ, max_occ_upper
         self.fasta = fasta
         if fasta is not None:
             self.pwm = PWM.open(pwm)
             self.chrs = read_chrom_sizes_from_fasta(fasta)
 
+    def upper_bound_track(self):
+        """<out>.occ.bedgraph.gz -> <out>.occ.upper_bound.bedgraph.gz (the reference strips the last 11 characters, :66)"""
+        return self.occ_track[:-len("bedgraph.gz")] + "upper_bound.bedgraph.gz"
+
 
 class NFRChunk(Chunk):
-    """NFR calls of one chunk (NFRCalling.py:52-118)"""
+    """NFR calls of one region (NFRCalling.py:52-118)"""
 
     def __init__(self, chunk):
-        self.start = chunk.start
-        self.end = chunk.end
-        self.chrom = chunk.chrom
+        self.chrom, self.start, self.end = chunk.chrom, chunk.start, chunk.end
         self.nfrs = []
 
     def initialize(self, parameters):
         self.params = parameters
 
+    def _read(self, path, name):
+        t = Track(self.chrom, self.start, self.end, name)
+        t.read_track(path)
+        return t
+
     def getOcc(self):
-        self.occ = Track(self.chrom, self.start, self.end, "Occupancy")
-        self.occ.read_track(self.params.occ_track)
-        upper_file = self.params.occ_track[:-11] + "upper_bound.bedgraph.gz"
-        self.occ_upper = Track(self.chrom, self.start, self.end, "Occupancy")
-        self.occ_upper.read_track(upper_file)
+        self.occ = self._read(self.params.occ_track, "Occupancy")
+        self.occ_upper = self._read(self.params.upper_bound_track(), "Occupancy")
 
     def getIns(self, vals=None):
-        """insertion track: from the GPU batch (`vals`), computed for this chunk alone, or read from --ins_track"""
-        if self.params.ins_track is None:
-            self.ins = InsertionTrack(self.chrom, self.start, self.end)
-            if vals is not None:
-                self.ins.vals = vals
-            else:
-                self.ins.calculateInsertions(self.params.bam)
+        """insertion track: the slice of the GPU batch (`vals`), or this region alone through getInsertions, or --ins_track"""
+        if self.params.ins_track is not None:
+            self.ins = self._read(self.params.ins_track, "Insertion")
+            return
+        self.ins = InsertionTrack(self.chrom, self.start, self.end)
+        if vals is None:
+            self.ins.calculateInsertions(self.params.bam)
         else:
-            self.ins = Track(self.chrom, self.start, self.end, "Insertion")
-            self.ins.read_track(self.params.ins_track)
+            self.ins.vals = vals
 
     def getBias(self):
         self.bias = InsertionBiasTrack(self.chrom, self.start, self.end, log=True)
         if self.params.fasta is not None:
             self.bias.computeBias(self.params.fasta, self.params.chrs, self.params.pwm)
 
-    def findNFRs(self):
-        """regions between consecutive calls, 73 / 72 bp off the dyads, that are depleted of nucleosomes (:96-110)"""
+    def dyads(self):
+        """positions of the combined calls overlapping the region, in file order"""
         tbx = TabixFile(self.params.calls)
-        nucs = []
-        if self.chrom in tbx.contigs:
-            for row in tbx.fetch(self.chrom, self.start, self.end):
-                nucs.append(int(row.split("\t")[1]))
-        tbx.close()
-        for j in range(1, len(nucs)):
-            left = nucs[j - 1] + 73
-            right = nucs[j] - 72
-            if right <= left:
-                continue
-            candidate = NFR(left, right, self)
-            if candidate.min_upper < self.params.max_occ_upper and candidate.occ < self.params.max_occ:
-                self.nfrs.append(candidate)
+        try:
+            if self.chrom not in tbx.contigs:
+                return []
+            return [int(row.split("\t")[1]) for row in tbx.fetch(self.chrom, self.start, self.end)]
+        finally:
+            tbx.close()
+
+    def findNFRs(self):
+        """gaps between consecutive dyads that are wide enough and depleted of nucleosomes (NFRCalling.py:96-110)"""
+        nucs = self.dyads()
+        gaps = [(a + DYAD_LEFT, b - DYAD_RIGHT) for a, b in zip(nucs[:-1], nucs[1:])]
+        for left, right in gaps:
+            if right > left:
+                candidate = NFR(left, right, self)
+                if candidate.passes(self.params):
+                    self.nfrs.append(candidate)
 
     def process(self, params, ins_vals=None):
         self.initialize(params)
@@ -112,5 +124,4 @@ class NFRChunk(Chunk):
         self.findNFRs()
 
     def removeData(self):
-        for name in list(self.__dict__.keys()):
-            delattr(self, name)
+        self.__dict__.clear()

@@ -60,27 +60,32 @@ class NucList(ChunkList):
 
 
 def merge(occ_peaks, nuc_calls, sep=120):
-    """two-pointer merge (merge.py:69-96): nucleosome calls win; an occupancy peak is kept only if no call lies within
-    `sep` of it (chromosomes compared as strings, both lists sorted)"""
+    """Combined map of two position-sorted lists (merge.py:69-96).  Nucleosome calls always survive; an occupancy peak
+    survives only if the next unconsumed call on its chromosome is more than `sep` away from it (then whichever of the two
+    comes first in (chromosome string, position) order is emitted).  A peak within `sep` of the pending call is dropped
+    without consuming the call."""
     keep = NucList()
-    i = j = 0
-    while i < len(occ_peaks) and j < len(nuc_calls):
-        if occ_peaks[i].chrom < nuc_calls[j].chrom:
-            keep.append(occ_peaks[i])
-            i += 1
-        elif occ_peaks[i].chrom > nuc_calls[j].chrom:
-            keep.append(nuc_calls[j])
-            j += 1
-        elif occ_peaks[i].start < (nuc_calls[j].start - sep):
-            keep.append(occ_peaks[i])
-            i += 1
-        elif occ_peaks[i].start > (nuc_calls[j].start + sep):
-            keep.append(nuc_calls[j])
-            j += 1
-        else:
-            i += 1
-    keep.extend(NucList(*nuc_calls[j:]))
-    keep.extend(NucList(*occ_peaks[i:]))
+    calls = iter(nuc_calls)
+    call = next(calls, None)
+    for peak in occ_peaks:
+        while call is not None:
+            if peak.chrom != call.chrom:
+                ahead = call.chrom < peak.chrom            # the call's chromosome sorts first: emit it, look at the next call
+            else:
+                gap = peak.start - call.start
+                if -sep <= gap <= sep:
+                    peak = None                            # shadowed by the pending call
+                    break
+                ahead = gap > sep
+            if not ahead:
+                break
+            keep.append(call)
+            call = next(calls, None)
+        if peak is not None:
+            keep.append(peak)
+    while call is not None:
+        keep.append(call)
+        call = next(calls, None)
     return keep
 
 
