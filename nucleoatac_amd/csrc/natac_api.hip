@@ -415,6 +415,7 @@ int natac_set_sizes(natac_ctx *c, const double *sizes, int upper) {
     c->sizes_upper = upper;
     c->have_sizes = true;
     c->srow_dirty = true;
+    c->fft_dirty = true;             // the template spectra carry the size weights
     ++c->model_gen;
     return NATAC_OK;
 }
@@ -540,7 +541,7 @@ static int ensure_fft(natac_ctx *c) {
     c->d_fft_k = nullptr;
     const int npair = (c->R + 1) / 2;
     if ((rc = dev_alloc(&c->d_fft_k, (size_t)npair * 2 * natac::FFT_N))) return rc;
-    hipLaunchKernelGGL(natac_fft_template, dim3(npair), dim3(64), 0, c->stream, c->d_vmat, c->R, c->W, c->d_fft_tw, c->d_fft_k);
+    hipLaunchKernelGGL(natac_fft_template, dim3(npair), dim3(64), 0, c->stream, c->d_vmat, c->d_srow, c->R, c->W, c->d_fft_tw, c->d_fft_k);
     HIPCHK(hipGetLastError());
     c->fft_dirty = false;
     return NATAC_OK;

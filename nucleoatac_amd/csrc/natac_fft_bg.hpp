@@ -157,9 +157,11 @@ __device__ __forceinline__ void fft512_inv(double (&re)[8], double (&im)[8], con
     __builtin_amdgcn_wave_barrier();
 }
 
-// K[pair] = FFT(V_a + i V_b) in the layout fft512_fwd produces; kout[pair][re/im][m][lane].  One wave per pair.
-__global__ void __launch_bounds__(64) natac_fft_template(const double *__restrict__ vmat, int R, int W, const double *__restrict__ tw,
-                                                           double *__restrict__ kout) {
+// K[pair] = FFT(s_a V_a + i s_b V_b) in the layout fft512_fwd produces; kout[pair][re/im][m][lane].  One wave per pair.
+// The insert-size weights s_r (BiasMat2D.normByInsertDist, chunkmat2d.py:154-156) are folded into the template: the
+// correlation is linear, so sum_r (s_r B0_r) * V_r = sum_r B0_r * (s_r V_r) and the kernel transforms the unweighted products.
+__global__ void __launch_bounds__(64) natac_fft_template(const double *__restrict__ vmat, const double *__restrict__ srow, int R, int W,
+                                                           const double *__restrict__ tw, double *__restrict__ kout) {
     __shared__ double2 sa[FFT_LA], sb[FFT_LB];
     const int lane = threadIdx.x, pair = blockIdx.x;
     const int ra = 2 * pair, rb = 2 * pair + 1;
@@ -169,8 +171,8 @@ __global__ void __launch_bounds__(64) natac_fft_template(const double *__restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int u = lane + 64 * j;
-        re[j] = (u < W) ? vmat[ra * W + u] : 0.0;
-        im[j] = (u < W && rb < R) ? vmat[rb * W + u] : 0.0;
+        re[j] = (u < W) ? srow[ra] * vmat[ra * W + u] : 0.0;
+        im[j] = (u < W && rb < R) ? srow[rb] * vmat[rb * W + u] : 0.0;
     }
     fft512_fwd(re, im, t, sa, sb, lane);
     double *o = kout + (size_t)pair * 2 * FFT_N;
@@ -289,10 +291,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 lds_wait16(x, y);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    re[j] = (sa * x[j]) * carry[j];
-                    im[j] = (sb * x[j]) * y[j];
+                    re[j] = x[j] * carry[j];
+                    im[j] = x[j] * y[j];
                     carry[j] = y[j];
-                    q[j] += re[j] + im[j];
+                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
                 }
             } else {          // shared right factor y; x = left factor of b; carry = left factor of a
                 lds_read8_b64(x, Et + (A - floor_half(ib - 1)) + lane);
@@ -300,10 +302,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 lds_wait16(x, y);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    re[j] = (sa * carry[j]) * y[j];
-                    im[j] = (sb * x[j]) * y[j];
+                    re[j] = carry[j] * y[j];
+                    im[j] = x[j] * y[j];
                     carry[j] = x[j];
-                    q[j] += re[j] + im[j];
+                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
                 }
             }
         } else {
@@ -312,9 +314,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int u = lane + 64 * j;
-                re[j] = (sa * ela[u]) * era[u];
-                im[j] = (sb * elb[u]) * erb[u];
-                q[j] += re[j] + im[j];
+                re[j] = ela[u] * era[u];
+                im[j] = elb[u] * erb[u];
+                q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
             }
         }
         fft512_fwd(re, im, tww, ca, cb, lane);

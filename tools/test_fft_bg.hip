@@ -65,7 +65,7 @@ int main(int argc, char **argv) {
     double *d_tw, *d_k; const int npair = (R + 1) / 2;
     CK(hipMalloc(&d_tw, tw.size() * 8)); CK(hipMemcpy(d_tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_k, (size_t)npair * 2 * FFT_N * 8));
-    hipLaunchKernelGGL(natac_fft_template, dim3(npair), dim3(64), 0, 0, d_vm, R, W, d_tw, d_k);
+    hipLaunchKernelGGL(natac_fft_template, dim3(npair), dim3(64), 0, 0, d_vm, d_srow, R, W, d_tw, d_k);
     CK(hipDeviceSynchronize());
     // direct kernel (G=17)
     {
