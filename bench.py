@@ -16,7 +16,7 @@ Workloads (--workload):
                   (natac_batch_release_outputs) when they do not all fit in HBM.
 
 Also reported (rank 0, N = 1): the host-to-host rate -- packed inputs in (pinned) host memory -> per-base tracks back in
-(pinned) host memory, sub-batches pipelined over three contexts so that uploads, kernels and downloads overlap -- and the CPU
+(pinned) host memory, sub-batches pipelined over six contexts so that uploads, kernels and downloads overlap -- and the CPU
 baseline (the oracle in the reference's Pool.map shape on the box's host cores).
 
 Launch: python bench.py --gpus 1            (default)
@@ -62,8 +62,8 @@ def parse():
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU baseline's optimised-mode sample (0 = 2000)")
     ap.add_argument("--cpu-literal-chunks", type=int, default=0, help="chunks in the literal-mode sample (0 = auto)")
     ap.add_argument("--no-h2h", action="store_true", help="skip the pipelined host-to-host measurement")
-    ap.add_argument("--h2h-sub", type=int, default=5000, help="chunks per pipelined sub-batch")
-    ap.add_argument("--h2h-threads", type=int, default=4, help="contexts (host threads) of the host-to-host pipeline")
+    ap.add_argument("--h2h-sub", type=int, default=2500, help="chunks per pipelined sub-batch")
+    ap.add_argument("--h2h-threads", type=int, default=6, help="contexts (host threads) of the host-to-host pipeline")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--share-device", action="store_true",

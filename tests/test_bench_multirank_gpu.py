@@ -39,7 +39,7 @@ def test_single_rank_default_contract():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
     assert d["cpu_baseline"]["literal"]["chunks"] == 16 and d["cpu_baseline"]["optimised"]["chunks"] == 32
     h = d["host_to_host"]            # pipelined host -> host rate: pinned buffers, 3 contexts, sub-batches of 1000 chunks
-    assert h["host_to_host_mbp_s"] > 0 and h["sub_batches"] == 3 and h["contexts"] == 4 and h["gb_down_per_step"] > 0
+    assert h["host_to_host_mbp_s"] > 0 and h["sub_batches"] == 3 and h["contexts"] == 6 and h["gb_down_per_step"] > 0
 
 
 def test_cfg4_strong_scaling_two_ranks_share_device():
