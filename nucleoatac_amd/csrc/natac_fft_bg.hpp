@@ -102,8 +102,22 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
 // forward 512-point FFT of the wave's data (lane n, register j <-> element n + 64 j); result: lane b, register m holds the
 // bin of "stage-3 butterfly b, output m" (a fixed permutation of the frequencies, identical for signal and template).
 // sa / sb: the wave's LDS scratch, FFT_LA and FFT_LB doubles for the real and for the imaginary parts each.
+// NATAC_FFT_ABL (tools/test_fft_bg.hip only): 1 = no LDS transposes (wrong results; what the round trips cost),
+// 2 = no template-spectrum loads, 3 = no exp(bias) operand reads
+#ifndef NATAC_FFT_ABL
+#define NATAC_FFT_ABL 0
+#endif
 __device__ __forceinline__ void fft512_fwd(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sa, double2 *sb, int lane) {
     dft8<false>(re, im);
+    if (NATAC_FFT_ABL == 1) {
+#pragma unroll
+        for (int m = 1; m < 8; ++m) { const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])); im[m] = fma(re[m], t.w1i[m], im[m] * t.w1r[m]); re[m] = xr; }
+        dft8<false>(re, im);
+#pragma unroll
+        for (int m = 1; m < 8; ++m) { const double xr = fma(re[m], t.w2r[m], -(im[m] * t.w2i[m])); im[m] = fma(re[m], t.w2i[m], im[m] * t.w2r[m]); re[m] = xr; }
+        dft8<false>(re, im);
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 1 (layout A: lane + 72 m)
         const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])), xi = fma(re[m], t.w1i[m], im[m] * t.w1r[m]);
@@ -285,10 +299,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         double re[8], im[8];
         if (pairs_full) {
             double x[8], y[8];
+            if (NATAC_FFT_ABL == 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { x[j] = 1.0 + 1e-3 * (pair + j); y[j] = 1.0 - 1e-3 * (lane + j); }
+            }
             if (lodd) {       // shared left factor x; y = right factor of b; carry = right factor of a
-                lds_read8_b64(x, Et + (A - floor_half(ia - 1)) + lane);
-                lds_read8_b64(y, Et + (A + floor_half(ib)) + lane);
-                lds_wait16(x, y);
+                if (NATAC_FFT_ABL != 3) {
+                    lds_read8_b64(x, Et + (A - floor_half(ia - 1)) + lane);
+                    lds_read8_b64(y, Et + (A + floor_half(ib)) + lane);
+                    lds_wait16(x, y);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     re[j] = x[j] * carry[j];
@@ -297,9 +317,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
                 }
             } else {          // shared right factor y; x = left factor of b; carry = left factor of a
-                lds_read8_b64(x, Et + (A - floor_half(ib - 1)) + lane);
-                lds_read8_b64(y, Et + (A + floor_half(ia)) + lane);
-                lds_wait16(x, y);
+                if (NATAC_FFT_ABL != 3) {
+                    lds_read8_b64(x, Et + (A - floor_half(ib - 1)) + lane);
+                    lds_read8_b64(y, Et + (A + floor_half(ia)) + lane);
+                    lds_wait16(x, y);
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     re[j] = carry[j] * y[j];
@@ -323,7 +345,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const double *k = ktab + (size_t)pair * 2 * FFT_N;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
-            const double kr = k[m * 64 + lane], ki = k[FFT_N + m * 64 + lane];
+            const double kr = NATAC_FFT_ABL == 2 ? 0.5 + m : k[m * 64 + lane], ki = NATAC_FFT_ABL == 2 ? 0.25 * m : k[FFT_N + m * 64 + lane];
             accr[m] = fma(re[m], kr, fma(im[m], ki, accr[m]));
             acci[m] = fma(im[m], kr, fma(-re[m], ki, acci[m]));
         }

@@ -57,6 +57,12 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(d_boff, boff.data(), (nc + 1) * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ooff, ooff.data(), (nc + 1) * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_bias, bias.data(), bias.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_vm, vm.data(), vm.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_srow, srow.data(), R * 8, hipMemcpyHostToDevice));
+    {   // exp(bias) array the kernels stage their windows from (natac_exp_bias in the library)
+        std::vector<double> eb(bias.size());
+        for (size_t i = 0; i < bias.size(); ++i) eb[i] = exp(bias[i]);
+        double *d_eb; CK(hipMalloc(&d_eb, eb.size() * 8)); CK(hipMemcpy(d_eb, eb.data(), eb.size() * 8, hipMemcpyHostToDevice));
+        ct.ebias = d_eb;
+    }
     ct.nc = nc; ct.chunk_len = d_len; ct.frag_off = d_foff; ct.bias_off = d_boff; ct.bias = d_bias; ct.bias_left = bl; ct.bias_right = br; ct.out_off = d_ooff;
     v.mat = d_vm; v.srow = d_srow; v.lower = lo; v.upper = up; v.w = 60; v.R = R; v.W = W;
     // twiddles + template spectra
