@@ -76,3 +76,34 @@ def test_nuc_cores_pool_equals_serial(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(gzip.open(out + ".nucpos.bed.gz", "rt").read())
     assert outs[0] == outs[1] and len(outs[0]) > 0
+
+
+def test_run_two_ranks_equal_one_rank(tmp_path):
+    """`nucleoatac run` (all five steps chained through their files) under torchrun: occ and nuc shard the chunk list, vprocess /
+    merge / nfr run on rank 0 between barriers; every output equals the single-process run byte for byte"""
+    bed, bam, fa, _, _ = _inputs(tmp_path)
+    outs = {}
+    for world in (1, 2):
+        out = str(tmp_path / ("run%d" % world))
+        sub = ["run", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--write_all"]
+        if world == 1:
+            cmd = [sys.executable, "-m", "nucleoatac_amd.nucleoatac.cli"] + sub
+            env = dict(os.environ)
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                   "127.0.0.1", "--master-port", "29543", "-m", "nucleoatac_amd.nucleoatac.cli"] + sub
+            env = dict(os.environ, NATAC_DIST_BACKEND="gloo", NATAC_DEVICE="0")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[world] = out
+    for n in ("occ.bedgraph.gz", "occ.lower_bound.bedgraph.gz", "occ.upper_bound.bedgraph.gz", "occpeaks.bed.gz", "nucpos.bed.gz",
+              "nucpos.redundant.bed.gz", "nucleoatac_signal.bedgraph.gz", "nucleoatac_signal.smooth.bedgraph.gz",
+              "nucleoatac_raw.bedgraph.gz", "nucleoatac_background.bedgraph.gz", "nucmap_combined.bed.gz", "nfrpos.bed.gz",
+              "ins.bedgraph.gz"):
+        a = gzip.open(outs[1] + "." + n, "rt").read()
+        b = gzip.open(outs[2] + "." + n, "rt").read()
+        assert a == b, n
+    for n in ("nuc_dist.txt", "fragmentsizes.txt", "VMat"):
+        assert open(outs[1] + "." + n).read() == open(outs[2] + "." + n).read(), n
+    assert len(gzip.open(outs[1] + ".nucpos.bed.gz", "rt").read()) > 0
+    assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]

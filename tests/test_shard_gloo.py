@@ -77,3 +77,41 @@ def test_two_rank_gloo_equals_single_process():
         assert a["occ_sum"] == b["occ_sum"] and np.array_equal(a["ins"], b["ins"])
     # the cross-chunk reduction is done in chunk order -> bit-identical to the unsharded sum
     assert np.array_equal(ordered_sum([a["nuc_dist"] for a in allr]), ordered_sum([b["nuc_dist"] for b in ref]))
+
+
+def test_bench_cfg4_shards_partition_the_workload():
+    """bench.py --workload cfg4: every rank draws the same count vector, balances the chunk list and generates only its shard
+    from counter-seeded blocks; the shards of 1, 2 and 3 ranks are the same chunks (fragments, bias, coordinates) in the same
+    order, whatever the sub-batch size"""
+    import argparse
+    import importlib.util
+    import os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def shards(world, sub):
+        a = argparse.Namespace(workload="cfg4", chunks=5000, chunk_len=700, frags_per_chunk=60, sub_chunks=sub, seed=0)
+        out = []
+        for r in range(world):
+            subs, desc, info = bench.make_workload(a, r, world)
+            out.append((subs, info))
+        return out
+
+    def flat(parts):
+        pks = [pk for subs, _ in parts for pk in subs]
+        return (np.concatenate([p.chunk_start for p in pks]), np.concatenate([p.chunk_len for p in pks]),
+                np.concatenate([np.diff(p.frag_off) for p in pks]), np.concatenate([p.frag_lpos for p in pks]),
+                np.concatenate([p.frag_ilen for p in pks]), np.concatenate([p.bias_log for p in pks]))
+
+    one = flat(shards(1, 1700))
+    assert len(one[0]) == 5000 and np.all(np.diff(one[0]) > 0)
+    for world, sub in ((2, 1700), (3, 900), (2, 2500)):
+        parts = shards(world, sub)
+        got = flat(parts)
+        for x, y in zip(one, got):
+            assert np.array_equal(x, y), (world, sub)
+        imb = parts[0][1]["imbalance"]
+        assert len(imb["bp_per_rank"]) == world and imb["bp_max_over_mean"] < 1.02 and parts[0][1]["scaling"] == "strong"
