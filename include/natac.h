@@ -57,7 +57,7 @@ enum {
     NATAC_T_OCC_UPPER = 8,  /* smoothed_upper */
     NATAC_T_OCC_COV = 9,    /* OccChunk.getCov                       Occupancy.py:221-224 */
     NATAC_T_INS = 10,       /* int32 insertion counts, getInsertions pyatac/fragments.pyx:43-67 */
-    NATAC_T_OCC_PREFILL = 11, /* smoothed_vals BEFORE the NaN fill */
+    NATAC_T_OCC_PREFILL = 11, /* smoothed_vals BEFORE the NaN fill (formed on the first download / track_ptr request) */
     NATAC_T_COUNT = 12
 };
 
@@ -120,7 +120,7 @@ int natac_batch_release_outputs(natac_batch *b);
  * BACKGROUND, NORM, SMOOTH.  smooth_sd = NucParameters.smooth_sd (cli default 10).  Asynchronous. */
 int natac_run_nuc(natac_batch *b, double smooth_sd);
 /* OccChunk.process up to getCov + the call_peaks NaN fill (Occupancy.py:241-247): fills the grid arrays,
- * OCC_PREFILL, OCC, OCC_LOWER, OCC_UPPER, OCC_COV.  Asynchronous. */
+ * OCC, OCC_LOWER, OCC_UPPER, OCC_COV (OCC_PREFILL, the smoothed occupancy before the fill, on request).  Asynchronous. */
 int natac_run_occ(natac_batch *b);
 /* InsertionTrack.calculateInsertions (pyatac/tracks.py:164-168) for every chunk: fills INS. */
 int natac_run_ins(natac_batch *b, int lower, int upper);

@@ -69,6 +69,8 @@ struct natac_ctx {
     double occ_b_floor = 0;          // see OccModelDev::b_floor
     // gaussian windows (cached by (M, sd))
     double *d_win_nuc = nullptr, *d_win_occ = nullptr;
+    double *d_wb_occ = nullptr;      // block weights of natac_occ_smooth_blk for (win_occ_M, wb_step)
+    int wb_M = 0, wb_step = 0;
     int win_nuc_M = 0, win_occ_M = 0;
     double win_nuc_sd = -1, win_occ_sd = -1;
     double win_nuc_sum = 0, win_occ_sum = 0;   // sequential sums of the window values (the all-valid denominator)
@@ -95,6 +97,10 @@ struct natac_batch {
     int *d_len = nullptr, *d_lpos = nullptr, *d_ilen = nullptr, *d_centre = nullptr, *d_status = nullptr;
     long long *d_frag_off = nullptr, *d_bias_off = nullptr, *d_out_off = nullptr, *d_grid_off = nullptr;
     double *d_bias = nullptr, *d_ebias = nullptr;
+    unsigned long long *d_occ_minkey = nullptr;   // natac_occ_smooth_blk: per-chunk minimum finite smoothed occupancy (double_key)
+    int *d_occ_nan = nullptr, n_tiles_os = 0, os_width = 0;
+    int2 *d_tiles_os = nullptr;
+    bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
     int ranges256_w = -1;
     int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;   // bgG: lanes' output count of the direct kernel, -1 = FFT tiles
@@ -115,8 +121,7 @@ struct natac_batch {
     double *d_grid[3] = {nullptr, nullptr, nullptr};
     bool nuc_done = false, occ_done = false, ins_done = false, cov_from_nuc = false, ebias_fresh = false;
     // device-side candidate search
-    double *d_cmin = nullptr, *d_jitter = nullptr, *d_pk_out = nullptr;
-    unsigned char *d_pkflag = nullptr;
+    double *d_jitter = nullptr, *d_pk_out = nullptr;
     long long *d_cap_off = nullptr, *d_pk_offs = nullptr;
     int *d_slot = nullptr, *d_pk_count = nullptr, *d_pk_chunk = nullptr, *d_pk_pos = nullptr;
     long long n_jitter = 0, pk_cap = 0, pk_n = -1, slot_total = 0;
@@ -355,7 +360,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     prof_collect(c);
     dev_free(c->d_vmat); dev_free(c->d_srow); dev_free(c->d_sizes);
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
-    dev_free(c->d_win_nuc); dev_free(c->d_win_occ);
+    dev_free(c->d_win_nuc); dev_free(c->d_win_occ); dev_free(c->d_wb_occ);
     dev_free(c->d_fft_tw); dev_free(c->d_fft_k);
     dev_free(c->d_occ_q4); dev_free(c->d_occ_rho);
     if (c->t0) (void)hipEventDestroy(c->t0);
@@ -688,8 +693,9 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_len); dev_free(b->d_lpos); dev_free(b->d_ilen); dev_free(b->d_centre); dev_free(b->d_status);
     dev_free(b->d_frag_off); dev_free(b->d_bias_off); dev_free(b->d_out_off); dev_free(b->d_grid_off); dev_free(b->d_bias);
     dev_free(b->d_ebias);
+    dev_free(b->d_occ_minkey); dev_free(b->d_occ_nan); dev_free(b->d_tiles_os);
     dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
-    dev_free(b->d_cmin); dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_pkflag); dev_free(b->d_cap_off);
+    dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
     dev_free(b->d_bnum); dev_free(b->d_bcov);
@@ -707,13 +713,12 @@ int natac_batch_release_outputs(natac_batch *b) {
     prof_collect(c);
     for (int i = 0; i < NATAC_T_COUNT; ++i) { dev_free(b->d_track[i]); b->d_track[i] = nullptr; }
     for (int i = 0; i < 3; ++i) { dev_free(b->d_grid[i]); b->d_grid[i] = nullptr; }
-    dev_free(b->d_bnum); dev_free(b->d_bcov); dev_free(b->d_gsum); dev_free(b->d_pkflag); dev_free(b->d_pk_out);
+    dev_free(b->d_bnum); dev_free(b->d_bcov); dev_free(b->d_gsum); dev_free(b->d_pk_out);
     dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos); dev_free(b->d_opk_vals); dev_free(b->d_opk_keep); dev_free(b->d_nuc_dist);
     b->d_bnum = b->d_bcov = b->d_gsum = b->d_pk_out = b->d_opk_vals = b->d_nuc_dist = nullptr;
-    b->d_pkflag = nullptr;
     b->d_pk_chunk = b->d_pk_pos = b->d_opk_keep = nullptr;
     b->pk_cap = 0; b->pk_n = -1; b->opk_cap = 0; b->opk_n = -1;
-    b->nuc_done = b->occ_done = b->ins_done = b->cov_from_nuc = false;
+    b->nuc_done = b->occ_done = b->ins_done = b->cov_from_nuc = b->prefill_valid = false;
     return NATAC_OK;     // offset / tile tables stay: the next natac_run_* only re-allocates the arrays
 }
 
@@ -821,6 +826,62 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     return NATAC_OK;
 }
 
+// natac_occ_smooth (one base per lane, any step / window): smoothed occupancy -> dst_occ (un-filled), bounds -> dst_lo / dst_hi (or null)
+static void launch_occ_smooth_generic(natac_batch *b, const ChunkTable &ct, const OccModelDev &om, int M, double *dst_occ, double *dst_lo,
+                                      double *dst_hi) {
+    natac_ctx *c = b->ctx;
+    const int h = (M - 1) / 2;
+    const int NB = 2 * ((h + c->step - 1) / c->step) + 2, NG = (255 + 2 * h) / c->step + 3;
+    const size_t lds = ((size_t)((M + 1) & ~1) + (size_t)c->step * NB + 3 * (size_t)NG) * sizeof(double);
+    hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream2, ct, b->d_tiles256, om, c->d_win_occ, M,
+                       b->d_grid[0], b->d_grid[1], b->d_grid[2], dst_occ, dst_lo, dst_hi);
+}
+
+// block weights of natac_occ_smooth_blk: wb[bi][j] = sum of the window taps that fall on block bmin + bi for a base at offset j
+// of its block -- the table natac_occ_smooth forms per workgroup, same summation order
+static int ensure_block_weights(natac_ctx *c, int M, double sd, int NB) {
+    if (c->d_wb_occ && c->wb_M == M && c->wb_step == c->step) return NATAC_OK;
+    HIPCHK(sync_all(c));
+    dev_free(c->d_wb_occ);
+    c->d_wb_occ = nullptr;
+    const int h = (M - 1) / 2, step = c->step;
+    std::vector<double> w((size_t)M), wb((size_t)step * NB);
+    for (int i = 0; i < M; ++i) {           // as ensure_window
+        const double n = (double)i - (M - 1) / 2.0, q = n / sd;
+        w[i] = std::exp(-0.5 * (q * q));
+    }
+    for (int j = 0; j < step; ++j)
+        for (int bi = 0; bi < NB; ++bi) {
+            const int bmin = -(h / step);    // h is a multiple of step
+            double sacc = 0.0;
+            for (int d = 0; d < step; ++d) {
+                const int n = j + h - (bmin + bi) * step - d;
+                if (n >= 0 && n < M) sacc += w[n];
+            }
+            wb[(size_t)bi * step + j] = sacc;
+        }
+    int rc = dev_upload(c, &c->d_wb_occ, wb.data(), wb.size());
+    if (rc) return rc;
+    HIPCHK(sync_all(c));
+    c->wb_M = M;
+    c->wb_step = step;
+    return NATAC_OK;
+}
+
+// OCC_PREFILL (smoothed_vals before call_peaks' NaN fill) is not part of the default pass: written on the first request
+static int materialise_prefill(natac_batch *b) {
+    if (b->prefill_valid) return NATAC_OK;
+    natac_ctx *c = b->ctx;
+    int rc = ensure_track(b, NATAC_T_OCC_PREFILL);
+    if (rc) return rc;
+    const ChunkTable ct = make_table(b);
+    const OccModelDev om = make_occ(c);
+    launch_occ_smooth_generic(b, ct, om, 2 * c->flank + 1, b->d_track[NATAC_T_OCC_PREFILL], nullptr, nullptr);
+    HIPCHK(hipGetLastError());
+    b->prefill_valid = true;
+    return NATAC_OK;
+}
+
 int natac_run_occ(natac_batch *b) {
     if (!b) return fail(NATAC_E_ARG, "batch is NULL");
     natac_ctx *c = b->ctx;
@@ -861,8 +922,9 @@ int natac_run_occ(natac_batch *b) {
     }
     for (int i = 0; i < 3; ++i)      // released by natac_batch_release_outputs
         if (!b->d_grid[i] && (rc = dev_alloc(&b->d_grid[i], (size_t)b->total_grid))) return rc;
-    for (int t : {NATAC_T_OCC, NATAC_T_OCC_LOWER, NATAC_T_OCC_UPPER, NATAC_T_OCC_COV, NATAC_T_OCC_PREFILL})
+    for (int t : {NATAC_T_OCC, NATAC_T_OCC_LOWER, NATAC_T_OCC_UPPER, NATAC_T_OCC_COV})
         if ((rc = ensure_track(b, t))) return rc;
+    b->prefill_valid = false;
     if (!b->d_ebias && b->d_bias && (rc = dev_alloc(&b->d_ebias, (size_t)b->nb))) return rc;
     const ChunkTable ct = make_table(b);
     const OccModelDev om = make_occ(c);
@@ -944,13 +1006,29 @@ int natac_run_occ(natac_batch *b) {
     }
     prof_end(c, ev);
     prof_begin(c, NATAC_K_OCC_SMOOTH, ev, c->stream2);
+    const bool blk = (c->step == 5) && (((M - 1) / 2) % c->step == 0);     // natac_occ_smooth_blk<5>
+    if (blk) {
+        const int h = (M - 1) / 2, NB = 2 * (h / c->step) + 2;
+        if ((rc = ensure_block_weights(c, M, sd, NB))) return rc;
+        if (b->os_width != 256 * c->step) {
+            if ((rc = build_tiles(b, 256 * c->step, &b->d_tiles_os, &b->n_tiles_os))) return rc;
+            b->os_width = 256 * c->step;
+        }
+        if (!b->d_occ_minkey && (rc = dev_alloc(&b->d_occ_minkey, (size_t)b->nc))) return rc;
+        if (!b->d_occ_nan && (rc = dev_alloc(&b->d_occ_nan, (size_t)b->nc))) return rc;
+        HIPCHK(hipMemsetAsync(b->d_occ_minkey, 0xff, (size_t)b->nc * sizeof(unsigned long long), c->stream2));
+        HIPCHK(hipMemsetAsync(b->d_occ_nan, 0, (size_t)b->nc * sizeof(int), c->stream2));
+        hipLaunchKernelGGL((natac_occ_smooth_blk<5>), dim3(b->n_tiles_os), dim3(256), ((size_t)3 * (256 + NB) + 256 * 5) * sizeof(double), c->stream2, ct,
+                           b->d_tiles_os, om, c->d_win_occ, M, c->d_wb_occ, NB, b->d_grid[0], b->d_grid[1], b->d_grid[2],
+                           b->d_track[NATAC_T_OCC], b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER], b->d_occ_minkey,
+                           b->d_occ_nan);
+    } else {
+        if ((rc = ensure_track(b, NATAC_T_OCC_PREFILL))) return rc;
+        launch_occ_smooth_generic(b, ct, om, M, b->d_track[NATAC_T_OCC_PREFILL], b->d_track[NATAC_T_OCC_LOWER],
+                                  b->d_track[NATAC_T_OCC_UPPER]);
+        b->prefill_valid = true;
+    }
     {
-        const int h = (M - 1) / 2;
-        const int NB = 2 * ((h + c->step - 1) / c->step) + 2, NG = (255 + 2 * h) / c->step + 3;
-        const size_t lds = ((size_t)((M + 1) & ~1) + (size_t)c->step * NB + 3 * (size_t)NG) * sizeof(double);
-        hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream2, ct, b->d_tiles256, om, c->d_win_occ, M,
-                           b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_track[NATAC_T_OCC_PREFILL],
-                           b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER]);
         if (b->nuc_done && b->cov_from_nuc && c->flank == b->nuc_w && c->occ_upper == b->nuc_upper) {
             // natac_frag_gather of natac_run_nuc already wrote OCC_COV = nuc_cov + nfr_cov for this geometry
         } else if (b->nuc_done && c->flank == b->nuc_w && c->occ_upper == b->nuc_upper)
@@ -962,8 +1040,12 @@ int natac_run_occ(natac_batch *b) {
     }
     prof_end(c, ev);
     prof_begin(c, NATAC_K_OCC_FILL, ev, c->stream2);
-    hipLaunchKernelGGL(natac_fill_nan_min, dim3(b->nc), dim3(256), 0, c->stream2, ct, b->d_track[NATAC_T_OCC_PREFILL],
-                       b->d_track[NATAC_T_OCC]);
+    if (blk)     // in place, and only the chunks that hold a NaN
+        hipLaunchKernelGGL(natac_fill_nan_chunks, dim3(b->nc), dim3(256), 0, c->stream2, ct, b->d_occ_minkey, b->d_occ_nan,
+                           b->d_track[NATAC_T_OCC]);
+    else
+        hipLaunchKernelGGL(natac_fill_nan_min, dim3(b->nc), dim3(256), 0, c->stream2, ct, b->d_track[NATAC_T_OCC_PREFILL],
+                           b->d_track[NATAC_T_OCC]);
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
     b->occ_done = true;
@@ -1059,19 +1141,32 @@ static int run_peaks_impl(natac_batch *b, const double *sig_a, const double *sig
         if ((rc = dev_alloc(&b->d_slot, (size_t)b->slot_total))) return rc;
         b->pk_order = order;
     }
-    if (!b->d_cmin && (rc = dev_alloc(&b->d_cmin, (size_t)b->nc))) return rc;
-    if (!b->d_pkflag && (rc = dev_alloc(&b->d_pkflag, (size_t)b->total_bp))) return rc;
     if (!b->d_pk_count && (rc = dev_alloc(&b->d_pk_count, (size_t)b->nc))) return rc;
     if (!b->d_pk_offs && (rc = dev_alloc(&b->d_pk_offs, (size_t)b->nc + 1))) return rc;
     const ChunkTable ct = make_table(b);
     const double *norm = sig_a, *sm = sig_b;
     natac_ctx::Ev ev;
     prof_begin(c, NATAC_K_CAND, ev);
-    hipLaunchKernelGGL(natac_chunk_min_combined, dim3(b->nc), dim3(256), 0, c->stream, ct, norm, sm, b->d_cmin);
-    hipLaunchKernelGGL(natac_peak_flags, dim3(b->n_tiles256), dim3(256), (size_t)(256 + 2 * order) * sizeof(double), c->stream, ct,
-                       b->d_tiles256, norm, sm, b->d_cmin, b->d_jitter, min_signal, boundary, order, b->d_pkflag);
-    hipLaunchKernelGGL(natac_peak_reduce, dim3(b->nc), dim3(256), 0, c->stream, ct, b->d_pkflag, norm, sm, b->d_cmin, sep, b->d_cap_off,
-                       b->d_slot, b->d_pk_count, b->d_status);
+    {   // one workgroup per chunk: LDS = a segment of the jittered signal + the chunk's list of maxima
+        const int nj = (maxL + 255) / 256;
+        const int seg = std::min(nj * 256, 4096);
+        const int pk_cap = (std::min(PEAK_MAX, maxL / (order + 1) + 2) + 7) & ~7;
+        const size_t lds = (size_t)((seg + 2 * order + 1) & ~1) * sizeof(double) + (size_t)pk_cap * (sizeof(double) + sizeof(int) + 1);
+#define NATAC_PEAKS_REG(NJ)                                                                                                        \
+    case NJ:                                                                                                                       \
+        hipLaunchKernelGGL((natac_peaks_chunk_reg<NJ>), dim3(b->nc), dim3(256), lds, c->stream, ct, norm, sm, b->d_jitter, min_signal, \
+                           boundary, order, sep, pk_cap, b->d_cap_off, b->d_slot, b->d_pk_count, b->d_status);                    \
+        break;
+        switch (nj <= 16 ? nj : 0) {
+            NATAC_PEAKS_REG(1) NATAC_PEAKS_REG(2) NATAC_PEAKS_REG(3) NATAC_PEAKS_REG(4) NATAC_PEAKS_REG(5) NATAC_PEAKS_REG(6)
+            NATAC_PEAKS_REG(7) NATAC_PEAKS_REG(8) NATAC_PEAKS_REG(9) NATAC_PEAKS_REG(10) NATAC_PEAKS_REG(11) NATAC_PEAKS_REG(12)
+            NATAC_PEAKS_REG(13) NATAC_PEAKS_REG(14) NATAC_PEAKS_REG(15) NATAC_PEAKS_REG(16)
+            default:   // chunks longer than 4,096 bases: segments, signal re-read from memory (L2)
+                hipLaunchKernelGGL(natac_peaks_chunk, dim3(b->nc), dim3(256), lds, c->stream, ct, norm, sm, b->d_jitter, min_signal,
+                                   boundary, order, sep, seg, pk_cap, b->d_cap_off, b->d_slot, b->d_pk_count, b->d_status);
+        }
+#undef NATAC_PEAKS_REG
+    }
     hipLaunchKernelGGL(natac_scan_counts, dim3(1), dim3(1024), 0, c->stream, b->d_pk_count, b->nc, b->d_pk_offs);
     long long total = 0;
     HIPCHK(hipGetLastError());
@@ -1232,6 +1327,7 @@ int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes)
     const size_t need = (size_t)b->total_bp * (track == NATAC_T_INS ? sizeof(int) : sizeof(double));
     if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, track needs %zu", dst_bytes, need);
     HIPCHK(hipSetDevice(b->ctx->device));
+    if (track == NATAC_T_OCC_PREFILL && (rc = materialise_prefill(b))) return rc;
     HIPCHK(hipMemcpyAsync(dst, b->d_track[track], need, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(sync_all(b->ctx));
     prof_collect(b->ctx);
@@ -1262,6 +1358,11 @@ int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes) {
 int natac_batch_track_ptr(natac_batch *b, int track, void **dptr) {
     if (!b || !dptr) return fail(NATAC_E_ARG, "null argument");
     if (track < 0 || track >= NATAC_T_COUNT) return fail(NATAC_E_ARG, "bad track id");
+    if (track == NATAC_T_OCC_PREFILL && b->occ_done) {
+        HIPCHK(hipSetDevice(b->ctx->device));
+        int rc = materialise_prefill(b);
+        if (rc) return rc;
+    }
     *dptr = b->d_track[track];
     return NATAC_OK;
 }

@@ -1044,8 +1044,132 @@ __global__ void __launch_bounds__(256) natac_occ_smooth(ChunkTable ct, const int
     }
     const long long o = ct.out_off[chunk] + g;
     s_occ[o] = den == 0.0 ? qn : nv / den;
-    s_lo[o] = den == 0.0 ? qn : nl / den;
-    s_hi[o] = den == 0.0 ? qn : nh / den;
+    if (s_lo) s_lo[o] = den == 0.0 ? qn : nl / den;
+    if (s_hi) s_hi[o] = den == 0.0 ? qn : nh / den;
+}
+
+// doubles as unsigned keys with the same order (atomicMin over the finite values of a chunk)
+__device__ __forceinline__ unsigned long long double_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_double(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
+// The same smoothing, one lane per step-block (STEP bases), for windows with h = (M - 1) / 2 a multiple of STEP: the STEP
+// bases of a block see the same 2 h / STEP + 2 blocks, so a lane reads each block's three values once for all of them (16
+// LDS reads per base instead of 104) and the block weights wb[bi][j] -- the table natac_occ_smooth builds per workgroup,
+// here precomputed by the host in the same summation order -- are wave-uniform scalar loads.  Term order, NaN skipping and
+// the cut last block are those of natac_occ_smooth: identical bits.  Also leaves, per chunk, the minimum finite smoothed
+// occupancy (as double_key, atomicMin) and whether it holds a NaN, for natac_fill_nan_chunks.
+// tile = (chunk, x0), x0 a multiple of 256 STEP.  Dynamic LDS: 3 x (256 + NB) + 256 STEP doubles.
+template <int STEP>
+__global__ void __launch_bounds__(256) natac_occ_smooth_blk(ChunkTable ct, const int2 *__restrict__ tiles, OccModelDev om,
+                                                              const double *__restrict__ win, int M,
+                                                              const double *__restrict__ wb /* [NB][STEP] */, int NB,
+                                                              const double *__restrict__ g_occ, const double *__restrict__ g_lo,
+                                                              const double *__restrict__ g_hi, double *__restrict__ s_occ,
+                                                              double *__restrict__ s_lo, double *__restrict__ s_hi,
+                                                              unsigned long long *__restrict__ cmin_key, int *__restrict__ cnan) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int h = (M - 1) / 2, nbh = h / STEP;
+    const int NG = 256 + NB;
+    double *gv = smem, *gl = gv + NG, *gh = gl + NG;
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, x0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    const int nk = (L - om.halfstep + STEP - 1) / STEP;
+    const long long gb = ct.grid_off[chunk];
+    const int kb0 = x0 / STEP, kfirst = kb0 - nbh;
+    const double qn = __builtin_nan("");
+    for (int u = threadIdx.x; u < NG; u += 256) {
+        const int kb = kfirst + u;
+        double v = qn, lo = qn, hi = qn;
+        if (kb >= 0 && kb < nk) { v = g_occ[gb + kb]; lo = g_lo[gb + kb]; hi = g_hi[gb + kb]; }
+        gv[u] = v; gl[u] = lo; gh[u] = hi;
+    }
+    __syncthreads();
+    const int kme = kb0 + threadIdx.x, base0 = kme * STEP;
+    double nv[STEP], nl[STEP], nh[STEP], den[STEP];
+#pragma unroll
+    for (int j = 0; j < STEP; ++j) { nv[j] = 0.0; nl[j] = 0.0; nh[j] = 0.0; den[j] = 0.0; }
+    if (base0 < L) {
+        for (int bi = 0; bi < NB; ++bi) {
+            const int u = threadIdx.x + bi, kb = kme - nbh + bi;
+            const double v = gv[u], lo = gl[u], hi = gh[u];
+            double w[STEP];
+#pragma unroll
+            for (int j = 0; j < STEP; ++j) w[j] = wb[bi * STEP + j];    // wave-uniform: one group of scalar loads
+            const bool skip = v != v;                           // NaN block (no inserts) or outside the chunk
+            const double vz = skip ? 0.0 : v, lz = skip ? 0.0 : lo, hz = skip ? 0.0 : hi;
+#pragma unroll
+            for (int j = 0; j < STEP; ++j) w[j] = skip ? 0.0 : w[j];
+            if (!skip && (kb + 1) * STEP > L) {                 // block cut by the chunk end: only existing bases count
+#pragma unroll
+                for (int j = 0; j < STEP; ++j) {
+                    double wc = 0.0;
+                    for (int p = kb * STEP; p < L; ++p) {
+                        const int n = base0 + j + h - p;
+                        if (n >= 0 && n < M) wc += win[n];
+                    }
+                    w[j] = wc;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < STEP; ++j) {
+                nv[j] = fma(w[j], vz, nv[j]); nl[j] = fma(w[j], lz, nl[j]); nh[j] = fma(w[j], hz, nh[j]); den[j] += w[j];
+            }
+        }
+    }
+    // results -> the wave's LDS strip (lane-major: [lane][j], conflict-free for odd STEP) -> coalesced stores of 64 STEP bases
+    double mn = __builtin_inf();
+    int anynan = 0;
+    const long long ob = ct.out_off[chunk];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *strip = gh + NG + wv * (64 * STEP);
+    const int wbase = (kb0 + wv * 64) * STEP;                   // first base of the wave
+#pragma unroll
+    for (int trk = 0; trk < 3; ++trk) {
+#pragma unroll
+        for (int j = 0; j < STEP; ++j) {
+            const double num = trk == 0 ? nv[j] : (trk == 1 ? nl[j] : nh[j]);
+            strip[lane * STEP + j] = den[j] == 0.0 ? qn : num / den[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        double *dst = trk == 0 ? s_occ : (trk == 1 ? s_lo : s_hi);
+#pragma unroll
+        for (int i = 0; i < STEP; ++i) {
+            const int g = wbase + i * 64 + lane;
+            if (g < L) {
+                const double o = strip[i * 64 + lane];
+                dst[ob + g] = o;
+                if (trk == 0) { if (o != o) anynan = 1; else mn = fmin(mn, o); }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    mn = wave_min(mn);
+    anynan = wave_or(anynan);
+    if ((threadIdx.x & 63) == 0) {
+        if (mn != __builtin_inf()) atomicMin(cmin_key + chunk, double_key(mn));
+        if (anynan) atomicOr(cnan + chunk, 1);
+    }
+}
+
+// call_peaks' in-place NaN fill for the track natac_occ_smooth_blk wrote (see natac_fill_nan_min): chunks without a NaN -- or
+// without a finite value -- are left alone; one workgroup per chunk.
+__global__ void __launch_bounds__(256) natac_fill_nan_chunks(ChunkTable ct, const unsigned long long *__restrict__ cmin_key,
+                                                               const int *__restrict__ cnan, double *__restrict__ track) {
+    const int chunk = blockIdx.x;
+    if (!cnan[chunk]) return;
+    const unsigned long long key = cmin_key[chunk];
+    if (key == ~0ull) return;
+    const double mn = key_double(key);
+    const int L = ct.chunk_len[chunk];
+    double *p = track + ct.out_off[chunk];
+    for (int g = threadIdx.x; g < L; g += 256)
+        if (p[g] != p[g]) p[g] = mn;
 }
 
 // occ coverage (all insert sizes < upper, window 2*flank+1): Occupancy.py:221-224.  When the occupancy window
@@ -1458,123 +1582,233 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 //   3. x[g] >= min_signal, boundary <= g < L - boundary;
 //   4. reduce_peaks: visit peaks by decreasing x, keep a peak and drop every peak closer than `sep` (utils.py:56-78).
 // ------------------------------------------------------------------------------------------------
-constexpr int PEAK_MAX = 2048;   // peaks per chunk held in LDS by natac_peak_reduce (L <= 2048 * (order + 1))
+constexpr int PEAK_MAX = 2048;   // peaks per chunk held in LDS by natac_peaks_chunk (more: status bit 1, host fallback)
 
-__global__ void __launch_bounds__(256) natac_chunk_min_combined(ChunkTable ct, const double *__restrict__ norm,
-                                                                  const double *__restrict__ smooth, double *__restrict__ cmin) {
+// steps 4 + output of the peak search for one chunk (see natac_peaks_chunk): n maxima in (pos, sig, state = 0), ascending
+__device__ __forceinline__ void peaks_thin_and_write(int n, int pk_cap, int sep, const double *sig, const int *pos, unsigned char *state,
+                                                      int *wave_cnt, int *__restrict__ dst, int *__restrict__ count_out,
+                                                      int *__restrict__ status_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool overflow = n > pk_cap;
+    if (overflow) n = pk_cap;
+    // ---- 4. reduce_peaks as parallel rounds.  A kept peak (state 1) has no free peak closer than sep once its round is
+    // over, so in later rounds the tests below never meet one: "free or kept" in the first pass only covers peaks that another
+    // thread keeps during the same pass
+    for (;;) {
+        int nfree = 0;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            if (state[i] != 0) continue;
+            const double si = sig[i];
+            const int pi = pos[i];
+            bool top = true;
+            for (int k = i - 1; top && k >= 0 && pi - pos[k] < sep; --k) top = !(state[k] <= 1 && sig[k] > si);
+            for (int k = i + 1; top && k < n && pos[k] - pi < sep; ++k) top = !(state[k] <= 1 && sig[k] >= si);
+            if (top) state[i] = 1; else ++nfree;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) {
+            if (state[i] != 0) continue;
+            const int pi = pos[i];
+            bool ex = false;
+            for (int k = i - 1; !ex && k >= 0 && pi - pos[k] < sep; --k) ex = state[k] == 1;
+            for (int k = i + 1; !ex && k < n && pos[k] - pi < sep; ++k) ex = state[k] == 1;
+            if (ex) { state[i] = 2; --nfree; }
+        }
+        if (__syncthreads_or(nfree > 0) == 0) break;
+    }
+    // ---- kept positions, ascending
+    int m_out = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        const bool kp = i < n && state[i] == 1;
+        const unsigned long long m = __ballot(kp);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = m_out;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (kp) dst[off + __popcll(m & ((1ull << lane) - 1ull))] = pos[i];
+        m_out += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *count_out = m_out;
+        if (overflow) atomicOr(status_out, 2);
+    }
+}
+
+// One workgroup per chunk does the whole search: minimum of the finite values, the jittered local-maximum test on
+// segments of `seg` bases staged in LDS, ordered compaction of the maxima, greedy thinning, and writes the kept positions
+// (ascending) into the chunk's slot region cand_slot[cap_off[chunk] ...] and their number into count[chunk].
+// The thinning runs as parallel rounds: a free peak that out-ranks every free peak closer than `sep` is kept and excludes
+// those neighbours -- the same set the reference's sequential visit by decreasing signal produces (a peak is only ever
+// excluded by a kept peak of higher rank, and a kept peak is the highest-ranked free one of its neighbourhood at the time it
+// is visited).  Rank: larger signal first, ties: the later position first (a stable ascending sort read backwards).
+// Dynamic LDS: ys[seg + 2 order (even)] | sig[pk_cap] | pos[pk_cap] (int) | state[pk_cap] (bytes); seg a multiple of 256.
+__global__ void __launch_bounds__(256) natac_peaks_chunk(ChunkTable ct, const double *__restrict__ norm,
+                                                           const double *__restrict__ smooth, const double *__restrict__ jitter,
+                                                           double min_signal, int boundary, int order, int sep, int seg, int pk_cap,
+                                                           const long long *__restrict__ cap_off, int *__restrict__ cand_slot,
+                                                           int *__restrict__ count, int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4];
+    __shared__ int wave_cnt[4];
+    const int ysn = (seg + 2 * order + 1) & ~1;
+    double *ys = smem;                              // jittered signal, index u <-> base clip(x0 - order + u)
+    double *sig = ys + ysn;
+    int *pos = (int *)(sig + pk_cap);
+    unsigned char *state = (unsigned char *)(pos + pk_cap);   // 0 free, 1 kept, 2 excluded
     const int chunk = blockIdx.x;
     const int L = ct.chunk_len[chunk];
     const long long ob = ct.out_off[chunk];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // ---- 1. minimum finite value of the combined signal
     double mn = __builtin_inf();
     for (int g = threadIdx.x; g < L; g += 256) {
         const double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
         if (v == v) mn = fmin(mn, v);
     }
     mn = wave_min(mn);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+    if (lane == 0) red[wave] = mn;
     __syncthreads();
-    if (threadIdx.x == 0) cmin[chunk] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    const double fillv = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    if (fillv == __builtin_inf()) {                 // all-NaN chunk: nothing
+        if (threadIdx.x == 0) count[chunk] = 0;
+        return;
+    }
+    // ---- 2. + 3. local maxima of the jittered signal, thresholds, ordered compaction
+    int n = 0;
+    for (int x0 = 0; x0 < L; x0 += seg) {
+        const int len = min(seg, L - x0);
+        __syncthreads();
+        for (int u = threadIdx.x; u < len + 2 * order; u += 256) {
+            int g = x0 - order + u;
+            g = g < 0 ? 0 : (g > L - 1 ? L - 1 : g);                 // numpy take(..., mode='clip')
+            double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
+            if (v != v) v = fillv;
+            ys[u] = v * (1 + jitter[g]);
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < len; j0 += 256) {
+            const int t = j0 + threadIdx.x, g = x0 + t;
+            bool pk = t < len;
+            double v = 0.0;
+            if (pk) {
+                const double y = ys[t + order];
+                for (int sft = 1; sft <= order && pk; ++sft) pk = (y > ys[t + order + sft]) && (y > ys[t + order - sft]);
+            }
+            if (pk) {
+                v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
+                if (v != v) v = fillv;
+                pk = (v >= min_signal) && (g >= boundary) && (g < L - boundary);
+            }
+            const unsigned long long m = __ballot(pk);
+            if (lane == 0) wave_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = n;
+            for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+            const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            if (pk) {
+                const int i = off + __popcll(m & ((1ull << lane) - 1ull));
+                if (i < pk_cap) { pos[i] = g; sig[i] = v; state[i] = 0; }
+            }
+            n += tot;
+            __syncthreads();
+        }
+    }
+    peaks_thin_and_write(n, pk_cap, sep, sig, pos, state, wave_cnt, cand_slot + cap_off[chunk], count + chunk, status + chunk);
 }
 
-__global__ void __launch_bounds__(256) natac_peak_flags(ChunkTable ct, const int2 *__restrict__ tiles,
-                                                          const double *__restrict__ norm, const double *__restrict__ smooth,
-                                                          const double *__restrict__ cmin, const double *__restrict__ jitter,
-                                                          double min_signal, int boundary, int order,
-                                                          unsigned char *__restrict__ flag) {
+// The same search for batches whose chunks all fit one segment (L <= 256 NJ): every thread keeps its NJ bases in registers,
+// so the signal is read from memory once, with all loads of a thread in flight together (the general kernel above walks
+// the chunk three times with one dependent load per iteration).  LDS as above with seg = 256 NJ.
+template <int NJ>
+__global__ void __launch_bounds__(256) natac_peaks_chunk_reg(ChunkTable ct, const double *__restrict__ norm,
+                                                               const double *__restrict__ smooth, const double *__restrict__ jitter,
+                                                               double min_signal, int boundary, int order, int sep, int pk_cap,
+                                                               const long long *__restrict__ cap_off, int *__restrict__ cand_slot,
+                                                               int *__restrict__ count, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *ys = smem;   // [256 + 2*order] jittered signal, index u <-> base clip(x0 - order + u)
-    const int2 t = tiles[blockIdx.x];
-    const int chunk = t.x, x0 = t.y;
-    const int L = ct.chunk_len[chunk];
-    const long long ob = ct.out_off[chunk];
-    const double fillv = cmin[chunk];
-    for (int u = threadIdx.x; u < 256 + 2 * order; u += 256) {
-        int g = x0 - order + u;
-        g = g < 0 ? 0 : (g > L - 1 ? L - 1 : g);                 // numpy take(..., mode='clip')
-        double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
-        if (v != v) v = fillv;
-        ys[u] = v * (1 + jitter[g]);
-    }
-    __syncthreads();
-    const int g = x0 + threadIdx.x;
-    if (g >= L) return;
-    bool pk = (fillv != __builtin_inf());                          // all-NaN chunk: nothing
-    const double y = ys[threadIdx.x + order];
-    for (int sft = 1; sft <= order && pk; ++sft)
-        pk = (y > ys[threadIdx.x + order + sft]) && (y > ys[threadIdx.x + order - sft]);
-    if (pk) {
-        double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
-        if (v != v) v = fillv;
-        pk = (v >= min_signal) && (g >= boundary) && (g < L - boundary);
-    }
-    flag[ob + g] = pk ? 1 : 0;
-}
-
-// one workgroup per chunk: compact the flagged bases, order them by decreasing signal, greedy thinning, write the kept
-// positions (ascending) into the chunk's slot region cand_slot[cap_off[chunk] ...] and their number into count[chunk].
-__global__ void __launch_bounds__(256) natac_peak_reduce(ChunkTable ct, const unsigned char *__restrict__ flag,
-                                                           const double *__restrict__ norm, const double *__restrict__ smooth,
-                                                           const double *__restrict__ cmin, int sep,
-                                                           const long long *__restrict__ cap_off, int *__restrict__ cand_slot,
-                                                           int *__restrict__ count, int *__restrict__ status) {
-    __shared__ int pos[PEAK_MAX];
-    __shared__ double sig[PEAK_MAX];
-    __shared__ int ord[PEAK_MAX];
-    __shared__ unsigned char state[PEAK_MAX];   // 0 free, 1 kept, 2 excluded
+    __shared__ double red[4];
     __shared__ int wave_cnt[4];
+    __shared__ int row_cnt[4 * NJ];
+    const int ysn = (256 * NJ + 2 * order + 1) & ~1;
+    double *ys = smem;                              // jittered signal, index u <-> base clip(u - order)
+    double *sig = ys + ysn;
+    int *pos = (int *)(sig + pk_cap);
+    unsigned char *state = (unsigned char *)(pos + pk_cap);
     const int chunk = blockIdx.x;
     const int L = ct.chunk_len[chunk];
     const long long ob = ct.out_off[chunk];
-    const double fillv = cmin[chunk];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int n = 0;
-    bool overflow = false;
-    for (int base = 0; base < L; base += 256) {
-        const int g = base + threadIdx.x;
-        const bool f = (g < L) && flag[ob + g];
-        const unsigned long long m = __ballot(f);
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = n;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        if (f) {
-            const int i = off + __popcll(m & ((1ull << lane) - 1ull));
-            if (i < PEAK_MAX) {
-                double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
-                if (v != v) v = fillv;
-                pos[i] = g;
-                sig[i] = v;
-                state[i] = 0;
-            }
+    double v[NJ], jt[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int g = threadIdx.x + 256 * j;
+        v[j] = __builtin_nan("");
+        jt[j] = 0.0;
+        if (g < L) {
+            v[j] = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
+            jt[j] = jitter[g];
         }
-        n += tot;
-        __syncthreads();
     }
-    if (n > PEAK_MAX) { overflow = true; n = PEAK_MAX; }
-    // rank by decreasing signal (ties: later position first, like a stable ascending sort read backwards)
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double si = sig[i];
-        int r = 0;
-        for (int j = 0; j < n; ++j) r += (sig[j] > si) || (sig[j] == si && j > i);
-        ord[r] = i;
+    double mn = __builtin_inf();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (v[j] == v[j]) mn = fmin(mn, v[j]);
+    mn = wave_min(mn);
+    if (lane == 0) red[wave] = mn;
+    __syncthreads();
+    const double fillv = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    if (fillv == __builtin_inf()) {                 // all-NaN chunk: nothing
+        if (threadIdx.x == 0) count[chunk] = 0;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int g = threadIdx.x + 256 * j;
+        if (v[j] != v[j]) v[j] = fillv;
+        if (g < L) {
+            const double y = v[j] * (1 + jt[j]);
+            ys[order + g] = y;
+            if (g == 0)
+                for (int u = 0; u < order; ++u) ys[u] = y;                 // numpy take(..., mode='clip')
+            if (g == L - 1)
+                for (int u = 0; u < order; ++u) ys[order + L + u] = y;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int t = 0; t < n; ++t) {
-            const int i = ord[t];
-            if (state[i]) continue;
-            state[i] = 1;
-            for (int k = i - 1; k >= 0 && pos[i] - pos[k] < sep; --k) if (!state[k]) state[k] = 2;
-            for (int k = i + 1; k < n && pos[k] - pos[i] < sep; ++k) if (!state[k]) state[k] = 2;
+    // maxima of the thread's bases, then one ordered compaction for all NJ rows (base order = row-major over (j, thread))
+    unsigned long long bal[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int g = threadIdx.x + 256 * j;
+        bool pk = g < L;
+        if (pk) {
+            const double y = ys[g + order];
+            for (int sft = 1; sft <= order && pk; ++sft) pk = (y > ys[g + order + sft]) && (y > ys[g + order - sft]);
         }
-        int m = 0;
-        int *dst = cand_slot + cap_off[chunk];
-        for (int i = 0; i < n; ++i) if (state[i] == 1) dst[m++] = pos[i];
-        count[chunk] = m;
-        if (overflow) atomicOr(&status[chunk], 2);
+        pk = pk && (v[j] >= min_signal) && (g >= boundary) && (g < L - boundary);
+        bal[j] = __ballot(pk);
+        if (lane == 0) row_cnt[j * 4 + wave] = __popcll(bal[j]);
     }
+    __syncthreads();
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int off = n;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int cw = row_cnt[j * 4 + w];
+            off += (w < wave) ? cw : 0;
+            n += cw;
+        }
+        if ((bal[j] >> lane) & 1ull) {
+            const int i = off + __popcll(bal[j] & ((1ull << lane) - 1ull));
+            if (i < pk_cap) { pos[i] = threadIdx.x + 256 * j; sig[i] = v[j]; state[i] = 0; }
+        }
+    }
+    __syncthreads();
+    peaks_thin_and_write(n, pk_cap, sep, sig, pos, state, wave_cnt, cand_slot + cap_off[chunk], count + chunk, status + chunk);
 }
 
 // exclusive prefix sum of per-chunk counts (single workgroup) + total

@@ -140,7 +140,7 @@ class BatchRunner(object):
         out = {}
         self.flat = getattr(self, "flat", {})
         for name, t in (("smoothed_vals", L.T_OCC), ("smoothed_lower", L.T_OCC_LOWER), ("smoothed_upper", L.T_OCC_UPPER),
-                        ("cov", L.T_OCC_COV), ("smoothed_prefill", L.T_OCC_PREFILL)):
+                        ("cov", L.T_OCC_COV)):
             self.flat[name] = b.track(t)
             out[name] = b.split(self.flat[name])
         grids = [b.grid(g) for g in (L.G_OCC, L.G_LOWER, L.G_UPPER)]
