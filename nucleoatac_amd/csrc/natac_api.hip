@@ -99,7 +99,8 @@ struct natac_batch {
     double *d_bias = nullptr, *d_ebias = nullptr;
     unsigned long long *d_occ_minkey = nullptr;   // natac_occ_smooth_blk: per-chunk minimum finite smoothed occupancy (double_key)
     int *d_occ_nan = nullptr, n_tiles_os = 0, os_width = 0;
-    int2 *d_tiles_os = nullptr;
+    int2 *d_tiles_os = nullptr, *d_tiles1k = nullptr;
+    int n_tiles1k = 0;
     bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
     int ranges256_w = -1;
@@ -693,7 +694,7 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_len); dev_free(b->d_lpos); dev_free(b->d_ilen); dev_free(b->d_centre); dev_free(b->d_status);
     dev_free(b->d_frag_off); dev_free(b->d_bias_off); dev_free(b->d_out_off); dev_free(b->d_grid_off); dev_free(b->d_bias);
     dev_free(b->d_ebias);
-    dev_free(b->d_occ_minkey); dev_free(b->d_occ_nan); dev_free(b->d_tiles_os);
+    dev_free(b->d_occ_minkey); dev_free(b->d_occ_nan); dev_free(b->d_tiles_os); dev_free(b->d_tiles1k);
     dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
     dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
@@ -813,9 +814,16 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     prof_begin(c, NATAC_K_SMOOTH_NUC, ev);
     {
         const int h = (M - 1) / 2;
-        const size_t lds = ((size_t)2 * (256 + 2 * h)) * sizeof(double);
-        hipLaunchKernelGGL((natac_smooth_same<true>), dim3(b->n_tiles256), dim3(256), lds, c->stream, ct, b->d_tiles256,
-                           c->d_win_nuc, M, c->win_nuc_sum, b->d_track[NATAC_T_NORM], b->d_track[NATAC_T_SMOOTH]);
+        if (h == 30) {      // the cli's smooth_sd = 10: four bases per lane
+            if (!b->d_tiles1k && (rc = build_tiles(b, 1024, &b->d_tiles1k, &b->n_tiles1k))) return rc;
+            hipLaunchKernelGGL((natac_smooth_same4<true, 30>), dim3(b->n_tiles1k), dim3(256), (size_t)8 * SM4_S(30) * sizeof(double),
+                               c->stream, ct, b->d_tiles1k, c->d_win_nuc, c->win_nuc_sum, b->d_track[NATAC_T_NORM],
+                               b->d_track[NATAC_T_SMOOTH]);
+        } else {
+            const size_t lds = ((size_t)2 * (256 + 2 * h)) * sizeof(double);
+            hipLaunchKernelGGL((natac_smooth_same<true>), dim3(b->n_tiles256), dim3(256), lds, c->stream, ct, b->d_tiles256,
+                               c->d_win_nuc, M, c->win_nuc_sum, b->d_track[NATAC_T_NORM], b->d_track[NATAC_T_SMOOTH]);
+        }
     }
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
@@ -1061,8 +1069,15 @@ int natac_run_ins(natac_batch *b, int lower, int upper) {
     const ChunkTable ct = make_table(b);
     natac_ctx::Ev ev;
     prof_begin(c, NATAC_K_INS, ev, c->stream2);
-    HIPCHK(hipMemsetAsync(b->d_track[NATAC_T_INS], 0, (size_t)b->total_bp * sizeof(int), c->stream2));
-    hipLaunchKernelGGL(natac_insertions, dim3(b->nc), dim3(256), 0, c->stream2, ct, lower, upper, (int *)b->d_track[NATAC_T_INS]);
+    int maxL = 0;
+    for (int i = 0; i < b->nc; ++i) maxL = std::max(maxL, b->h_len[i]);
+    if ((size_t)maxL * sizeof(int) <= 60 * 1024) {
+        hipLaunchKernelGGL(natac_insertions_lds, dim3(b->nc), dim3(256), (size_t)maxL * sizeof(int), c->stream2, ct, lower, upper,
+                           (int *)b->d_track[NATAC_T_INS]);
+    } else {
+        HIPCHK(hipMemsetAsync(b->d_track[NATAC_T_INS], 0, (size_t)b->total_bp * sizeof(int), c->stream2));
+        hipLaunchKernelGGL(natac_insertions, dim3(b->nc), dim3(256), 0, c->stream2, ct, lower, upper, (int *)b->d_track[NATAC_T_INS]);
+    }
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
     b->ins_done = true;

@@ -449,6 +449,77 @@ __global__ void __launch_bounds__(256) natac_smooth_same(ChunkTable ct, const in
     y[ob + g] = (den == 0.0) ? __builtin_nan("") : num / den;
 }
 
+// The same smoothing with four consecutive bases per lane for the window M = 2 H + 1 (compile time): a lane reads its
+// 4 + 2 H inputs once (16 LDS reads per base instead of 61; LDS holds the tile as four phase arrays so that lanes read
+// consecutive addresses) and every term order is natac_smooth_same's: identical bits.  The NaN-aware denominator is formed
+// per WAVE: only waves whose bases see a NaN or a chunk edge under their windows pay for it.
+// tile = (chunk, x0), x0 a multiple of 1024.  Dynamic LDS: 2 x 4 x SM4_S(H) doubles.
+__host__ __device__ constexpr int SM4_S(int H) { return (1024 + 2 * H) / 4 + 2; }
+
+template <bool CLAMP, int H>
+__global__ void __launch_bounds__(256) natac_smooth_same4(ChunkTable ct, const int2 *__restrict__ tiles,
+                                                            const double *__restrict__ win, double win_sum,
+                                                            const double *__restrict__ x, double *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int gap_s[4];
+    constexpr int M = 2 * H + 1, S = SM4_S(H), NU = 1024 + 2 * H;
+    double *xs = smem;               // value (NaN -> 0): element u (base x0 - H + u) at (u & 3) S + (u >> 2)
+    double *ok = smem + 4 * S;       // 1 / 0, same layout
+    const int2 t = tiles[blockIdx.x];
+    const int chunk = t.x, x0 = t.y;
+    const int L = ct.chunk_len[chunk];
+    const long long ob = ct.out_off[chunk];
+    if (threadIdx.x < 4) gap_s[threadIdx.x] = 0;
+    __syncthreads();
+    for (int u = threadIdx.x; u < NU; u += 256) {
+        const int g = x0 - H + u;
+        double v = 0.0, o = 0.0;
+        if (g >= 0 && g < L) {
+            v = x[ob + g];
+            if (v != v) { v = 0.0; } else { o = 1.0; if (CLAMP && v < 0) v = 0.0; }
+        }
+        xs[(u & 3) * S + (u >> 2)] = v;
+        ok[(u & 3) * S + (u >> 2)] = o;
+        if (o == 0.0) {              // element u lies under the windows of the tile's bases u - 2H .. u (beyond L: never written)
+            const int w0 = max(u - 2 * H, 0) >> 8, w1 = min(u, 1023) >> 8;
+            if (g < L + H) { gap_s[w0] = 1; gap_s[w1] = 1; }
+        }
+    }
+    __syncthreads();
+    const int tid = threadIdx.x, g0 = x0 + 4 * tid;
+    if (g0 >= L) return;
+    const bool gap = gap_s[tid >> 6] != 0;          // wave-uniform
+    double num[4] = {0.0, 0.0, 0.0, 0.0}, den[4] = {win_sum, win_sum, win_sum, win_sum};
+    if (!gap) {
+#pragma unroll
+        for (int kk = 0; kk < 2 * H + 4; ++kk) {
+            const int k = 2 * H + 3 - kk;               // inputs in descending order = taps n ascending for every output
+            const double r = xs[(k & 3) * S + tid + (k >> 2)];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int n = o + 2 * H - k;
+                if (n >= 0 && n < M) num[o] = fma(win[n], r, num[o]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) den[o] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 2 * H + 4; ++kk) {
+            const int k = 2 * H + 3 - kk;
+            const double r = xs[(k & 3) * S + tid + (k >> 2)], q = ok[(k & 3) * S + tid + (k >> 2)];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int n = o + 2 * H - k;
+                if (n >= 0 && n < M) { num[o] = fma(win[n], r, num[o]); den[o] = fma(win[n], q, den[o]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (g0 + o < L) y[ob + g0 + o] = (den[o] == 0.0) ? __builtin_nan("") : num[o] / den[o];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3  occupancy grid MLE (nucleoatac/Occupancy.py:104-146).
 // For grid point k of a chunk (base g = halfstep + k*step):
@@ -1227,6 +1298,26 @@ __global__ void __launch_bounds__(256) natac_fill_nan_min(ChunkTable ct, const d
 // K6  per-base insertion counts (pyatac/fragments.pyx:43-67): +1 at l and at r = l+n-1 for lower<=n<upper.
 // One workgroup walks the fragments of one chunk; integer atomics (order-independent, bit-exact).
 // ------------------------------------------------------------------------------------------------
+// chunks that fit LDS (the host checks the longest one): counts in LDS, every base written once -- no memset, no global atomics
+__global__ void __launch_bounds__(256) natac_insertions_lds(ChunkTable ct, int lower, int upper, int *__restrict__ ins) {
+    extern __shared__ int cnt_s[];
+    const int chunk = blockIdx.x;
+    const int L = ct.chunk_len[chunk];
+    const long long fa = ct.frag_off[chunk], fb = ct.frag_off[chunk + 1];
+    for (int g = threadIdx.x; g < L; g += 256) cnt_s[g] = 0;
+    __syncthreads();
+    for (long long f = fa + threadIdx.x; f < fb; f += 256) {
+        const int n = ct.ilen[f];
+        if (n < lower || n >= upper) continue;
+        const int l = ct.lpos[f], r = l + n - 1;
+        if (l >= 0 && l < L) atomicAdd(&cnt_s[l], 1);
+        if (r >= 0 && r < L) atomicAdd(&cnt_s[r], 1);
+    }
+    __syncthreads();
+    int *out = ins + ct.out_off[chunk];
+    for (int g = threadIdx.x; g < L; g += 256) out[g] = cnt_s[g];
+}
+
 __global__ void __launch_bounds__(256) natac_insertions(ChunkTable ct, int lower, int upper, int *__restrict__ ins) {
     const int chunk = blockIdx.x;
     const int L = ct.chunk_len[chunk];

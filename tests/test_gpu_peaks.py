@@ -117,3 +117,30 @@ def test_track_peaks_on_occupancy_equal_host_call_peaks(ctx):
         hp += [int(x) for x in p]
     assert len(cc) > 3000 and np.array_equal(cc, hc) and np.array_equal(cp, hp)
     b.free()
+
+
+def test_long_chunks_take_the_segmented_search_and_the_global_insertion_counts(ctx):
+    """chunks longer than 4,096 bases: peak search in LDS segments (signal re-read per segment); longer than 15,360: insertion
+    counts by global atomics instead of the per-chunk LDS histogram.  Both equal the host functions."""
+    from oracle import natac_oracle as O
+    rng = np.random.default_rng(17)
+    lens = [17000, 4097, 2120]
+    fr, off = [], [0]
+    for Lc in lens:
+        n = rng.integers(30, 400, size=Lc // 4)
+        c = np.sort(rng.integers(-50, Lc + 50, size=len(n)))
+        fr.append((c - (n - 1) // 2, n))
+        off.append(off[-1] + len(n))
+    pk = PackedChunks(np.arange(3) * 30000, lens, off, np.concatenate([x[0] for x in fr]), np.concatenate([x[1] for x in fr]), None, None)
+    b = ctx.upload(pk)
+    b.run_nuc(10)
+    b.run_ins(0, 2000)
+    for kw in (dict(min_signal=0, sep=25, boundary=60, order=12), dict(min_signal=0.02, sep=120, boundary=30, order=1)):
+        cc, cp, lr, var, z = b.run_peaks(**kw)
+        hc, hp = _host_peaks(b, pk, **kw)
+        assert len(cc) > 100 and np.array_equal(cc, hc) and np.array_equal(cp, hp)
+    ins = b.split(b.track(L.T_INS))
+    for k, Lc in enumerate(lens):
+        assert np.array_equal(ins[k], O.get_insertions(fr[k][0], fr[k][1], 0, Lc).astype(np.int32))
+    assert not b.status().any()
+    b.free()
