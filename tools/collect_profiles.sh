@@ -3,6 +3,7 @@
 # Kernel-trace statistics of the default bench, separate PMC passes (each under its own timeout), the default bench line.
 R=$PWD
 OUT=${1:-$R/gpurun_out/prof}
+case $OUT in /*) ;; *) OUT=$R/$OUT ;; esac
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline --no-h2h > /tmp/kt.log 2>&1
