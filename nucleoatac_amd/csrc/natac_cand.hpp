@@ -99,33 +99,51 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const double *psh1 = Ew + c1 + (LODD ? A - m0 : A + m0), *psh2 = Ew + c2 + (LODD ? A - m0 : A + m0);
     const double *pnw1 = Ew + c1 + (LODD ? A + m0 + 1 : A - m0), *pnw2 = Ew + c2 + (LODD ? A + m0 + 1 : A - m0);
     constexpr int DSH = LODD ? -1 : 1, DNW = LODD ? 1 : -1;
+    // template values and size weights of pair k (rows 2k, 2k+1), requested one trip ahead of their use: the L2 round trip of
+    // these loads is as long as the arithmetic of a trip and three waves per SIMD do not hide it
+    struct PairT { double va0, va1, vb0, vb1, sa, sb; };
+    const double hm = h2 ? 1.0 : 0.0;                          // idle second column: clamped (valid) address, zero template
+    auto load_pair = [&](int k) {
+        PairT t;
+        t.sa = vm.srow[2 * k]; t.sb = vm.srow[2 * k + 1];
+        t.va0 = vmat[2 * k * W + c1]; t.va1 = vmat[2 * k * W + c2];
+        t.vb0 = vmat[(2 * k + 1) * W + c1]; t.vb1 = vmat[(2 * k + 1) * W + c2];
+        return t;
+    };
     // one pair: row a multiplies the carried factor `cin`, row b the newly read one, which is handed on in `cout`
-    auto pair_step = [&](int k, const double (&cin)[Q][2], double (&cout)[Q][2]) {
-        const double sa = vm.srow[2 * k], sb = vm.srow[2 * k + 1];
-        const double va0 = vmat[2 * k * W + c1], va1 = h2 ? vmat[2 * k * W + c2] : 0.0;
-        const double vb0 = vmat[(2 * k + 1) * W + c1], vb1 = h2 ? vmat[(2 * k + 1) * W + c2] : 0.0;
-        const double wa0 = sa * (va0 * va0), wa1 = sa * (va1 * va1);     // weights of S_BV2: s_r v^2
-        const double wb0 = sb * (vb0 * vb0), wb1 = sb * (vb1 * vb1);
+    auto pair_step = [&](const PairT &t, const double (&cin)[Q][2], double (&cout)[Q][2]) {
+        const double va0 = t.va0, va1 = hm * t.va1, vb0 = t.vb0, vb1 = hm * t.vb1;
+        const double wa0 = t.sa * (va0 * va0), wa1 = t.sa * (va1 * va1);     // weights of S_BV2: s_r v^2
+        const double wb0 = t.sb * (vb0 * vb0), wb1 = t.sb * (vb1 * vb1);
+        double s0[Q], s1[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {                          // all 16 LDS operands of the step are requested before the arithmetic
+            s0[q] = psh1[q * EWP]; s1[q] = psh2[q * EWP];
+            cout[q][0] = pnw1[q * EWP]; cout[q][1] = pnw2[q * EWP];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const double s0 = psh1[q * EWP], s1 = psh2[q * EWP];
-            const double n0 = pnw1[q * EWP], n1 = pnw2[q * EWP];
-            a1[q][0] = fma(s0, fma(vb0, n0, va0 * cin[q][0]), a1[q][0]);
-            a1[q][1] = fma(s1, fma(vb1, n1, va1 * cin[q][1]), a1[q][1]);
-            a2[q][0] = fma(s0, fma(wb0, n0, wa0 * cin[q][0]), a2[q][0]);
-            a2[q][1] = fma(s1, fma(wb1, n1, wa1 * cin[q][1]), a2[q][1]);
-            cout[q][0] = n0;
-            cout[q][1] = n1;
+            const double n0 = cout[q][0], n1 = cout[q][1];
+            a1[q][0] = fma(s0[q], fma(vb0, n0, va0 * cin[q][0]), a1[q][0]);
+            a1[q][1] = fma(s1[q], fma(vb1, n1, va1 * cin[q][1]), a1[q][1]);
+            a2[q][0] = fma(s0[q], fma(wb0, n0, wa0 * cin[q][0]), a2[q][0]);
+            a2[q][1] = fma(s1[q], fma(wb1, n1, wa1 * cin[q][1]), a2[q][1]);
         }
         psh1 += DSH; psh2 += DSH; pnw1 += DNW; pnw2 += DNW;
     };
     double carry2[Q][2];
     int k = 0;
+    PairT t0 = load_pair(0), t1 = load_pair(min(1, npair - 1));
     for (; k + 2 <= npair; k += 2) {                          // two pairs per trip: the carried factor ping-pongs, no copies
-        pair_step(k, carry, carry2);
-        pair_step(k + 1, carry2, carry);
+        const PairT u0 = load_pair(min(k + 2, npair - 1));
+        pair_step(t0, carry, carry2);
+        t0 = u0;
+        const PairT u1 = load_pair(min(k + 3, npair - 1));
+        pair_step(t1, carry2, carry);
+        t1 = u1;
     }
-    if (k < npair) pair_step(k, carry, carry2);
+    if (k < npair) pair_step(t0, carry, carry2);
     // ---- exact zero-cell test, only for windows whose exp(bias) values are small enough for a product to underflow
     // (the host launches natac_candidates4 instead when the template / size distribution hold exact zeros)
     bool zero[Q];
