@@ -99,14 +99,48 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
     }
 }
 
+#ifndef NATAC_FFT_ABL
+#define NATAC_FFT_ABL 0
+#endif
+// complex scratch of the transposes: interleaved double2 (two planes of doubles with 8-byte accesses measured 5 % slower)
+#define CST(p, i, xr, xi) do { (p)[(i)] = make_double2((xr), (xi)); } while (0)
+#define CLD(p, i, xr, xi) do { const double2 v_ = (p)[(i)]; (xr) = v_.x; (xi) = v_.y; } while (0)
+
+// the two halves of fft512_fwd after the first in-register DFT: twiddle + transpose 1 (so that the caller can place loads
+// between them), then DFT + twiddle + transpose 2 + DFT
+__device__ __forceinline__ void fft512_fwd_t1(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sa, int lane) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 1 (layout A: lane + 72 m)
+        const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])), xi = fma(re[m], t.w1i[m], im[m] * t.w1r[m]);
+        CST(sa, lane + 72 * m, m ? xr : re[0], m ? xi : im[0]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int m2 = lane >> 3, n1 = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) CLD(sa, 72 * m2 + n1 + 8 * j, re[j], im[j]);
+    __builtin_amdgcn_wave_barrier();   // sb* may alias sa*
+}
+__device__ __forceinline__ void fft512_fwd_rest(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sb, int lane) {
+    const int m2 = lane >> 3, n1 = lane & 7;
+    dft8<false>(re, im);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 2 (layout B: element n1 of butterfly 8 m2 + m)
+        const double xr = fma(re[m], t.w2r[m], -(im[m] * t.w2i[m])), xi = fma(re[m], t.w2i[m], im[m] * t.w2r[m]);
+        CST(sb, n1 * 65 + 8 * m2 + m, m ? xr : re[0], m ? xi : im[0]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) CLD(sb, n * 65 + lane, re[n], im[n]);
+    dft8<false>(re, im);
+    __builtin_amdgcn_wave_barrier();
+}
+
 // forward 512-point FFT of the wave's data (lane n, register j <-> element n + 64 j); result: lane b, register m holds the
 // bin of "stage-3 butterfly b, output m" (a fixed permutation of the frequencies, identical for signal and template).
 // sa / sb: the wave's LDS scratch, FFT_LA and FFT_LB doubles for the real and for the imaginary parts each.
 // NATAC_FFT_ABL (tools/test_fft_bg.hip only): 1 = no LDS transposes (wrong results; what the round trips cost),
 // 2 = no template-spectrum loads, 3 = no exp(bias) operand reads
-#ifndef NATAC_FFT_ABL
-#define NATAC_FFT_ABL 0
-#endif
+
 __device__ __forceinline__ void fft512_fwd(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sa, double2 *sb, int lane) {
     dft8<false>(re, im);
     if (NATAC_FFT_ABL == 1) {
@@ -118,52 +152,33 @@ __device__ __forceinline__ void fft512_fwd(double (&re)[8], double (&im)[8], con
         dft8<false>(re, im);
         return;
     }
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 1 (layout A: lane + 72 m)
-        const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])), xi = fma(re[m], t.w1i[m], im[m] * t.w1r[m]);
-        sa[lane + 72 * m] = make_double2(m ? xr : re[0], m ? xi : im[0]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int m2 = lane >> 3, n1 = lane & 7;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const double2 v = sa[72 * m2 + n1 + 8 * j]; re[j] = v.x; im[j] = v.y; }
-    __builtin_amdgcn_wave_barrier();   // sb* may alias sa*
-    dft8<false>(re, im);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {                      // twiddle + transpose 2 (layout B: element n1 of butterfly 8 m2 + m)
-        const double xr = fma(re[m], t.w2r[m], -(im[m] * t.w2i[m])), xi = fma(re[m], t.w2i[m], im[m] * t.w2r[m]);
-        sb[n1 * 65 + 8 * m2 + m] = make_double2(m ? xr : re[0], m ? xi : im[0]);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int n = 0; n < 8; ++n) { const double2 v = sb[n * 65 + lane]; re[n] = v.x; im[n] = v.y; }
-    dft8<false>(re, im);
-    __builtin_amdgcn_wave_barrier();
+    fft512_fwd_t1(re, im, t, sa, lane);
+    fft512_fwd_rest(re, im, t, sb, lane);
 }
 
 // exact inverse of fft512_fwd up to the factor 512
 __device__ __forceinline__ void fft512_inv(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sa, double2 *sb, int lane) {
     dft8<true>(re, im);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) sb[n * 65 + lane] = make_double2(re[n], im[n]);
+    for (int n = 0; n < 8; ++n) CST(sb, n * 65 + lane, re[n], im[n]);
     __builtin_amdgcn_wave_barrier();
     const int m2 = lane >> 3, n1 = lane & 7;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const double2 v = sb[n1 * 65 + 8 * m2 + m];
-        const double xr = v.x, xi = v.y;
+        double xr, xi;
+        CLD(sb, n1 * 65 + 8 * m2 + m, xr, xi);
         re[m] = m ? fma(xr, t.w2r[m], xi * t.w2i[m]) : xr;                 // * conj(W)
         im[m] = m ? fma(xi, t.w2r[m], -(xr * t.w2i[m])) : xi;
     }
     __builtin_amdgcn_wave_barrier();
     dft8<true>(re, im);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sa[72 * m2 + n1 + 8 * j] = make_double2(re[j], im[j]);
+    for (int j = 0; j < 8; ++j) CST(sa, 72 * m2 + n1 + 8 * j, re[j], im[j]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const double2 v = sa[lane + 72 * m];
-        const double xr = v.x, xi = v.y;
+        double xr, xi;
+        CLD(sa, lane + 72 * m, xr, xi);
         re[m] = m ? fma(xr, t.w1r[m], xi * t.w1i[m]) : xr;
         im[m] = m ? fma(xi, t.w1r[m], -(xr * t.w1i[m])) : xi;
     }
@@ -292,11 +307,65 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int j = 0; j < 8; ++j) carry[j] = c0[lane + 64 * j];
     }
+    if (pairs_full && NATAC_FFT_ABL == 0) {
+        // Software pipeline of a row pair: the template spectrum is requested at the top of the trip (the whole transform covers
+        // its L2 round trip; left to the compiler the loads sit right before the last DFT) and the exp(bias) operands of the
+        // NEXT pair after the last DFT, so that the accumulation covers their LDS round trip.
+        double x[8], y[8];
+        auto issue_xy = [&](int pair) {
+            const int ia = vm.lower + 2 * pair, ib = ia + 1;
+            if (lodd) {       // shared left factor x; y = right factor of b
+                lds_read8_b64(x, Et + (A - floor_half(ia - 1)) + lane);
+                lds_read8_b64(y, Et + (A + floor_half(ib)) + lane);
+            } else {          // shared right factor y; x = left factor of b
+                lds_read8_b64(x, Et + (A - floor_half(ib - 1)) + lane);
+                lds_read8_b64(y, Et + (A + floor_half(ia)) + lane);
+            }
+        };
+        issue_xy(0);
+        for (int pair = 0; pair < npair; ++pair) {
+            const double sa = vm.srow[2 * pair], sb = vm.srow[2 * pair + 1];
+            const double *k = ktab + (size_t)pair * 2 * FFT_N;
+            double kr[8], ki[8], re[8], im[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { kr[m] = k[m * 64 + lane]; ki[m] = k[FFT_N + m * 64 + lane]; }
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait16(x, y);
+            if (lodd) {       // carry = right factor of a
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    re[j] = x[j] * carry[j];
+                    im[j] = x[j] * y[j];
+                    carry[j] = y[j];
+                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
+                }
+            } else {          // carry = left factor of a
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    re[j] = carry[j] * y[j];
+                    im[j] = x[j] * y[j];
+                    carry[j] = x[j];
+                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
+                }
+            }
+            fft512_fwd(re, im, tww, ca, cb, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_xy(min(pair + 1, npair - 1));
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
+                accr[m] = fma(re[m], kr[m], fma(im[m], ki[m], accr[m]));
+                acci[m] = fma(im[m], kr[m], fma(-re[m], ki[m], acci[m]));
+            }
+        }
+        lds_wait16(x, y);     // the re-read of the last trip
+    } else   // odd row count (or an ablation build): the plain loop
     for (int pair = 0; pair < npair; ++pair) {
         const int ra = 2 * pair, rb = ra + 1;
         const int ia = vm.lower + ra, ib = (rb < vm.R) ? ia + 1 : ia;   // odd R: the missing row reads row a's (valid) window with weight 0
         const double sa = vm.srow[ra], sb = (rb < vm.R) ? vm.srow[rb] : 0.0;
         double re[8], im[8];
+        const double *k = ktab + (size_t)pair * 2 * FFT_N;
+        double kr[8], ki[8];
         if (pairs_full) {
             double x[8], y[8];
             if (NATAC_FFT_ABL == 3) {
@@ -342,12 +411,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
         fft512_fwd(re, im, tww, ca, cb, lane);
-        const double *k = ktab + (size_t)pair * 2 * FFT_N;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { kr[m] = NATAC_FFT_ABL == 2 ? 0.5 + m : k[m * 64 + lane]; ki[m] = NATAC_FFT_ABL == 2 ? 0.25 * m : k[FFT_N + m * 64 + lane]; }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
-            const double kr = NATAC_FFT_ABL == 2 ? 0.5 + m : k[m * 64 + lane], ki = NATAC_FFT_ABL == 2 ? 0.25 * m : k[FFT_N + m * 64 + lane];
-            accr[m] = fma(re[m], kr, fma(im[m], ki, accr[m]));
-            acci[m] = fma(im[m], kr, fma(-re[m], ki, acci[m]));
+            accr[m] = fma(re[m], kr[m], fma(im[m], ki[m], accr[m]));
+            acci[m] = fma(im[m], kr[m], fma(-re[m], ki[m], acci[m]));
         }
     }
     fft512_inv(accr, acci, tww, ca, cb, lane);
