@@ -4,6 +4,7 @@ GPU (libnatac_hip.so): coverage, raw signal, background, normalised + smoothed s
 log-likelihood ratio / multinomial variance / z (natac_run_candidates), dense correlate for the operator-level
 SignalTrack / BiasTrack classes.  Host: peak calling, thresholds, the L-BFGS fuzziness fit.
 """
+import os
 from bisect import bisect_left
 from copy import copy
 
@@ -266,9 +267,18 @@ def nuc_batch(chunks, params, ctx=None, with_flat=False):
             for name, label in (("nuc_signal", "signal"), ("bias", "bias"), ("norm_signal", "normalized signal"),
                                 ("smoothed", "Smooth Signal")):
                 setattr(nc, name, Track(ch.chrom, ch.start, ch.end, label, vals=res[name][k].copy()))
-            if params.occ_track is not None:
-                nc.getOcc()
             out.append(nc)
+        if params.occ_track is not None:
+            # three tabix region reads per chunk (NucleosomeCalling.py:284-293), ~1 ms each: spread over host threads (the
+            # native reader releases the GIL; every thread has its own readers, pyatac/tracks.py:_tabix)
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(16, os.cpu_count() or 1, len(out)))
+            if nthr == 1:
+                for nc in out:
+                    nc.getOcc()
+            else:
+                with ThreadPoolExecutor(nthr) as ex:
+                    list(ex.map(NucChunk.getOcc, out, chunksize=1))
         # candidate search (call_peaks on norm + smoothed, NucleosomeCalling.py:297-301) and LR / z for every candidate
         # of every chunk on the device: nothing round-trips between the signal kernels and the statistics
         cc, cp, lr, var, z = run.batch.run_peaks(min_signal=0, sep=params.redundant_sep,

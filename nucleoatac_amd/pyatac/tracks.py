@@ -1,6 +1,7 @@
 """Per-base signal tracks (API of the reference's pyatac/tracks.py:16-222)."""
 import gzip
 import os
+import threading
 
 import numpy as np
 
@@ -8,15 +9,17 @@ from .chunk import Chunk
 from .utils import smooth
 
 
-_TABIX = {}
+_LOCAL = threading.local()
 
 
 def _tabix(path):
-    """one open index per file (NucChunk.getOcc reads three tracks per chunk, NucleosomeCalling.py:284-293): the native
-    reader when libnatac_hip.so is there, else the pure-Python one"""
+    """one open index per file and thread (NucChunk.getOcc reads three tracks per chunk, NucleosomeCalling.py:284-293; the
+    batched driver reads the chunks of a batch from several threads and a reader holds one file position): the native reader
+    when libnatac_hip.so is there, else the pure-Python one"""
     from ..tabix import NativeTabix, TabixFile
+    cache = _LOCAL.__dict__.setdefault("tabix", {})
     key = (path, os.path.getmtime(path + ".tbi"))
-    tb = _TABIX.get(path)
+    tb = cache.get(path)
     if tb is None or tb[0] != key:
         if tb is not None:
             tb[1].close()
@@ -25,7 +28,7 @@ def _tabix(path):
         except ImportError:
             rd = TabixFile(path)
         tb = (key, rd)
-        _TABIX[path] = tb
+        cache[path] = tb
     return tb[1]
 
 

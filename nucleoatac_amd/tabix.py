@@ -222,3 +222,9 @@ class NativeTabix(object):
         if self._h:
             self._lib.natac_tbx_close(self._h)
             self._h = None
+
+    def __del__(self):          # readers cached per thread go away with their thread
+        try:
+            self.close()
+        except Exception:
+            pass
