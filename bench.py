@@ -203,6 +203,30 @@ def pmc_traffic_bytes(kernel_substr):
     return (f + w) * 1024.0
 
 
+def pmc_valu_issue():
+    """{kernel: share of the SIMDs' issue cycles spent on VALU instructions} for the heavy kernels, from the newest committed PMC
+    summary: SQ_INSTS_VALU (wave-instructions) x 4 cycles (a wave64 fp64 / fp32 instruction occupies its SIMD for 4 cycles) over
+    1,024 SIMDs x the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs).  None when no profile is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.csv")))
+    if not files:
+        return None
+    per = {}
+    with open(files[-1]) as fh:
+        for row in csv.reader(l for l in fh if not l.startswith("#")):
+            if len(row) == 4 and row[1] in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "kernel_ns_under_pmc"):
+                per.setdefault(row[0], {})[row[1]] = float(row[2]) / float(row[3])
+    out = {}
+    for k, v in per.items():
+        if len(v) == 3 and v["kernel_ns_under_pmc"] > 2e6:        # kernels above 2 ms
+            cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+            name = k.replace("void ", "").replace("natac::", "")
+            out[name] = {"valu_wave_instructions": int(v["SQ_INSTS_VALU"]), "clock_ghz": round(cyc / v["kernel_ns_under_pmc"], 3),
+                         "valu_issue_frac": round(v["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), 3)}
+    return out or None
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def make_workload(a, rank, world):
     """list of PackedChunks sub-batches of this rank + description"""
@@ -511,6 +535,7 @@ def main():
                                              "executed_tflops": round(fft_tflops, 2), "peak": FP64_PEAK_TFLOPS,
                                              "unit": "TFLOP/s", "frac_executed": round(fft_tflops / FP64_PEAK_TFLOPS, 4)}},
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
+            "valu_issue_from_committed_pmc": pmc_valu_issue() if a.workload == "cfg3" else None,
             "host": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2),
                      "download_5_tracks_and_candidates_s": None if t_dn is None else round(t_dn, 2),
                      "pcie_inclusive_mbp_s_no_overlap": None if t_dn is None else round(

@@ -1165,18 +1165,19 @@ __global__ void __launch_bounds__(256) natac_occ_smooth_blk(ChunkTable ct, const
     double nv[STEP], nl[STEP], nh[STEP], den[STEP];
 #pragma unroll
     for (int j = 0; j < STEP; ++j) { nv[j] = 0.0; nl[j] = 0.0; nh[j] = 0.0; den[j] = 0.0; }
-    if (base0 < L) {
+    // only the last block of a chunk can be cut by the chunk end, and only when L is not a whole number of blocks past the
+    // half step: the per-lane test is compiled in for those chunks only (block-uniform)
+    auto sweep = [&](auto may_cut) {
         for (int bi = 0; bi < NB; ++bi) {
             const int u = threadIdx.x + bi, kb = kme - nbh + bi;
             const double v = gv[u], lo = gl[u], hi = gh[u];
             double w[STEP];
 #pragma unroll
             for (int j = 0; j < STEP; ++j) w[j] = wb[bi * STEP + j];    // wave-uniform: one group of scalar loads
-            const bool skip = v != v;                           // NaN block (no inserts) or outside the chunk
-            const double vz = skip ? 0.0 : v, lz = skip ? 0.0 : lo, hz = skip ? 0.0 : hi;
-#pragma unroll
-            for (int j = 0; j < STEP; ++j) w[j] = skip ? 0.0 : w[j];
-            if (!skip && (kb + 1) * STEP > L) {                 // block cut by the chunk end: only existing bases count
+            const bool skip = v != v;                           // NaN block (no inserts) or outside the chunk: adds w * 0 = +0 to
+            const double vz = skip ? 0.0 : v, lz = skip ? 0.0 : lo, hz = skip ? 0.0 : hi;   // every sum (the table weights are finite)
+            const double okf = skip ? 0.0 : 1.0;                // den + w as fma(w, 1, den): the same bits
+            if (decltype(may_cut)::value && !skip && (kb + 1) * STEP > L) {   // cut block: only existing bases count
 #pragma unroll
                 for (int j = 0; j < STEP; ++j) {
                     double wc = 0.0;
@@ -1189,9 +1190,13 @@ __global__ void __launch_bounds__(256) natac_occ_smooth_blk(ChunkTable ct, const
             }
 #pragma unroll
             for (int j = 0; j < STEP; ++j) {
-                nv[j] = fma(w[j], vz, nv[j]); nl[j] = fma(w[j], lz, nl[j]); nh[j] = fma(w[j], hz, nh[j]); den[j] += w[j];
+                nv[j] = fma(w[j], vz, nv[j]); nl[j] = fma(w[j], lz, nl[j]); nh[j] = fma(w[j], hz, nh[j]);
+                den[j] = fma(w[j], okf, den[j]);
             }
         }
+    };
+    if (base0 < L) {
+        if (nk * STEP > L) sweep(std::true_type{}); else sweep(std::false_type{});
     }
     // results -> the wave's LDS strip (lane-major: [lane][j], conflict-free for odd STEP) -> coalesced stores of 64 STEP bases
     double mn = __builtin_inf();
