@@ -48,7 +48,7 @@ struct natac_ctx {
     hipStream_t stream2 = nullptr;   // occ stage + insertions: independent of the nuc stage, overlaps with it
     hipDeviceProp_t prop;
     // constants
-    double *d_vmat = nullptr, *d_srow = nullptr, *d_sizes = nullptr;
+    double *d_vmat = nullptr, *d_vmat_pad = nullptr, *d_srow = nullptr, *d_sizes = nullptr;   // d_vmat_pad: VMatDev::matp
     int vlower = 0, vupper = 0, vw = 0, R = 0, W = 0, sizes_upper = 0;
     bool have_vmat = false, have_sizes = false, srow_dirty = true;
     bool vmat_zero = false, srow_zero = false;
@@ -359,7 +359,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
     prof_collect(c);
-    dev_free(c->d_vmat); dev_free(c->d_srow); dev_free(c->d_sizes);
+    dev_free(c->d_vmat); dev_free(c->d_vmat_pad); dev_free(c->d_srow); dev_free(c->d_sizes);
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
     dev_free(c->d_win_nuc); dev_free(c->d_win_occ); dev_free(c->d_wb_occ);
     dev_free(c->d_fft_tw); dev_free(c->d_fft_k);
@@ -398,6 +398,15 @@ int natac_set_vmat(natac_ctx *c, const double *mat, int lower, int upper, int w)
     c->vlower = lower; c->vupper = upper; c->vw = w; c->R = upper - lower; c->W = 2 * w + 1;
     int rc = dev_upload(c, &c->d_vmat, mat, (size_t)c->R * c->W);
     if (rc) return rc;
+    {   // the same rows between VPAD zero columns (natac_frag_gather)
+        const int WP = c->W + 2 * VPAD;
+        std::vector<double> padded((size_t)c->R * WP, 0.0);
+        for (int r = 0; r < c->R; ++r) std::copy(mat + (size_t)r * c->W, mat + (size_t)(r + 1) * c->W, padded.begin() + (size_t)r * WP + VPAD);
+        dev_free(c->d_vmat_pad);
+        c->d_vmat_pad = nullptr;
+        if ((rc = dev_upload(c, &c->d_vmat_pad, padded.data(), padded.size()))) return rc;
+        HIPCHK(sync_all(c));   // `padded` is a local
+    }
     c->vmat_zero = false;
     for (size_t i = 0; i < (size_t)c->R * c->W; ++i) if (mat[i] == 0.0) { c->vmat_zero = true; break; }
     HIPCHK(sync_all(c));
@@ -600,7 +609,7 @@ static ChunkTable make_table(natac_batch *b) {
 }
 static VMatDev make_vmat(natac_ctx *c) {
     VMatDev v;
-    v.mat = c->d_vmat; v.srow = c->d_srow; v.lower = c->vlower; v.upper = c->vupper; v.w = c->vw; v.R = c->R; v.W = c->W;
+    v.mat = c->d_vmat; v.matp = c->d_vmat_pad; v.srow = c->d_srow; v.lower = c->vlower; v.upper = c->vupper; v.w = c->vw; v.R = c->R; v.W = c->W;
     v.has_zero = (c->vmat_zero || c->srow_zero) ? 1 : 0;
     return v;
 }

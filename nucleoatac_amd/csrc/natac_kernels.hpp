@@ -30,8 +30,11 @@ struct ChunkTable {
     const long long *grid_off;  // [nc+1]
 };
 
+constexpr int VPAD = 64;   // zero columns on both sides of every row of VMatDev::matp (natac_frag_gather)
+
 struct VMatDev {
     const double *mat;   // R x W row-major
+    const double *matp;  // R x (W + 2 VPAD): the same rows between VPAD zero columns
     const double *srow;  // [R] sizes[lower + r]
     int lower, upper, w, R, W;
     int has_zero;        // the template or srow holds an exact 0 (host-computed)
@@ -163,8 +166,6 @@ __device__ __forceinline__ int advance_while_less(const int *a, int from, int n,
     return f;
 }
 
-constexpr int GATHER_FMAX = 1024;   // fragments of a 256-base tile staged in LDS (denser tiles read global memory)
-
 // fragment range [t0, t1) of every 256-base tile: centres within [x0 - w, x0 + 255 + w]; one thread per tile
 __global__ void __launch_bounds__(256) natac_tile_ranges256(ChunkTable ct, const int2 *__restrict__ tiles, int ntiles, int w,
                                                               int2 *__restrict__ ranges) {
@@ -180,52 +181,81 @@ __global__ void __launch_bounds__(256) natac_tile_ranges256(ChunkTable ct, const
 
 // occ_cov != nullptr: also writes nuc_cov + nfr_cov (OccChunk.getCov, Occupancy.py:221-224, when the occupancy window and size
 // range coincide with the V-plot's: exact integers).
+//
+// One wave = 64 consecutive bases.  The fragments that can touch them (centre-sorted, ~45 on configs[2]) are taken 64 at a
+// time, one per lane, and compacted by size class through a per-wave LDS strip (ballot + mbcnt); their centres / template
+// row offsets then reach all lanes as SCALARS (v_readlane with the loop counter), four nucleosome-sized fragments per trip,
+// so four template-row reads (one coalesced segment each) are in flight before the first value is added.  The rows come
+// from a copy of the template with VPAD zero columns on both sides: a base outside a fragment's window reads a zero
+// instead of being masked out, and list tails are padded with a fragment whose window lies left of the wave (zeros again).
+// The additions per base keep the list (= centre) order; + 0.0 leaves the sum's bits alone.  Round 1's loop walked one
+// fragment per trip through generic pointers (flat loads) with a dependent L2 read each: ~700 cycles per fragment and
+// wave, 5.9 ms per launch -- latency- and not, as first thought, L2-bandwidth-bound.
 __global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const int2 *__restrict__ tiles,
                                                            const int2 *__restrict__ ranges, VMatDev vm,
                                                            double *__restrict__ nuc_cov, double *__restrict__ nfr_cov,
                                                            double *__restrict__ raw, double *__restrict__ occ_cov) {
-    __shared__ int cen_s[GATHER_FMAX];
-    __shared__ int iln_s[GATHER_FMAX];
+    __shared__ int strip_s[4][3][64];
     const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, g = t.y + threadIdx.x;
     const int L = ct.chunk_len[chunk];
     const int2 tr = ranges[blockIdx.x];
     const int nt = tr.y - tr.x;
-    const int *cen = ct.centre + ct.frag_off[chunk] + tr.x;
-    const int *iln = ct.ilen + ct.frag_off[chunk] + tr.x;
-    const bool staged = nt <= GATHER_FMAX;
-    if (staged) {
-        for (int i = threadIdx.x; i < nt; i += 256) { cen_s[i] = cen[i]; iln_s[i] = iln[i]; }
-        __syncthreads();
-        cen = cen_s;
-        iln = iln_s;
-    }
-    // Wave-uniform walk over the fragments that can touch the wave's 64 bases, in list (= centre) order: every lane adds the
-    // template value of its own column, so a step is one coalesced read of (part of) a template row instead of 64 scattered
-    // ones, and the order of the additions per base is the list order as before (bit-identical sums).  Only nucleosome-sized
-    // fragments load a template row: the kernel is bound by those L2 reads (measured: a branch-free variant that loaded a
-    // clamped row for every fragment was 30 % slower; persistent workgroups with the whole template in LDS, 138 of the CU's
-    // 160 KiB, were 35-120 % slower -- 8-16 waves per CU cannot hide the per-segment chain of dependent index loads).
-    const int lane = threadIdx.x & 63;
+    const int *__restrict__ cen = ct.centre + ct.frag_off[chunk] + tr.x;
+    const int *__restrict__ iln = ct.ilen + ct.frag_off[chunk] + tr.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gw0 = g - lane;                                  // first base of the wave
     if (gw0 >= L) return;                                      // wave-uniform
-    int f = advance_while_less(cen, 0, nt, gw0 - vm.w, lane);
-    const int fend = advance_while_less(cen, f, nt, gw0 + 63 + vm.w + 1, lane);
+    const double *__restrict__ matp = vm.matp;
+    const int W = vm.W, WP = W + 2 * VPAD, lower = vm.lower, upper = vm.upper;
+    const int goff = vm.w - g;                                 // column of this base in a fragment's template row: c + goff
+    const int clo = gw0 - vm.w, chi = gw0 + 63 + vm.w;         // centres that can touch the wave's bases
+    const int cfill = clo - 1;                                 // a centre whose window ends left of the wave: columns -64 .. -1
+    int *sc = strip_s[wv][0], *so = strip_s[wv][1], *sf = strip_s[wv][2];
     int cnt_nuc = 0, cnt_nfr = 0;
     double acc = 0.0;
-    for (; f < fend; ++f) {
-        const int c = cen[f], n = iln[f];                      // broadcast reads
-        const int d = c - g + vm.w;                            // this base's column of the template
-        const bool in = (d >= 0) && (d < vm.W);
-        if (n >= vm.lower) {                                   // wave-uniform branches (n is per fragment)
-            if (n < vm.upper) {
-                if (in) {
-                    ++cnt_nuc;
-                    acc += vm.mat[(n - vm.lower) * vm.W + d];
-                }
+    // all fragments of the tile's range (those of its four waves; no per-wave search: its dependent loads cost more than
+    // filtering the other waves' fragments out of the batch)
+    int nxc = cfill, nxn = -1;                                 // the batch after the current one is already requested
+    if (lane < nt) { nxc = cen[lane]; nxn = iln[lane]; }
+    for (int base = 0; base < nt; base += 64) {
+        const int myc = nxc, myn = nxn;
+        const int fi = base + 64 + lane;
+        nxc = cfill; nxn = -1;
+        if (fi < nt) { nxc = cen[fi]; nxn = iln[fi]; }
+        const bool mine = myc >= clo && myc <= chi;
+        const bool isnuc = mine && myn >= lower && myn < upper, isnfr = mine && myn >= 0 && myn < lower;
+        const unsigned long long mnuc = __ballot(isnuc), mnfr = __ballot(isnfr);
+        const int nn = __popcll(mnuc), nf = __popcll(mnfr);
+        if (nn + nf == 0) continue;                            // wave-uniform
+        sc[lane] = cfill; so[lane] = VPAD; sf[lane] = cfill;      // tails: row 0, its left zero columns
+        __builtin_amdgcn_wave_barrier();
+        if (isnuc) {
+            const int p = __builtin_amdgcn_mbcnt_hi((unsigned)(mnuc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mnuc, 0u));
+            sc[p] = myc;
+            so[p] = (myn - lower) * WP + VPAD;
+        }
+        if (isnfr) sf[__builtin_amdgcn_mbcnt_hi((unsigned)(mnfr >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mnfr, 0u))] = myc;
+        __builtin_amdgcn_wave_barrier();
+        const int cc = sc[lane], oo = so[lane], cf = sf[lane];
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < nf; ++i) {                         // short fragments: coverage only
+            const int d = __builtin_amdgcn_readlane(cf, i) + goff;
+            cnt_nfr += ((unsigned)d < (unsigned)W) ? 1 : 0;
+        }
+        for (int i = 0; i < nn; i += 8) {                      // nucleosome-sized: coverage + template value, eight reads in flight
+            double v[8];
+            int d[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                d[q] = __builtin_amdgcn_readlane(cc, i + q) + goff;
+                v[q] = matp[__builtin_amdgcn_readlane(oo, i + q) + d[q]];
             }
-        } else if (n >= 0) {
-            if (in) ++cnt_nfr;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                cnt_nuc += ((unsigned)d[q] < (unsigned)W) ? 1 : 0;
+                acc += v[q];
+            }
         }
     }
     if (g >= L) return;
