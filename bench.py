@@ -402,8 +402,25 @@ def main():
         import torch
         import torch.distributed as dist
         if a.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # the collectives here are the contract's barrier and the max / sum of three scalars, never data: if RCCL cannot
+            # come up on this node (or the ranks share one GPU) the run goes on over gloo instead of dying
+            try:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:      # noqa: BLE001
+                sys.stderr.write("bench: RCCL unavailable (%s: %s); barrier / reductions over gloo\n" % (type(e).__name__, str(e)[:200]))
+                try:
+                    dist.destroy_process_group()
+                except Exception:       # noqa: BLE001
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"      # rank 0 hosts the new store itself
+                a.dist_backend = "gloo"
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=a.dist_backend)
 

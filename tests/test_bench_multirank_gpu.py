@@ -62,3 +62,17 @@ def test_cfg4_strong_scaling_two_ranks_share_device():
     imb = c2["shard_imbalance"]
     assert len(imb["bp_per_rank"]) == 2 and sum(imb["bp_per_rank"]) == c2["bp_total"] and imb["bp_max_over_mean"] < 1.05
     assert c1["sub_batches_this_rank"] == 4 and c2["sub_batches_this_rank"] == 2
+
+
+def test_rccl_failure_falls_back_to_gloo():
+    """default backend (RCCL) with two ranks on ONE GPU: RCCL refuses the duplicate device; the bench's collectives (barrier,
+    max / sum of three scalars) are not data, so it goes on over gloo and still prints its line"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29536", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--chunks", "2000", "--share-device", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RCCL unavailable" in out.stderr
+    d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0
