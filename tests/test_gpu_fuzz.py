@@ -1,0 +1,32 @@
+"""GPU: a short run of tools/fuzz_parity.py -- random ragged chunk sets (lengths 121..9000, densities 0..12 fragments per base,
+fragment-free stretches, with / without bias, sizes at the model's edges): every track, insertion counts and the candidate
+search against the CPU oracle.  (The release check ran ~2,400 rounds / 10 M bases of the same generator.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_chunk_sets_match_the_oracle():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity as F
+    from helpers import golden
+    from nucleoatac_amd.device import Context
+    from nucleoatac_amd.synth import synth_occ_distributions, synth_size_distribution
+    par = golden("params_example")
+    sizes = synth_size_distribution(251)
+    nucp, nfrp = synth_occ_distributions(251)
+    ctx = Context(0)
+    ctx.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
+    ctx.set_sizes(sizes)
+    ctx.set_occ_model(nucp, nfrp, step=5, flank=60)
+    rng = np.random.default_rng(2024)
+    bp = 0
+    for r in range(30):
+        bp += F.one_round(ctx, rng, par, sizes, nucp, nfrp, r)[0]
+    ctx.close()
+    assert bp > 30000
