@@ -48,9 +48,30 @@ def ensure_distributed():
         return dist, False
     backend = os.environ.get("NATAC_DIST_BACKEND", "nccl")
     if backend == "nccl":
+        # only barriers and the gather of small per-chunk results go through the group (never track data): if RCCL cannot come
+        # up on this node the run continues over gloo
+        import sys
         import torch
-        torch.cuda.set_device(local)
-    dist.init_process_group(backend=backend)
+        dev = int(os.environ.get("NATAC_DEVICE", local))          # the GPU this rank computes on (default: LOCAL_RANK)
+        try:
+            torch.cuda.set_device(dev)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("all_reduce probe returned %r" % probe.item())
+        except Exception as e:      # noqa: BLE001
+            sys.stderr.write("nucleoatac_amd: RCCL unavailable (%s: %s); process group over gloo\n" % (type(e).__name__, str(e)[:200]))
+            try:
+                dist.destroy_process_group()
+            except Exception:       # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"      # rank 0 hosts the new store itself
+            dist.init_process_group(backend="gloo")
+    else:
+        dist.init_process_group(backend=backend)
     return dist, True
 
 
