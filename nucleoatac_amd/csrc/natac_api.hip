@@ -104,6 +104,7 @@ struct natac_batch {
     bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
     int ranges256_w = -1;
+    int ranges_occ_key[3] = {-1, -1, -1};   // (step, halfstep, flank) the occupancy tiles' fragment ranges were formed for
     int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;   // bgG: lanes' output count of the direct kernel, -1 = FFT tiles
     int grid_step = 0, grid_half = 0;
     // fast occupancy path: per-block sums of g_n / g_f, their tile table and the list of tiles left to natac_occ_mle
@@ -934,6 +935,7 @@ int natac_run_occ(natac_batch *b) {
         dev_free(b->d_ranges_occ);
         b->d_ranges_occ = nullptr;
         if ((rc = dev_alloc(&b->d_ranges_occ, (size_t)b->n_tiles_occ))) return rc;
+        b->ranges_occ_key[0] = -1;       // new tile table: ranges not formed yet
         b->grid_step = c->step;
         b->grid_half = c->halfstep;
     }
@@ -980,8 +982,12 @@ int natac_run_occ(natac_batch *b) {
                            (size_t)2 * OCC_FMAX * sizeof(int);
         if (lds > 64 * 1024)
             return fail(NATAC_E_ARG, "occupancy window / step too large for the device tile (step=%d flank=%d upper=%d)", c->step, c->flank, U);
-        hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
-                           b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
+        if (b->ranges_occ_key[0] != c->step || b->ranges_occ_key[1] != c->halfstep || b->ranges_occ_key[2] != c->flank) {
+            // an index over the (immutable) fragment list, like the 256-base tiles' ranges: formed once per batch and geometry
+            hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
+                               b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
+            b->ranges_occ_key[0] = c->step; b->ranges_occ_key[1] = c->halfstep; b->ranges_occ_key[2] = c->flank;
+        }
         const int *d_list = nullptr, *d_count = nullptr;
         unsigned grid_general = (unsigned)b->n_tiles_occ;
         if (fast) {
