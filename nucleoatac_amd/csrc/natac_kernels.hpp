@@ -1937,24 +1937,43 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk_reg(ChunkTable ct, cons
     peaks_thin_and_write(n, pk_cap, sep, sig, pos, state, wave_cnt, cand_slot + cap_off[chunk], count + chunk, status + chunk);
 }
 
-// exclusive prefix sum of per-chunk counts (single workgroup) + total
+// exclusive prefix sum of per-chunk counts (single workgroup) + total: tiles of 4,096 counts, four consecutive ones per thread
+// (coalesced), wave scans by shuffles, the 16 wave totals through LDS, a running carry between tiles
 __global__ void __launch_bounds__(1024) natac_scan_counts(const int *__restrict__ count, int nc, long long *__restrict__ offs) {
-    __shared__ long long part[1024];
-    const int t = threadIdx.x;
-    const int per = (nc + 1023) / 1024;
-    const int a = t * per, b = (a + per < nc) ? a + per : nc;
-    long long sum = 0;
-    for (int i = a; i < b; ++i) sum += count[i];
-    part[t] = sum;
-    __syncthreads();
-    if (t == 0) {
-        long long run = 0;
-        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
-        offs[nc] = run;
+    __shared__ long long wtot[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    long long carry = 0;
+    for (int base = 0; base < nc; base += 4096) {
+        const int i0 = base + 4 * t;
+        int c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = (i0 + q < nc) ? count[i0 + q] : 0;
+        const long long mine = (long long)c[0] + c[1] + c[2] + c[3];
+        long long incl = mine;                               // inclusive scan over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        long long before = carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const long long v = wtot[w];
+            before += (w < wave) ? v : 0;
+            total += v;
+        }
+        long long run = before + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (i0 + q < nc) offs[i0 + q] = run;
+            run += c[q];
+        }
+        carry += total;
+        __syncthreads();
     }
-    __syncthreads();
-    long long run = part[t];
-    for (int i = a; i < b; ++i) { offs[i] = run; run += count[i]; }
+    if (t == 0) offs[nc] = carry;
 }
 
 __global__ void __launch_bounds__(256) natac_compact_candidates(int nc, const int *__restrict__ count,
