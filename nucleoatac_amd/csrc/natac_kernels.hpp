@@ -30,7 +30,7 @@ struct ChunkTable {
     const long long *grid_off;  // [nc+1]
 };
 
-constexpr int VPAD = 64;   // zero columns on both sides of every row of VMatDev::matp (natac_frag_gather)
+constexpr int VPAD = 128;  // zero columns on both sides of every row of VMatDev::matp (natac_frag_gather)
 
 struct VMatDev {
     const double *mat;   // R x W row-major
@@ -182,39 +182,48 @@ __global__ void __launch_bounds__(256) natac_tile_ranges256(ChunkTable ct, const
 // occ_cov != nullptr: also writes nuc_cov + nfr_cov (OccChunk.getCov, Occupancy.py:221-224, when the occupancy window and size
 // range coincide with the V-plot's: exact integers).
 //
-// One wave = 64 consecutive bases.  The fragments that can touch them (centre-sorted, ~45 on configs[2]) are taken 64 at a
-// time, one per lane, and compacted by size class through a per-wave LDS strip (ballot + mbcnt); their centres / template
-// row offsets then reach all lanes as SCALARS (v_readlane with the loop counter), four nucleosome-sized fragments per trip,
-// so four template-row reads (one coalesced segment each) are in flight before the first value is added.  The rows come
-// from a copy of the template with VPAD zero columns on both sides: a base outside a fragment's window reads a zero
-// instead of being masked out, and list tails are padded with a fragment whose window lies left of the wave (zeros again).
-// The additions per base keep the list (= centre) order; + 0.0 leaves the sum's bits alone.  Round 1's loop walked one
-// fragment per trip through generic pointers (flat loads) with a dependent L2 read each: ~700 cycles per fragment and
-// wave, 5.9 ms per launch -- latency- and not, as first thought, L2-bandwidth-bound.
-__global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const int2 *__restrict__ tiles,
-                                                           const int2 *__restrict__ ranges, VMatDev vm,
-                                                           double *__restrict__ nuc_cov, double *__restrict__ nfr_cov,
-                                                           double *__restrict__ raw, double *__restrict__ occ_cov) {
-    __shared__ int strip_s[4][3][64];
+// One wave = 128 consecutive bases, two adjacent ones per lane (a fragment is visited by (121 + 128) / 128 = 1.9 waves instead
+// of 2.9 with 64).  The fragments that can touch them (centre-sorted, ~60 on configs[2]) are taken 64 at a time, one per
+// lane, and compacted by size class through a per-wave LDS strip (ballot + mbcnt); their centres / template row offsets then
+// reach all lanes as SCALARS (v_readlane with the loop counter), eight nucleosome-sized fragments per trip, so eight
+// template reads -- the two adjacent columns of the lane's bases, 16 bytes -- are in flight before the first value is
+// added.  The rows come from a copy of the template with VPAD zero columns on both sides: a base outside a fragment's
+// window reads a zero instead of being masked out, and list tails are padded with a fragment whose window lies left of the
+// wave (zeros again).  The additions per base keep the list (= centre) order; + 0.0 leaves the sum's bits alone.  Round 1's
+// loop walked one fragment per trip through generic pointers (flat loads) with a dependent L2 read each: ~700 cycles per
+// fragment and wave, 5.9 ms per launch -- latency- and not, as first thought, L2-bandwidth-bound.
+template <int NBL>
+struct __attribute__((packed, aligned(8))) GatherCols { double v[NBL]; };   // columns d - NBL + 1 .. d of a padded template row
+
+// NBL adjacent bases per lane; tile = 256 bases = 256 / (64 NBL) waves
+template <int NBL>
+__global__ void __launch_bounds__(256 / NBL) natac_frag_gather(ChunkTable ct, const int2 *__restrict__ tiles,
+                                                                 const int2 *__restrict__ ranges, VMatDev vm,
+                                                                 double *__restrict__ nuc_cov, double *__restrict__ nfr_cov,
+                                                                 double *__restrict__ raw, double *__restrict__ occ_cov) {
+    constexpr int WB = 64 * NBL;                               // bases per wave
+    static_assert(WB <= VPAD, "template padding");
+    __shared__ int strip_s[256 / WB][3][64];
     const int2 t = tiles[blockIdx.x];
-    const int chunk = t.x, g = t.y + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int chunk = t.x, gw0 = t.y + WB * wv, g = gw0 + NBL * lane;     // the lane's bases: g .. g + NBL - 1
     const int L = ct.chunk_len[chunk];
     const int2 tr = ranges[blockIdx.x];
     const int nt = tr.y - tr.x;
     const int *__restrict__ cen = ct.centre + ct.frag_off[chunk] + tr.x;
     const int *__restrict__ iln = ct.ilen + ct.frag_off[chunk] + tr.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gw0 = g - lane;                                  // first base of the wave
     if (gw0 >= L) return;                                      // wave-uniform
     const double *__restrict__ matp = vm.matp;
     const int W = vm.W, WP = W + 2 * VPAD, lower = vm.lower, upper = vm.upper;
-    const int goff = vm.w - g;                                 // column of this base in a fragment's template row: c + goff
-    const int clo = gw0 - vm.w, chi = gw0 + 63 + vm.w;         // centres that can touch the wave's bases
-    const int cfill = clo - 1;                                 // a centre whose window ends left of the wave: columns -64 .. -1
+    const int goff = vm.w - g;                                 // column of base g in a fragment's template row: c + goff (g + b: b less)
+    const int clo = gw0 - vm.w, chi = gw0 + WB - 1 + vm.w;     // centres that can touch the wave's bases
+    const int cfill = clo - 1;                                 // a centre whose window ends left of the wave: columns -WB .. -1
     int *sc = strip_s[wv][0], *so = strip_s[wv][1], *sf = strip_s[wv][2];
-    int cnt_nuc = 0, cnt_nfr = 0;
-    double acc = 0.0;
-    // all fragments of the tile's range (those of its four waves; no per-wave search: its dependent loads cost more than
+    int cnt_nuc[NBL], cnt_nfr[NBL];
+    double acc[NBL];
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) { cnt_nuc[b] = 0; cnt_nfr[b] = 0; acc[b] = 0.0; }
+    // all fragments of the tile's range (those of all its waves; no per-wave search: its dependent loads cost more than
     // filtering the other waves' fragments out of the batch)
     int nxc = cfill, nxn = -1;                                 // the batch after the current one is already requested
     if (lane < nt) { nxc = cen[lane]; nxn = iln[lane]; }
@@ -241,29 +250,38 @@ __global__ void __launch_bounds__(256) natac_frag_gather(ChunkTable ct, const in
         __builtin_amdgcn_wave_barrier();
         for (int i = 0; i < nf; ++i) {                         // short fragments: coverage only
             const int d = __builtin_amdgcn_readlane(cf, i) + goff;
-            cnt_nfr += ((unsigned)d < (unsigned)W) ? 1 : 0;
-        }
-        for (int i = 0; i < nn; i += 8) {                      // nucleosome-sized: coverage + template value, eight reads in flight
-            double v[8];
-            int d[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int b = 0; b < NBL; ++b) cnt_nfr[b] += ((unsigned)(d - b) < (unsigned)W) ? 1 : 0;
+        }
+        constexpr int NQ = 16 / NBL;                           // reads in flight per trip (16 columns per lane)
+        for (int i = 0; i < nn; i += NQ) {                     // nucleosome-sized: coverage + template values
+            GatherCols<NBL> v[NQ];
+            int d[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
                 d[q] = __builtin_amdgcn_readlane(cc, i + q) + goff;
-                v[q] = matp[__builtin_amdgcn_readlane(oo, i + q) + d[q]];
+                v[q] = *(const GatherCols<NBL> *)(matp + (__builtin_amdgcn_readlane(oo, i + q) + d[q] - (NBL - 1)));
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                cnt_nuc += ((unsigned)d[q] < (unsigned)W) ? 1 : 0;
-                acc += v[q];
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int b = 0; b < NBL; ++b) {
+                    cnt_nuc[b] += ((unsigned)(d[q] - b) < (unsigned)W) ? 1 : 0;
+                    acc[b] += v[q].v[NBL - 1 - b];
+                }
             }
         }
     }
-    if (g >= L) return;
     const long long o = ct.out_off[chunk] + g;
-    nuc_cov[o] = (double)cnt_nuc;
-    nfr_cov[o] = (double)cnt_nfr;
-    raw[o] = acc;
-    if (occ_cov) occ_cov[o] = (double)(cnt_nuc + cnt_nfr);
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) {
+        if (g + b < L) {
+            nuc_cov[o + b] = (double)cnt_nuc[b];
+            nfr_cov[o + b] = (double)cnt_nfr[b];
+            raw[o + b] = acc[b];
+            if (occ_cov) occ_cov[o + b] = (double)(cnt_nuc[b] + cnt_nfr[b]);
+        }
+    }
 }
 
 // occ coverage when the occupancy window / size range coincide with the V-plot's: cov = nuc_cov + nfr_cov (exact integers)
