@@ -271,10 +271,11 @@ static void launch_candidates(natac_ctx *c, const ChunkTable &ct, const VMatDev 
     const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
     const int ZN = (((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1) + 5 + 32) & ~1, ON = (c->W + 1) & ~1;
     const size_t lds4 = ((size_t)4 * CAND_PER_WAVE * ((EW + 1) & ~1) + ZN + ON) * sizeof(double);
-    // paired-row kernel (natac_cand.hpp): needs the background kernel's window sums, no single-cell row, whole row pairs and
+    // paired-row kernel (natac_cand.hpp): needs the background kernel's window sums, no single-cell row, whole row pairs, a template
+    // at least 64 columns wide (every lane's first column exists) and
     // a model without exact zeros (those take the per-cell zero test of natac_candidates4).  NATAC_CAND_OLD=1: validation.
     const size_t ldsp = (size_t)4 * CAND_PER_WAVE * CANDP_STRIDE * sizeof(double);
-    if (bnum && bcov && c->vlower >= 2 && (c->R & 1) == 0 && !vm.has_zero && EW <= CANDP_STRIDE && !getenv("NATAC_CAND_FULL") &&
+    if (bnum && bcov && c->vlower >= 2 && (c->R & 1) == 0 && c->W >= 64 && !vm.has_zero && EW <= CANDP_STRIDE && !getenv("NATAC_CAND_FULL") &&
         !getenv("NATAC_CAND_OLD")) {
         const long long per_block = 4 * CAND_PER_WAVE;
         const dim3 grid((unsigned)((n + per_block - 1) / per_block));

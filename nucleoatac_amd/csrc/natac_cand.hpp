@@ -41,7 +41,8 @@ __device__ __forceinline__ int row_lower_bound(const int *__restrict__ a, int lo
 constexpr int CANDP_STRIDE = 376;   // doubles per candidate window in LDS (compile-time: every LDS address of the sweep is a
                                     // running base register + an immediate); V-plots with W + upper - 2 > 376 use natac_candidates4
 
-// LODD: parity of vm.lower.  Requires vm.lower >= 2, R even, EW <= CANDP_STRIDE, bnum / bcov of the current model (host-checked).
+// LODD: parity of vm.lower.  Requires vm.lower >= 2, R even, W >= 64, EW <= CANDP_STRIDE, bnum / bcov of the current model
+// (host-checked).
 template <bool LODD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) natac_candidates_paired(
     ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk, const int *__restrict__ cand_pos, int ncand,

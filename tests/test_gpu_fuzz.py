@@ -30,3 +30,15 @@ def test_random_chunk_sets_match_the_oracle():
         bp += F.one_round(ctx, rng, par, sizes, nucp, nfrp, r)[0]
     ctx.close()
     assert bp > 30000
+
+
+def test_random_model_geometries_match_the_oracle():
+    """a short run of tools/fuzz_generic.py: random V-plot bounds / row counts / widths (incl. narrower than a wave: the paired
+    candidate kernel must hand over), smoothing widths, occupancy window / step / size range / alpha grids"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_generic as G
+    from helpers import golden
+    par = golden("params_example")
+    rng = np.random.default_rng(99)
+    bp = sum(G.one_round(rng, par) for _ in range(25))
+    assert bp > 10000
