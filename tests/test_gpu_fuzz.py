@@ -42,3 +42,18 @@ def test_random_model_geometries_match_the_oracle():
     rng = np.random.default_rng(99)
     bp = sum(G.one_round(rng, par) for _ in range(25))
     assert bp > 10000
+
+
+def test_random_dropin_calls_match_the_oracle():
+    """a short run of tools/fuzz_dropins.py: the Cython functions' replacements and the operator-level helpers on random
+    regions / fragment sets / chunk lists / windows / PWMs"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_dropins as D
+    from nucleoatac_amd.device import Context
+    from nucleoatac_amd.synth import synth_occ_distributions
+    D.one_round.model = synth_occ_distributions(251)
+    rng = np.random.default_rng(5)
+    with Context(0) as c:
+        c.set_occ_model(*D.one_round.model, step=5, flank=60)
+        for _ in range(150):
+            D.one_round(c, rng)
