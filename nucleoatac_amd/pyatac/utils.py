@@ -18,7 +18,9 @@ def reduce_peaks(peaks, sig, sep):
     n = peaks.size
     keep = np.zeros(n, dtype=bool)
     dead = np.zeros(n, dtype=bool)
-    for ind in np.argsort(sig)[::-1]:
+    # stable order (equal heights: the later position first), the device kernel's rule; the reference's default argsort is an
+    # unstable introsort, so among exactly equal heights its visiting order depends on the numpy build (utils.py:61)
+    for ind in np.argsort(sig, kind="stable")[::-1]:
         if dead[ind]:
             continue
         keep[ind] = dead[ind] = True

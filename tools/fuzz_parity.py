@@ -19,6 +19,17 @@ from nucleoatac_amd.synth import synth_occ_distributions, synth_size_distributio
 from oracle import natac_oracle as O  # noqa: E402
 
 
+def call_peaks_stable(sigvals, **kw):
+    """O.call_peaks with reduce_peaks' argsort made STABLE.  The reference sorts with numpy's default introsort
+    (pyatac/utils.py:61), so among peaks of exactly equal height -- occupancy saturated at 1.0 over a dense stretch -- its
+    visiting order depends on the numpy build; the device uses the stable order (ties: the later position first), which
+    is what the unstable sort returns whenever it does not permute equal keys."""
+    import unittest.mock as mock
+    real = np.argsort
+    with mock.patch.object(np, "argsort", lambda a, *x, **k: real(a, kind="stable")):
+        return O.call_peaks(sigvals, **kw)
+
+
 def one_round(ctx, rng, par, sizes, nucp, nfrp, rnd):
     nch = int(rng.integers(1, 7))
     lens = [int(rng.choice([121, 122, 125, 126, int(rng.integers(127, 700)), int(rng.integers(700, 3000)),
@@ -58,6 +69,10 @@ def one_round(ctx, rng, par, sizes, nucp, nfrp, rnd):
                                            L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER, L.T_OCC_COV, L.T_INS)}
     kw = dict(min_signal=0, sep=int(rng.choice([25, 40, 120])), boundary=int(rng.choice([0, 30, 60])), order=int(rng.choice([1, 5, 12])))
     cc, cp, lr, var, z = b.run_peaks(**kw)
+    min_occ = float(rng.choice([0.0, 0.1, 0.3]))
+    osep = int(rng.choice([60, 120]))
+    oc_c, oc_p, oc_occ, oc_lo, oc_up, oc_rd, oc_keep, nd = b.run_occ_peaks(min_occ=min_occ, sep=osep)
+    st2 = b.status()
     for k, Lc in enumerate(lens):
         l, n = fr[k]
         bias_k = pk.chunk_bias(k) if with_bias else None
@@ -78,9 +93,27 @@ def one_round(ctx, rng, par, sizes, nucp, nfrp, rnd):
             filled = oc["smoothed_vals"].copy()
             O.call_peaks(filled)
             assert_track(tr[L.T_OCC][k], filled, "occ post-fill")
+        if not (st[k] & 1) and not (st2[k] & 2):
+            # OccChunk.callPeaks + getNucDist (Occupancy.py:225-240) restated on the device's own tracks
+            occv, lov, upv, covv = tr[L.T_OCC][k], tr[L.T_OCC_LOWER][k], tr[L.T_OCC_UPPER][k], tr[L.T_OCC_COV][k]
+            pk_ = np.asarray(call_peaks_stable(occv.copy(), sep=osep, min_signal=min_occ), np.int64)
+            m = oc_c == k
+            if not np.array_equal(oc_p[m], pk_):
+                raise AssertionError(("occ peaks", k, Lc, min_occ, osep, oc_p[m][:12], pk_[:12], int(np.isnan(occv).sum()), st[k], st2[k]))
+            if not (np.array_equal(oc_occ[m], occv[pk_]) and np.array_equal(oc_lo[m], lov[pk_], equal_nan=True) and np.array_equal(oc_rd[m], covv[pk_])):
+                raise AssertionError(("occ peak values", k, Lc, oc_occ[m][:6], occv[pk_][:6], oc_lo[m][:6], lov[pk_][:6], oc_rd[m][:6], covv[pk_][:6]))
+            keep = (lov[pk_] > min_occ) & (covv[pk_] > 0)
+            assert np.array_equal(oc_keep[m].astype(bool), keep)
+            cen = l + (n - 1) // 2
+            ref_nd = np.zeros(251)
+            for p_ in pk_[keep]:
+                sel = (cen >= p_ - 60) & (cen <= p_ + 60) & (n >= 0) & (n < 251)
+                h = np.bincount(n[sel], minlength=251)[:251].astype(np.float64)
+                ref_nd += h / h.sum()
+            assert np.allclose(nd[k], ref_nd, rtol=1e-12, atol=1e-15), ("nuc_dist", k)
         if not (st[k] & 2):
             comb = tr[L.T_NORM][k] + tr[L.T_SMOOTH][k]
-            hp = np.asarray(O.call_peaks(comb.copy(), **kw), np.int64)
+            hp = np.asarray(call_peaks_stable(comb.copy(), **kw), np.int64)
             assert np.array_equal(cp[cc == k], hp), ("peaks", k, Lc, kw)
     b.free()
     return sum(lens), int(off[-1])
