@@ -31,9 +31,13 @@ def call_peaks_stable(sigvals, **kw):
 
 
 def one_round(ctx, rng, par, sizes, nucp, nfrp, rnd):
-    nch = int(rng.integers(1, 7))
-    lens = [int(rng.choice([121, 122, 125, 126, int(rng.integers(127, 700)), int(rng.integers(700, 3000)),
-                            int(rng.integers(3000, 9000))])) for _ in range(nch)]
+    if rng.random() < 0.12:          # many short chunks: tile tables / offsets across chunk borders
+        nch = int(rng.integers(40, 160))
+        lens = [int(rng.integers(121, 520)) for _ in range(nch)]
+    else:
+        nch = int(rng.integers(1, 7))
+        lens = [int(rng.choice([121, 122, 125, 126, int(rng.integers(127, 700)), int(rng.integers(700, 3000)),
+                                int(rng.integers(3000, 9000))])) for _ in range(nch)]
     with_bias = rng.random() < 0.7
     fr = []
     for Lc in lens:
