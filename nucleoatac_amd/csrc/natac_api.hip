@@ -1179,23 +1179,38 @@ static int run_peaks_impl(natac_batch *b, const double *sig_a, const double *sig
     const double *norm = sig_a, *sm = sig_b;
     natac_ctx::Ev ev;
     prof_begin(c, NATAC_K_CAND, ev);
-    {   // one workgroup per chunk: LDS = a segment of the jittered signal + the chunk's list of maxima
-        const int nj = (maxL + 255) / 256;
-        const int seg = std::min(nj * 256, 4096);
+    {   // one workgroup per chunk: LDS = the jittered signal (or a segment of it) + the chunk's list of maxima
         const int pk_cap = (std::min(PEAK_MAX, maxL / (order + 1) + 2) + 7) & ~7;
-        const size_t lds = (size_t)((seg + 2 * order + 1) & ~1) * sizeof(double) + (size_t)pk_cap * (sizeof(double) + sizeof(int) + 1);
-#define NATAC_PEAKS_REG(NJ)                                                                                                        \
-    case NJ:                                                                                                                       \
-        hipLaunchKernelGGL((natac_peaks_chunk_reg<NJ>), dim3(b->nc), dim3(256), lds, c->stream, ct, norm, sm, b->d_jitter, min_signal, \
-                           boundary, order, sep, pk_cap, b->d_cap_off, b->d_slot, b->d_pk_count, b->d_status);                    \
-        break;
-        switch (nj <= 16 ? nj : 0) {
-            NATAC_PEAKS_REG(1) NATAC_PEAKS_REG(2) NATAC_PEAKS_REG(3) NATAC_PEAKS_REG(4) NATAC_PEAKS_REG(5) NATAC_PEAKS_REG(6)
-            NATAC_PEAKS_REG(7) NATAC_PEAKS_REG(8) NATAC_PEAKS_REG(9) NATAC_PEAKS_REG(10) NATAC_PEAKS_REG(11) NATAC_PEAKS_REG(12)
-            NATAC_PEAKS_REG(13) NATAC_PEAKS_REG(14) NATAC_PEAKS_REG(15) NATAC_PEAKS_REG(16)
-            default:   // chunks longer than 4,096 bases: segments, signal re-read from memory (L2)
-                hipLaunchKernelGGL(natac_peaks_chunk, dim3(b->nc), dim3(256), lds, c->stream, ct, norm, sm, b->d_jitter, min_signal,
-                                   boundary, order, sep, seg, pk_cap, b->d_cap_off, b->d_slot, b->d_pk_count, b->d_status);
+        const size_t lds_lists = (size_t)pk_cap * (sizeof(double) + sizeof(int) + 1);
+        const int bt = maxL <= 4096 ? 256 : 1024;               // threads per workgroup of the register variant
+        const int nj = (maxL + bt - 1) / bt;
+        const size_t lds_reg = (size_t)((bt * nj + 2 * order + 1) & ~1) * sizeof(double) + lds_lists;
+#define NATAC_PEAKS_REG(NJ, BT)                                                                                                    \
+    case NJ: {                                                                                                                     \
+        auto kfn = natac_peaks_chunk_reg<NJ, BT>;                                                                                  \
+        if (lds_reg > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg)); \
+        hipLaunchKernelGGL(kfn, dim3(b->nc), dim3(BT), lds_reg, c->stream, ct, norm, sm, b->d_jitter, min_signal, boundary, order, sep, \
+                           pk_cap, b->d_cap_off, b->d_slot, b->d_pk_count, b->d_status);                                          \
+        break;                                                                                                                     \
+    }
+        if (bt == 256) {
+            switch (nj) {
+                NATAC_PEAKS_REG(1, 256) NATAC_PEAKS_REG(2, 256) NATAC_PEAKS_REG(3, 256) NATAC_PEAKS_REG(4, 256) NATAC_PEAKS_REG(5, 256)
+                NATAC_PEAKS_REG(6, 256) NATAC_PEAKS_REG(7, 256) NATAC_PEAKS_REG(8, 256) NATAC_PEAKS_REG(9, 256) NATAC_PEAKS_REG(10, 256)
+                NATAC_PEAKS_REG(11, 256) NATAC_PEAKS_REG(12, 256) NATAC_PEAKS_REG(13, 256) NATAC_PEAKS_REG(14, 256)
+                NATAC_PEAKS_REG(15, 256) NATAC_PEAKS_REG(16, 256)
+            }
+        } else if (nj <= 16 && lds_reg <= 150 * 1024) {        // chunks up to 16,384 bases: the whole chunk in LDS, 16 waves
+            switch (nj) {
+                NATAC_PEAKS_REG(5, 1024) NATAC_PEAKS_REG(6, 1024) NATAC_PEAKS_REG(7, 1024) NATAC_PEAKS_REG(8, 1024) NATAC_PEAKS_REG(9, 1024)
+                NATAC_PEAKS_REG(10, 1024) NATAC_PEAKS_REG(11, 1024) NATAC_PEAKS_REG(12, 1024) NATAC_PEAKS_REG(13, 1024)
+                NATAC_PEAKS_REG(14, 1024) NATAC_PEAKS_REG(15, 1024) NATAC_PEAKS_REG(16, 1024)
+            }
+        } else {   // longer still: segments of 4,096 bases, signal read per segment
+            const int seg = 4096;
+            const size_t lds = (size_t)((seg + 2 * order + 1) & ~1) * sizeof(double) + lds_lists;
+            hipLaunchKernelGGL(natac_peaks_chunk, dim3(b->nc), dim3(256), lds, c->stream, ct, norm, sm, b->d_jitter, min_signal,
+                               boundary, order, sep, seg, pk_cap, b->d_cap_off, b->d_slot, b->d_pk_count, b->d_status);
         }
 #undef NATAC_PEAKS_REG
     }

@@ -1732,7 +1732,7 @@ constexpr int PEAK_MAX = 2048;   // peaks per chunk held in LDS by natac_peaks_c
 __device__ __forceinline__ void peaks_thin_and_write(int n, int pk_cap, int sep, const double *sig, const int *pos, unsigned char *state,
                                                       int *wave_cnt, int *__restrict__ dst, int *__restrict__ count_out,
                                                       int *__restrict__ status_out) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, bt = blockDim.x, nw = bt >> 6;   // wave_cnt holds nw <= 16 counts
     const bool overflow = n > pk_cap;
     if (overflow) n = pk_cap;
     // ---- 4. reduce_peaks as parallel rounds.  A kept peak (state 1) has no free peak closer than sep once its round is
@@ -1740,7 +1740,7 @@ __device__ __forceinline__ void peaks_thin_and_write(int n, int pk_cap, int sep,
     // thread keeps during the same pass
     for (;;) {
         int nfree = 0;
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += bt) {
             if (state[i] != 0) continue;
             const double si = sig[i];
             const int pi = pos[i];
@@ -1750,7 +1750,7 @@ __device__ __forceinline__ void peaks_thin_and_write(int n, int pk_cap, int sep,
             if (top) state[i] = 1; else ++nfree;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += bt) {
             if (state[i] != 0) continue;
             const int pi = pos[i];
             bool ex = false;
@@ -1762,16 +1762,17 @@ __device__ __forceinline__ void peaks_thin_and_write(int n, int pk_cap, int sep,
     }
     // ---- kept positions, ascending
     int m_out = 0;
-    for (int base = 0; base < n; base += 256) {
+    for (int base = 0; base < n; base += bt) {
         const int i = base + threadIdx.x;
         const bool kp = i < n && state[i] == 1;
         const unsigned long long m = __ballot(kp);
         if (lane == 0) wave_cnt[wave] = __popcll(m);
         __syncthreads();
         int off = m_out;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        int tot = 0;
+        for (int w = 0; w < nw; ++w) { const int cw = wave_cnt[w]; off += (w < wave) ? cw : 0; tot += cw; }
         if (kp) dst[off + __popcll(m & ((1ull << lane) - 1ull))] = pos[i];
-        m_out += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        m_out += tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1795,7 +1796,8 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk(ChunkTable ct, const do
                                                            int *__restrict__ count, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4];
-    __shared__ int wave_cnt[4];
+    __shared__ int wave_cnt[16];
+    __shared__ int row_cnt[4 * 16];
     const int ysn = (seg + 2 * order + 1) & ~1;
     double *ys = smem;                              // jittered signal, index u <-> base clip(x0 - order + u)
     double *sig = ys + ysn;
@@ -1807,9 +1809,17 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk(ChunkTable ct, const do
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // ---- 1. minimum finite value of the combined signal
     double mn = __builtin_inf();
-    for (int g = threadIdx.x; g < L; g += 256) {
-        const double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
-        if (v == v) mn = fmin(mn, v);
+    for (int g0 = threadIdx.x; g0 < L; g0 += 8 * 256) {      // eight independent loads per thread in flight
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int g = g0 + 256 * q;
+            v[q] = __builtin_nan("");
+            if (g < L) v[q] = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (v[q] == v[q]) mn = fmin(mn, v[q]);
     }
     mn = wave_min(mn);
     if (lane == 0) red[wave] = mn;
@@ -1824,58 +1834,88 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk(ChunkTable ct, const do
     for (int x0 = 0; x0 < L; x0 += seg) {
         const int len = min(seg, L - x0);
         __syncthreads();
-        for (int u = threadIdx.x; u < len + 2 * order; u += 256) {
-            int g = x0 - order + u;
-            g = g < 0 ? 0 : (g > L - 1 ? L - 1 : g);                 // numpy take(..., mode='clip')
-            double v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
-            if (v != v) v = fillv;
-            ys[u] = v * (1 + jitter[g]);
+        for (int u0 = threadIdx.x; u0 < len + 2 * order; u0 += 8 * 256) {
+            double v[8], jt[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int u = u0 + 256 * q;
+                int g = x0 - order + u;
+                g = g < 0 ? 0 : (g > L - 1 ? L - 1 : g);                 // numpy take(..., mode='clip')
+                v[q] = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
+                jt[q] = jitter[g];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int u = u0 + 256 * q;
+                if (u < len + 2 * order) ys[u] = ((v[q] != v[q]) ? fillv : v[q]) * (1 + jt[q]);
+            }
         }
         __syncthreads();
-        for (int j0 = 0; j0 < len; j0 += 256) {
-            const int t = j0 + threadIdx.x, g = x0 + t;
+        // the segment's <= 16 rows of 256 bases: local-maximum tests first, then the un-jittered values of the maxima (all
+        // loads of a thread in flight), thresholds, and one ordered compaction for all rows
+        unsigned pkf = 0;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int t = 256 * it + threadIdx.x;
             bool pk = t < len;
-            double v = 0.0;
             if (pk) {
                 const double y = ys[t + order];
                 for (int sft = 1; sft <= order && pk; ++sft) pk = (y > ys[t + order + sft]) && (y > ys[t + order - sft]);
             }
-            if (pk) {
-                v = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
-                if (v != v) v = fillv;
-                pk = (v >= min_signal) && (g >= boundary) && (g < L - boundary);
-            }
-            const unsigned long long m = __ballot(pk);
-            if (lane == 0) wave_cnt[wave] = __popcll(m);
-            __syncthreads();
+            pkf |= pk ? (1u << it) : 0u;
+        }
+        double v[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int g = x0 + 256 * it + threadIdx.x;
+            v[it] = 0.0;
+            if (pkf & (1u << it)) v[it] = smooth ? norm[ob + g] + smooth[ob + g] : norm[ob + g];
+        }
+        unsigned long long bal[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int g = x0 + 256 * it + threadIdx.x;
+            if (v[it] != v[it]) v[it] = fillv;
+            const bool pk = (pkf & (1u << it)) && (v[it] >= min_signal) && (g >= boundary) && (g < L - boundary);
+            bal[it] = __ballot(pk);
+            if (lane == 0) row_cnt[it * 4 + wave] = __popcll(bal[it]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
             int off = n;
-            for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-            const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-            if (pk) {
-                const int i = off + __popcll(m & ((1ull << lane) - 1ull));
-                if (i < pk_cap) { pos[i] = g; sig[i] = v; state[i] = 0; }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int cw = row_cnt[it * 4 + w];
+                off += (w < wave) ? cw : 0;
+                n += cw;
             }
-            n += tot;
-            __syncthreads();
+            if ((bal[it] >> lane) & 1ull) {
+                const int i = off + __popcll(bal[it] & ((1ull << lane) - 1ull));
+                if (i < pk_cap) { pos[i] = x0 + 256 * it + threadIdx.x; sig[i] = v[it]; state[i] = 0; }
+            }
         }
     }
+    __syncthreads();
     peaks_thin_and_write(n, pk_cap, sep, sig, pos, state, wave_cnt, cand_slot + cap_off[chunk], count + chunk, status + chunk);
 }
 
-// The same search for batches whose chunks all fit one segment (L <= 256 NJ): every thread keeps its NJ bases in registers,
+// The same search for batches whose chunks all fit one segment (L <= BT NJ; BT = 256 threads, or 1,024 for chunks up to 16,384
+// bases: gfx950 gives a workgroup up to 160 KB of LDS): every thread keeps its NJ bases in registers,
 // so the signal is read from memory once, with all loads of a thread in flight together (the general kernel above walks
 // the chunk three times with one dependent load per iteration).  LDS as above with seg = 256 NJ.
-template <int NJ>
-__global__ void __launch_bounds__(256) natac_peaks_chunk_reg(ChunkTable ct, const double *__restrict__ norm,
+template <int NJ, int BT>
+__global__ void __launch_bounds__(BT) natac_peaks_chunk_reg(ChunkTable ct, const double *__restrict__ norm,
                                                                const double *__restrict__ smooth, const double *__restrict__ jitter,
                                                                double min_signal, int boundary, int order, int sep, int pk_cap,
                                                                const long long *__restrict__ cap_off, int *__restrict__ cand_slot,
                                                                int *__restrict__ count, int *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double red[4];
-    __shared__ int wave_cnt[4];
-    __shared__ int row_cnt[4 * NJ];
-    const int ysn = (256 * NJ + 2 * order + 1) & ~1;
+    constexpr int NW = BT / 64;
+    __shared__ double red[NW];
+    __shared__ int wave_cnt[16];
+    __shared__ int row_cnt[NW * NJ];
+    const int ysn = (BT * NJ + 2 * order + 1) & ~1;
     double *ys = smem;                              // jittered signal, index u <-> base clip(u - order)
     double *sig = ys + ysn;
     int *pos = (int *)(sig + pk_cap);
@@ -1887,7 +1927,7 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk_reg(ChunkTable ct, cons
     double v[NJ], jt[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int g = threadIdx.x + 256 * j;
+        const int g = threadIdx.x + BT * j;
         v[j] = __builtin_nan("");
         jt[j] = 0.0;
         if (g < L) {
@@ -1902,14 +1942,16 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk_reg(ChunkTable ct, cons
     mn = wave_min(mn);
     if (lane == 0) red[wave] = mn;
     __syncthreads();
-    const double fillv = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    double fillv = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) fillv = fmin(fillv, red[w]);
     if (fillv == __builtin_inf()) {                 // all-NaN chunk: nothing
         if (threadIdx.x == 0) count[chunk] = 0;
         return;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int g = threadIdx.x + 256 * j;
+        const int g = threadIdx.x + BT * j;
         if (v[j] != v[j]) v[j] = fillv;
         if (g < L) {
             const double y = v[j] * (1 + jt[j]);
@@ -1925,7 +1967,7 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk_reg(ChunkTable ct, cons
     unsigned long long bal[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int g = threadIdx.x + 256 * j;
+        const int g = threadIdx.x + BT * j;
         bool pk = g < L;
         if (pk) {
             const double y = ys[g + order];
@@ -1933,7 +1975,7 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk_reg(ChunkTable ct, cons
         }
         pk = pk && (v[j] >= min_signal) && (g >= boundary) && (g < L - boundary);
         bal[j] = __ballot(pk);
-        if (lane == 0) row_cnt[j * 4 + wave] = __popcll(bal[j]);
+        if (lane == 0) row_cnt[j * NW + wave] = __popcll(bal[j]);
     }
     __syncthreads();
     int n = 0;
@@ -1941,14 +1983,14 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk_reg(ChunkTable ct, cons
     for (int j = 0; j < NJ; ++j) {
         int off = n;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int cw = row_cnt[j * 4 + w];
+        for (int w = 0; w < NW; ++w) {
+            const int cw = row_cnt[j * NW + w];
             off += (w < wave) ? cw : 0;
             n += cw;
         }
         if ((bal[j] >> lane) & 1ull) {
             const int i = off + __popcll(bal[j] & ((1ull << lane) - 1ull));
-            if (i < pk_cap) { pos[i] = threadIdx.x + 256 * j; sig[i] = v[j]; state[i] = 0; }
+            if (i < pk_cap) { pos[i] = threadIdx.x + BT * j; sig[i] = v[j]; state[i] = 0; }
         }
     }
     __syncthreads();
