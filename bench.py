@@ -27,7 +27,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -41,8 +40,8 @@ FLOP_PER_BP_BG = 2 * 146 * 121   # fp64 flop per base of the background correlat
 FLOP_PER_BP_BG_FFT = 73 * 364 * 64 / 392.0
 KERNEL_LABEL = {"background": "natac_background_fft (dense bias x VMat correlation, fp64 FFT)",
                 "occ_mle": "natac_occ_gsum + natac_occ_decide (occupancy grid MLE)",
-                "candidates": "natac_candidates4 + peak search (LR / variance / z of the candidates)"}
-KERNEL_SYMBOL = {"background": "natac_background_fft", "occ_mle": "natac_occ_", "candidates": "natac_candidates4"}
+                "candidates": "natac_peaks_chunk_reg + natac_candidates_paired (candidate search; LR / variance / z)"}
+KERNEL_SYMBOL = {"background": "natac_background_fft", "occ_mle": "natac_occ_", "candidates": "natac_candidates_paired"}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 H2H_TRACKS = ("T_NORM", "T_SMOOTH", "T_OCC", "T_OCC_LOWER", "T_OCC_UPPER")   # what `nucleoatac run` writes by default
@@ -58,6 +57,8 @@ def parse():
     ap.add_argument("--chunk-len", type=int, default=0)
     ap.add_argument("--frags-per-chunk", type=int, default=0)
     ap.add_argument("--sub-chunks", type=int, default=20000, help="cfg4: chunks per sub-batch")
+    ap.add_argument("--recycle", choices=["auto", "on", "off"], default="auto",
+                    help="release every sub-batch's outputs after its stages (auto: when they do not all fit in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU baseline's optimised-mode sample (0 = 2000)")
     ap.add_argument("--cpu-literal-chunks", type=int, default=0, help="chunks in the literal-mode sample (0 = auto)")
@@ -180,6 +181,25 @@ def _effective_cores():
     return n
 
 
+def pmc_source():
+    """where the committed counter numbers come from: newest profiles/*/pmc_summary.csv, the source stamp it was collected
+    with (tools/pmc_summarize.py) and whether that stamp matches the sources of this run"""
+    import glob
+    from nucleoatac_amd._lib import csrc_sha16
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.csv")))
+    if not files:
+        return None
+    stamp = None
+    with open(files[-1]) as fh:
+        for l in fh:
+            if l.startswith("# source_sha16="):
+                stamp = l.split("=", 1)[1].split()[0]
+    cur = csrc_sha16()
+    return {"file": os.path.relpath(files[-1], ROOT), "collected_at_source_sha16": stamp, "current_source_sha16": cur,
+            "stale": stamp != cur,
+            "note": "counters are read from the committed rocprofv3 --pmc summary, not measured in this run"}
+
+
 def pmc_traffic_bytes(kernel_substr):
     """HBM bytes per step of the kernels whose name contains `kernel_substr`, from the newest committed rocprofv3 PMC summary
     (profiles/*/pmc_summary.csv): (FETCH_SIZE + WRITE_SIZE) x 1024.  FETCH_SIZE is NOT doubled: the guide's x2 correction
@@ -300,24 +320,24 @@ def setup_ctx(device, par, sizes, nucp, nfrp):
     return ctx
 
 
-def run_stages(batch):
-    batch.run_nuc(10)
-    batch.run_occ()
-    batch.run_ins(0, 2000)
-    # candidate search (call_peaks, sep 25 / order 12 / boundary 60 as NucChunk.findAllNucs) + LR / var / z, on the device;
-    # like the per-base tracks, the candidate arrays stay resident in HBM inside the timed region
-    return batch.run_peaks(min_signal=0, sep=25, boundary=60, order=12, download=False)
+def bench_stages(tracks=()):
+    """the stages of one step: nuc + occ + ins + candidate search (call_peaks, sep 25 / order 12 / boundary 60 as
+    NucChunk.findAllNucs) with LR / var / z on the device; like the per-base tracks, the candidate arrays stay resident in
+    HBM inside the timed region"""
+    from nucleoatac_amd.executor import Stages
+    return Stages(nuc_sd=10, occ=True, ins=(0, 2000), peaks=dict(min_signal=0, sep=25, boundary=60, order=12), tracks=tracks)
 
 
 # ------------------------------------------------------------------------------------------------ host-to-host pipeline
 def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_threads):
-    """SURVEY.md section 8(d)'s boundary: packed inputs in host memory -> per-base tracks back in host memory.  The chunk list is
-    cut into sub-batches; `n_threads` host threads, each with its own natac context (stream) on the same GPU, take them in
-    turn: upload (from pinned memory), all stages, download of the five default output tracks + the candidate arrays into
-    pinned memory.  The contexts' uploads, kernels and downloads overlap on the device; no hipMalloc / hipFree happens in
-    the steady state (the library's block pool).  One untimed pass (allocations) precedes `steps` timed ones."""
+    """SURVEY.md section 8(d)'s boundary: packed inputs in host memory -> per-base tracks back in host memory, through the
+    product's own executor (nucleoatac_amd/executor.py::PipelinedExecutor, the class `nucleoatac occ` / `nuc` run on): the
+    chunk list is cut into sub-batches; `n_threads` host threads, each with its own natac context (stream) on the same GPU,
+    take them in turn: upload (from pinned memory), all stages, download of the five default output tracks + the candidate
+    arrays into pinned slots.  One untimed pass (allocations) precedes `steps` timed ones."""
     from nucleoatac_amd import _lib as L
-    from nucleoatac_amd.device import pinned_copy, pinned_empty
+    from nucleoatac_amd.device import pinned_copy
+    from nucleoatac_amd.executor import PipelinedExecutor
     from nucleoatac_amd.packing import PackedChunks
     nsub = max(1, (pk.n_chunks + sub_chunks - 1) // sub_chunks)
     subs = []
@@ -327,63 +347,27 @@ def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_thread
                                  frag_lpos=pinned_copy(s.frag_lpos), frag_ilen=pinned_copy(s.frag_ilen), bias_off=s.bias_off,
                                  bias_log=pinned_copy(s.bias_log)))
     tracks = [getattr(L, t) for t in H2H_TRACKS]
-    max_bp = max(s.total_bp for s in subs)
-    state = dict(err=None)
-    gate = threading.Barrier(n_threads + 1)
-    acct = [[0, 0] for _ in range(n_threads)]
 
-    def worker(tid):
-        try:
-            ctx = setup_ctx(device, par, sizes, nucp, nfrp)
-            outs = [pinned_empty(max_bp, np.float64) for _ in tracks]
+    def configure(ctx):
+        ctx.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
+        ctx.set_sizes(sizes)
+        ctx.set_occ_model(nucp, nfrp, step=5, flank=60)
 
-            def one(k, count):
-                s = subs[k]
-                b = ctx.upload(s)
-                n = run_stages(b)
-                for t, o in zip(tracks, outs):
-                    b.track(t, out=o[:s.total_bp])
-                cand = b.download_peaks(n)
-                b.free()
-                assert len(cand[0]) == n
-                if count:
-                    acct[tid][0] += len(tracks) * 8 * s.total_bp + n * 32
-                    acct[tid][1] += s.frag_lpos.nbytes + s.frag_ilen.nbytes + s.bias_log.nbytes
-
-            for k in range(tid, nsub, n_threads):            # untimed pass: allocations, pool warm-up
-                one(k, False)
-            ctx.sync()
-            gate.wait()                                      # all contexts warm: the clock starts
-            for _ in range(steps):
-                for k in range(tid, nsub, n_threads):
-                    one(k, True)
-            ctx.sync()
-            gate.wait()                                      # all done: the clock stops
-            ctx.close()
-        except Exception as e:      # pragma: no cover
-            state["err"] = e
-            gate.abort()
-            raise
-
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(n_threads)]
-    for t in th:
-        t.start()
-    try:
-        gate.wait()
+    with PipelinedExecutor(device, configure, bench_stages(tracks), n_contexts=n_threads, slots_per_context=1) as ex:
+        for r in ex.map((s, None) for s in subs):            # untimed pass: contexts, pool blocks, pinned slots
+            r.release()
+        ex.bytes_down = ex.bytes_up = 0
         t0 = time.perf_counter()
-        gate.wait()
+        ncand = 0
+        for r in ex.map((s, None) for _ in range(steps) for s in subs):
+            ncand += len(r.peaks[0])
+            r.release()
         dt = time.perf_counter() - t0
-    except threading.BrokenBarrierError:
-        dt = float("nan")
-    for t in th:
-        t.join()
-    if state["err"] is not None:
-        raise state["err"]
-    down = sum(x[0] for x in acct)
-    up = sum(x[1] for x in acct)
+        down, up = ex.bytes_down, ex.bytes_up
     return dict(host_to_host_mbp_s=round(pk.total_bp * steps / dt / 1e6, 2), seconds=round(dt, 3), steps=steps,
                 sub_batches=nsub, chunks_per_sub_batch=sub_chunks, contexts=n_threads,
-                tracks_downloaded=list(H2H_TRACKS) + ["candidates (chunk, pos, lr, var, z)"],
+                executor="nucleoatac_amd.executor.PipelinedExecutor (product code)",
+                tracks_downloaded=list(H2H_TRACKS) + ["candidates (chunk, pos, lr, var, z)"], candidates_per_step=ncand // max(1, steps),
                 gb_down_per_step=round(down / steps / 1e9, 3), gb_up_per_step=round(up / steps / 1e9, 3),
                 pcie_gbs_down=round(down / dt / 1e9, 2), pcie_gbs_up=round(up / dt / 1e9, 2),
                 note="pinned host buffers both ways; uploads, kernels and downloads of different sub-batches overlap")
@@ -441,23 +425,17 @@ def main():
         cpu = cpu_baseline(subs[0], par, sizes, nucp, nfrp, a.cpu_chunks, a.cpu_literal_chunks)
 
     ctx = setup_ctx(local_rank, par, sizes, nucp, nfrp)
+    from nucleoatac_amd.executor import ResidentShard
     t_up = time.time()
-    batches = [ctx.upload(s) for s in subs]
-    ctx.sync()
-    t_up = time.time() - t_up
     # outputs of every sub-batch stay resident if they fit (~175 B per base incl. internal arrays); else they are recycled
-    mem = ctx.device_info()["mem_bytes"]
-    recycle = len(batches) > 1 and my_bp * 175.0 > 0.8 * mem
+    shard = ResidentShard(ctx, subs, recycle={"auto": "auto", "on": True, "off": False}[a.recycle])
+    t_up = time.time() - t_up
+    batches, recycle, last_n = shard.batches, shard.recycle, shard.last_n
+    stages = bench_stages()
     n_cand = [0]
-    last_n = [0] * len(batches)
 
     def step():
-        n_cand[0] = 0
-        for i, b in enumerate(batches):
-            last_n[i] = run_stages(b)
-            n_cand[0] += last_n[i]
-            if recycle:
-                b.release_outputs()
+        n_cand[0] = shard.step(stages)
 
     on_gpu = dist is not None and a.dist_backend == "nccl"
 
@@ -507,8 +485,7 @@ def main():
         cand = batches[0].download_peaks(last_n[0])
         t_dn = time.time() - t_dn
         assert np.isfinite(cand[4][:1000]).any()
-    for b in batches:
-        b.free()
+    shard.close()
     h2h = None
     if rank == 0 and world == 1 and not a.no_h2h and a.workload != "cfg4":
         ctx.close()
@@ -530,6 +507,11 @@ def main():
         direct_tflops = FLOP_PER_BP_BG * bp_per_launch / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
         fft_tflops = FLOP_PER_BP_BG_FFT * bp_per_launch / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
         step_gbs = ALG_BYTES_PER_BP[a.workload] * my_bp / (dt / a.steps) / 1e9
+        valu = pmc_valu_issue() if a.workload == "cfg3" else None
+        dom_issue = None
+        if valu:
+            hit = [v["valu_issue_frac"] for k, v in valu.items() if KERNEL_SYMBOL[dom] in k]
+            dom_issue = max(hit) if hit else None
         out = {
             "metric": "Mbp/s through occ+nuc signal pipeline", "value": round(value, 3), "unit": "Mbp/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -541,6 +523,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_LABEL[dom],
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": pmc_source() if a.workload == "cfg3" else None,
+                         # the meaningful fraction for this kernel: share of the SIMDs' issue cycles its fp64 VALU stream uses
+                         "fp64_issue_frac": dom_issue,
                          "avg_launch_ms": round(dom_avg_s * 1e3, 3), "launches": int(dom_n),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "whole_step": {"algorithmic_gb": round(ALG_BYTES_PER_BP[a.workload] * my_bp / 1e9, 3),
@@ -552,7 +537,7 @@ def main():
                                              "executed_tflops": round(fft_tflops, 2), "peak": FP64_PEAK_TFLOPS,
                                              "unit": "TFLOP/s", "frac_executed": round(fft_tflops / FP64_PEAK_TFLOPS, 4)}},
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
-            "valu_issue_from_committed_pmc": pmc_valu_issue() if a.workload == "cfg3" else None,
+            "valu_issue_from_committed_pmc": valu,
             "host": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2),
                      "download_5_tracks_and_candidates_s": None if t_dn is None else round(t_dn, 2),
                      "pcie_inclusive_mbp_s_no_overlap": None if t_dn is None else round(

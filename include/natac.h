@@ -8,6 +8,7 @@
  *   (2) the two Cython extension modules:
  *         pyatac/fragments.pyx:17   makeFragmentMat               -> natac_make_fragment_mat
  *         pyatac/fragments.pyx:43   getInsertions                 -> natac_get_insertions / natac_run_ins
+ *         pyatac/fragments.pyx:71   getStrandedInsertions         -> natac_get_stranded_insertions
  *         pyatac/fragments.pyx:123  getFragmentSizesFromChunkList -> natac_fragment_sizes
  *         nucleoatac/multinomial_cov.pyx:20 calculateCov          -> natac_calculate_cov
  * Every entry point below names the reference code it replaces.  INTEGRATION.md shows the ctypes binding a
@@ -131,6 +132,13 @@ int natac_run_ins(natac_batch *b, int lower, int upper);
  *   z    Nucleosome.getZScore   NucleosomeCalling.py:123-127   (norm_signal / sqrt(var)) */
 int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chunk, const int32_t *cand_pos,
                          double *lr, double *var, double *z);
+/* calculateCov (nucleoatac/multinomial_cov.pyx:20-31) at MANY candidates of the batch at once, in one of three arithmetic variants
+ * (BASELINE configs[4]: "fp64 multinomial_cov path, tolerance sweep"; needs natac_run_nuc first).  Candidate k's probability
+ * vector is SignalDistribution's p = B window / sum (NucleosomeCalling.py:70-76), v = the V-plot, r = int(nuc_cov[pos]) (:125).
+ * mode 0 = closed form r (sum p v^2 - (sum p v)^2) in fp64 -- what natac_run_candidates reports; mode 1 = the .pyx's literal
+ * O(N^2) pair sum in fp64; mode 2 = the closed form evaluated in fp32.  var[n_cand] on the host. */
+int natac_run_candidates_cov(natac_batch *b, int64_t n_cand, const int32_t *cand_chunk, const int32_t *cand_pos, int mode,
+                             double *var);
 /* Candidate search + statistics entirely on the device (needs natac_run_nuc first):
  * utils.call_peaks(norm + smoothed, min_signal, sep, boundary, order) exactly as NucChunk.findAllNucs calls it
  * (nucleoatac/NucleosomeCalling.py:297-301, pyatac/utils.py:56-102), followed by LR / variance / z for every candidate.
@@ -173,6 +181,10 @@ int natac_make_fragment_mat(natac_ctx *ctx, int64_t n_frags, const int64_t *l, c
 /* getInsertions, pyatac/fragments.pyx:43-67: out[end-start] float64. */
 int natac_get_insertions(natac_ctx *ctx, int64_t n_frags, const int64_t *l, const int32_t *n, int64_t start,
                          int64_t end, int lower, int upper, double *out);
+/* getStrandedInsertions, pyatac/fragments.pyx:71-97: plus[end-start] = insertions at left fragment ends, minus[end-start] = at
+ * right fragment ends (plus + minus == natac_get_insertions). */
+int natac_get_stranded_insertions(natac_ctx *ctx, int64_t n_frags, const int64_t *l, const int32_t *n, int64_t start,
+                                  int64_t end, int lower, int upper, double *plus, double *minus);
 /* getFragmentSizesFromChunkList, pyatac/fragments.pyx:123-145 (one chromosome's fragments, its chunks):
  * sizes[upper-lower] float64 counts (not normalised). */
 int natac_fragment_sizes(natac_ctx *ctx, int64_t n_frags, const int64_t *l, const int32_t *n, int32_t n_chunks,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "natac_run_occ": (C.c_int, [_vp]),
     "natac_run_ins": (C.c_int, [_vp, C.c_int, C.c_int]),
     "natac_run_candidates": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "natac_run_candidates_cov": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, _vp]),
     "natac_run_peaks": (C.c_int, [_vp, _f64, C.c_int, C.c_int, C.c_int, _vp, _i64, C.POINTER(_i64)]),
     "natac_download_peaks": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "natac_run_track_peaks": (C.c_int, [_vp, C.c_int, _f64, C.c_int, C.c_int, C.c_int, _vp, _i64, C.POINTER(_i64)]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "natac_batch_track_ptr": (C.c_int, [_vp, C.c_int, _pp]),
     "natac_make_fragment_mat": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
     "natac_get_insertions": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),
+    "natac_get_stranded_insertions": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _vp]),
     "natac_fragment_sizes": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _vp, C.c_int, C.c_int, _vp]),
     "natac_calculate_cov": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.POINTER(_f64)]),
     "natac_smooth": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, _vp]),
@@ -81,6 +83,20 @@ SIGNATURES = {
     "natac_timer_start": (C.c_int, [_vp]),
     "natac_timer_stop": (C.c_int, [_vp, C.POINTER(_f64)]),
 }
+
+
+def csrc_sha16():
+    """first 16 hex digits of the sha256 over the library's sources (csrc/* and include/natac.h, sorted by name): stamps
+    profiles so that a counter summary collected from an older build is recognisable"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "natac.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 class NatacError(RuntimeError):

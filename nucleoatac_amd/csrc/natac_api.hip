@@ -5,6 +5,7 @@
 #include "natac_fft_bg.hpp"
 #include "natac_occ_fast.hpp"
 #include "natac_cand.hpp"
+#include "natac_covsweep.hpp"
 #include "natac_cores.hpp"
 #include "natac_writer.hpp"
 #include "natac_tabix.hpp"
@@ -731,6 +732,9 @@ int natac_batch_release_outputs(natac_batch *b) {
     b->d_pk_chunk = b->d_pk_pos = b->d_opk_keep = nullptr;
     b->pk_cap = 0; b->pk_n = -1; b->opk_cap = 0; b->opk_n = -1;
     b->nuc_done = b->occ_done = b->ins_done = b->cov_from_nuc = b->prefill_valid = false;
+    // the per-chunk status words describe the outputs that were just dropped
+    HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->nc * sizeof(int), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return NATAC_OK;     // offset / tile tables stay: the next natac_run_* only re-allocates the arrays
 }
 
@@ -1141,6 +1145,84 @@ int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chu
     return NATAC_OK;
 }
 
+int natac_run_candidates_cov(natac_batch *b, int64_t n_cand, const int32_t *cand_chunk, const int32_t *cand_pos, int mode,
+                             double *var) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    natac_ctx *c = b->ctx;
+    if (!b->nuc_done) return fail(NATAC_E_STATE, "natac_run_nuc must run before natac_run_candidates_cov");
+    if (mode < 0 || mode > 2) return fail(NATAC_E_ARG, "mode must be 0 (closed form), 1 (literal) or 2 (closed form in fp32)");
+    if (n_cand < 0 || (n_cand > 0 && (!cand_chunk || !cand_pos || !var))) return fail(NATAC_E_ARG, "null argument");
+    if (n_cand == 0) return NATAC_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_srow(c);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n_cand; ++k) {
+        const int ci = cand_chunk[k];
+        if (ci < 0 || ci >= b->nc || cand_pos[k] < 0 || cand_pos[k] >= b->h_len[ci])
+            return fail(NATAC_E_ARG, "candidate %lld out of range (chunk %d pos %d)", (long long)k, ci, cand_pos[k]);
+    }
+    const int N = c->R * c->W;
+    const int NBLK = 64;                       // row groups of the literal pair sum per candidate
+    const int64_t SLAB = 2048;                 // candidates per pass: 2048 x N doubles = 289 MB for the default V-plot
+    const ChunkTable ct = make_table(b);
+    const VMatDev vm = make_vmat(c);
+    const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
+    int *d_cc = nullptr, *d_cp = nullptr;
+    double *d_p = nullptr, *d_out = nullptr;
+    const int64_t slab = std::min<int64_t>(SLAB, n_cand);
+    if ((rc = dev_alloc(&d_cc, (size_t)slab)) || (rc = dev_alloc(&d_cp, (size_t)slab)) || (rc = dev_alloc(&d_p, (size_t)slab * N)) ||
+        (rc = dev_alloc(&d_out, (size_t)slab * NBLK))) {
+        dev_free(d_cc); dev_free(d_cp); dev_free(d_p); dev_free(d_out);
+        return rc;
+    }
+    std::vector<double> part((size_t)slab * NBLK);
+    hipError_t e = hipSuccess;
+    for (int64_t k0 = 0; k0 < n_cand && e == hipSuccess; k0 += slab) {
+        const int64_t m = std::min<int64_t>(slab, n_cand - k0);
+        e = hipMemcpyAsync(d_cc, cand_chunk + k0, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_cp, cand_pos + k0, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(natac_cand_window_probs, dim3((unsigned)m), dim3(256), (size_t)(EW + 2) * sizeof(double), c->stream, ct, vm,
+                           d_cc, d_cp, d_p);
+        const int per = mode == 1 ? NBLK : 1;
+        if (mode == 1)
+            hipLaunchKernelGGL(natac_cov_literal_many, dim3(NBLK, (unsigned)m), dim3(256), 0, c->stream, d_p, c->d_vmat, N, d_out);
+        else if (mode == 0)
+            hipLaunchKernelGGL((natac_cov_closed_many<double>), dim3((unsigned)m), dim3(256), 0, c->stream, d_p, c->d_vmat, N, d_out);
+        else
+            hipLaunchKernelGGL((natac_cov_closed_many<float>), dim3((unsigned)m), dim3(256), 0, c->stream, d_p, c->d_vmat, N, d_out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_out, (size_t)m * per * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) break;
+        for (int64_t k = 0; k < m; ++k) {
+            double s = 0;
+            for (int j = 0; j < per; ++j) s += part[(size_t)k * per + j];
+            var[k0 + k] = s;
+        }
+    }
+    dev_free(d_cc); dev_free(d_cp); dev_free(d_p); dev_free(d_out);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "candidates_cov: %s", hipGetErrorString(e));
+    // r = int(nuc_cov[pos]) like the .pyx's `int r` (NucleosomeCalling.py:125): one gather of the coverage values
+    std::vector<double> reads((size_t)n_cand);
+    {
+        std::vector<long long> idx((size_t)n_cand);
+        for (int64_t k = 0; k < n_cand; ++k) idx[(size_t)k] = b->h_out_off[cand_chunk[k]] + cand_pos[k];
+        long long *d_idx = nullptr;
+        double *d_r = nullptr;
+        if ((rc = dev_upload(c, &d_idx, idx.data(), (size_t)n_cand))) return rc;
+        if ((rc = dev_alloc(&d_r, (size_t)n_cand))) { dev_free(d_idx); return rc; }
+        hipLaunchKernelGGL(natac_gather_f64, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, c->stream,
+                           b->d_track[NATAC_T_NUC_COV], d_idx, (long long)n_cand, d_r);
+        e = hipMemcpyAsync(reads.data(), d_r, (size_t)n_cand * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        dev_free(d_idx); dev_free(d_r);
+        if (e != hipSuccess) return fail(NATAC_E_HIP, "candidates_cov: %s", hipGetErrorString(e));
+    }
+    for (int64_t k = 0; k < n_cand; ++k) var[k] = var[k] * (double)(int)reads[(size_t)k];
+    return NATAC_OK;
+}
+
 static int run_peaks_impl(natac_batch *b, const double *sig_a, const double *sig_b, bool with_stats, double min_signal, int sep,
                           int boundary, int order, const double *jitter, int64_t n_jitter, int64_t *n_cand) {
     if (!b || !jitter || !n_cand) return fail(NATAC_E_ARG, "null argument");
@@ -1470,6 +1552,38 @@ int natac_get_insertions(natac_ctx *c, int64_t nf, const int64_t *l, const int32
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     dev_free(d_l); dev_free(d_n); dev_free(d_i); dev_free(d_o);
     if (e != hipSuccess) return fail(NATAC_E_HIP, "get_insertions: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
+int natac_get_stranded_insertions(natac_ctx *c, int64_t nf, const int64_t *l, const int32_t *n, int64_t start, int64_t end, int lower,
+                                  int upper, double *plus, double *minus) {
+    if (!c || !plus || !minus || (nf > 0 && (!l || !n))) return fail(NATAC_E_ARG, "null argument");
+    if (end <= start) return fail(NATAC_E_ARG, "empty region");
+    const long long npos = end - start;
+    if (npos > 0x3fffffffLL) return fail(NATAC_E_ARG, "region too long");
+    HIPCHK(hipSetDevice(c->device));
+    long long *d_l = nullptr; int *d_n = nullptr, *d_i = nullptr; double *d_o = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_l, (const long long *)l, (size_t)nf))) return rc;
+    if ((rc = dev_upload(c, &d_n, n, (size_t)nf))) { dev_free(d_l); return rc; }
+    if ((rc = dev_alloc(&d_i, (size_t)2 * npos))) { dev_free(d_l); dev_free(d_n); return rc; }
+    if ((rc = dev_alloc(&d_o, (size_t)2 * npos))) { dev_free(d_l); dev_free(d_n); dev_free(d_i); return rc; }
+    hipError_t e = hipMemsetAsync(d_i, 0, (size_t)2 * npos * sizeof(int), c->stream);
+    if (e == hipSuccess) {
+        if (nf > 0) {
+            int blocks = (int)std::min<long long>((nf + 255) / 256, 4096);
+            hipLaunchKernelGGL(natac_stranded_insertions_region, dim3(blocks), dim3(256), 0, c->stream, d_l, d_n, (long long)nf,
+                               (long long)start, (int)npos, lower, upper, d_i, d_i + npos);
+        }
+        int blocks = (int)std::min<long long>((2 * npos + 255) / 256, 4096);
+        hipLaunchKernelGGL(natac_i32_to_f64, dim3(blocks), dim3(256), 0, c->stream, d_i, d_o, 2 * npos);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(plus, d_o, (size_t)npos * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(minus, d_o + npos, (size_t)npos * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_l); dev_free(d_n); dev_free(d_i); dev_free(d_o);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "get_stranded_insertions: %s", hipGetErrorString(e));
     return NATAC_OK;
 }
 

@@ -2139,6 +2139,21 @@ __global__ void natac_insertions_region(const long long *__restrict__ l, const i
     }
 }
 
+// getStrandedInsertions, pyatac/fragments.pyx:71-97: left ends -> plus, right ends -> minus
+__global__ void natac_stranded_insertions_region(const long long *__restrict__ l, const int *__restrict__ n, long long nf,
+                                                 long long start, int npos, int lower, int upper, int *__restrict__ plus,
+                                                 int *__restrict__ minus) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < nf; i += stride) {
+        const int ilen = n[i];
+        if (ilen < lower || ilen >= upper) continue;
+        const long long lp = l[i] - start, rp = lp + ilen - 1;
+        if (lp >= 0 && lp < npos) atomicAdd(&plus[lp], 1);
+        if (rp >= 0 && rp < npos) atomicAdd(&minus[rp], 1);
+    }
+}
+
 __global__ void natac_i32_to_f64(const int *__restrict__ a, double *__restrict__ b, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;

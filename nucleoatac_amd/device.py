@@ -159,6 +159,15 @@ class Context(object):
                                                int(lower), int(upper), _ptr(out)))
         return out
 
+    def get_stranded_insertions(self, l, n, start, end, lower=0, upper=2000):
+        """getStrandedInsertions (pyatac/fragments.pyx:71-97): (plus, minus)."""
+        l = np.ascontiguousarray(l, dtype=np.int64)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        plus, minus = np.empty(end - start, dtype=np.float64), np.empty(end - start, dtype=np.float64)
+        L.check(self._lib.natac_get_stranded_insertions(self._h, l.shape[0], _ptr(l), _ptr(n), int(start), int(end),
+                                                        int(lower), int(upper), _ptr(plus), _ptr(minus)))
+        return plus, minus
+
     def fragment_sizes(self, l, n, chunk_starts, chunk_ends, lower, upper):
         """getFragmentSizesFromChunkList (pyatac/fragments.pyx:123-145), one chromosome."""
         l = np.ascontiguousarray(l, dtype=np.int64)
@@ -329,6 +338,18 @@ class DeviceBatch(object):
         lr, var, z = (np.empty(n, dtype=np.float64) for _ in range(3))
         L.check(self._lib.natac_run_candidates(self._h, n, _ptr(cc), _ptr(cp), _ptr(lr), _ptr(var), _ptr(z)))
         return lr, var, z
+
+    def run_candidates_cov(self, cand_chunk, cand_pos, mode="closed"):
+        """calculateCov at many candidates in one arithmetic variant (natac_run_candidates_cov): "closed" (fp64 closed form),
+        "literal" (the .pyx's O(N^2) pair sum, fp64) or "fp32" (closed form in float)"""
+        cc = np.ascontiguousarray(cand_chunk, dtype=np.int32)
+        cp = np.ascontiguousarray(cand_pos, dtype=np.int32)
+        if cc.shape != cp.shape:
+            raise ValueError("cand_chunk / cand_pos shape mismatch")
+        var = np.empty(cc.shape[0], dtype=np.float64)
+        L.check(self._lib.natac_run_candidates_cov(self._h, cc.shape[0], _ptr(cc), _ptr(cp),
+                                                   {"closed": 0, "literal": 1, "fp32": 2}[mode], _ptr(var)))
+        return var
 
     def run_peaks(self, min_signal=0.0, sep=25, boundary=60, order=12, download=True):
         """candidate search + LR / var / z on the device (natac_run_peaks): call_peaks(norm + smoothed, ...) of every chunk

@@ -136,7 +136,10 @@ class BatchRunner(object):
         if st.any():
             k = int(np.flatnonzero(st)[0])
             b.free()
-            raise ValueError("min() arg is an empty sequence (occupancy likelihood undefined in chunk %d)" % k)
+            where = "%s\t%d\t%d" % (self.pk.chroms[k], int(self.pk.chunk_start[k]), int(self.pk.chunk_start[k]) + int(self.pk.chunk_len[k])) \
+                if self.pk.chroms else "chunk %d of the batch" % k
+            # the reference's helper prints the chunk's BED line before re-raising (run_occ.py:33-37)
+            raise ValueError("min() arg is an empty sequence (occupancy likelihood undefined in %s)" % where)
         out = {}
         self.flat = getattr(self, "flat", {})
         for name, t in (("smoothed_vals", L.T_OCC), ("smoothed_lower", L.T_OCC_LOWER), ("smoothed_upper", L.T_OCC_UPPER),

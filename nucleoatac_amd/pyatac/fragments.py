@@ -161,15 +161,9 @@ def getInsertions(bamfile, chrom, start, end, lower, upper, atac=1):
 
 
 def getStrandedInsertions(bamfile, chrom, start, end, lower, upper, atac=1):
-    """(plus, minus) = insertions at the left / right fragment end -- pyatac/fragments.pyx:71-97.
-    Two calls of the insertion kernel on degenerate fragments (right end moved onto the left and vice versa)."""
+    """(plus, minus) = insertions at the left / right fragment ends -- pyatac/fragments.pyx:71-97"""
     l, n = FragmentStore.open(bamfile).fetch(chrom, max(0, start - upper), end + upper, atac)
-    keep = (n >= lower) & (n < upper)
-    l, n = l[keep], n[keep]
-    one = np.ones(len(l), dtype=np.int32)
-    plus = _ctx().get_insertions(l, one, start, end, 0, 2) / 2.0          # n == 1: l == r, counted twice
-    minus = _ctx().get_insertions(l + n - 1, one, start, end, 0, 2) / 2.0
-    return plus, minus
+    return _ctx().get_stranded_insertions(l, n, start, end, lower, upper)
 
 
 def getAllFragmentSizes(bamfile, lower, upper, atac=1):

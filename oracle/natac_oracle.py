@@ -68,6 +68,18 @@ def get_insertions(l, n, start, end, lower=0, upper=2000):
     return out
 
 
+def get_stranded_insertions(l, n, start, end, lower=0, upper=2000):
+    """(plus, minus) per-base insertion counts  [pyatac/fragments.pyx:71-97]: for lower <= n < upper the left end l
+    counts on the plus strand, the right end r = l+n-1 on the minus strand, each when inside [start,end)."""
+    plus = np.zeros(end - start, dtype=np.float64)
+    minus = np.zeros(end - start, dtype=np.float64)
+    keep = (n >= lower) & (n < upper)
+    lk, rk = l[keep], l[keep] + n[keep] - 1
+    np.add.at(plus, lk[(lk >= start) & (lk < end)] - start, 1.0)
+    np.add.at(minus, rk[(rk >= start) & (rk < end)] - start, 1.0)
+    return plus, minus
+
+
 def get_ins_from_mat(mat, lower, upper):
     """ChunkMat2D.getIns [pyatac/chunkmat2d.py:74-84]: collapse a V-plot matrix to insertions.
 

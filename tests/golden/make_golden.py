@@ -335,6 +335,15 @@ def case_ins_edge():
         it.calculateInsertions(bam, lower=lo, upper=up)
         check("edge getInsertions [%d,%d)" % (lo, up), it.vals, O.get_insertions(l, n, s, e, lo, up), exact=True)
         out["ins_%d_%d" % (lo, up)] = it.vals
+        # getStrandedInsertions (pyatac/fragments.pyx:71-97): plus = left ends, minus = right ends
+        from pyatac.fragments import getStrandedInsertions
+        plus, minus = getStrandedInsertions(bam, "chrS", s, e, lo, up)
+        op, om = O.get_stranded_insertions(l, n, s, e, lo, up)
+        check("edge getStrandedInsertions plus [%d,%d)" % (lo, up), plus, op, exact=True)
+        check("edge getStrandedInsertions minus [%d,%d)" % (lo, up), minus, om, exact=True)
+        assert np.array_equal(plus + minus, it.vals)
+        out["plus_%d_%d" % (lo, up)] = plus
+        out["minus_%d_%d" % (lo, up)] = minus
     fm = FragmentMat2D("chrS", s - 60, e + 60, 0, 251)
     fm.makeFragmentMat(bam)
     check("edge makeFragmentMat", fm.mat, O.make_fragment_mat(l, n, s - 60, e + 60, 0, 251), exact=True)

@@ -11,33 +11,7 @@ from helpers import GOLDEN, golden
 from nucleoatac_amd.pyatac.fragments import FragmentStore
 
 
-def _bgzf(data, blk=3000):
-    out = bytearray()
-    for o in range(0, len(data), blk):
-        chunk = data[o:o + blk]
-        co = zlib.compressobj(6, zlib.DEFLATED, -15)
-        comp = co.compress(chunk) + co.flush()
-        bsize = 18 + len(comp) + 8
-        out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", bsize - 1)
-        out += comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
-    out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
-    return bytes(out)
-
-
-def _write_bam(path, refs, records):
-    text = b"@HD\tVN:1.0\tSO:coordinate\n"
-    d = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
-    for name, ln in refs:
-        nm = name.encode() + b"\0"
-        d += struct.pack("<i", len(nm)) + nm + struct.pack("<i", ln)
-    for ref_id, pos, flag, tlen in records:
-        rn = b"r\0"
-        seq_len = 10
-        body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(rn), 30, 4680, 1, flag, seq_len, ref_id, pos + 50, tlen)
-        body += rn + struct.pack("<I", (seq_len << 4) | 0) + bytes((seq_len + 1) // 2) + bytes([30] * seq_len)
-        d += struct.pack("<i", len(body)) + body
-    with open(path, "wb") as f:
-        f.write(_bgzf(d))
+from helpers import bgzf_bytes as _bgzf, write_bam as _write_bam  # noqa: E402
 
 
 def test_native_decoder_matches_truth_and_python(tmp_path):

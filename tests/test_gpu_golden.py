@@ -108,6 +108,9 @@ def test_cython_dropins_edge_cases(ctx):
     for lo, up in ((0, 2000), (0, 251), (2, 251), (100, 300)):
         out = ctx.get_insertions(l, n, s, e, lo, up)
         assert out.dtype == np.float64 and np.array_equal(out, g["ins_%d_%d" % (lo, up)])
+        plus, minus = ctx.get_stranded_insertions(l, n, s, e, lo, up)      # getStrandedInsertions, fragments.pyx:71-97
+        assert plus.dtype == np.float64 and np.array_equal(plus, g["plus_%d_%d" % (lo, up)])
+        assert np.array_equal(minus, g["minus_%d_%d" % (lo, up)])
     ms, me = int(g["mat_start"]), int(g["mat_end"])
     mat = ctx.make_fragment_mat(l, n, ms, me, 0, 251)
     ref = np.zeros_like(mat)
@@ -122,6 +125,8 @@ def test_cython_dropins_edge_cases(ctx):
     # empty fragment list
     z = ctx.get_insertions(np.zeros(0, np.int64), np.zeros(0, np.int32), 10, 20)
     assert z.shape == (10,) and not z.any()
+    zp, zm = ctx.get_stranded_insertions(np.zeros(0, np.int64), np.zeros(0, np.int32), 10, 20)
+    assert zp.shape == zm.shape == (10,) and not zp.any() and not zm.any()
 
 
 def test_calculate_cov_reference_fixture(ctx):

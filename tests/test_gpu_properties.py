@@ -3,7 +3,7 @@ plus ragged / empty / extreme edge cases.  Oracle comparisons are limited to a r
 import numpy as np
 import pytest
 
-from helpers import assert_track, golden
+from helpers import assert_track, cancel_scale, golden
 from nucleoatac_amd import _lib as L
 from nucleoatac_amd.packing import PackedChunks
 from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions, synth_size_distribution
@@ -184,8 +184,9 @@ def test_ragged_and_empty_chunks_match_oracle(ctx):
         assert_track(tr[L.T_NFR_COV][k], nt["nfr_cov"], "nfr_cov", exact=True)
         assert_track(tr[L.T_RAW][k], nt["raw"], "raw")
         assert_track(tr[L.T_BACKGROUND][k], nt["bg"], "bg")
-        assert_track(tr[L.T_NORM][k], nt["norm"], "norm", atol=1e-8)
-        assert_track(tr[L.T_SMOOTH][k], nt["smoothed"], "smoothed", atol=1e-8)
+        sc = cancel_scale(nt["raw"], nt["bg"])
+        assert_track(tr[L.T_NORM][k], nt["norm"], "norm", scale=sc)
+        assert_track(tr[L.T_SMOOTH][k], nt["smoothed"], "smoothed", scale=sc)
         assert_track(tr[L.T_OCC_PREFILL][k], oc["smoothed_vals"], "occ")
         assert_track(tr[L.T_OCC_LOWER][k], oc["smoothed_lower"], "occ lower")
         assert_track(tr[L.T_OCC_UPPER][k], oc["smoothed_upper"], "occ upper")
@@ -295,7 +296,7 @@ def test_background_fft_fallback_tiles_match_oracle(ctx):
             nt = O.nuc_chunk_tracks(l, n, 0, Lc, pk.chunk_bias(k), -246, par["vmat"], 105, 251, sizes)
         assert np.array_equal(np.isnan(bg[k]), np.isnan(nt["bg"])), k
         assert_track(bg[k], nt["bg"], "bg %d" % k)
-        assert_track(nm[k], nt["norm"], "norm %d" % k, atol=1e-8)
+        assert_track(nm[k], nt["norm"], "norm %d" % k, scale=cancel_scale(nt["raw"], nt["bg"]))
     assert np.isnan(bg[0]).sum() > 0 and np.isnan(bg[0]).sum() < 600 and not np.isnan(bg[3]).any()
     b.free()
 

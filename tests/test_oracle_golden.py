@@ -117,6 +117,8 @@ def test_insertion_edge_cases():
     l, n, s, e = g["l"], g["n"], int(g["start"]), int(g["end"])
     for lo, up in ((0, 2000), (0, 251), (2, 251), (100, 300)):
         assert np.array_equal(O.get_insertions(l, n, s, e, lo, up), g["ins_%d_%d" % (lo, up)])
+        plus, minus = O.get_stranded_insertions(l, n, s, e, lo, up)
+        assert np.array_equal(plus, g["plus_%d_%d" % (lo, up)]) and np.array_equal(minus, g["minus_%d_%d" % (lo, up)])
     mat = O.make_fragment_mat(l, n, int(g["mat_start"]), int(g["mat_end"]), 0, 251)
     ref = np.zeros_like(mat)
     ref[g["mat_rows"], g["mat_cols"]] = g["mat_vals"]
