@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-h2h", action="store_true", help="skip the pipelined host-to-host measurement")
     ap.add_argument("--h2h-sub", type=int, default=2500, help="chunks per pipelined sub-batch")
     ap.add_argument("--h2h-threads", type=int, default=6, help="contexts (host threads) of the host-to-host pipeline")
+    ap.add_argument("--cli-chunks", type=int, default=10000, help="chunks of the CLI end-to-end measurement (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--share-device", action="store_true",
@@ -353,7 +354,7 @@ def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_thread
         ctx.set_sizes(sizes)
         ctx.set_occ_model(nucp, nfrp, step=5, flank=60)
 
-    with PipelinedExecutor(device, configure, bench_stages(tracks), n_contexts=n_threads, slots_per_context=1) as ex:
+    with PipelinedExecutor(device, configure, bench_stages(tracks), n_contexts=n_threads, slots_per_context=2) as ex:
         for r in ex.map((s, None) for s in subs):            # untimed pass: contexts, pool blocks, pinned slots
             r.release()
         ex.bytes_down = ex.bytes_up = 0
@@ -373,6 +374,44 @@ def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_thread
                 note="pinned host buffers both ways; uploads, kernels and downloads of different sub-batches overlap")
 
 
+# ------------------------------------------------------------------------------------------------ CLI end to end
+def cli_end_to_end(n_chunks, cores, seed=0):
+    """`nucleoatac occ` and `nucleoatac nuc` as a user runs them, on a slice of the configs[2] workload written as input files
+    (BED + reads .npz + genome .npz): files in -> .bedgraph.gz + .tbi + calls out, everything included (reading the inputs,
+    PWM bias of the genome on the GPU, packing, the pipelined executor, the native writers, bgzip + tabix).  `nuc` runs with
+    --cores for its per-nucleosome L-BFGS fits (host)."""
+    import contextlib
+    import shutil
+    import tempfile
+    from nucleoatac_amd.nucleoatac.cli import main as cli_main
+    from nucleoatac_amd.synth import write_cli_dataset
+    d = tempfile.mkdtemp(prefix="natac_cli_")
+    try:
+        bed, bam, fa = write_cli_dataset(d, n_chunks, 2120, 500, seed=seed)
+        out = os.path.join(d, "e2e")
+        bp = n_chunks * 2120
+        with contextlib.redirect_stdout(sys.stderr):
+            t0 = time.perf_counter()
+            cli_main(["occ", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores)])
+            t_occ = time.perf_counter() - t0
+            cli_main(["vprocess", "--sizes", out + ".nuc_dist.txt", "--out", out])
+            t0 = time.perf_counter()
+            cli_main(["nuc", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores), "--occ_track",
+                      out + ".occ.bedgraph.gz", "--vmat", out + ".VMat", "--sizes", out + ".fragmentsizes.txt"])
+            t_nuc = time.perf_counter() - t0
+        size = lambda suffix: os.path.getsize(out + suffix)
+        n_calls = sum(1 for _ in __import__("gzip").open(out + ".nucpos.bed.gz", "rt"))
+        return dict(occ_mbp_s=round(bp / t_occ / 1e6, 2), nuc_mbp_s=round(bp / t_nuc / 1e6, 3), cores=cores, chunks=n_chunks, bp=bp,
+                    occ_seconds=round(t_occ, 2), nuc_seconds=round(t_nuc, 2), nucleosome_calls=n_calls,
+                    occ_track_bytes=sum(size("." + n + ".bedgraph.gz") for n in ("occ", "occ.lower_bound", "occ.upper_bound")),
+                    nuc_track_bytes=sum(size("." + n + ".bedgraph.gz") for n in ("nucleoatac_signal", "nucleoatac_signal.smooth")),
+                    out_dir=os.path.dirname(d) or "/tmp",
+                    note="files in (BED, reads .npz, genome .npz) -> .bedgraph.gz + .tbi + .bed.gz out; occ writes 3 tracks + peaks, nuc "
+                         "2 tracks + calls; nuc is bounded by the host L-BFGS fuzziness fits (one per call, --cores processes)")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
@@ -382,31 +421,13 @@ def main():
     dist = None
     if a.share_device:
         local_rank = 0
+        os.environ["NATAC_DEVICE"] = "0"
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        if a.dist_backend == "nccl":
-            # the collectives here are the contract's barrier and the max / sum of three scalars, never data: if RCCL cannot
-            # come up on this node (or the ranks share one GPU) the run goes on over gloo instead of dying
-            try:
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-                probe = torch.ones(1, device="cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                assert int(probe.item()) == world
-            except Exception as e:      # noqa: BLE001
-                sys.stderr.write("bench: RCCL unavailable (%s: %s); barrier / reductions over gloo\n" % (type(e).__name__, str(e)[:200]))
-                try:
-                    dist.destroy_process_group()
-                except Exception:       # noqa: BLE001
-                    pass
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"      # rank 0 hosts the new store itself
-                a.dist_backend = "gloo"
-                dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend=a.dist_backend)
+        # one shared helper for the CLI and the bench (nucleoatac_amd/shard.py): gloo control plane first, then an RCCL group
+        # whose use is decided collectively; the only collectives are the contract's barrier and the max / sum of scalars
+        from nucleoatac_amd import shard as dshard
+        dist, _ = dshard.ensure_distributed(prefer=a.dist_backend, device=local_rank)
+        a.dist_backend = dshard.control_backend()
 
     from nucleoatac_amd import _lib as L
     from nucleoatac_amd.synth import synth_occ_distributions, synth_size_distribution
@@ -442,10 +463,7 @@ def main():
     def barrier():
         ctx.sync()
         if dist is not None:
-            if on_gpu:
-                import torch
-                torch.cuda.synchronize()
-            dist.barrier()
+            dshard.barrier(sync_cuda=True)
 
     for _ in range(a.warmup):
         step()
@@ -462,15 +480,17 @@ def main():
     dt = time.perf_counter() - t0
     barrier()
     total_bp, total_frags, total_cand = my_bp, my_frags, n_cand[0]
+    per_rank = None
     if dist is not None:
-        import torch
-        dev = "cuda" if on_gpu else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot = torch.tensor([my_bp, my_frags, n_cand[0]], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_bp, total_frags, total_cand = (int(x) for x in tot.tolist())
+        my_dt = dt
+        dt = dshard.all_reduce_scalars([dt], "max")[0]
+        total_bp, total_frags, total_cand = (int(x) for x in dshard.all_reduce_scalars([my_bp, my_frags, n_cand[0]], "sum"))
+        # per-rank timings so that a scaling run is diagnosable: who generated / uploaded / stepped how long
+        rows = [None] * world
+        dist.all_gather_object(rows, dict(rank=rank, generate_s=round(t_gen, 2), upload_s=round(t_up, 2),
+                                          ms_per_step=round(my_dt / a.steps * 1e3, 3), bp=my_bp, fragments=my_frags,
+                                          device=local_rank))
+        per_rank = rows
     prof = ctx.profile()
     ms_per_step = dt / a.steps * 1e3
     value = total_bp * a.steps / dt / 1e6
@@ -491,6 +511,12 @@ def main():
         ctx.close()
         ctx = None
         h2h = host_to_host(subs[0], local_rank, par, sizes, nucp, nfrp, a.steps, a.h2h_sub, a.h2h_threads)
+    e2e = None
+    if rank == 0 and world == 1 and a.cli_chunks > 0 and a.workload == "cfg3":
+        if ctx is not None:
+            ctx.close()
+            ctx = None
+        e2e = cli_end_to_end(a.cli_chunks, _effective_cores(), seed=a.seed)
 
     if rank == 0:
         # roofline of the dominant kernel class of this run (largest HIP-event time on the launch stream)
@@ -537,6 +563,7 @@ def main():
                                              "executed_tflops": round(fft_tflops, 2), "peak": FP64_PEAK_TFLOPS,
                                              "unit": "TFLOP/s", "frac_executed": round(fft_tflops / FP64_PEAK_TFLOPS, 4)}},
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
+            "per_rank": per_rank, "control_plane": a.dist_backend if dist is not None else None,
             "valu_issue_from_committed_pmc": valu,
             "host": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2),
                      "download_5_tracks_and_candidates_s": None if t_dn is None else round(t_dn, 2),
@@ -545,13 +572,15 @@ def main():
         }
         if h2h is not None:
             out["host_to_host"] = h2h
+        if e2e is not None:
+            out["cli_end_to_end"] = e2e
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if ctx is not None:
         ctx.close()
     if dist is not None:
-        dist.barrier()
+        dshard.barrier()
         dist.destroy_process_group()
 
 

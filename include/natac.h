@@ -228,6 +228,12 @@ int natac_write_bedgraph(const char *path, int append, int compress, int finish,
                          const int64_t *chunk_start, const int64_t *out_off, const double *vals, int write_zero,
                          int n_threads, int64_t *bytes_written);
 
+/* BED-like rows with python-2 float columns, written natively: row r = names[chrom_id[r]] \t start[r] \t end[r] (\t vals[r][c])* --
+ * the text of OccPeak.asBed / Nucleosome.asBed (nucleoatac/Occupancy.py:166-171, NucleosomeCalling.py:195-199) for millions of rows.
+ * vals is row-major [n_rows x n_cols] (n_cols <= 32), NaN prints as "nan".  append != 0 appends to `path`. */
+int natac_write_bed_rows(const char *path, int append, int64_t n_rows, const int32_t *chrom_id, const char *const *names,
+                         int32_t n_names, const int64_t *start, const int64_t *end, const double *vals, int32_t n_cols);
+
 /* bgzip: compress a text file into BGZF members of <= 0xff00 input bytes + the EOF marker (the reference's
  * pysam.tabix_compress, pyatac/utils.py:135-141 / run_nuc.py:204-214). */
 int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads);

@@ -292,4 +292,38 @@ inline int write_bedgraph(const char *path, bool append, int compress, bool fini
     return 0;
 }
 
+// BED-like rows with python-2 float columns: chrom \t start \t end (\t value)* \n -- what OccPeak.asBed / Nucleosome.asBed
+// produce (nucleoatac/Occupancy.py:166-171, NucleosomeCalling.py:195-199), formatted natively for millions of rows.
+// returns 0 ok, 1 cannot open, 2 write error
+inline int write_bed_rows(const char *path, bool append, int64_t n_rows, const int32_t *chrom_id, const char *const *names,
+                          const int64_t *start, const int64_t *end, const double *vals, int n_cols) {
+    std::string out;
+    out.reserve((size_t)n_rows * (32 + (size_t)n_cols * 16) + 64);
+    char line[64 + 40 * 32];
+    if (n_cols > 32) return 2;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        char *p = line;
+        const char *nm = names[chrom_id[r]];
+        const size_t nl = std::strlen(nm);
+        if (nl > 256) { out.append(line, (size_t)(p - line)); out.append(nm, nl); p = line; }
+        else { std::memcpy(p, nm, nl); p += nl; }
+        *p++ = '\t';
+        p = fmt_i64(p, start[r]);
+        *p++ = '\t';
+        p = fmt_i64(p, end[r]);
+        for (int c = 0; c < n_cols; ++c) {
+            *p++ = '\t';
+            const double v = vals[(size_t)r * n_cols + c];
+            if (v != v) { *p++ = 'n'; *p++ = 'a'; *p++ = 'n'; }
+            else p = fmt_py2_float(p, v);
+        }
+        *p++ = '\n';
+        out.append(line, (size_t)(p - line));
+    }
+    FILE *f = std::fopen(path, append ? "ab" : "wb");
+    if (!f) return 1;
+    const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    return (std::fclose(f) == 0 && ok) ? 0 : 2;
+}
+
 }  // namespace natac_writer

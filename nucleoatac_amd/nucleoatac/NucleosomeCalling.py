@@ -92,6 +92,31 @@ def norm(x, v, w, mean):
     return y * (w / y.max())
 
 
+_OCC_POOL = None
+
+
+def occ_reader_pool():
+    """ONE module-level thread pool for the tabix region reads of NucChunk.getOcc (NucleosomeCalling.py:284-293): the readers
+    are thread-local (pyatac/tracks.py:_tabix), so keeping the threads alive across batches keeps every thread's three parsed
+    .tbi indexes alive too, instead of re-opening and re-parsing them in up to 16 new threads per batch."""
+    global _OCC_POOL
+    if _OCC_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _OCC_POOL = ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1)), thread_name_prefix="natac-occ-reader")
+    return _OCC_POOL
+
+
+def read_occ_tracks(occ_track, chrom, start, end):
+    """(occ, lower, upper) values of [start, end) from the three track files `occ` wrote (NucChunk.getOcc)"""
+    base = occ_track[:-11]
+    out = []
+    for f in (occ_track, base + "lower_bound.bedgraph.gz", base + "upper_bound.bedgraph.gz"):
+        t = Track(chrom, start, end, "Occupancy")
+        t.read_track(f)
+        out.append(t.vals)
+    return out
+
+
 FAST_FD = True    # batched finite differences in fit_fuzz_one (False: scipy's own numerical gradient)
 
 
@@ -271,14 +296,10 @@ def nuc_batch(chunks, params, ctx=None, with_flat=False):
         if params.occ_track is not None:
             # three tabix region reads per chunk (NucleosomeCalling.py:284-293), ~1 ms each: spread over host threads (the
             # native reader releases the GIL; every thread has its own readers, pyatac/tracks.py:_tabix)
-            from concurrent.futures import ThreadPoolExecutor
-            nthr = max(1, min(16, os.cpu_count() or 1, len(out)))
-            if nthr == 1:
-                for nc in out:
-                    nc.getOcc()
+            if len(out) == 1:
+                out[0].getOcc()
             else:
-                with ThreadPoolExecutor(nthr) as ex:
-                    list(ex.map(NucChunk.getOcc, out, chunksize=1))
+                list(occ_reader_pool().map(NucChunk.getOcc, out, chunksize=1))
         # candidate search (call_peaks on norm + smoothed, NucleosomeCalling.py:297-301) and LR / z for every candidate
         # of every chunk on the device: nothing round-trips between the signal kernels and the statistics
         cc, cp, lr, var, z = run.batch.run_peaks(min_signal=0, sep=params.redundant_sep,

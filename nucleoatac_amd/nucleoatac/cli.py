@@ -101,11 +101,11 @@ def nucleoatac_parser():
 
 
 def _rank0_only(fn, args):
-    """vprocess / merge / nfr are single-process steps: under torchrun rank 0 runs them, the others wait"""
-    from ..shard import barrier, env_rank_world
-    rank = env_rank_world()[0]
-    if rank == 0:
-        fn(args)
+    """vprocess / merge are single-process steps (a template, a merge of two call files): under torchrun rank 0 runs them and
+    the others wait for its ok / failed flag (shard.run_on_rank0), so a failure on rank 0 ends every rank at once.  `nfr` is
+    sharded across the ranks like occ and nuc (run_nfr.py)."""
+    from ..shard import barrier, run_on_rank0
+    run_on_rank0(fn, args)
     barrier()
 
 
@@ -129,7 +129,7 @@ def nucleoatac_main(args):
     elif args.call == "nfr":
         from .run_nfr import run_nfr
         print("---------Calling NFR positions----------------------------------------")
-        _rank0_only(run_nfr, args)
+        run_nfr(args)
     elif args.call == "run":
         # the five steps chained through their output files exactly as the reference does (cli.py:34-64)
         parser = nucleoatac_parser()
@@ -164,7 +164,8 @@ def nucleoatac_main(args):
         print("---------Step4: Making combined nucleosome position map ------------------------")
         _rank0_only(run_merge, merge_args)
         print("---------Step5: Calling NFR positions-------------------------------------------")
-        _rank0_only(run_nfr, nfr_args)
+        run_nfr(nfr_args)
+        barrier()
     else:
         raise SystemExit("usage: nucleoatac {run,occ,vprocess,nuc,merge,nfr} ...")
 

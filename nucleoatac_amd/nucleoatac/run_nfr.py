@@ -1,13 +1,18 @@
 """`nucleoatac nfr` (reference: nucleoatac/run_nfr.py:71-130): NFR positions between the combined nucleosome calls, plus the
 insertion track of the regions when none is given.  The reference's pool.map over chunks becomes one GPU batch per
-BATCH_CHUNKS chunks for the insertion counts (natac_run_ins) and one native multi-threaded writer call per batch."""
+BATCH_CHUNKS chunks for the insertion counts (natac_run_ins) and one native multi-threaded writer call per batch.  With
+torchrun / WORLD_SIZE > 1 the chunk list is sharded across the ranks like `occ` and `nuc` (rank part files, concatenated by
+rank 0 in chunk order): the per-chunk loop is host work -- two tabix reads, one PWM launch -- and would otherwise keep every
+other rank waiting in a barrier for as long as one process needs for the whole genome."""
 import os
+import shutil
 
 import numpy as np
 
 from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
+from ..shard import barrier, ensure_distributed, env_rank_world
 from ..writer import bgzip_file, tabix_index, write_bedgraph
 from .NFRCalling import NFRChunk, NFRParameters
 
@@ -50,20 +55,30 @@ def run_nfr(args):
         chunks = ChunkList.read(args.bed, chromDict=chrs_fasta, min_offset=max(pwm.up, pwm.down))
     else:
         chunks = ChunkList.read(args.bed)
+    ensure_distributed()
     if args.bam is not None:
+        from ..shard import shared_fragment_store
+        shared_fragment_store(args.bam)      # decoded once per node; FragmentStore.open(args.bam) returns it on every rank
         chunks.checkChroms(read_chrom_sizes_from_bam(args.bam), chrom_source="BAM file")
     chunks.merge()
     params = NFRParameters(args.occ_track, args.calls, args.ins_track, args.bam, max_occ=args.max_occ,
                            max_occ_upper=args.max_occ_upper, fasta=args.fasta, pwm=args.pwm)
     make_ins = params.ins_track is None
-    ins_path = args.out + ".ins.bedgraph.gz"
+    rank, world, _ = env_rank_world()
+    lens = np.array([c.length() for c in chunks], dtype=np.float64)
+    cum = np.concatenate(([0.0], np.cumsum(lens)))
+    cuts = [int(np.searchsorted(cum, cum[-1] * r / world, "left")) for r in range(world)] + [len(chunks)]
+    chunks = chunks[cuts[rank]:max(cuts[rank], cuts[rank + 1])]
+    suffix = "" if world == 1 else ".rank%d" % rank
+    ins_path = args.out + ".ins.bedgraph.gz" + suffix
     nb = max(1, (len(chunks) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
-    with open(args.out + ".nfrpos.bed", "w") as nfr_handle:
+    with open(args.out + ".nfrpos.bed" + suffix, "w") as nfr_handle:
         for bi in range(nb):
             part = chunks[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
             if not part:
                 if make_ins:
-                    write_bedgraph(ins_path, [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL, finish=True)
+                    write_bedgraph(ins_path, [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL,
+                                   finish=(rank == world - 1))
                 break
             off = flat = None
             if make_ins:
@@ -80,7 +95,18 @@ def run_nfr(args):
                 nfr.removeData()
             if make_ins:      # Track.write_track of every chunk's insertion track (run_nfr.py:55-67) through the native writer
                 write_bedgraph(ins_path, [c.chrom for c in part], [c.start for c in part], off, flat, append=bi > 0,
-                               compress=COMPRESS_LEVEL, finish=(bi == nb - 1))
+                               compress=COMPRESS_LEVEL, finish=(bi == nb - 1 and rank == world - 1))
+    barrier()          # every rank has closed its part files
+    if rank != 0:
+        return
+    if world > 1:      # text lines / BGZF members concatenate: rank order == chunk order
+        for base in [args.out + ".nfrpos.bed"] + ([args.out + ".ins.bedgraph.gz"] if make_ins else []):
+            with open(base, "wb") as fo:
+                for r in range(world):
+                    with open(base + ".rank%d" % r, "rb") as fi:
+                        shutil.copyfileobj(fi, fo)
+                    os.remove(base + ".rank%d" % r)
+        ins_path = args.out + ".ins.bedgraph.gz"
     bgzip_file(args.out + ".nfrpos.bed", level=COMPRESS_LEVEL)       # pysam.tabix_compress + tabix_index (run_nfr.py:121-128)
     tabix_index(args.out + ".nfrpos.bed.gz")
     if make_ins:

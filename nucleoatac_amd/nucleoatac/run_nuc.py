@@ -1,20 +1,30 @@
-"""`nucleoatac nuc` (reference: nucleoatac/run_nuc.py:141-201): NucleoATAC signal tracks + nucleosome calls."""
-import gzip
+"""`nucleoatac nuc` (reference: nucleoatac/run_nuc.py:141-201): NucleoATAC signal tracks + nucleosome calls.
+
+Like `occ` (run_occ.py) the chunk list goes through `nucleoatac_amd.executor.PipelinedExecutor`; a writer thread consumes the
+finished sub-batches in chunk order -- native run-length bedGraph + BGZF for the tracks, then the calls: the candidate
+statistics (LR, z) come from the device, the thresholds of `findAllNucs` (NucleosomeCalling.py:303-311) are applied to whole
+sub-batches with numpy, `reduce_peaks` and the per-nucleosome L-BFGS fuzziness fit (NucleosomeCalling.py:137-194, host by
+SURVEY.md section 8f row 3) run per chunk, the fits on the `--cores` process pool while the GPU works on the next sub-batches."""
 import os
 import shutil
 
 import numpy as np
 
+from .. import _lib as L
+from ..executor import PipelinedExecutor, Stages
+from ..pipeline import pack
 from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
-from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
+from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta, reduce_peaks
 from ..pyatac.VMat import VMat
-from ..shard import balanced_ranges, barrier, ensure_distributed, env_rank_world
-from ..writer import bgzip_file, tabix_index, write_bedgraph
-from .NucleosomeCalling import NucParameters, nuc_batch
+from ..shard import balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, shared_fragment_store
+from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
+from .NucleosomeCalling import NucParameters, fit_fuzz_chunk, nuc_batch, occ_reader_pool, read_occ_tracks
+from .run_occ import _Writer
 
-BATCH_CHUNKS = 4096
+BATCH_CHUNKS = int(os.environ.get("NATAC_BATCH_CHUNKS", "4096"))
+N_CONTEXTS = int(os.environ.get("NATAC_CONTEXTS", "3"))
 COMPRESS_LEVEL = 4
 
 
@@ -39,6 +49,74 @@ def _nucHelperBatch(chunks, params):
     return out
 
 
+def batch_calls(r, params, pool=None, pool_workers=1):
+    """NucChunk.findAllNucs + fit for every chunk of a finished sub-batch (NucleosomeCalling.py:294-324) from the device's
+    candidate arrays: returns {"nucpos": rows, "nucpos.redundant": rows} with rows = (chunk index, position, 10 value columns:
+    z, occ, occ_lower, occ_upper, lr, norm_signal, nuc_signal, nuc_cov, nfr_cov, fuzz) in chunk / position order."""
+    part, pk = r.tag, r.packed
+    cc, cp, lr, _var, z = r.peaks
+    tr = r.tracks
+    over = set(int(k) for k in np.nonzero(r.status & 2)[0])
+    idx = pk.out_off[cc] + cp
+    nuc_cov = tr[L.T_NUC_COV][idx]
+    with np.errstate(invalid="ignore"):
+        keep = (nuc_cov > params.min_reads) & (lr > params.min_lr) & (z >= params.min_z)     # the reference's order: reads, LR, z
+    if over:
+        keep &= ~np.isin(cc, list(over))
+    kc, kp, kidx = cc[keep], cp[keep], idx[keep]
+    vals = np.empty((len(kc), 10), dtype=np.float64)
+    vals[:, 0], vals[:, 4] = z[keep], lr[keep]
+    vals[:, 1:4] = np.nan
+    vals[:, 5], vals[:, 6] = tr[L.T_NORM][kidx], tr[L.T_RAW][kidx]
+    vals[:, 7], vals[:, 8] = nuc_cov[keep], tr[L.T_NFR_COV][kidx]
+    bounds = np.searchsorted(kc, np.arange(len(part) + 1))
+    called = [k for k in range(len(part)) if bounds[k + 1] > bounds[k]]
+    if params.occ_track is not None and called:
+        # three tabix region reads per chunk with calls (NucChunk.getOcc, NucleosomeCalling.py:284-293) on the persistent reader pool
+        def occ_of(k):
+            ch = part[k]
+            try:
+                return read_occ_tracks(params.occ_track, ch.chrom, ch.start, ch.end)
+            except Exception:      # noqa: BLE001 -- Nucleosome.getOcc: any failure gives NaN (NucleosomeCalling.py:128-135)
+                return None
+        for k, res in zip(called, occ_reader_pool().map(occ_of, called)):
+            if res is not None:
+                a, e = int(bounds[k]), int(bounds[k + 1])
+                for j in range(3):
+                    vals[a:e, 1 + j] = res[j][kp[a:e]]
+    # fuzziness fits: one task per chunk with calls (the smoothed values are copied out of the pinned slot)
+    sm = tr[L.T_SMOOTH]
+    tasks = [(sm[int(pk.out_off[k]):int(pk.out_off[k + 1])].copy(), kp[int(bounds[k]):int(bounds[k + 1])].astype(np.int64),
+              params.nonredundant_sep, params.smooth_sd) for k in called]
+    if pool is None or len(tasks) < 2:
+        fits = [fit_fuzz_chunk(t) for t in tasks]
+    else:
+        fits = list(pool.map(fit_fuzz_chunk, tasks, chunksize=max(1, len(tasks) // (4 * pool_workers))))
+    nonred = np.zeros(len(kc), dtype=bool)
+    for k, f in zip(called, fits):
+        a, e = int(bounds[k]), int(bounds[k + 1])
+        vals[a:e, 9] = [x[0] for x in f]
+        keys = kp[a:e]
+        nr = reduce_peaks(keys, list(vals[a:e, 0]), params.nonredundant_sep)
+        nonred[a:e] = np.isin(keys, nr)
+    out = {"nucpos": (kc[nonred], kp[nonred], vals[nonred]), "nucpos.redundant": (kc[~nonred], kp[~nonred], vals[~nonred])}
+    if over:     # chunks with more local maxima than the device peak finder holds per chunk: the per-chunk API path, merged in order
+        for k in sorted(over):
+            nc = nuc_batch([part[k]], params)[0]
+            for name, ids in (("nucpos", nc.nonredundant), ("nucpos.redundant", nc.redundant)):
+                rows = [nc.nuc_collection[int(i)] for i in sorted(ids)]
+                if not rows:
+                    continue
+                c0, p0, v0 = out[name]
+                at = int(np.searchsorted(c0, k))
+                add = np.array([[n.z, n.occ, n.occ_lower, n.occ_upper, n.lr, n.norm_signal, n.nuc_signal, n.nuc_cov, n.nfr_cov, n.fuzz]
+                                for n in rows], dtype=np.float64)
+                where = np.full(len(rows), at)
+                out[name] = (np.insert(c0, where, k), np.insert(p0, where, [n.start - part[k].start for n in rows]),
+                             np.insert(v0, where, add, axis=0))
+    return out
+
+
 def run_nuc(args):
     vmat = VMat.open(args.vmat)
     chrs = read_chrom_sizes_from_fasta(args.fasta) if args.fasta else read_chrom_sizes_from_bam(args.bam)
@@ -48,12 +126,18 @@ def run_nuc(args):
                             min_length=args.nuc_sep * 2)
     chunks.slop(chrs, up=args.nuc_sep // 2, down=args.nuc_sep // 2)
     chunks.merge()
-    if args.sizes is not None:
-        fragment_dist = FragmentSizes.open(args.sizes)
-    else:
-        fragment_dist = FragmentSizes(0, upper=vmat.upper)
-        fragment_dist.calculateSizes(args.bam, chunks)
-    params = NucParameters(vmat=vmat, fragmentsizes=fragment_dist, bam=args.bam, fasta=args.fasta, pwm=args.pwm,
+    ensure_distributed()
+    rank, world, _ = env_rank_world()
+    st = shared_fragment_store(args.bam)
+    fragment_dist = None
+    if rank == 0:           # global pre-step once
+        if args.sizes is not None:
+            fragment_dist = FragmentSizes.open(args.sizes)
+        else:
+            fragment_dist = FragmentSizes(0, upper=vmat.upper)
+            fragment_dist.calculateSizes(st, chunks)
+    fragment_dist = broadcast_object(fragment_dist)
+    params = NucParameters(vmat=vmat, fragmentsizes=fragment_dist, bam=st, fasta=args.fasta, pwm=args.pwm,
                            occ_track=args.occ_track, sd=args.sd, nonredundant_sep=args.nuc_sep,
                            redundant_sep=args.redundant_sep, min_z=args.min_z, min_lr=args.min_lr, atac=args.atac)
     pool = None
@@ -69,40 +153,56 @@ def run_nuc(args):
     outputs = ["nucpos", "nucpos.redundant", "nucleoatac_signal", "nucleoatac_signal.smooth"]
     if args.write_all:
         outputs += ["nucleoatac_background", "nucleoatac_raw"]
-    ensure_distributed()
-    rank, world, _ = env_rank_world()
     lo, hi = balanced_ranges([c.length() for c in chunks], np.arange(len(chunks) + 1), world)[rank]
     mine = chunks[lo:hi]
     suffix = "" if world == 1 else ".rank%d" % rank
-    track_keys = {"nucleoatac_signal": "norm_signal", "nucleoatac_signal.smooth": "smoothed",
-                  "nucleoatac_background": "bias", "nucleoatac_raw": "nuc_signal"}
-    tracks = [n for n in outputs if n in track_keys]
-    paths = {n: args.out + "." + n + ".bedgraph.gz" + suffix for n in tracks}
-    handles = {n: open(args.out + "." + n + ".bed" + suffix, "w") for n in outputs if n.startswith("nucpos")}
-    nb = max(1, (len(mine) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
-    for bi in range(nb):
-        part = mine[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
-        if not part:
-            for n in tracks:
-                write_bedgraph(paths[n], [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL, finish=True)
-            break
+    track_of = {"nucleoatac_signal": L.T_NORM, "nucleoatac_signal.smooth": L.T_SMOOTH, "nucleoatac_background": L.T_BACKGROUND,
+                "nucleoatac_raw": L.T_RAW}
+    track_of = {n: t for n, t in track_of.items() if n in outputs}
+    paths = {n: args.out + "." + n + ".bedgraph.gz" + suffix for n in track_of}
+    call_paths = {n: args.out + "." + n + ".bed" + suffix for n in outputs if n.startswith("nucpos")}
+    for p in call_paths.values():
+        open(p, "w").close()
+    parts = [mine[i:i + BATCH_CHUNKS] for i in range(0, len(mine), BATCH_CHUNKS)]
+    if not parts:
+        for n in track_of:
+            write_bedgraph(paths[n], [], [], [0], np.zeros(0), append=False, compress=COMPRESS_LEVEL, finish=(rank == world - 1))
+
+    def calls(r):
+        part = r.tag
+        names = sorted(set(c.chrom for c in part))
+        idx = {c: i for i, c in enumerate(names)}
+        cid_of = np.array([idx[c.chrom] for c in part], dtype=np.int32)
+        start_of = np.array([c.start for c in part], dtype=np.int64)
+        for name, (kc, kp, vals) in batch_calls(r, params, pool, getattr(args, "cores", 1) or 1).items():
+            if len(kc):
+                pos = start_of[kc] + kp
+                write_bed_rows(call_paths[name], names, cid_of[kc], pos, pos + 1, vals)
+
+    if parts:
+        # the calls need coverage, raw and smoothed values at the candidates: downloaded with the tracks that are written
+        need = tuple(dict.fromkeys(list(track_of.values()) + [L.T_NORM, L.T_SMOOTH, L.T_RAW, L.T_NUC_COV, L.T_NFR_COV]))
+        stages = Stages(nuc_sd=params.smooth_sd, occ=False, ins=None,
+                        peaks=dict(min_signal=0, sep=params.redundant_sep, boundary=params.nonredundant_sep // 2,
+                                   order=params.redundant_sep // 2), tracks=need)
+        writer = _Writer(paths, track_of, calls, len(parts), rank == world - 1)
+        writer.start()
+        fa_chrs = read_chrom_sizes_from_fasta(params.fasta) if params.fasta is not None else params.chrs
+
+        def items():
+            for part in parts:
+                yield pack(part, st, params.fasta, fa_chrs, params.pwm, atac=params.atac, window=params.window, upper=params.upper), part
+
+        device = int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         try:
-            nucs, flat = nuc_batch(part, params, with_flat=True)
+            with PipelinedExecutor(device, params.install, stages, n_contexts=min(N_CONTEXTS, len(parts))) as ex:
+                for r in ex.map(items()):
+                    writer.put(r)
         except Exception:
-            print("Caught exception when processing:\n" + "\n".join(c.asBed() for c in part[:3]) + "\n")
+            print("Caught exception when processing:\n" + "\n".join(c.asBed() for c in mine[:3]) + "\n")
             raise
-        chroms, starts = [c.chrom for c in part], [c.start for c in part]
-        for n in tracks:
-            write_bedgraph(paths[n], chroms, starts, flat["out_off"], flat[track_keys[n]], append=bi > 0,
-                           compress=COMPRESS_LEVEL, finish=(bi == nb - 1 and rank == world - 1))
-        for nuc in nucs:
-            for i in sorted(nuc.nonredundant):
-                nuc.nuc_collection[i].write(handles["nucpos"])
-            for i in sorted(nuc.redundant):
-                nuc.nuc_collection[i].write(handles["nucpos.redundant"])
-            nuc.removeData()
-    for h in handles.values():
-        h.close()
+        finally:
+            writer.finish()
     if pool is not None:
         pool.shutdown()
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)

@@ -1,28 +1,40 @@
 """`nucleoatac occ` (reference: nucleoatac/run_occ.py:77-148): occupancy tracks + peaks + nucleosomal size
-distribution.  The per-chunk Pool.map of the reference is replaced by GPU batches; with torchrun / WORLD_SIZE > 1
-the chunk list is sharded across GPUs (nucleoatac_amd/shard.py) and rank r writes `<out>.rank<r>.*` part files
-that rank 0 concatenates in chunk order."""
-import gzip
+distribution.
+
+The reference maps `_occHelper` over the chunks with a process pool and hands every result to writer processes through
+JoinableQueues, so computing and writing overlap (run_occ.py:101-123).  Here the chunk list goes through
+`nucleoatac_amd.executor.PipelinedExecutor`: sub-batches of thousands of chunks are packed on the host, uploaded, computed and
+downloaded by several contexts of one GPU in turn, and a writer thread formats + BGZF-compresses the finished sub-batches in
+chunk order while the next ones are still on the device.  With torchrun / WORLD_SIZE > 1 the chunk list is sharded across
+GPUs (nucleoatac_amd/shard.py) and rank r writes `<out>.*.rank<r>` part files that rank 0 concatenates in chunk order; the
+global pre-steps (BAM decode, insert-size histogram, modelNFR) run once, on rank 0."""
 import os
+import queue
 import shutil
+import threading
 
 import numpy as np
 
+from .. import _lib as L
+from ..executor import PipelinedExecutor, Stages
+from ..pipeline import chunk_fragment_counts, pack
 from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
-from ..shard import balanced_ranges, barrier, ensure_distributed, env_rank_world, gather_in_chunk_order, ordered_sum
-from ..writer import bgzip_file, tabix_index, write_bedgraph
+from ..shard import (balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, gather_in_chunk_order,
+                     ordered_sum, shared_fragment_store)
+from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
 from .Occupancy import FragmentMixDistribution, OccupancyParameters, occ_batch
 
-BATCH_CHUNKS = 4096   # chunks per GPU batch (the reference maps cores*5 chunks per pool.map round)
+BATCH_CHUNKS = int(os.environ.get("NATAC_BATCH_CHUNKS", "4096"))   # chunks per sub-batch (the reference maps cores*5 chunks per round)
+N_CONTEXTS = int(os.environ.get("NATAC_CONTEXTS", "3"))            # contexts (streams) of the pipelined executor
 COMPRESS_LEVEL = 4     # BGZF deflate level of the track files
 
 
 def _occHelper(arg):
     """(nuc_dist, OccupancyTrack, [OccPeak]) for one chunk -- same return shape as the reference's helper
-    (run_occ.py:23-39); `_occHelperBatch` is what the driver uses"""
+    (run_occ.py:23-39); `_occHelperBatch` is what the API offers for lists"""
     chunk, params = arg
     return _occHelperBatch([chunk], params)[0]
 
@@ -39,6 +51,51 @@ def _occHelperBatch(chunks, params):
     return out
 
 
+class _Writer(threading.Thread):
+    """consumes finished sub-batches in order on its own thread: native run-length bedGraph + BGZF for every track
+    (Track.write_track, pyatac/tracks.py:37-74; run_occ.py:41-59 are the reference's writer processes), then `extra(result)`,
+    then the result's pinned buffers go back to the executor"""
+
+    def __init__(self, paths, track_of, extra, n_batches, last_rank):
+        threading.Thread.__init__(self, daemon=True)
+        self.paths, self.track_of, self.extra, self.nb, self.last_rank = paths, track_of, extra, n_batches, last_rank
+        self.q = queue.Queue(maxsize=2)
+        self.err = None
+        self.seconds = 0.0
+
+    def run(self):
+        import time
+        while True:
+            r = self.q.get()
+            if r is None:
+                return
+            try:
+                if self.err is None:
+                    t0 = time.perf_counter()
+                    part = r.tag
+                    chroms, starts = [c.chrom for c in part], [c.start for c in part]
+                    for name, path in self.paths.items():
+                        write_bedgraph(path, chroms, starts, r.packed.out_off, r.tracks[self.track_of[name]], append=r.seq > 0,
+                                       compress=COMPRESS_LEVEL, finish=(r.seq == self.nb - 1 and self.last_rank))
+                    self.extra(r)
+                    self.seconds += time.perf_counter() - t0
+            except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
+                self.err = e
+            finally:
+                r.release()
+
+    def put(self, r):
+        if self.err is not None:
+            raise self.err
+        self.q.put(r)
+
+    def finish(self):
+        self.q.put(None)
+        self.join()
+        if self.err is not None:
+            raise self.err
+
+
 def run_occ(args):
     chrs = read_chrom_sizes_from_fasta(args.fasta) if args.fasta else read_chrom_sizes_from_bam(args.bam)
     pwm = PWM.open(args.pwm)
@@ -46,56 +103,99 @@ def run_occ(args):
                             min_offset=args.flank + args.upper // 2 + max(pwm.up, pwm.down) + args.nuc_sep // 2)
     chunks.slop(chrs, up=args.nuc_sep // 2, down=args.nuc_sep // 2)
     chunks.merge()
-    fragment_dist = FragmentMixDistribution(0, upper=args.upper)
-    if args.sizes is not None:
-        tmp = FragmentSizes.open(args.sizes)
-        fragment_dist.fragmentsizes = FragmentSizes(0, args.upper, vals=tmp.get(0, args.upper))
-    else:
-        fragment_dist.getFragmentSizes(args.bam, chunks)
-    fragment_dist.modelNFR()
     ensure_distributed()
     rank, world, _ = env_rank_world()
+    # global pre-steps once: BAM decode + shared arrays, size histogram (a3) and modelNFR on rank 0
+    st = shared_fragment_store(args.bam)
+    fragment_dist = None
     if rank == 0:
+        fragment_dist = FragmentMixDistribution(0, upper=args.upper)
+        if args.sizes is not None:
+            tmp = FragmentSizes.open(args.sizes)
+            fragment_dist.fragmentsizes = FragmentSizes(0, args.upper, vals=tmp.get(0, args.upper))
+        else:
+            fragment_dist.getFragmentSizes(st, chunks)
+        fragment_dist.modelNFR()
         fragment_dist.fragmentsizes.save(args.out + ".fragmentsizes.txt")
+    fragment_dist = broadcast_object(fragment_dist)
     params = OccupancyParameters(fragment_dist, args.upper, args.fasta, args.pwm, sep=args.nuc_sep, min_occ=args.min_occ,
-                                 flank=args.flank, bam=args.bam, ci=args.confidence_interval, step=args.step)
-    from ..pyatac.fragments import FragmentStore
-    st = FragmentStore.open(args.bam)
-    nfr_per_chunk = [len(st.fetch(c.chrom, c.start, c.end)[0]) for c in chunks]
-    lo, hi = balanced_ranges([c.length() for c in chunks], np.concatenate(([0], np.cumsum(nfr_per_chunk))), world)[rank]
+                                 flank=args.flank, bam=st, ci=args.confidence_interval, step=args.step)
+    lens = np.array([c.length() for c in chunks], dtype=np.int64)
+    lo, hi = balanced_ranges(lens, np.concatenate(([0], np.cumsum(chunk_fragment_counts(st, chunks)))), world)[rank]
     mine = chunks[lo:hi]
     suffix = "" if world == 1 else ".rank%d" % rank
-    names = {"occ": "smoothed_vals", "occ.lower_bound": "smoothed_lower", "occ.upper_bound": "smoothed_upper"}
-    paths = {n: args.out + "." + n + ".bedgraph.gz" + suffix for n in names}
-    peaks_handle = open(args.out + ".occpeaks.bed" + suffix, "w")
+    track_of = {"occ": L.T_OCC, "occ.lower_bound": L.T_OCC_LOWER, "occ.upper_bound": L.T_OCC_UPPER}
+    paths = {n: args.out + "." + n + ".bedgraph.gz" + suffix for n in track_of}
+    peaks_path = args.out + ".occpeaks.bed" + suffix
+    open(peaks_path, "w").close()
+    parts = [mine[i:i + BATCH_CHUNKS] for i in range(0, len(mine), BATCH_CHUNKS)]
     dists = []
-    nb = max(1, (len(mine) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
-    for bi in range(nb):
-        part = mine[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
-        if not part:
-            for n in names:
-                write_bedgraph(paths[n], [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL, finish=True)
-            break
+    if not parts:
+        for n in track_of:
+            write_bedgraph(paths[n], [], [], [0], np.zeros(0), append=False, compress=COMPRESS_LEVEL, finish=(rank == world - 1))
+
+    def peaks_and_dists(r):
+        """OccChunk.callPeaks + getNucDist results of a sub-batch (device: natac_run_occ_peaks): the kept peaks as occpeaks.bed
+        rows, the per-chunk nucleosomal size distributions for the ordered sum (run_occ.py:118-123)"""
+        part = r.tag
+        cc, cp, p_occ, p_lo, p_up, p_rd, keep, nuc_dist = r.occ_peaks
+        over = np.nonzero(r.status & 2)[0]
+        if len(over):
+            # chunks with more local maxima than the device peak finder holds per chunk: the per-chunk API path (host call_peaks)
+            redo = {int(k): occ_batch([part[int(k)]], params)[0] for k in over}
+            fine = ~np.isin(cc, over)
+            for k in range(len(part)):           # rows must stay in chunk order: write around the re-done chunks
+                if k in redo:
+                    with open(peaks_path, "a") as fh:
+                        for i in sorted(redo[k].peaks.keys()):
+                            redo[k].peaks[i].write(fh)
+                    nuc_dist[k] = redo[k].getNucDist()
+                else:
+                    m = fine & (cc == k) & (keep != 0)
+                    _rows(part, cc[m], cp[m], p_occ[m], p_lo[m], p_up[m], p_rd[m])
+        else:
+            m = keep != 0
+            _rows(part, cc[m], cp[m], p_occ[m], p_lo[m], p_up[m], p_rd[m])
+        dists.extend(nuc_dist)
+
+    def _rows(part, cc, cp, p_occ, p_lo, p_up, p_rd):
+        if not len(cc):
+            return
+        names = sorted(set(c.chrom for c in part))
+        idx = {c: i for i, c in enumerate(names)}
+        cid = np.array([idx[c.chrom] for c in part], dtype=np.int32)[cc]
+        pos = np.array([c.start for c in part], dtype=np.int64)[cc] + cp
+        write_bed_rows(peaks_path, names, cid, pos, pos + 1, np.stack([p_occ, p_lo, p_up, p_rd], axis=1))
+
+    if parts:
+        stages = Stages(nuc_sd=None, occ=True, ins=None, occ_peaks=dict(min_occ=params.min_occ, sep=params.sep),
+                        tracks=tuple(track_of.values()))
+        writer = _Writer(paths, track_of, peaks_and_dists, len(parts), rank == world - 1)
+        writer.start()
+
+        def items():
+            for part in parts:
+                yield pack(part, st, params.fasta, params.chrs, params.pwm if params.fasta is not None else None,
+                           window=params.window, upper=params.upper), part
+
+        device = int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         try:
-            occs, flat = occ_batch(part, params, with_flat=True)
-        except Exception:
-            print("Caught exception when processing:\n" + "\n".join(c.asBed() for c in part[:3]) + "\n")
-            raise
-        chroms, starts = [c.chrom for c in part], [c.start for c in part]
-        for n, key in names.items():     # native multi-threaded run-length writer + BGZF (tracks.py:37-74, run_occ.py:130-136)
-            write_bedgraph(paths[n], chroms, starts, flat["out_off"], flat[key], append=bi > 0, compress=COMPRESS_LEVEL,
-                           finish=(bi == nb - 1 and rank == world - 1))
-        for oc in occs:
-            dists.append(oc.getNucDist())
-            for i in sorted(oc.peaks.keys()):
-                oc.peaks[i].write(peaks_handle)
-            oc.removeData()
-    peaks_handle.close()
+            with PipelinedExecutor(device, lambda ctx: params.occ_calc_params.install(ctx, step=params.step, flank=params.flank),
+                                   stages, n_contexts=min(N_CONTEXTS, len(parts))) as ex:
+                for r in ex.map(items()):
+                    if (r.status & 1).any():
+                        k = int(np.flatnonzero(r.status & 1)[0])
+                        print("Caught exception when processing:\n" + r.tag[k].asBed() + "\n")
+                        r.release()
+                        raise ValueError("min() arg is an empty sequence (occupancy likelihood undefined in %s)" % r.tag[k].asBed())
+                    writer.put(r)
+        finally:
+            writer.finish()
     dists = gather_in_chunk_order(dists, dst=0)
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
     if rank == 0:
         if world > 1:   # BGZF members / text lines concatenate: rank order == chunk order
-            for n in list(names) + ["occpeaks"]:
+            for n in list(track_of) + ["occpeaks"]:
                 base = args.out + "." + n + (".bed" if n == "occpeaks" else ".bedgraph.gz")
                 with open(base, "wb") as fo:
                     for r in range(world):
@@ -105,7 +205,7 @@ def run_occ(args):
         # bgzip + tabix of every output like the reference (run_occ.py:130-136)
         bgzip_file(args.out + ".occpeaks.bed", level=COMPRESS_LEVEL)
         tabix_index(args.out + ".occpeaks.bed.gz")
-        for n in names:
+        for n in track_of:
             tabix_index(args.out + "." + n + ".bedgraph.gz")
         nuc_dist = ordered_sum(dists) if dists else np.zeros(args.upper)
         FragmentSizes(0, args.upper, vals=nuc_dist).save(args.out + ".nuc_dist.txt")

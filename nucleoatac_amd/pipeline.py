@@ -24,6 +24,23 @@ def bias_window(window, upper):
     return max(BIAS_LEFT, ext), max(BIAS_RIGHT, ext + 1)
 
 
+def chunk_fragment_counts(st, chunks):
+    """number of reads near every chunk (pos in [start - 1024, end), what FragmentStore.fetch returns): the fragment term of
+    the shard balance.  One searchsorted per chromosome instead of one fetch per chunk."""
+    st = FragmentStore.open(st)
+    n = np.zeros(len(chunks), dtype=np.int64)
+    chroms = np.array([c.chrom for c in chunks])
+    starts = np.array([c.start for c in chunks], dtype=np.int64)
+    ends = np.array([c.end for c in chunks], dtype=np.int64)
+    for chrom in set(chroms.tolist()):
+        if chrom not in st.pos:
+            continue
+        m = np.nonzero(chroms == chrom)[0]
+        p = st.pos[chrom]
+        n[m] = np.searchsorted(p, ends[m], "left") - np.searchsorted(p, starts[m] - 1024, "left")
+    return n
+
+
 def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN, window=None, upper=None):
     """PackedChunks for a list of Chunk objects.  The log-bias slice of every chunk is the PWM score of
     [start-246, end+247) (InsertionBiasTrack.computeBias, as in nucleoatac/Occupancy.py:212-214) or None; `window` /
@@ -147,18 +164,20 @@ class BatchRunner(object):
             self.flat[name] = b.track(t)
             out[name] = b.split(self.flat[name])
         grids = [b.grid(g) for g in (L.G_OCC, L.G_LOWER, L.G_UPPER)]
+        # grid point k of a chunk covers bases [k*step, min((k+1)*step, L)) (Occupancy.py:136-146); bases past the last grid
+        # point's block stay NaN.  One gather for the whole batch instead of an np.repeat per chunk.
         step = self.ctx.occ_step
         half = (step - 1) // 2
-        off = 0
-        out["vals"], out["lower_bound"], out["upper_bound"] = [], [], []
-        for k in range(self.pk.n_chunks):
-            Lk = int(self.pk.chunk_len[k])
-            nk = len(range(half, Lk, step))
-            for key, g in zip(("vals", "lower_bound", "upper_bound"), grids):
-                v = np.full(Lk, np.nan)
-                v[:min(Lk, nk * step)] = np.repeat(g[off:off + nk], step)[:min(Lk, nk * step)]
-                out[key].append(v)
-            off += nk
+        lens = self.pk.chunk_len.astype(np.int64)
+        nk = np.where(lens > half, (lens - half + step - 1) // step, 0)
+        goff = np.concatenate(([0], np.cumsum(nk)))
+        rel = np.arange(self.pk.total_bp, dtype=np.int64) - np.repeat(self.pk.out_off[:-1], lens)
+        k = rel // step
+        ok = k < np.repeat(nk, lens)
+        gi = np.where(ok, np.repeat(goff[:-1], lens) + k, 0)
+        for key, g in zip(("vals", "lower_bound", "upper_bound"), grids):
+            flat = np.where(ok, g[gi] if len(g) else np.nan, np.nan)
+            out[key] = b.split(flat)
         return out
 
     def nuc(self, smooth_sd):

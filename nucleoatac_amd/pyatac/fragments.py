@@ -17,9 +17,14 @@ _CACHE = {}
 class FragmentStore(object):
     """per-chromosome arrays of forward proper-pair reads: pos (leftmost coordinate, sorted), tlen (|template length|)"""
 
-    def __init__(self, chroms, lengths, pos, tlen):
+    def __init__(self, chroms, lengths, pos, tlen, trusted=False):
         self.references = list(chroms)
         self.lengths = [int(x) for x in lengths]
+        if trusted:      # arrays published by another FragmentStore (shard.shared_fragment_store): already int64, |tlen|, sorted
+            self.pos = {c: pos[c] for c in self.references}
+            self.tlen = {c: tlen[c] for c in self.references}
+            self.max_tlen = max([int(t.max()) for t in self.tlen.values() if len(t)] + [0])
+            return
         self.pos = {c: np.ascontiguousarray(pos[c], dtype=np.int64) for c in self.references}
         self.tlen = {c: np.ascontiguousarray(np.abs(tlen[c]), dtype=np.int64) for c in self.references}
         for c in self.references:
@@ -45,6 +50,11 @@ class FragmentStore(object):
             raise ValueError("unsupported alignment source %r (expected FragmentStore, .bam or .npz)" % (src,))
         _CACHE[src] = st
         return st
+
+    @staticmethod
+    def register(src, store):
+        """make FragmentStore.open(src) return `store` (a store built elsewhere, e.g. mapped from shared memory)"""
+        _CACHE[src] = store
 
     @staticmethod
     def from_npz(path):

@@ -33,11 +33,21 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def ensure_distributed():
+_STATE = {"gpu_group": None, "backend": None}
+GROUP_TIMEOUT_S = 12 * 3600      # single-rank phases (merge, a slow shard) may hold the others in a barrier for a long time
+
+
+def ensure_distributed(prefer=None, device=None):
     """Under torchrun (WORLD_SIZE > 1) make sure the process group exists before any rank-dependent work: run_occ /
     run_nuc called through the API (not cli.main) would otherwise skip the barrier and the gather silently and rank 0
-    would merge part files that other ranks are still writing.  Backend: RCCL ("nccl") or NATAC_DIST_BACKEND=gloo.
-    Returns (dist module or None, True if this call created the group)."""
+    would merge part files that other ranks are still writing.
+
+    The control plane -- barriers, gathers of small per-chunk objects, the ok / failed flag of single-rank steps -- is a gloo
+    group (CPU, always available) with a long timeout; there is no data-path collective.  When `prefer` (default: the
+    NATAC_DIST_BACKEND environment variable, else "nccl") is "nccl", an RCCL subgroup is created on top of it and probed; whether
+    it is used is decided COLLECTIVELY (a MIN all-reduce of the per-rank probe results over gloo), so one rank with a broken
+    RCCL cannot leave the others waiting in an RCCL collective.  `barrier()` then synchronises over RCCL when all ranks have
+    it, over gloo otherwise.  Returns (dist module or None, True if this call created the group)."""
     rank, world, local = env_rank_world()
     if world <= 1:
         return None, False
@@ -46,40 +56,147 @@ def ensure_distributed():
         if dist.get_world_size() != world:
             raise RuntimeError("WORLD_SIZE=%d but the torch.distributed group has %d ranks" % (world, dist.get_world_size()))
         return dist, False
-    backend = os.environ.get("NATAC_DIST_BACKEND", "nccl")
-    if backend == "nccl":
-        # only barriers and the gather of small per-chunk results go through the group (never track data): if RCCL cannot come
-        # up on this node the run continues over gloo
-        import sys
-        import torch
-        dev = int(os.environ.get("NATAC_DEVICE", local))          # the GPU this rank computes on (default: LOCAL_RANK)
+    import datetime
+    import sys
+    import torch
+    prefer = prefer or os.environ.get("NATAC_DIST_BACKEND", "nccl")
+    dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=GROUP_TIMEOUT_S))
+    _STATE["backend"] = "gloo"
+    if prefer == "nccl":
+        dev = int(device if device is not None else os.environ.get("NATAC_DEVICE", local))   # the GPU this rank computes on
+        ok, why, grp = 1, "", None
         try:
+            if not torch.cuda.is_available():
+                raise RuntimeError("no GPU visible to torch")
             torch.cuda.set_device(dev)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
-            probe = torch.ones(1, device="cuda")
-            dist.all_reduce(probe)
-            torch.cuda.synchronize()
-            if int(probe.item()) != world:
-                raise RuntimeError("all_reduce probe returned %r" % probe.item())
         except Exception as e:      # noqa: BLE001
-            sys.stderr.write("nucleoatac_amd: RCCL unavailable (%s: %s); process group over gloo\n" % (type(e).__name__, str(e)[:200]))
-            try:
-                dist.destroy_process_group()
-            except Exception:       # noqa: BLE001
-                pass
-            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-            os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"      # rank 0 hosts the new store itself
-            dist.init_process_group(backend="gloo")
-    else:
-        dist.init_process_group(backend=backend)
+            ok, why = 0, "%s: %s" % (type(e).__name__, str(e)[:200])
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                   # does every rank have a usable GPU + torch runtime?
+        if int(flag.item()) == 1:
+            # ranks that share one GPU (functional tests on a 1-GPU box) cannot form an RCCL communicator: agree on that too
+            devs = [None] * world
+            dist.all_gather_object(devs, dev)
+            if len(set(devs)) < world:
+                ok, why = 0, "ranks share GPUs %s" % devs
+            else:
+                try:
+                    grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=GROUP_TIMEOUT_S))
+                    probe = torch.ones(1, device="cuda")
+                    dist.all_reduce(probe, group=grp)
+                    torch.cuda.synchronize()
+                    if int(probe.item()) != world:
+                        raise RuntimeError("all_reduce probe returned %r" % probe.item())
+                except Exception as e:      # noqa: BLE001
+                    ok, why = 0, "%s: %s" % (type(e).__name__, str(e)[:200])
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            _STATE["gpu_group"], _STATE["backend"] = grp, "nccl"
+        elif rank == 0 or why:
+            sys.stderr.write("nucleoatac_amd: RCCL group not used (%s); barriers over gloo\n" % (why or "another rank could not join"))
     return dist, True
 
 
-def barrier():
+def control_backend():
+    """"nccl" when barrier() synchronises over RCCL, "gloo" otherwise, None without a group"""
+    return _STATE["backend"]
+
+
+def barrier(sync_cuda=False):
     """all ranks reach this point (no-op on one rank; raises if WORLD_SIZE > 1 without a process group)"""
     dist, _ = ensure_distributed()
     if dist is not None:
-        dist.barrier()
+        if _STATE["gpu_group"] is not None:
+            if sync_cuda:
+                import torch
+                torch.cuda.synchronize()
+            dist.barrier(group=_STATE["gpu_group"])
+        else:
+            dist.barrier()
+
+
+def all_reduce_scalars(values, op="sum"):
+    """element-wise sum / max of a short list of floats over the ranks (control plane; identity on one rank)"""
+    dist, _ = ensure_distributed()
+    if dist is None:
+        return [float(v) for v in values]
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
+def run_on_rank0(fn, *args):
+    """single-rank step (vprocess, merge): rank 0 runs `fn`, the other ranks wait for its ok / failed flag -- a failure on
+    rank 0 raises on every rank instead of leaving them in a barrier until the group times out."""
+    rank, world, _ = env_rank_world()
+    if world <= 1:
+        return fn(*args)
+    dist, _ = ensure_distributed()
+    import torch
+    err = None
+    out = None
+    if rank == 0:
+        try:
+            out = fn(*args)
+        except BaseException as e:      # noqa: BLE001 -- re-raised below, after the other ranks were told
+            err = e
+    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+    dist.broadcast(flag, src=0)
+    if err is not None:
+        raise err
+    if int(flag.item()):
+        raise RuntimeError("rank 0 failed in %s (see its traceback)" % getattr(fn, "__name__", "a single-rank step"))
+    return out
+
+
+def broadcast_object(obj, src=0):
+    """the object of rank `src` on every rank (small python objects: size distributions, fitted models)"""
+    dist, _ = ensure_distributed()
+    if dist is None:
+        return obj
+    box = [obj if env_rank_world()[0] == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def shared_fragment_store(bam):
+    """FragmentStore of `bam`, decoded ONCE per node: rank 0 decodes the BAM (native streaming decoder) and publishes the
+    per-chromosome arrays as .npy files in shared memory (/dev/shm); the other ranks map them read-only instead of decoding
+    the whole file again (global pre-steps once, before sharding).  One rank: plain FragmentStore.open."""
+    from .pyatac.fragments import FragmentStore
+    rank, world, _ = env_rank_world()
+    if world <= 1 or isinstance(bam, FragmentStore):
+        return FragmentStore.open(bam)
+    import hashlib
+    import tempfile
+    dist, _ = ensure_distributed()
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    tag = hashlib.sha1(("%s|%s|%s" % (os.path.abspath(bam), os.environ.get("MASTER_PORT", ""), os.environ.get("TORCHELASTIC_RUN_ID", ""))).encode()).hexdigest()[:16]
+    base = os.path.join(root, "natac_frags_%s" % tag)
+    meta = None
+    if rank == 0:
+        st = FragmentStore.open(bam)
+        for i, c in enumerate(st.references):
+            np.save("%s.%d.pos.npy" % (base, i), st.pos[c])
+            np.save("%s.%d.tlen.npy" % (base, i), st.tlen[c])
+        meta = (st.references, st.lengths)
+    meta = broadcast_object(meta)
+    if rank != 0:
+        refs, lens = meta
+        st = FragmentStore(refs, lens, {c: np.load("%s.%d.pos.npy" % (base, i), mmap_mode="r") for i, c in enumerate(refs)},
+                           {c: np.load("%s.%d.tlen.npy" % (base, i), mmap_mode="r") for i, c in enumerate(refs)}, trusted=True)
+        FragmentStore.register(bam, st)
+    dist.barrier()                       # every rank has mapped the files: rank 0 unlinks them (the mappings stay valid)
+    if rank == 0:
+        for i in range(len(meta[0])):
+            for kind in ("pos", "tlen"):
+                try:
+                    os.remove("%s.%d.%s.npy" % (base, i, kind))
+                except OSError:
+                    pass
+    return st
 
 
 def my_shard(packed, rank=None, world=None, kappa=4.0):

@@ -113,3 +113,50 @@ def synth_occ_distributions(upper=251):
     nuc[x < 115] = 0
     nuc[nuc <= 0] = min(nfr.min() * 0.1, nuc[nuc > 0].min() * 0.001)
     return nuc / nuc.sum(), nfr / nfr.sum()
+
+
+def write_cli_dataset(out_dir, n_chunks, chunk_len=2120, frags_per_chunk=500, seed=0, n_chroms=4, genome_gap=1000, slop=60):
+    """The synthetic chunk set as INPUT FILES of the command line: `<out_dir>/windows.bed` (one window per chunk, `slop` bp
+    shorter on both sides so that the drivers' +-nuc_sep/2 slop restores `chunk_len`), `reads.bam.npz` (the forward
+    proper-pair reads, FragmentStore.save_npz format) and `genome.fa.npz` (seeded random ACGT; the Tn5 bias comes from the PWM
+    score of this sequence, like in a real run).  Chunks are spread over `n_chroms` chromosomes.  Returns (bed, bam, fasta)."""
+    import os
+    pk = make_synthetic_chunks(n_chunks, chunk_len, frags_per_chunk, seed=seed, with_bias=False, genome_gap=genome_gap)
+    rng = np.random.default_rng([int(seed), 0x636c69])
+    per = -(-n_chunks // n_chroms)
+    names = ["chrS%d" % (i + 1) for i in range(n_chroms)]
+    stride = chunk_len + genome_gap
+    chrom_len = per * stride + 20000
+    bed_lines = []
+    pos = {c: [] for c in names}
+    tl = {c: [] for c in names}
+    cid = np.repeat(np.arange(n_chunks), np.diff(pk.frag_off))
+    start_in_chrom = (np.arange(n_chunks) % per) * stride + 10000
+    chrom_of = np.arange(n_chunks) // per
+    l_abs = start_in_chrom[cid] + pk.frag_lpos.astype(np.int64)
+    n_all = pk.frag_ilen.astype(np.int64)
+    ok = (l_abs - 4 >= 0) & (l_abs + n_all + 4 < chrom_len)
+    for ci, c in enumerate(names):
+        m = ok & (chrom_of[cid] == ci)
+        p, t = l_abs[m] - 4, n_all[m] + 8
+        o = np.argsort(p, kind="stable")
+        pos[c], tl[c] = p[o], t[o]
+    for k in range(n_chunks):
+        s = int(start_in_chrom[k])
+        bed_lines.append("%s\t%d\t%d\n" % (names[int(chrom_of[k])], s + slop, s + chunk_len - slop))
+    os.makedirs(out_dir, exist_ok=True)
+    bed = os.path.join(out_dir, "windows.bed")
+    with open(bed, "w") as fh:
+        fh.writelines(bed_lines)
+    bam = os.path.join(out_dir, "reads.bam.npz")
+    arrs = dict(chrom_names=np.array(names), chrom_lengths=np.array([chrom_len] * n_chroms))
+    for c in names:
+        arrs["pos_" + c], arrs["tlen_" + c] = pos[c], tl[c]
+    np.savez(bam, **arrs)
+    fa = os.path.join(out_dir, "genome.fa.npz")
+    farr = dict(chrom_names=np.array(names), chrom_lengths=np.array([chrom_len] * n_chroms))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for c in names:
+        farr["seq_" + c] = acgt[rng.integers(0, 4, size=chrom_len)]
+    np.savez(fa, **farr)
+    return bed, bam, fa

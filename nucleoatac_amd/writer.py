@@ -26,6 +26,22 @@ def write_bedgraph(path, chroms, chunk_start, out_off, vals, append=False, compr
     return nb.value
 
 
+def write_bed_rows(path, names, chrom_id, start, end, vals, append=True):
+    """rows `chrom start end v0 v1 ...` with python-2 float text (natac_write_bed_rows): OccPeak.asBed / Nucleosome.asBed lines
+    for whole batches at once.  names: list of chromosome names, chrom_id: index into it per row, vals: (n_rows, n_cols)."""
+    lib = L.load()
+    chrom_id = np.ascontiguousarray(chrom_id, dtype=np.int32)
+    start = np.ascontiguousarray(start, dtype=np.int64)
+    end = np.ascontiguousarray(end, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(len(chrom_id), -1)
+    if not (len(start) == len(end) == len(chrom_id)):
+        raise ValueError("inconsistent row arrays")
+    arr = (C.c_char_p * max(1, len(names)))(*[str(c).encode("ascii") for c in names])
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.check(lib.natac_write_bed_rows(str(path).encode(), 1 if append else 0, len(chrom_id), vp(chrom_id), arr, len(names),
+                                     vp(start), vp(end), vp(vals), vals.shape[1]))
+
+
 def bgzip_file(src, dst=None, level=4, n_threads=0, remove=True):
     """BGZF-compress a text file (pysam.tabix_compress of the reference); returns the path of the .gz"""
     import os

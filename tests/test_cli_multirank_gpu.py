@@ -78,21 +78,23 @@ def test_nuc_cores_pool_equals_serial(tmp_path):
     assert outs[0] == outs[1] and len(outs[0]) > 0
 
 
-def test_run_two_ranks_equal_one_rank(tmp_path):
-    """`nucleoatac run` (all five steps chained through their files) under torchrun: occ and nuc shard the chunk list, vprocess /
-    merge / nfr run on rank 0 between barriers; every output equals the single-process run byte for byte"""
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_run_n_ranks_equal_one_rank(tmp_path, ranks):
+    """`nucleoatac run` (all five steps chained through their files) under torchrun with 2 and with 8 ranks (all on GPU 0): occ,
+    nuc and nfr shard the chunk list, the BAM is decoded once and shared, vprocess / merge run on rank 0 behind an ok / failed
+    flag; every output equals the single-process run byte for byte"""
     bed = os.path.join(GOLDEN, "ref_example.bed")
     bam, fa = synth_saccer3(str(tmp_path), read_bed3(bed), seed=3)
     outs = {}
-    for world in (1, 2):
+    for world in (1, ranks):
         out = str(tmp_path / ("run%d" % world))
         sub = ["run", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--write_all", "--cores", "4"]
         if world == 1:
             cmd = [sys.executable, "-m", "nucleoatac_amd.nucleoatac.cli"] + sub
             env = dict(os.environ)
         else:
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                   "127.0.0.1", "--master-port", "29543", "-m", "nucleoatac_amd.nucleoatac.cli"] + sub
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                   "127.0.0.1", "--master-port", str(29543 + world), "-m", "nucleoatac_amd.nucleoatac.cli"] + sub
             env = dict(os.environ, NATAC_DIST_BACKEND="gloo", NATAC_DEVICE="0")
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -102,9 +104,23 @@ def test_run_two_ranks_equal_one_rank(tmp_path):
               "nucleoatac_raw.bedgraph.gz", "nucleoatac_background.bedgraph.gz", "nucmap_combined.bed.gz", "nfrpos.bed.gz",
               "ins.bedgraph.gz"):
         a = gzip.open(outs[1] + "." + n, "rt").read()
-        b = gzip.open(outs[2] + "." + n, "rt").read()
+        b = gzip.open(outs[ranks] + "." + n, "rt").read()
         assert a == b, n
     for n in ("nuc_dist.txt", "fragmentsizes.txt", "VMat"):
-        assert open(outs[1] + "." + n).read() == open(outs[2] + "." + n).read(), n
+        assert open(outs[1] + "." + n).read() == open(outs[ranks] + "." + n).read(), n
     assert len(gzip.open(outs[1] + ".nucpos.bed.gz", "rt").read()) > 0
     assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]
+
+
+def test_rank0_failure_ends_every_rank(tmp_path):
+    """a single-rank step that fails on rank 0 (merge of a missing file) must end ALL ranks promptly -- the others get rank 0's
+    failed flag instead of waiting in a barrier until the process group times out"""
+    import time
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", "-m", "nucleoatac_amd.nucleoatac.cli", "merge", "--occpeaks", str(tmp_path / "missing.bed.gz"),
+           "--nucpos", str(tmp_path / "missing2.bed.gz"), "--out", str(tmp_path / "m")]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, NATAC_DIST_BACKEND="gloo", NATAC_DEVICE="0"),
+                       cwd=ROOT)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "rank 0 failed" in r.stderr or "No such file" in r.stderr or "Error" in r.stderr
