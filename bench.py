@@ -394,15 +394,19 @@ def cli_end_to_end(n_chunks, cores, seed=0):
             t0 = time.perf_counter()
             cli_main(["occ", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores)])
             t_occ = time.perf_counter() - t0
+            from nucleoatac_amd.nucleoatac import run_nuc as _rn, run_occ as _ro
+            occ_phases = dict(_ro.LAST_TIMINGS)
             cli_main(["vprocess", "--sizes", out + ".nuc_dist.txt", "--out", out])
             t0 = time.perf_counter()
             cli_main(["nuc", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores), "--occ_track",
                       out + ".occ.bedgraph.gz", "--vmat", out + ".VMat", "--sizes", out + ".fragmentsizes.txt"])
             t_nuc = time.perf_counter() - t0
+            nuc_phases = dict(_rn.LAST_TIMINGS)
         size = lambda suffix: os.path.getsize(out + suffix)
         n_calls = sum(1 for _ in __import__("gzip").open(out + ".nucpos.bed.gz", "rt"))
         return dict(occ_mbp_s=round(bp / t_occ / 1e6, 2), nuc_mbp_s=round(bp / t_nuc / 1e6, 3), cores=cores, chunks=n_chunks, bp=bp,
                     occ_seconds=round(t_occ, 2), nuc_seconds=round(t_nuc, 2), nucleosome_calls=n_calls,
+                    occ_phases_s=occ_phases, nuc_phases_s=nuc_phases,
                     occ_track_bytes=sum(size("." + n + ".bedgraph.gz") for n in ("occ", "occ.lower_bound", "occ.upper_bound")),
                     nuc_track_bytes=sum(size("." + n + ".bedgraph.gz") for n in ("nucleoatac_signal", "nucleoatac_signal.smooth")),
                     out_dir=os.path.dirname(d) or "/tmp",

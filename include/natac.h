@@ -228,6 +228,27 @@ int natac_write_bedgraph(const char *path, int append, int compress, int finish,
                          const int64_t *chunk_start, const int64_t *out_off, const double *vals, int write_zero,
                          int n_threads, int64_t *bytes_written);
 
+/* ---- device-side track writer (SURVEY.md section 8f row 1 moved onto the GPU) ------------------------------------------------- */
+/* Track.write_track, pyatac/tracks.py:37-74, for one per-base track of a batch ON THE DEVICE: run-length detection (including the
+ * reference's rule that a run directly followed by a NaN is not written, tracks.py:56-66), python-2 `str(float)` ('%.12g' with exact
+ * 192-bit integer arithmetic) and the line layout `chrom \t start \t end \t value \n`, chunk i on names[chrom_id[i]] at chunk_start[i].
+ * compress = 0: the text itself; compress != 0: BGZF members of <= 0xff00 text bytes each (no EOF marker; the bgzip step of
+ * run_occ.py:130-136) from a line-structured LZ77 + a Huffman code built for this text (csrc/natac_deflate.hpp).  write_zero as
+ * in natac_write_bedgraph.  The result stays on the device until the next call; fetch it with natac_batch_format_fetch.
+ * n_bytes = size of the result, n_text_bytes = size of the text, n_lines = lines written, n_hard = values whose 12th digit could
+ * not be decided from the truncated power-of-ten table (only |v| >= 1e12 or < 1e-44 can; the caller then formats this track
+ * with natac_write_bedgraph instead).  Byte-identical to natac_write_bedgraph's text when n_hard == 0. */
+int natac_batch_format_track(natac_batch *b, int track, const int32_t *chrom_id, const char *const *names, int32_t n_names,
+                             const int64_t *chunk_start, int write_zero, int compress, int64_t *n_bytes, int64_t *n_text_bytes,
+                             int64_t *n_lines, int32_t *n_hard);
+int natac_batch_format_fetch(natac_batch *b, void *dst, size_t dst_bytes);
+/* the device formatter on arbitrary doubles (validation): out_off[i] .. out_off[i+1] = python-2 str(vals[i]); out_cap >= 24 n */
+int natac_format_doubles(natac_ctx *ctx, const double *vals, int64_t n, char *out, size_t out_cap, int64_t *out_off, int32_t *n_hard);
+/* host restatement of the device BGZF encoder (no GPU): text + line start offsets -> the members natac_batch_format_track(compress)
+ * produces for the same text, byte for byte */
+int natac_bgzf_lines_host(const char *text, int64_t n, const int64_t *line_off, int64_t n_lines, void *out, size_t out_cap,
+                          int64_t *n_bytes);
+
 /* BED-like rows with python-2 float columns, written natively: row r = names[chrom_id[r]] \t start[r] \t end[r] (\t vals[r][c])* --
  * the text of OccPeak.asBed / Nucleosome.asBed (nucleoatac/Occupancy.py:166-171, NucleosomeCalling.py:195-199) for millions of rows.
  * vals is row-major [n_rows x n_cols] (n_cols <= 32), NaN prints as "nan".  append != 0 appends to `path`. */

@@ -63,6 +63,11 @@ SIGNATURES = {
     "natac_calculate_occupancy": (C.c_int, [_vp, _vp, _vp, _vp]),
     "natac_write_bedgraph": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, _i32, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                              C.POINTER(_i64)]),
+    "natac_batch_format_track": (C.c_int, [_vp, C.c_int, _vp, _vp, _i32, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64),
+                                 C.POINTER(_i64), C.POINTER(_i32)]),
+    "natac_batch_format_fetch": (C.c_int, [_vp, _vp, _sz]),
+    "natac_format_doubles": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp, C.POINTER(_i32)]),
+    "natac_bgzf_lines_host": (C.c_int, [C.c_char_p, _i64, _vp, _i64, _vp, _sz, C.POINTER(_i64)]),
     "natac_write_bed_rows": (C.c_int, [C.c_char_p, C.c_int, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]),
     "natac_bgzip_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "natac_tabix_index": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_i64)]),

@@ -6,6 +6,7 @@
 #include "natac_occ_fast.hpp"
 #include "natac_cand.hpp"
 #include "natac_covsweep.hpp"
+#include "natac_textz.hpp"
 #include "natac_cores.hpp"
 #include "natac_writer.hpp"
 #include "natac_tabix.hpp"
@@ -82,6 +83,9 @@ struct natac_ctx {
     double prof_ms[NATAC_K_COUNT] = {0};
     int64_t prof_n[NATAC_K_COUNT] = {0};
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    // device-side track writer (natac_textz.hpp): power-of-ten table of the '%.12g' formatter, CRC-32 tables
+    natac_text::P10 *d_p10 = nullptr;
+    natac_deflate::CrcTables *d_crc = nullptr;
 };
 
 struct natac_bam {
@@ -132,6 +136,8 @@ struct natac_batch {
     bool pk_has_stats = false;
     int nuc_w = -1, nuc_upper = -1;   // V-plot geometry natac_run_nuc ran with (coverage tracks depend on it)
     double *d_bnum = nullptr, *d_bcov = nullptr;   // per-base sum B V / sum B of the background kernel (candidate statistics)
+    unsigned char *d_fmt_out = nullptr;            // result of the last natac_batch_format_track (text or BGZF members)
+    long long fmt_bytes = -1;
     long long nuc_gen = -1;                        // model generation natac_run_nuc ran with
 };
 
@@ -314,6 +320,166 @@ static void launch_bg(natac_batch *b, const ChunkTable &ct, const VMatDev &vm) {
                        b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov);
 }
 
+/* ---------------- device-side track writer (natac_textfmt.hpp, natac_deflate.hpp, natac_textz.hpp) ---------------- */
+
+static int ensure_text_tables(natac_ctx *c) {
+    if (c->d_p10 && c->d_crc) return NATAC_OK;
+    int rc;
+    if (!c->d_p10 && (rc = dev_upload(c, &c->d_p10, natac_text::H_P10, sizeof(natac_text::H_P10) / sizeof(natac_text::P10)))) return rc;
+    if (!c->d_crc) {
+        natac_deflate::CrcTables t;
+        natac_deflate::crc_init(t);
+        if ((rc = dev_upload(c, &c->d_crc, &t, 1))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return NATAC_OK;
+}
+
+// exclusive scan of in[0..n) into out[0..n], out[n] = total (device arrays; n > 0)
+template <class T>
+static int dev_scan(natac_ctx *c, const T *in, long long n, unsigned long long *out) {
+    using namespace natac_textz;
+    const long long nblk = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    unsigned long long *sums = nullptr;
+    int rc = dev_alloc(&sums, (size_t)nblk + 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL((tz_scan_block_sums<T>), dim3((unsigned)nblk), dim3(256), 0, c->stream, in, n, sums);
+    hipLaunchKernelGGL(tz_scan_sums, dim3(1), dim3(1024), 0, c->stream, sums, nblk);
+    hipLaunchKernelGGL((tz_scan_final<T>), dim3((unsigned)nblk), dim3(256), 0, c->stream, in, n, sums, out);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    dev_free(sums);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "scan: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
+struct TmpFree {               // frees device temporaries at scope exit
+    std::vector<void *> v;
+    ~TmpFree() { for (void *p : v) dev_free(p); }
+    template <class T> T *keep(T *p) { v.push_back((void *)p); return p; }
+};
+
+// text / BGZF of a device array of per-base values laid out like the batch's tracks.  Result stays in b->d_fmt_out.
+static int format_values(natac_batch *b, const double *d_vals, const int32_t *chrom_id, const char *const *names, int32_t n_names,
+                         const int64_t *chunk_start, int write_zero, int compress, int64_t *n_bytes, int64_t *n_text_bytes, int64_t *n_lines,
+                         int32_t *n_hard) {
+    using namespace natac_textz;
+    natac_ctx *c = b->ctx;
+    int rc = ensure_text_tables(c);
+    if (rc) return rc;
+    dev_free(b->d_fmt_out);
+    b->d_fmt_out = nullptr;
+    b->fmt_bytes = -1;
+    // name table
+    std::vector<char> cat;
+    std::vector<int> noff(1, 0);
+    for (int i = 0; i < n_names; ++i) {
+        const size_t l = names[i] ? strlen(names[i]) : 0;
+        if (l == 0 || l > 64) return fail(NATAC_E_ARG, "chromosome name %d must have 1..64 characters", i);
+        cat.insert(cat.end(), names[i], names[i] + l);
+        noff.push_back((int)cat.size());
+    }
+    for (int i = 0; i < b->nc; ++i)
+        if (chrom_id[i] < 0 || chrom_id[i] >= n_names) return fail(NATAC_E_ARG, "chunk %d: chromosome id %d out of range", i, chrom_id[i]);
+    if (b->total_bp >= 0xffffffffLL) return fail(NATAC_E_ARG, "batch too long for the device writer (%lld bases)", b->total_bp);
+    TmpFree tmp;
+    char *d_names = nullptr;
+    int *d_noff = nullptr, *d_cid = nullptr, *d_tc = nullptr, *d_C = nullptr, *d_hard = nullptr;
+    long long *d_cs = nullptr, *d_line_off = nullptr;
+    unsigned long long *d_tb = nullptr, *d_boff = nullptr, *d_lidx = nullptr;
+    unsigned int *d_R = nullptr;
+    unsigned char *d_len8 = nullptr, *d_isl = nullptr, *d_text = nullptr;
+#define TRYF(x) do { if ((rc = (x)) != NATAC_OK) return rc; } while (0)
+    TRYF(dev_upload(c, &d_names, cat.data(), cat.size())); tmp.keep(d_names);
+    TRYF(dev_upload(c, &d_noff, noff.data(), noff.size())); tmp.keep(d_noff);
+    TRYF(dev_upload(c, &d_cid, chrom_id, (size_t)b->nc)); tmp.keep(d_cid);
+    TRYF(dev_upload(c, (long long **)&d_cs, (const long long *)chunk_start, (size_t)b->nc)); tmp.keep(d_cs);
+    TRYF(dev_alloc(&d_hard, 1)); tmp.keep(d_hard);
+    HIPCHK(hipMemsetAsync(d_hard, 0, sizeof(int), c->stream));
+    TextJob job;
+    job.vals = d_vals; job.out_off = b->d_out_off; job.chunk_len = b->d_len; job.tiles = b->d_tiles256; job.ntiles = b->n_tiles256;
+    job.chrom_id = d_cid; job.chunk_start = d_cs; job.names = d_names; job.name_off = d_noff; job.p10 = c->d_p10;
+    job.write_zero = write_zero & 1; job.keep_before_nan = (write_zero >> 1) & 1;
+    const int nt = b->n_tiles256;
+    TRYF(dev_alloc(&d_tc, (size_t)nt)); tmp.keep(d_tc);
+    TRYF(dev_alloc(&d_tb, (size_t)nt + 1)); tmp.keep(d_tb);
+    hipLaunchKernelGGL(tz_flags_count, dim3(nt), dim3(256), 0, c->stream, job, d_tc);
+    TRYF(dev_scan(c, d_tc, (long long)nt, d_tb));
+    unsigned long long nruns = 0;
+    HIPCHK(hipMemcpy(&nruns, d_tb + nt, sizeof nruns, hipMemcpyDeviceToHost));
+    TRYF(dev_alloc(&d_R, (size_t)nruns)); tmp.keep(d_R);
+    TRYF(dev_alloc(&d_C, (size_t)nruns)); tmp.keep(d_C);
+    hipLaunchKernelGGL(tz_scatter_runs, dim3(nt), dim3(256), 0, c->stream, job, d_tb, d_R, d_C);
+    TRYF(dev_alloc(&d_len8, (size_t)nruns)); tmp.keep(d_len8);
+    TRYF(dev_alloc(&d_isl, (size_t)nruns)); tmp.keep(d_isl);
+    const unsigned rb = (unsigned)((nruns + 255) / 256);
+    hipLaunchKernelGGL(tz_line_len, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_isl, d_hard);
+    TRYF(dev_alloc(&d_boff, (size_t)nruns + 1)); tmp.keep(d_boff);
+    TRYF(dev_alloc(&d_lidx, (size_t)nruns + 1)); tmp.keep(d_lidx);
+    TRYF(dev_scan(c, d_len8, (long long)nruns, d_boff));
+    TRYF(dev_scan(c, d_isl, (long long)nruns, d_lidx));
+    unsigned long long n_text = 0, nlines = 0;
+    int hard = 0;
+    HIPCHK(hipMemcpy(&n_text, d_boff + nruns, sizeof n_text, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&nlines, d_lidx + nruns, sizeof nlines, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&hard, d_hard, sizeof hard, hipMemcpyDeviceToHost));
+    if (n_text_bytes) *n_text_bytes = (int64_t)n_text;
+    if (n_lines) *n_lines = (int64_t)nlines;
+    if (n_hard) *n_hard = hard;
+    if (n_text == 0) { b->fmt_bytes = 0; if (n_bytes) *n_bytes = 0; return NATAC_OK; }
+    TRYF(dev_alloc(&d_text, (size_t)n_text + 64));
+    TRYF(dev_alloc(&d_line_off, (size_t)nlines + 1)); tmp.keep(d_line_off);
+    hipLaunchKernelGGL(tz_write_lines, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_boff, d_lidx, d_text,
+                       d_line_off);
+    if (!compress) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { dev_free(d_text); return fail(NATAC_E_HIP, "format_track: %s", hipGetErrorString(e)); }
+        b->d_fmt_out = d_text;
+        b->fmt_bytes = (long long)n_text;
+        if (n_bytes) *n_bytes = (int64_t)n_text;
+        return NATAC_OK;
+    }
+    tmp.keep(d_text);
+    namespace nd = natac_deflate;
+    const long long nblk = ((long long)n_text + nd::BLK - 1) / nd::BLK;
+    unsigned int *d_hist = nullptr, *d_sizes = nullptr;
+    nd::Codes *d_codes = nullptr;
+    unsigned char *d_regions = nullptr, *d_out = nullptr;
+    unsigned long long *d_pos = nullptr;
+    TRYF(dev_alloc(&d_hist, (size_t)nd::NLL + nd::ND)); tmp.keep(d_hist);
+    HIPCHK(hipMemsetAsync(d_hist, 0, (nd::NLL + nd::ND) * sizeof(unsigned int), c->stream));
+    const size_t lds_count = 65536 + (nd::NLL + nd::ND) * sizeof(unsigned int);
+    hipLaunchKernelGGL(tz_count_tokens, dim3((unsigned)nblk), dim3(256), lds_count, c->stream, d_text, (long long)n_text, d_line_off,
+                       (long long)nlines, d_hist);
+    unsigned int hist[nd::NLL + nd::ND];
+    HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hist[256] += (unsigned int)nblk;                        // one end-of-block per member
+    nd::Codes codes;
+    if (!nd::build_codes(hist, hist + nd::NLL, codes)) return fail(NATAC_E_ARG, "format_track: Huffman table description too long");
+    TRYF(dev_upload(c, &d_codes, &codes, 1)); tmp.keep(d_codes);
+    TRYF(dev_alloc(&d_regions, (size_t)nblk * nd::REGION)); tmp.keep(d_regions);
+    HIPCHK(hipMemsetAsync(d_regions, 0, (size_t)nblk * nd::REGION, c->stream));
+    TRYF(dev_alloc(&d_sizes, (size_t)nblk)); tmp.keep(d_sizes);
+    TRYF(dev_alloc(&d_pos, (size_t)nblk + 1)); tmp.keep(d_pos);
+    const size_t lds_emit = 65536 + ((sizeof(nd::Codes) + 15) & ~(size_t)15);
+    hipLaunchKernelGGL(tz_emit_members, dim3((unsigned)nblk), dim3(256), lds_emit, c->stream, d_text, (long long)n_text, d_line_off,
+                       (long long)nlines, d_codes, c->d_crc, d_regions, d_sizes);
+    HIPCHK(hipGetLastError());
+    TRYF(dev_scan(c, d_sizes, nblk, d_pos));
+    unsigned long long total = 0;
+    HIPCHK(hipMemcpy(&total, d_pos + nblk, sizeof total, hipMemcpyDeviceToHost));
+    TRYF(dev_alloc(&d_out, (size_t)total + 64));
+    hipLaunchKernelGGL(tz_compact, dim3((unsigned)nblk), dim3(256), 0, c->stream, d_regions, d_sizes, d_pos, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { dev_free(d_out); return fail(NATAC_E_HIP, "format_track: %s", hipGetErrorString(e)); }
+#undef TRYF
+    b->d_fmt_out = d_out;
+    b->fmt_bytes = (long long)total;
+    if (n_bytes) *n_bytes = (int64_t)total;
+    return NATAC_OK;
+}
+
 extern "C" {
 
 int natac_abi_version(void) { return NATAC_ABI_VERSION; }
@@ -367,6 +533,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     dev_free(c->d_win_nuc); dev_free(c->d_win_occ); dev_free(c->d_wb_occ);
     dev_free(c->d_fft_tw); dev_free(c->d_fft_k);
     dev_free(c->d_occ_q4); dev_free(c->d_occ_rho);
+    dev_free(c->d_p10); dev_free(c->d_crc);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -711,7 +878,7 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
-    dev_free(b->d_bnum); dev_free(b->d_bcov);
+    dev_free(b->d_bnum); dev_free(b->d_bcov); dev_free(b->d_fmt_out);
     dev_free(b->d_blk_off); dev_free(b->d_gsum); dev_free(b->d_tiles_gs); dev_free(b->d_defer);
     dev_free(b->d_opk_vals); dev_free(b->d_nuc_dist); dev_free(b->d_opk_keep);
     for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
@@ -730,6 +897,7 @@ int natac_batch_release_outputs(natac_batch *b) {
     dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos); dev_free(b->d_opk_vals); dev_free(b->d_opk_keep); dev_free(b->d_nuc_dist);
     b->d_bnum = b->d_bcov = b->d_gsum = b->d_pk_out = b->d_opk_vals = b->d_nuc_dist = nullptr;
     b->d_pk_chunk = b->d_pk_pos = b->d_opk_keep = nullptr;
+    dev_free(b->d_fmt_out); b->d_fmt_out = nullptr; b->fmt_bytes = -1;
     b->pk_cap = 0; b->pk_n = -1; b->opk_cap = 0; b->opk_n = -1;
     b->nuc_done = b->occ_done = b->ins_done = b->cov_from_nuc = b->prefill_valid = false;
     // the per-chunk status words describe the outputs that were just dropped
@@ -1783,6 +1951,91 @@ int natac_calculate_occupancy(natac_ctx *c, const double *inserts, const double 
 }
 
 /* ---------------- native track writer ---------------- */
+
+/* ---------------- device-side track writer: entry points (helpers above extern "C") ---------------- */
+
+int natac_batch_format_track(natac_batch *b, int track, const int32_t *chrom_id, const char *const *names, int32_t n_names,
+                             const int64_t *chunk_start, int write_zero, int compress, int64_t *n_bytes, int64_t *n_text_bytes,
+                             int64_t *n_lines, int32_t *n_hard) {
+    if (!b || !chrom_id || !names || !chunk_start || n_names <= 0) return fail(NATAC_E_ARG, "null argument");
+    int rc = track_ready(b, track);
+    if (rc) return rc;
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_all(c));
+    if (track == NATAC_T_OCC_PREFILL && (rc = materialise_prefill(b))) return rc;
+    if (track != NATAC_T_INS)
+        return format_values(b, b->d_track[track], chrom_id, names, n_names, chunk_start, write_zero, compress, n_bytes, n_text_bytes, n_lines,
+                             n_hard);
+    double *d_tmp = nullptr;                   // insertion counts are int32 on the device; the writer takes float64 like the reference's track
+    if ((rc = dev_alloc(&d_tmp, (size_t)b->total_bp))) return rc;
+    const int blocks = (int)std::min<long long>((b->total_bp + 255) / 256, 65536);
+    hipLaunchKernelGGL(natac_i32_to_f64, dim3(blocks), dim3(256), 0, c->stream, (const int *)b->d_track[NATAC_T_INS], d_tmp, b->total_bp);
+    rc = format_values(b, d_tmp, chrom_id, names, n_names, chunk_start, write_zero, compress, n_bytes, n_text_bytes, n_lines, n_hard);
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(d_tmp);
+    return rc;
+}
+
+int natac_batch_format_fetch(natac_batch *b, void *dst, size_t dst_bytes) {
+    if (!b || (!dst && dst_bytes)) return fail(NATAC_E_ARG, "null argument");
+    if (b->fmt_bytes < 0) return fail(NATAC_E_STATE, "natac_batch_format_track has not run");
+    if ((long long)dst_bytes < b->fmt_bytes) return fail(NATAC_E_ARG, "destination holds %zu bytes, result has %lld", dst_bytes, b->fmt_bytes);
+    if (b->fmt_bytes == 0) return NATAC_OK;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipMemcpyAsync(dst, b->d_fmt_out, (size_t)b->fmt_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return NATAC_OK;
+}
+
+int natac_format_doubles(natac_ctx *c, const double *vals, int64_t n, char *out, size_t out_cap, int64_t *out_off, int32_t *n_hard) {
+    if (!c || !vals || !out || !out_off || n <= 0) return fail(NATAC_E_ARG, "bad argument");
+    if (out_cap < (size_t)n * natac_text::MAX_VALUE_CHARS) return fail(NATAC_E_ARG, "out must hold %d bytes per value", natac_text::MAX_VALUE_CHARS);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_text_tables(c);
+    if (rc) return rc;
+    double *d_v = nullptr;
+    char *d_o = nullptr;
+    int *d_len = nullptr, *d_hard = nullptr;
+    if ((rc = dev_upload(c, &d_v, vals, (size_t)n))) return rc;
+    TmpFree tmp;
+    tmp.keep(d_v);
+    if ((rc = dev_alloc(&d_o, (size_t)n * natac_text::MAX_VALUE_CHARS))) return rc;
+    tmp.keep(d_o);
+    if ((rc = dev_alloc(&d_len, (size_t)n + 1))) return rc;
+    tmp.keep(d_len);
+    HIPCHK(hipMemsetAsync(d_len + n, 0, sizeof(int), c->stream));
+    d_hard = d_len + n;
+    hipLaunchKernelGGL(natac_textz::tz_format_values, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_v, (long long)n, c->d_p10, d_o,
+                       d_len, d_hard);
+    std::vector<int> len((size_t)n + 1);
+    std::vector<char> raw((size_t)n * natac_text::MAX_VALUE_CHARS);
+    HIPCHK(hipMemcpyAsync(len.data(), d_len, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(raw.data(), d_o, raw.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    long long o = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        out_off[i] = o;
+        memcpy(out + o, raw.data() + (size_t)i * natac_text::MAX_VALUE_CHARS, (size_t)len[(size_t)i]);
+        o += len[(size_t)i];
+    }
+    out_off[n] = o;
+    if (n_hard) *n_hard = len[(size_t)n];
+    return NATAC_OK;
+}
+
+int natac_bgzf_lines_host(const char *text, int64_t n, const int64_t *line_off, int64_t n_lines, void *out, size_t out_cap, int64_t *n_bytes) {
+    if (!text || !line_off || !n_bytes || n < 0 || n_lines < 0) return fail(NATAC_E_ARG, "bad argument");
+    std::string res;
+    if (!natac_deflate::bgzf_lines_host((const unsigned char *)text, n, (const long long *)line_off, n_lines, res))
+        return fail(NATAC_E_ARG, "Huffman table description too long");
+    *n_bytes = (int64_t)res.size();
+    if (res.size() > out_cap) return fail(NATAC_E_ARG, "destination holds %zu bytes, result has %zu", out_cap, res.size());
+    if (out && !res.empty()) memcpy(out, res.data(), res.size());
+    return NATAC_OK;
+}
+
+/* ---------------- native track writer + bgzip ---------------- */
 
 int natac_write_bedgraph(const char *path, int append, int compress, int finish, int32_t n_chunks, const char *const *chroms,
                          const int64_t *chunk_start, const int64_t *out_off, const double *vals, int write_zero, int n_threads,

@@ -1,0 +1,148 @@
+// natac_textfmt.hpp -- Track.write_track (pyatac/tracks.py:37-74) ON THE DEVICE: run-length detection, the reference's
+// run-before-NaN rule, python-2 `str(float)` (= '%.12g', ".0" appended to integral text) and the bedGraph line layout as
+// HIP kernels, so that a per-base float64 track leaves the GPU as the exact bytes the reference's writer processes would
+// produce.  The host-side formatter (natac_writer.hpp) manages 30-60 Mbp/s per track on the box's
+// 16 cores; the GPU formats a 212-Mbp track in milliseconds.
+//
+// '%.12g' on the device: |v| = m * 2^e2 exactly (m normalised to 64 bits); with s = 11 - floor(log10 |v|) the twelve significant
+// digits are D = round_half_even(|v| * 10^s).  10^s comes from a table of 128-bit truncated mantissas (natac_pow10.inc, generated
+// with exact integer arithmetic by tools/gen_pow10_table.py) and m * 10^s is formed exactly as a 192-bit product.  For
+// 0 <= s <= 55 (1e-44 <= |v| < 1e12: every value a track holds in practice) the table entry is exact, so the product, its
+// remainder and therefore ties are exact -- the result is the correctly rounded one that printf / to_chars give.  Outside that
+// range the entry is a truncation (relative error < 2^-127): the rounding decision can only differ from the exact one when
+// the 88+ bits below the half bit are all ones; that case (probability ~2^-88 per value) is COUNTED (`hard`), never guessed --
+// the caller falls back to the host formatter for that track.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NATAC_HD __host__ __device__
+#else
+#define NATAC_HD
+#endif
+
+namespace natac_text {
+
+struct P10 { uint64_t hi, lo; int e; int exact; };
+
+static const P10 H_P10[] = {      // host copy; natac_api.hip uploads it once per context for the kernels
+#include "natac_pow10.inc"
+};
+
+NATAC_HD inline uint64_t mul64(uint64_t a, uint64_t b, uint64_t *hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *hi = __umul64hi(a, b);
+    return a * b;
+#else
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    *hi = (uint64_t)(p >> 64);
+    return (uint64_t)p;
+#endif
+}
+
+NATAC_HD inline int clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+
+NATAC_HD inline char *put_u64(char *p, uint64_t v) {
+    char tmp[20];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + (v % 10)); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+NATAC_HD inline char *put_i64(char *p, long long v) {
+    if (v < 0) { *p++ = '-'; return put_u64(p, (uint64_t)(-(v + 1)) + 1); }
+    return put_u64(p, (uint64_t)v);
+}
+NATAC_HD inline int digits_i64(long long v) {
+    int n = v < 0 ? 1 : 0;
+    uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v;
+    do { ++n; u /= 10; } while (u);
+    return n;
+}
+
+// python-2 str(float) of a non-NaN double: '%.12g' + ".0" for integral text.  Returns the end pointer; *hard is incremented
+// when the rounding could not be decided from the truncated table entry (see the header).  tab = the P10 table.
+NATAC_HD inline char *fmt_py2_float(char *p, double v, const P10 *tab, int *hard) {
+    union { double d; uint64_t u; } cv;
+    cv.d = v;
+    const uint64_t bits = cv.u;
+    const bool neg = (bits >> 63) != 0;
+    const int ef = (int)((bits >> 52) & 0x7ff);
+    const uint64_t frac = bits & 0xfffffffffffffull;
+    if (ef == 0x7ff) {
+        if (frac) { *p++ = 'n'; *p++ = 'a'; *p++ = 'n'; return p; }
+        if (neg) *p++ = '-';
+        *p++ = 'i'; *p++ = 'n'; *p++ = 'f';
+        return p;
+    }
+    if (neg) *p++ = '-';
+    if (ef == 0 && frac == 0) { *p++ = '0'; *p++ = '.'; *p++ = '0'; return p; }
+    uint64_t m = ef ? (frac | (1ull << 52)) : frac;
+    int e2 = ef ? ef - 1075 : -1074;
+    const int lz = clz64(m);
+    m <<= lz;
+    e2 -= lz;                                            // |v| = m 2^e2, 2^63 <= m < 2^64
+    int e10 = ((e2 + 63) * 78913) >> 18;                 // floor((e2 + 63) log10 2): floor(log10 |v|) or one less
+    uint64_t D = 0;
+    for (int it = 0; it < 3; ++it) {
+        const int s = 11 - e10;
+        const P10 T = tab[s - NATAC_P10_SMIN];
+        uint64_t l1, h1;
+        const uint64_t l0 = mul64(m, T.lo, &l1);
+        const uint64_t h0 = mul64(m, T.hi, &h1);
+        const uint64_t p0 = l0;
+        const uint64_t p1 = l1 + h0;
+        const uint64_t p2 = h1 + (p1 < l1 ? 1 : 0);      // m * T = p2:p1:p0 (192 bits), |v| 10^s = that * 2^(e2 + T.e)
+        const int sh = -(e2 + T.e) - 128;                // D = p2 >> sh, 22 <= sh <= 63 when e10 is right (or one less)
+        const uint64_t D0 = p2 >> sh;
+        if (D0 >= 1000000000000ull) { ++e10; continue; }  // the guess was one too small
+        const uint64_t hb = (p2 >> (sh - 1)) & 1;
+        const uint64_t mask = (1ull << (sh - 1)) - 1;
+        const uint64_t rest = p2 & mask;
+        bool up;
+        if (T.exact) up = hb && ((rest | p1 | p0) != 0 || (D0 & 1));
+        else {
+            up = hb != 0;
+            if (!hb && rest == mask && p1 == ~0ull) ++*hard;          // a carry out of the truncated tail would flip the decision
+        }
+        D = D0 + (up ? 1 : 0);
+        if (D < 100000000000ull) { --e10; continue; }    // (cannot happen with the floor guess; kept as a guard)
+        if (D >= 1000000000000ull) { D = 100000000000ull; ++e10; }   // 999999999999.5+ rounded up to 10^12
+        break;
+    }
+    char dg[12];
+    for (int i = 11; i >= 0; --i) { dg[i] = (char)('0' + (int)(D % 10)); D /= 10; }
+    int nd = 12;
+    while (nd > 1 && dg[nd - 1] == '0') --nd;            // %g strips trailing zeros
+    if (e10 < -4 || e10 >= 12) {                         // scientific: d[.ddd]e+XX (at least two exponent digits); has an 'e': no ".0"
+        *p++ = dg[0];
+        if (nd > 1) { *p++ = '.'; for (int i = 1; i < nd; ++i) *p++ = dg[i]; }
+        *p++ = 'e';
+        int x = e10;
+        if (x < 0) { *p++ = '-'; x = -x; } else *p++ = '+';
+        if (x >= 100) { *p++ = (char)('0' + x / 100); x %= 100; *p++ = (char)('0' + x / 10); *p++ = (char)('0' + x % 10); }
+        else { *p++ = (char)('0' + x / 10); *p++ = (char)('0' + x % 10); }
+    } else if (e10 >= 0) {
+        const int ni = e10 + 1;                          // integer digits
+        for (int i = 0; i < ni; ++i) *p++ = (i < nd) ? dg[i] : '0';
+        *p++ = '.';
+        if (nd > ni) { for (int i = ni; i < nd; ++i) *p++ = dg[i]; }
+        else *p++ = '0';                                 // integral text gets ".0"
+    } else {
+        *p++ = '0'; *p++ = '.';
+        for (int i = 0; i < -e10 - 1; ++i) *p++ = '0';
+        for (int i = 0; i < nd; ++i) *p++ = dg[i];
+    }
+    return p;
+}
+
+constexpr int MAX_VALUE_CHARS = 24;     // "-1.23456789012e-308" is 19
+
+}  // namespace natac_text

@@ -1,0 +1,474 @@
+// natac_textz.hpp -- device kernels of the track writer: per-base float64 track -> run-length bedGraph text
+// (natac_textfmt.hpp) -> BGZF members (natac_deflate.hpp).  One pass structure for any batch size:
+//
+//   tz_flags_count    run starts per 256-base tile                        (a run = equal consecutive values, NaNs together)
+//   scan              tile counts -> run index base
+//   tz_scatter_runs   R[k] = base index of run k, C[k] = its chunk
+//   tz_line_len       emitted? (NaN runs, zero runs, the reference's run-before-NaN rule) + length of the text line
+//   scan x2           line index, byte offset
+//   tz_write_lines    the text, line_off[]
+//   tz_count_tokens   token histogram of all members                      -> host builds ONE Huffman code per track (natac_deflate.hpp)
+//   tz_emit_members   one workgroup per 0xff00-byte member: tokens -> bits, CRC-32, BGZF framing
+//   tz_compact        members packed back to back
+#pragma once
+#include "natac_deflate.hpp"
+#include "natac_kernels.hpp"
+
+namespace natac_textz {
+
+using natac_text::P10;
+namespace nd = natac_deflate;
+
+struct TextJob {
+    const double *vals;            // per-base track of the batch
+    const long long *out_off;      // [nc + 1]
+    const int *chunk_len;          // [nc]
+    const int2 *tiles;             // (chunk, x0), 256-base tiles in chunk order
+    int ntiles;
+    const int *chrom_id;           // [nc] index into the name table
+    const long long *chunk_start;  // [nc] genomic start of the chunk
+    const char *names;             // concatenated chromosome names
+    const int *name_off;           // [n_names + 1]
+    const P10 *p10;
+    int write_zero, keep_before_nan;
+};
+
+__device__ __forceinline__ bool same_run(double a, double b) { return a == b || (a != a && b != b); }
+
+// ---- run starts ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tz_flags_count(TextJob job, int *__restrict__ tile_count) {
+    __shared__ int wsum[4];
+    const int2 t = job.tiles[blockIdx.x];
+    const int L = job.chunk_len[t.x];
+    const int x = t.y + threadIdx.x;
+    bool start = false;
+    if (x < L) {
+        const long long i = job.out_off[t.x] + x;
+        start = (x == 0) || !same_run(job.vals[i], job.vals[i - 1]);
+    }
+    const unsigned long long m = __ballot(start);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void __launch_bounds__(256) tz_scatter_runs(TextJob job, const unsigned long long *__restrict__ tile_base,
+                                                        unsigned int *__restrict__ R, int *__restrict__ C) {
+    __shared__ int wsum[4];
+    const int2 t = job.tiles[blockIdx.x];
+    const int L = job.chunk_len[t.x];
+    const int x = t.y + threadIdx.x;
+    bool start = false;
+    long long i = 0;
+    if (x < L) {
+        i = job.out_off[t.x] + x;
+        start = (x == 0) || !same_run(job.vals[i], job.vals[i - 1]);
+    }
+    const unsigned long long m = __ballot(start);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < w; ++k) before += wsum[k];
+    if (start) {
+        const unsigned long long k = tile_base[blockIdx.x] + before + __popcll(m & ((1ull << lane) - 1));
+        R[k] = (unsigned int)i;
+        C[k] = t.x;
+    }
+}
+
+// ---- exclusive scans (in: any integer type; out: unsigned long long) -------------------------------------------------------
+constexpr int SCAN_PER_BLOCK = 2048;
+template <class T>
+__global__ void __launch_bounds__(256) tz_scan_block_sums(const T *__restrict__ in, long long n, unsigned long long *__restrict__ sums) {
+    __shared__ unsigned long long red[4];
+    const long long base = (long long)blockIdx.x * SCAN_PER_BLOCK;
+    unsigned long long s = 0;
+    for (int j = 0; j < 8; ++j) {
+        const long long i = base + threadIdx.x * 8 + j;
+        if (i < n) s += (unsigned long long)in[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// exclusive scan of sums[0..n) in place by one workgroup; total -> sums[n]
+__global__ void __launch_bounds__(1024) tz_scan_sums(unsigned long long *__restrict__ sums, long long n) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < n; base += 1024) {
+        const long long i = base + threadIdx.x;
+        const unsigned long long v = i < n ? sums[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const unsigned long long add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n) sums[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[n] = carry;
+}
+template <class T>
+__global__ void __launch_bounds__(256) tz_scan_final(const T *__restrict__ in, long long n, const unsigned long long *__restrict__ sums,
+                                                      unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long wtot[4];
+    const long long base = (long long)blockIdx.x * SCAN_PER_BLOCK;
+    unsigned long long v[8], s = 0;
+    for (int j = 0; j < 8; ++j) {
+        const long long i = base + threadIdx.x * 8 + j;
+        v[j] = i < n ? (unsigned long long)in[i] : 0;
+        s += v[j];
+    }
+    // inclusive scan of the per-thread sums inside the wave, then across the four waves
+    unsigned long long inc = s;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned long long before = sums[blockIdx.x] + inc - s;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) before += wtot[k];
+    for (int j = 0; j < 8; ++j) {
+        const long long i = base + threadIdx.x * 8 + j;
+        if (i < n) out[i] = before;
+        before += v[j];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = before;     // total
+}
+
+// ---- lines ------------------------------------------------------------------------------------------------------------
+struct RunInfo {
+    long long a_rel, b_rel;        // run = [a_rel, b_rel) relative to the chunk start
+    double v;
+    int chunk;
+    bool emitted;
+};
+__device__ __forceinline__ RunInfo run_info(const TextJob &job, long long k, long long nruns, const unsigned int *R, const int *C) {
+    RunInfo r;
+    const long long a = R[k];
+    r.chunk = C[k];
+    const long long cb = job.out_off[r.chunk], ce = job.out_off[r.chunk + 1];
+    const long long b = (k + 1 < nruns && C[k + 1] == r.chunk) ? (long long)R[k + 1] : ce;
+    r.v = job.vals[a];
+    r.a_rel = a - cb;
+    r.b_rel = b - cb;
+    const bool nan_follows = b < ce && job.vals[b] != job.vals[b];
+    // Track.write_track (pyatac/tracks.py:56-66): NaN runs are skipped; a run directly followed by a NaN is lost because prev_value is
+    // overwritten before the flush; zero runs are written only with write_zero
+    r.emitted = !(r.v != r.v) && (r.v != 0.0 || job.write_zero) && (job.keep_before_nan || !nan_follows);
+    return r;
+}
+__device__ __forceinline__ char *format_line(char *p, const TextJob &job, const RunInfo &r, int *hard) {
+    const int cid = job.chrom_id[r.chunk];
+    const int n0 = job.name_off[cid], n1 = job.name_off[cid + 1];
+    for (int i = n0; i < n1; ++i) *p++ = job.names[i];
+    *p++ = '\t';
+    const long long s = job.chunk_start[r.chunk];
+    p = natac_text::put_i64(p, s + r.a_rel);
+    *p++ = '\t';
+    p = natac_text::put_i64(p, s + r.b_rel);
+    *p++ = '\t';
+    p = natac_text::fmt_py2_float(p, r.v, job.p10, hard);
+    *p++ = '\n';
+    return p;
+}
+constexpr int MAX_LINE = 160;      // name (<= 64) + 2 coordinates (<= 20 each) + value (<= 24) + 4 separators
+
+__global__ void __launch_bounds__(256) tz_line_len(TextJob job, long long nruns, const unsigned int *__restrict__ R, const int *__restrict__ C,
+                                                    unsigned char *__restrict__ len8, unsigned char *__restrict__ is_line, int *__restrict__ hard_total) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nruns) return;
+    const RunInfo r = run_info(job, k, nruns, R, C);
+    int n = 0, hard = 0;
+    if (r.emitted) {
+        char buf[MAX_LINE];
+        n = (int)(format_line(buf, job, r, &hard) - buf);
+    }
+    len8[k] = (unsigned char)n;
+    is_line[k] = n ? 1 : 0;
+    if (hard) atomicAdd(hard_total, hard);
+}
+
+__global__ void __launch_bounds__(256) tz_write_lines(TextJob job, long long nruns, const unsigned int *__restrict__ R, const int *__restrict__ C,
+                                                       const unsigned char *__restrict__ len8, const unsigned long long *__restrict__ byte_off,
+                                                       const unsigned long long *__restrict__ line_idx, unsigned char *__restrict__ text,
+                                                       long long *__restrict__ line_off) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nruns || !len8[k]) return;
+    const RunInfo r = run_info(job, k, nruns, R, C);
+    char buf[MAX_LINE];
+    int hard = 0;
+    const int n = (int)(format_line(buf, job, r, &hard) - buf);
+    unsigned char *dst = text + byte_off[k];
+    for (int i = 0; i < n; ++i) dst[i] = (unsigned char)buf[i];
+    line_off[line_idx[k]] = (long long)byte_off[k];
+}
+
+// python-2 str(float) of arbitrary doubles, MAX_VALUE_CHARS bytes reserved per value (test entry natac_format_doubles)
+__global__ void __launch_bounds__(256) tz_format_values(const double *__restrict__ v, long long n, const P10 *__restrict__ p10,
+                                                         char *__restrict__ out, int *__restrict__ len, int *__restrict__ hard_total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    char buf[natac_text::MAX_VALUE_CHARS];
+    int hard = 0;
+    const int m = (int)(natac_text::fmt_py2_float(buf, v[i], p10, &hard) - buf);
+    for (int k = 0; k < m; ++k) out[i * natac_text::MAX_VALUE_CHARS + k] = buf[k];
+    len[i] = m;
+    if (hard) atomicAdd(hard_total, hard);
+}
+
+// ---- deflate ------------------------------------------------------------------------------------------------------------
+struct DevCountSink {              // LDS histogram
+    unsigned int *ll, *d;
+    __device__ void literal(unsigned char c) { atomicAdd(&ll[c], 1u); }
+    __device__ void match(int L, int dist) {
+        int s, eb, ev;
+        nd::len_symbol(L, &s, &eb, &ev);
+        atomicAdd(&ll[s], 1u);
+        nd::dist_symbol(dist, &s, &eb, &ev);
+        atomicAdd(&d[s], 1u);
+    }
+};
+
+// first line index whose segment may touch the member starting at bs: the line containing bs
+__device__ __forceinline__ long long line_containing(const long long *line_off, long long nlines, long long pos) {
+    long long lo = 0, hi = nlines;              // first index with line_off > pos
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (line_off[mid] <= pos) lo = mid + 1; else hi = mid;
+    }
+    return lo > 0 ? lo - 1 : 0;
+}
+
+struct MemberGeom {
+    long long bs, be, k0, nseg;    // member byte range, first line, number of line segments inside
+};
+__device__ __forceinline__ MemberGeom member_geom(const long long *line_off, long long nlines, long long n_text, long long b) {
+    MemberGeom g;
+    g.bs = b * nd::BLK;
+    g.be = g.bs + nd::BLK < n_text ? g.bs + nd::BLK : n_text;
+    g.k0 = line_containing(line_off, nlines, g.bs);
+    long long lo = g.k0, hi = nlines;            // first line starting at or after be
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (line_off[mid] < g.be) lo = mid + 1; else hi = mid;
+    }
+    g.nseg = lo - g.k0;
+    return g;
+}
+
+template <class Sink>
+__device__ __forceinline__ void tokenize_my_segments(const unsigned char *lds_text, const MemberGeom &g, const long long *line_off,
+                                                     long long nlines, long long n_text, long long s0, long long s1, Sink &sink) {
+    for (long long s = s0; s < s1; ++s) {
+        const long long k = g.k0 + s;
+        const long long ls = line_off[k], le = (k + 1 < nlines) ? line_off[k + 1] : n_text;
+        const long long q0 = ls > g.bs ? ls : g.bs, q1 = le < g.be ? le : g.be;
+        if (q1 > q0) nd::tokenize_segment(lds_text, g.bs, g.bs, q0, q1, ls, k > 0 ? line_off[k - 1] : (long long)-1, sink);
+    }
+}
+
+__device__ __forceinline__ void load_member_text(unsigned char *lds_text, const unsigned char *text, const MemberGeom &g) {
+    const int n = (int)(g.be - g.bs);
+    const unsigned char *src = text + g.bs;      // bs is a multiple of 0xff00: 256-byte aligned
+    const int n16 = n >> 4;
+    const uint4 *s4 = (const uint4 *)src;
+    uint4 *d4 = (uint4 *)lds_text;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) d4[i] = s4[i];
+    for (int i = (n16 << 4) + threadIdx.x; i < n; i += blockDim.x) lds_text[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256) tz_count_tokens(const unsigned char *__restrict__ text, long long n_text,
+                                                        const long long *__restrict__ line_off, long long nlines,
+                                                        unsigned int *__restrict__ hist /* [NLL + ND] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *lds_text = smem;
+    unsigned int *h = (unsigned int *)(smem + 65536);
+    const MemberGeom g = member_geom(line_off, nlines, n_text, blockIdx.x);
+    for (int i = threadIdx.x; i < nd::NLL + nd::ND; i += 256) h[i] = 0;
+    load_member_text(lds_text, text, g);
+    __syncthreads();
+    const long long per = (g.nseg + 255) / 256;
+    const long long s0 = per * threadIdx.x < g.nseg ? per * threadIdx.x : g.nseg;
+    const long long s1 = s0 + per < g.nseg ? s0 + per : g.nseg;
+    DevCountSink sink{h, h + nd::NLL};
+    tokenize_my_segments(lds_text, g, line_off, nlines, n_text, s0, s1, sink);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nd::NLL + nd::ND; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+struct DevBitWriter {              // LSB-first bit stream into zero-initialised 32-bit words; words shared with a neighbour are OR-ed
+    unsigned int *words;
+    long long bitpos;              // next bit to write
+    unsigned long long acc;        // pending bits, acc bit 0 = stream bit (bitpos - nacc)
+    int nacc;
+    bool first;                    // the next flushed word is the first one of this writer (may be shared with the previous thread)
+    __device__ void init(unsigned int *w, long long start_bit) {
+        words = w;
+        const int sh = (int)(start_bit & 31);
+        bitpos = start_bit;
+        acc = 0;
+        nacc = sh;                 // pretend the low `sh` bits of the first word are pending zeros: OR-ing zeros is harmless
+        first = true;
+    }
+    __device__ void put(unsigned int v, int nb) {
+        acc |= (unsigned long long)v << nacc;
+        nacc += nb;
+        bitpos += nb;
+        if (nacc >= 32) {
+            unsigned int *dst = &words[(bitpos - nacc) >> 5];
+            if (first) { atomicOr(dst, (unsigned int)acc); first = false; }
+            else *dst = (unsigned int)acc;
+            acc >>= 32;
+            nacc -= 32;
+        }
+    }
+    __device__ void finish() {
+        if (nacc > 0) atomicOr(&words[(bitpos - nacc) >> 5], (unsigned int)acc);
+        nacc = 0;
+    }
+};
+struct DevEmitSink {
+    const nd::Codes *c;
+    DevBitWriter *w;
+    __device__ void literal(unsigned char ch) { w->put(c->ll_code[ch], c->ll_len[ch]); }
+    __device__ void match(int L, int dist) {
+        int s, eb, ev;
+        nd::len_symbol(L, &s, &eb, &ev);
+        w->put(c->ll_code[s] | ((unsigned int)ev << c->ll_len[s]), c->ll_len[s] + eb);
+        nd::dist_symbol(dist, &s, &eb, &ev);
+        w->put(c->d_code[s] | ((unsigned int)ev << c->d_len[s]), c->d_len[s] + eb);
+    }
+};
+
+__device__ __forceinline__ void or_bytes(unsigned int *words, long long byte_off, unsigned long long value, int nbytes) {
+    for (int i = 0; i < nbytes; ++i) {
+        const long long o = byte_off + i;
+        atomicOr(&words[o >> 2], (unsigned int)((value >> (8 * i)) & 0xff) << (8 * (o & 3)));
+    }
+}
+
+// One workgroup per member.  out_regions: nd::REGION bytes per member, zeroed; the member occupies bytes [2, 2 + size) of its
+// region (so that the deflate payload, 18 bytes later, starts on a 32-bit word).  sizes[b] = member size in bytes.
+__global__ void __launch_bounds__(256) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
+                                                        const long long *__restrict__ line_off, long long nlines,
+                                                        const nd::Codes *__restrict__ codes_g, const nd::CrcTables *__restrict__ crc_g,
+                                                        unsigned char *__restrict__ out_regions, unsigned int *__restrict__ sizes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *lds_text = smem;
+    nd::Codes *codes = (nd::Codes *)(smem + 65536);
+    __shared__ unsigned long long tbits[256];
+    __shared__ unsigned int crc_v[256];
+    __shared__ int crc_n[256];
+    __shared__ unsigned int crc_tab[256 + 32];
+    const MemberGeom g = member_geom(line_off, nlines, n_text, blockIdx.x);
+    {
+        const unsigned int *src = (const unsigned int *)codes_g;
+        unsigned int *dst = (unsigned int *)codes;
+        for (int i = threadIdx.x; i < (int)(sizeof(nd::Codes) / 4); i += 256) dst[i] = src[i];
+        const unsigned int *ct = (const unsigned int *)crc_g;
+        for (int i = threadIdx.x; i < 256 + 32; i += 256) crc_tab[i] = ct[i];
+    }
+    load_member_text(lds_text, text, g);
+    __syncthreads();
+    const int n = (int)(g.be - g.bs);
+    const long long per = (g.nseg + 255) / 256;
+    const long long s0 = per * threadIdx.x < g.nseg ? per * threadIdx.x : g.nseg;
+    const long long s1 = s0 + per < g.nseg ? s0 + per : g.nseg;
+    // pass A: bits of my segments
+    nd::BitCountSink bc{codes, 0};
+    tokenize_my_segments(lds_text, g, line_off, nlines, n_text, s0, s1, bc);
+    tbits[threadIdx.x] = (unsigned long long)bc.bits;
+    // CRC-32 of my 255-byte slice of the member
+    {
+        const int c0 = threadIdx.x * 255 < n ? threadIdx.x * 255 : n;
+        const int c1 = c0 + 255 < n ? c0 + 255 : n;
+        crc_v[threadIdx.x] = nd::crc_bytes(crc_tab, lds_text + c0, c1 - c0);
+        crc_n[threadIdx.x] = c1 - c0;
+    }
+    __syncthreads();
+    // exclusive scan of tbits (256 values) + tree combination of the slice CRCs
+    unsigned long long mine = tbits[threadIdx.x];
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned long long add = threadIdx.x >= off ? tbits[threadIdx.x - off] : 0;
+        __syncthreads();
+        tbits[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const unsigned long long total_tok_bits = tbits[255];
+    const unsigned long long my_start = tbits[threadIdx.x] - mine;
+    for (int step = 1; step < 256; step <<= 1) {
+        if ((threadIdx.x & (2 * step - 1)) == 0) {
+            const int o = threadIdx.x + step;
+            crc_v[threadIdx.x] = nd::crc_combine(crc_tab + 256, crc_v[threadIdx.x], crc_v[o], crc_n[o]);
+            crc_n[threadIdx.x] += crc_n[o];
+        }
+        __syncthreads();
+    }
+    const unsigned int crc = crc_v[0];
+    unsigned char *region = out_regions + (size_t)blockIdx.x * nd::REGION;
+    unsigned int *words = (unsigned int *)region;
+    const int eob_len = codes->ll_len[256];
+    const unsigned long long total_bits = (unsigned long long)codes->hdr_bits + total_tok_bits + eob_len;
+    long long payload = (long long)((total_bits + 7) >> 3);
+    const bool stored = 18 + payload + 8 > 65536;
+    if (!stored) {
+        // shared header: whole words by the first threads, the ragged last word OR-ed (the token stream continues in it)
+        const int hw = codes->hdr_bits >> 5, hr = codes->hdr_bits & 31;
+        for (int i = threadIdx.x; i < hw; i += 256) words[5 + i] = codes->hdr[i];
+        if (threadIdx.x == 0 && hr) atomicOr(&words[5 + hw], codes->hdr[hw]);
+        DevBitWriter bw;
+        bw.init(words + 5, (long long)codes->hdr_bits + (long long)my_start);
+        // init() treats the bits below the start as pending zeros; the first flushed word is OR-ed
+        DevEmitSink es{codes, &bw};
+        tokenize_my_segments(lds_text, g, line_off, nlines, n_text, s0, s1, es);
+        if (threadIdx.x == 255) bw.put(codes->ll_code[256], eob_len);
+        bw.finish();
+    } else {
+        payload = 5 + n;
+        if (threadIdx.x == 0) {
+            region[20] = 1;                                   // BFINAL = 1, BTYPE = 00, padding
+            region[21] = (unsigned char)(n & 0xff); region[22] = (unsigned char)(n >> 8);
+            region[23] = (unsigned char)(~n & 0xff); region[24] = (unsigned char)((~n >> 8) & 0xff);
+        }
+        for (int i = threadIdx.x; i < n; i += 256) region[25 + i] = lds_text[i];
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long total = 18 + payload + 8;
+        for (int i = 0; i < 16; ++i) region[2 + i] = nd::bgzf_hdr_byte(i);
+        region[18] = (unsigned char)((total - 1) & 0xff);
+        region[19] = (unsigned char)(((total - 1) >> 8) & 0xff);
+        if (stored) {
+            for (int i = 0; i < 4; ++i) { region[20 + payload + i] = (unsigned char)(crc >> (8 * i)); region[24 + payload + i] = (unsigned char)((unsigned int)n >> (8 * i)); }
+        } else {
+            or_bytes(words, 20 + payload, crc, 4);
+            or_bytes(words, 24 + payload, (unsigned int)n, 4);
+        }
+        sizes[blockIdx.x] = (unsigned int)total;
+    }
+}
+
+// members packed back to back: out[pos[b] ..) = region b bytes [2, 2 + size)
+__global__ void __launch_bounds__(256) tz_compact(const unsigned char *__restrict__ regions, const unsigned int *__restrict__ sizes,
+                                                   const unsigned long long *__restrict__ pos, unsigned char *__restrict__ out) {
+    const unsigned char *src = regions + (size_t)blockIdx.x * nd::REGION + 2;
+    unsigned char *dst = out + pos[blockIdx.x];
+    const int n = (int)sizes[blockIdx.x];
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+}  // namespace natac_textz

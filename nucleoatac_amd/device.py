@@ -258,6 +258,18 @@ class Context(object):
         L.check(rc)
         return float(out[0]), float(out[1]), float(out[2])
 
+    def format_doubles(self, vals):
+        """python-2 str(float) of every value, formatted ON THE DEVICE (natac_format_doubles; validation of the track writer's
+        '%.12g' arithmetic).  Returns (list of str, number of undecidable values)."""
+        v = _f64(np.ravel(vals))
+        n = v.shape[0]
+        out = np.empty(24 * n, dtype=np.uint8)
+        off = np.empty(n + 1, dtype=np.int64)
+        hard = C.c_int32(0)
+        L.check(self._lib.natac_format_doubles(self._h, _ptr(v), n, _ptr(out), out.nbytes, _ptr(off), C.byref(hard)))
+        raw = out.tobytes()
+        return [raw[off[i]:off[i + 1]].decode("ascii") for i in range(n)], hard.value
+
     # ---- profiling ---------------------------------------------------------------------------
     def profile_enable(self, on=True):
         L.check(self._lib.natac_profile_enable(self._h, 1 if on else 0))
@@ -402,6 +414,28 @@ class DeviceBatch(object):
         nd = np.empty((self.packed.n_chunks, upper), dtype=np.float64)
         L.check(self._lib.natac_download_nuc_dist(self._h, _ptr(nd), nd.nbytes))
         return cc, cp, occ, lo, up, rd, keep, nd
+
+    def format_track(self, t, chroms, chunk_start, write_zero=True, compress=True, keep_runs_before_nan=False, out=None):
+        """Track.write_track of per-base track `t` for every chunk ON THE DEVICE (natac_batch_format_track): returns
+        (bytes as a uint8 array -- bedGraph text, or BGZF members when `compress` --, info dict).  `chroms`: one chromosome name
+        per chunk; `out`: a function n_bytes -> uint8 buffer (e.g. a pinned slot) that receives the result."""
+        nc = self.packed.n_chunks
+        if len(chroms) != nc or len(chunk_start) != nc:
+            raise ValueError("one chromosome name and start per chunk")
+        names = sorted(set(str(c) for c in chroms))
+        idx = {c: i for i, c in enumerate(names)}
+        cid = np.array([idx[str(c)] for c in chroms], dtype=np.int32)
+        cs = np.ascontiguousarray(chunk_start, dtype=np.int64)
+        arr = (C.c_char_p * len(names))(*[c.encode("ascii") for c in names])
+        nb, nt, nl, hard = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        L.check(self._lib.natac_batch_format_track(self._h, int(t), _ptr(cid), arr, len(names), _ptr(cs),
+                                                   (1 if write_zero else 0) | (2 if keep_runs_before_nan else 0), 1 if compress else 0,
+                                                   C.byref(nb), C.byref(nt), C.byref(nl), C.byref(hard)))
+        buf = out(nb.value) if out is not None else np.empty(nb.value, dtype=np.uint8)
+        if buf.dtype != np.uint8 or buf.size < nb.value:
+            raise ValueError("out must give a uint8 buffer of at least %d bytes" % nb.value)
+        L.check(self._lib.natac_batch_format_fetch(self._h, _ptr(buf), buf.nbytes))
+        return buf[:nb.value], dict(bytes=nb.value, text_bytes=nt.value, lines=nl.value, hard=hard.value)
 
     def track(self, t, out=None):
         """download one per-base track (concatenated over chunks); `out`: destination array (e.g. pinned_empty)"""

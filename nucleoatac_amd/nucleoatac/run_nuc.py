@@ -21,7 +21,9 @@ from ..pyatac.VMat import VMat
 from ..shard import balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, shared_fragment_store
 from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
 from .NucleosomeCalling import NucParameters, fit_fuzz_chunk, nuc_batch, occ_reader_pool, read_occ_tracks
-from .run_occ import _Writer
+from .run_occ import _Phases, _Writer
+
+LAST_TIMINGS = {}
 
 BATCH_CHUNKS = int(os.environ.get("NATAC_BATCH_CHUNKS", "4096"))
 N_CONTEXTS = int(os.environ.get("NATAC_CONTEXTS", "3"))
@@ -118,6 +120,7 @@ def batch_calls(r, params, pool=None, pool_workers=1):
 
 
 def run_nuc(args):
+    ph = _Phases(LAST_TIMINGS)
     vmat = VMat.open(args.vmat)
     chrs = read_chrom_sizes_from_fasta(args.fasta) if args.fasta else read_chrom_sizes_from_bam(args.bam)
     pwm = PWM.open(args.pwm)
@@ -137,6 +140,7 @@ def run_nuc(args):
             fragment_dist = FragmentSizes(0, upper=vmat.upper)
             fragment_dist.calculateSizes(st, chunks)
     fragment_dist = broadcast_object(fragment_dist)
+    ph.mark("read_inputs_sizes")
     params = NucParameters(vmat=vmat, fragmentsizes=fragment_dist, bam=st, fasta=args.fasta, pwm=args.pwm,
                            occ_track=args.occ_track, sd=args.sd, nonredundant_sep=args.nuc_sep,
                            redundant_sep=args.redundant_sep, min_z=args.min_z, min_lr=args.min_lr, atac=args.atac)
@@ -168,7 +172,17 @@ def run_nuc(args):
         for n in track_of:
             write_bedgraph(paths[n], [], [], [0], np.zeros(0), append=False, compress=COMPRESS_LEVEL, finish=(rank == world - 1))
 
+    calls_s = [0.0]
+
     def calls(r):
+        import time
+        t0 = time.perf_counter()
+        try:
+            _calls(r)
+        finally:
+            calls_s[0] += time.perf_counter() - t0
+
+    def _calls(r):
         part = r.tag
         names = sorted(set(c.chrom for c in part))
         idx = {c: i for i, c in enumerate(names)}
@@ -203,6 +217,9 @@ def run_nuc(args):
             raise
         finally:
             writer.finish()
+        ph.mark("pipeline_wall")
+        LAST_TIMINGS["writer_inside_pipeline"] = round(writer.seconds, 3)
+        LAST_TIMINGS["calls_and_fits_inside_writer"] = round(calls_s[0], 3)
     if pool is not None:
         pool.shutdown()
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
@@ -221,3 +238,4 @@ def run_nuc(args):
                 tabix_index(base + ".gz")
             else:
                 tabix_index(base)
+    ph.mark("merge_bgzip_tabix")

@@ -27,6 +27,24 @@ from ..shard import (balanced_ranges, barrier, broadcast_object, ensure_distribu
 from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
 from .Occupancy import FragmentMixDistribution, OccupancyParameters, occ_batch
 
+LAST_TIMINGS = {}      # phase -> seconds of the last run_occ call of this process (bench.py's cli_end_to_end reports them)
+
+
+class _Phases(object):
+    """wall-clock seconds per named phase (cheap: two perf_counter calls per phase)"""
+
+    def __init__(self, store):
+        import time
+        self.store, self.clock = store, time.perf_counter
+        store.clear()
+        self.t = self.clock()
+
+    def mark(self, name):
+        now = self.clock()
+        self.store[name] = round(self.store.get(name, 0.0) + now - self.t, 3)
+        self.t = now
+
+
 BATCH_CHUNKS = int(os.environ.get("NATAC_BATCH_CHUNKS", "4096"))   # chunks per sub-batch (the reference maps cores*5 chunks per round)
 N_CONTEXTS = int(os.environ.get("NATAC_CONTEXTS", "3"))            # contexts (streams) of the pipelined executor
 COMPRESS_LEVEL = 4     # BGZF deflate level of the track files
@@ -97,6 +115,7 @@ class _Writer(threading.Thread):
 
 
 def run_occ(args):
+    ph = _Phases(LAST_TIMINGS)
     chrs = read_chrom_sizes_from_fasta(args.fasta) if args.fasta else read_chrom_sizes_from_bam(args.bam)
     pwm = PWM.open(args.pwm)
     chunks = ChunkList.read(args.bed, chromDict=chrs,
@@ -106,7 +125,9 @@ def run_occ(args):
     ensure_distributed()
     rank, world, _ = env_rank_world()
     # global pre-steps once: BAM decode + shared arrays, size histogram (a3) and modelNFR on rank 0
+    ph.mark("read_fasta_bed")
     st = shared_fragment_store(args.bam)
+    ph.mark("read_bam")
     fragment_dist = None
     if rank == 0:
         fragment_dist = FragmentMixDistribution(0, upper=args.upper)
@@ -118,6 +139,7 @@ def run_occ(args):
         fragment_dist.modelNFR()
         fragment_dist.fragmentsizes.save(args.out + ".fragmentsizes.txt")
     fragment_dist = broadcast_object(fragment_dist)
+    ph.mark("size_hist_modelNFR")
     params = OccupancyParameters(fragment_dist, args.upper, args.fasta, args.pwm, sep=args.nuc_sep, min_occ=args.min_occ,
                                  flank=args.flank, bam=st, ci=args.confidence_interval, step=args.step)
     lens = np.array([c.length() for c in chunks], dtype=np.int64)
@@ -173,10 +195,16 @@ def run_occ(args):
         writer = _Writer(paths, track_of, peaks_and_dists, len(parts), rank == world - 1)
         writer.start()
 
+        pack_s = [0.0]
+
         def items():
+            import time
             for part in parts:
-                yield pack(part, st, params.fasta, params.chrs, params.pwm if params.fasta is not None else None,
-                           window=params.window, upper=params.upper), part
+                t0 = time.perf_counter()
+                pk = pack(part, st, params.fasta, params.chrs, params.pwm if params.fasta is not None else None,
+                          window=params.window, upper=params.upper)
+                pack_s[0] += time.perf_counter() - t0
+                yield pk, part
 
         device = int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         try:
@@ -191,6 +219,9 @@ def run_occ(args):
                     writer.put(r)
         finally:
             writer.finish()
+        ph.mark("pipeline_wall")
+        LAST_TIMINGS["pack_inside_pipeline"] = round(pack_s[0], 3)
+        LAST_TIMINGS["writer_inside_pipeline"] = round(writer.seconds, 3)
     dists = gather_in_chunk_order(dists, dst=0)
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
     if rank == 0:
@@ -209,3 +240,4 @@ def run_occ(args):
             tabix_index(args.out + "." + n + ".bedgraph.gz")
         nuc_dist = ordered_sum(dists) if dists else np.zeros(args.upper)
         FragmentSizes(0, args.upper, vals=nuc_dist).save(args.out + ".nuc_dist.txt")
+    ph.mark("merge_bgzip_tabix")

@@ -60,3 +60,20 @@ def tabix_index(path, tbi_path=None, n_threads=0):
     L.check(lib.natac_tabix_index(str(path).encode(), None if tbi_path is None else str(tbi_path).encode(), int(n_threads),
                                   C.byref(n)))
     return n.value
+
+
+def bgzf_lines_host(text):
+    """host restatement of the device BGZF encoder (natac_bgzf_lines_host): the members natac_batch_format_track(compress) produces
+    for `text` (bytes, complete lines), without the EOF marker"""
+    lib = L.load()
+    text = bytes(text)
+    a = np.frombuffer(text, dtype=np.uint8)
+    off = np.concatenate(([0], np.flatnonzero(a[:-1] == 10) + 1)).astype(np.int64) if len(a) else np.zeros(0, np.int64)
+    out = np.empty(len(text) + (len(text) // 0xff00 + 2) * 64 + 1024, dtype=np.uint8)
+    nb = C.c_int64(0)
+    L.check(lib.natac_bgzf_lines_host(text, len(text), off.ctypes.data_as(C.c_void_p), len(off), out.ctypes.data_as(C.c_void_p),
+                                      out.nbytes, C.byref(nb)))
+    return out[:nb.value].tobytes()
+
+
+BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])

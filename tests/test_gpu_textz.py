@@ -1,0 +1,167 @@
+"""GPU: the device-side track writer (natac_batch_format_track: csrc/natac_textfmt.hpp + natac_textz.hpp + natac_deflate.hpp).
+Text: byte-identical to the native host writer (natac_write_bedgraph, itself pinned to the reference's Track.write_track rows and
+python-2 float formatting by tests/test_writer.py).  BGZF: inflates to that text and equals the host restatement of the encoder
+byte for byte; the file is a valid tabix-indexable bedGraph."""
+import gzip
+import io
+import os
+
+import numpy as np
+import pytest
+
+from helpers import golden, packed_from_golden
+from nucleoatac_amd import _lib as L
+from nucleoatac_amd.packing import PackedChunks
+from nucleoatac_amd.pyatac.tracks import _py2_float_str as f2s
+from nucleoatac_amd.synth import make_synthetic_chunks, synth_occ_distributions, synth_size_distribution
+from nucleoatac_amd.writer import BGZF_EOF, bgzf_lines_host, tabix_index, write_bedgraph
+
+pytestmark = pytest.mark.gpu
+
+TRACKS = (L.T_NORM, L.T_SMOOTH, L.T_RAW, L.T_BACKGROUND, L.T_OCC, L.T_OCC_PREFILL, L.T_OCC_LOWER, L.T_OCC_UPPER, L.T_NUC_COV, L.T_INS)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from nucleoatac_amd.device import Context
+    par = golden("params_example")
+    c = Context(0)
+    c.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
+    c.set_sizes(synth_size_distribution(251))
+    nucp, nfrp = synth_occ_distributions(251)
+    c.set_occ_model(nucp, nfrp, step=5, flank=60)
+    yield c
+    c.close()
+
+
+def test_device_formatter_is_python2_str(ctx):
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([
+        rng.random(100000), rng.normal(0, 1, 100000) * np.exp(rng.normal(0, 8, 100000)), 10.0 ** rng.uniform(-320, 308, 50000),
+        rng.integers(0, 10 ** 6, 50000).astype(float), (rng.integers(0, 10 ** 13, 50000) + 0.5) / 10.0 ** rng.integers(0, 14, 50000),
+        np.frombuffer(rng.integers(0, 2 ** 63, 100000, dtype=np.int64).tobytes(), dtype=np.float64),
+        np.array([0.0, -0.0, 1.0, 0.1, 1e-4, 9.99999999999e-5, 1e11, 1e12, 999999999999.5, 999999999999.4999, 1e-5, 123456789012.5,
+                  5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf, -np.inf, 1e22, 0.30000000000000004, 1e-44, 1e-45,
+                  100000000000.5, 99999999999.95, 2.5, 0.125])])
+    vals = vals[~np.isnan(vals)]
+    got, hard = ctx.format_doubles(vals)
+    assert hard == 0                      # undecidable cases need an exact tie at |v| >= 1e12: none in this sample
+    want = [f2s(float(v)) for v in vals]
+    bad = [(v, g, w) for v, g, w in zip(vals, got, want) if g != w]
+    assert not bad, bad[:10]
+    # the only inputs the truncated power-of-ten table cannot decide: exact ties beyond its exact range -- counted, not guessed
+    _, hard = ctx.format_doubles(np.array([1234567890125.0, 875485468971500.0]))
+    assert hard == 2
+
+
+def _native_text(tmp_path, chroms, starts, out_off, vals, **kw):
+    p = str(tmp_path / "native.bedgraph")
+    write_bedgraph(p, chroms, starts, out_off, vals, compress=0, **kw)
+    return open(p, "rb").read()
+
+
+def _ragged_batch(ctx):
+    rng = np.random.default_rng(5)
+    lens = [121, 122, 333, 1204, 700, 2120, 640]
+    fr = []
+    for i, Lc in enumerate(lens):
+        if i == 2:
+            l, n = np.zeros(0, np.int64), np.zeros(0, np.int64)
+        else:
+            n = np.concatenate((rng.integers(1, 400, size=60 + i * 40), [1, 2, 0, 1999, 2500, 250, 251]))
+            l = rng.integers(-300, Lc + 200, size=len(n))
+            if i == 5:                                   # a fragment-free stretch: NaN gaps in the occupancy tracks
+                keep = (l + n // 2 < 600) | (l + n // 2 > 1500)
+                l, n = l[keep], n[keep]
+        o = np.argsort(l + (n - 1) // 2, kind="stable")
+        fr.append((l[o], n[o]))
+    off = np.concatenate(([0], np.cumsum([len(x[0]) for x in fr])))
+    nb = [Lc + 493 for Lc in lens]
+    pk = PackedChunks(np.arange(len(lens)) * 5000 + 999000, lens, off, np.concatenate([x[0] for x in fr]),
+                      np.concatenate([x[1] for x in fr]), np.concatenate(([0], np.cumsum(nb))), rng.normal(0, 0.7, size=sum(nb)))
+    chroms = ["chrI", "chrI", "chrII", "chrII", "scaffold_12_random", "chrX", "chrX"]
+    return pk, chroms
+
+
+def test_device_text_equals_native_writer(ctx, tmp_path):
+    cases = []
+    pk, chroms = _ragged_batch(ctx)
+    cases.append((pk, chroms))
+    for name in ("chunks_basic", "chunks_gaps"):
+        g = golden(name)
+        gp = packed_from_golden(g)
+        cases.append((gp, ["chr%d" % (k % 3 + 1) for k in range(gp.n_chunks)]))
+    n_lines = n_nan_runs = 0
+    for pk, chroms in cases:
+        b = ctx.upload(pk)
+        b.run_nuc(10)
+        b.run_occ()
+        b.run_ins(0, 2000)
+        for t in TRACKS:
+            vals = b.track(t).astype(np.float64)
+            for wz, keep in ((True, False), (False, False), (True, True)):
+                text, info = b.format_track(t, chroms, pk.chunk_start, write_zero=wz, keep_runs_before_nan=keep, compress=False)
+                want = _native_text(tmp_path, chroms, pk.chunk_start, pk.out_off, vals, write_zero=wz, keep_runs_before_nan=keep)
+                assert info["hard"] == 0
+                assert text.tobytes() == want, (t, wz, keep)
+                assert info["text_bytes"] == len(want) and info["lines"] == want.count(b"\n")
+                n_lines += info["lines"]
+            n_nan_runs += int(np.isnan(vals).any())
+        b.free()
+    assert n_lines > 100000 and n_nan_runs >= 3           # NaN runs (and the runs before them) were exercised
+
+
+def test_device_bgzf_members(ctx, tmp_path):
+    from nucleoatac_amd.pyatac.tracks import Track
+    pk = make_synthetic_chunks(300, 2120, 500, seed=9)
+    chroms = ["chr%d" % (1 + k // 100) for k in range(pk.n_chunks)]
+    b = ctx.upload(pk)
+    b.run_nuc(10)
+    b.run_occ()
+    b.run_ins(0, 2000)
+    for t in (L.T_OCC, L.T_NORM, L.T_SMOOTH, L.T_INS, L.T_OCC_PREFILL):
+        text, ti = b.format_track(t, chroms, pk.chunk_start, compress=False)
+        z, zi = b.format_track(t, chroms, pk.chunk_start, compress=True)
+        text, z = text.tobytes(), z.tobytes()
+        assert zi["text_bytes"] == len(text) and zi["lines"] == ti["lines"]
+        assert gzip.GzipFile(fileobj=io.BytesIO(z + BGZF_EOF)).read() == text, t
+        assert z == bgzf_lines_host(text), t                     # the kernels and the host restatement emit the same members
+        print("track %d: %d lines, %.2f bytes of BGZF per line (text %.1f)" % (t, zi["lines"], len(z) / zi["lines"], len(text) / zi["lines"]))
+    # a complete file: members + EOF marker, tabix index, region reads give the values back
+    vals = b.track(L.T_OCC)
+    z, _ = b.format_track(L.T_OCC, chroms, pk.chunk_start, compress=True)
+    path = str(tmp_path / "occ.bedgraph.gz")
+    with open(path, "wb") as fh:
+        fh.write(z.tobytes() + BGZF_EOF)
+    assert tabix_index(path) > 100000
+    for k in (0, 150, 299):
+        s = int(pk.chunk_start[k])
+        tr = Track(chroms[k], s, s + 2120)
+        tr.read_track(path)
+        ref = vals[int(pk.out_off[k]):int(pk.out_off[k + 1])]
+        m = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(tr.vals), ~m)
+        assert np.array_equal(tr.vals[m], np.array([float(f2s(float(x))) for x in ref[m]]))
+    b.free()
+
+
+def test_device_writer_at_scale(ctx):
+    """20,000 configs[2] chunks (42.4 Mbp): one call per track; text size = what the native writer produces, members inflate"""
+    import time
+    pk = make_synthetic_chunks(20000, 2120, 500, seed=3)
+    chroms = ["chr%d" % (1 + k // 5000) for k in range(pk.n_chunks)]
+    b = ctx.upload(pk)
+    b.run_occ()
+    t0 = time.perf_counter()
+    z, info = b.format_track(L.T_OCC, chroms, pk.chunk_start, compress=True)
+    dt = time.perf_counter() - t0
+    print("device writer: %.1f Mbp track -> %d lines, %.1f MB of text, %.1f MB of BGZF in %.3f s (%.0f Mbp/s)" % (
+        pk.total_bp / 1e6, info["lines"], info["text_bytes"] / 1e6, info["bytes"] / 1e6, dt, pk.total_bp / dt / 1e6))
+    raw = gzip.GzipFile(fileobj=io.BytesIO(z.tobytes() + BGZF_EOF)).read()
+    assert len(raw) == info["text_bytes"] and raw.count(b"\n") == info["lines"]
+    vals = b.track(L.T_OCC)
+    k = 12345
+    seg = vals[int(pk.out_off[k]):int(pk.out_off[k]) + 3]
+    first = ("%s\t%d\t%d\t%s\n" % (chroms[k], int(pk.chunk_start[k]), int(pk.chunk_start[k]) + 1, f2s(float(seg[0])))).encode()
+    assert first in raw
+    b.free()
