@@ -330,7 +330,7 @@ def bench_stages(tracks=()):
 
 
 # ------------------------------------------------------------------------------------------------ host-to-host pipeline
-def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_threads):
+def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_threads, as_text=False):
     """SURVEY.md section 8(d)'s boundary: packed inputs in host memory -> per-base tracks back in host memory, through the
     product's own executor (nucleoatac_amd/executor.py::PipelinedExecutor, the class `nucleoatac occ` / `nuc` run on): the
     chunk list is cut into sub-batches; `n_threads` host threads, each with its own natac context (stream) on the same GPU,
@@ -346,15 +346,19 @@ def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_thread
         s = pk.subset(i * sub_chunks, min(pk.n_chunks, (i + 1) * sub_chunks))
         subs.append(PackedChunks(chunk_start=s.chunk_start, chunk_len=s.chunk_len, frag_off=s.frag_off,
                                  frag_lpos=pinned_copy(s.frag_lpos), frag_ilen=pinned_copy(s.frag_ilen), bias_off=s.bias_off,
-                                 bias_log=pinned_copy(s.bias_log)))
+                                 bias_log=pinned_copy(s.bias_log), chroms=["chr%d" % (1 + (i * sub_chunks + k) % 22) for k in range(s.n_chunks)]))
     tracks = [getattr(L, t) for t in H2H_TRACKS]
+    stages = bench_stages(tracks)
+    if as_text:      # the same five tracks as finished bedGraph.gz bytes: Track.write_track + bgzip on the device
+        from nucleoatac_amd.executor import Stages
+        stages = Stages(nuc_sd=10, occ=True, ins=(0, 2000), peaks=dict(min_signal=0, sep=25, boundary=60, order=12), text_tracks=tracks)
 
     def configure(ctx):
         ctx.set_vmat(par["vmat"], int(par["vlower"]), int(par["vupper"]))
         ctx.set_sizes(sizes)
         ctx.set_occ_model(nucp, nfrp, step=5, flank=60)
 
-    with PipelinedExecutor(device, configure, bench_stages(tracks), n_contexts=n_threads, slots_per_context=2) as ex:
+    with PipelinedExecutor(device, configure, stages, n_contexts=n_threads, slots_per_context=2) as ex:
         for r in ex.map((s, None) for s in subs):            # untimed pass: contexts, pool blocks, pinned slots
             r.release()
         ex.bytes_down = ex.bytes_up = 0
@@ -369,6 +373,7 @@ def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_thread
                 sub_batches=nsub, chunks_per_sub_batch=sub_chunks, contexts=n_threads,
                 executor="nucleoatac_amd.executor.PipelinedExecutor (product code)",
                 tracks_downloaded=list(H2H_TRACKS) + ["candidates (chunk, pos, lr, var, z)"], candidates_per_step=ncand // max(1, steps),
+                form="bedGraph.gz bytes (run-length text + BGZF formed on the device)" if as_text else "float64 arrays",
                 gb_down_per_step=round(down / steps / 1e9, 3), gb_up_per_step=round(up / steps / 1e9, 3),
                 pcie_gbs_down=round(down / dt / 1e9, 2), pcie_gbs_up=round(up / dt / 1e9, 2),
                 note="pinned host buffers both ways; uploads, kernels and downloads of different sub-batches overlap")
@@ -515,6 +520,7 @@ def main():
         ctx.close()
         ctx = None
         h2h = host_to_host(subs[0], local_rank, par, sizes, nucp, nfrp, a.steps, a.h2h_sub, a.h2h_threads)
+        h2h["as_bedgraph_gz"] = host_to_host(subs[0], local_rank, par, sizes, nucp, nfrp, a.steps, a.h2h_sub, a.h2h_threads, as_text=True)
     e2e = None
     if rank == 0 and world == 1 and a.cli_chunks > 0 and a.workload == "cfg3":
         if ctx is not None:

@@ -35,12 +35,15 @@ class Stages(object):
     ins         (lower, upper) for natac_run_ins, or None
     peaks       kwargs of DeviceBatch.run_peaks (candidate search + LR / var / z), or None
     occ_peaks   kwargs of DeviceBatch.run_occ_peaks (OccChunk.callPeaks + getNucDist), or None
-    tracks      per-base tracks to download (NATAC_T_* ids)
+    tracks      per-base tracks to download as arrays (NATAC_T_* ids)
+    text_tracks per-base tracks to bring back as finished bedGraph.gz bytes instead: Track.write_track + bgzip run on the device
+                (natac_batch_format_track); the sub-batch needs `chroms` and `chunk_start` (pipeline.pack sets them)
     """
 
-    def __init__(self, nuc_sd=10, occ=True, ins=(0, 2000), peaks=None, occ_peaks=None, tracks=()):
+    def __init__(self, nuc_sd=10, occ=True, ins=(0, 2000), peaks=None, occ_peaks=None, tracks=(), text_tracks=()):
         self.nuc_sd, self.occ, self.ins, self.peaks, self.occ_peaks = nuc_sd, occ, ins, peaks, occ_peaks
         self.tracks = tuple(int(t) for t in tracks)
+        self.text_tracks = tuple(int(t) for t in text_tracks)
 
     def run(self, batch):
         """launch every stage on `batch` (asynchronous except the candidate counts); returns the number of nuc candidates
@@ -96,13 +99,13 @@ class ResidentShard(object):
 
 class Result(object):
     """outputs of one sub-batch in page-locked host memory; `release()` hands the buffers back to the executor"""
-    __slots__ = ("seq", "packed", "tag", "tracks", "peaks", "occ_peaks", "status", "_slot", "_ex")
+    __slots__ = ("seq", "packed", "tag", "tracks", "text", "peaks", "occ_peaks", "status", "_slot", "_ex")
 
     def release(self):
         if self._slot is not None:
             self._ex._free_slot(self._slot)
             self._slot = None
-        self.tracks = self.peaks = self.occ_peaks = None
+        self.tracks = self.text = self.peaks = self.occ_peaks = None
 
 
 class _Slot(object):
@@ -175,10 +178,23 @@ class PipelinedExecutor(object):
             for t in st.tracks:
                 dt = np.int32 if t == L.T_INS else np.float64
                 r.tracks[t] = b.track(t, out=slot.view(t, b.total_bp, dt))
+            r.text = {}
+            for t in st.text_tracks:
+                # Track.write_track + bgzip on the device: BGZF members straight into the pinned slot
+                buf, info = b.format_track(t, packed.chroms, packed.chunk_start, compress=True,
+                                           out=lambda nbytes, t=t: slot.view(("z", t), nbytes, np.uint8))
+                if info["hard"]:        # a value whose 12th digit the device table cannot decide (|v| >= 1e12 ties): host formatter
+                    if t not in r.tracks:
+                        dt = np.int32 if t == L.T_INS else np.float64
+                        r.tracks[t] = b.track(t, out=slot.view(t, b.total_bp, dt))
+                    r.text[t] = None
+                else:
+                    r.text[t] = buf
             r.peaks = b.download_peaks(n) if st.peaks is not None else None
             r.occ_peaks = b.run_occ_peaks(**st.occ_peaks) if st.occ_peaks is not None else None
             r.status = b.status()
-            down = sum(a.nbytes for a in r.tracks.values()) + (n * 32 if st.peaks is not None else 0)
+            down = sum(a.nbytes for a in r.tracks.values()) + (n * 32 if st.peaks is not None else 0) + \
+                sum(a.nbytes for a in r.text.values() if a is not None)
             up = packed.frag_lpos.nbytes + packed.frag_ilen.nbytes + (packed.bias_log.nbytes if packed.bias_log is not None else 0)
             with self._lock:
                 self.bytes_down += down

@@ -21,7 +21,7 @@ from ..pyatac.VMat import VMat
 from ..shard import balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, shared_fragment_store
 from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
 from .NucleosomeCalling import NucParameters, fit_fuzz_chunk, nuc_batch, occ_reader_pool, read_occ_tracks
-from .run_occ import _Phases, _Writer
+from .run_occ import DEVICE_WRITER, _Phases, _Writer
 
 LAST_TIMINGS = {}
 
@@ -195,10 +195,13 @@ def run_nuc(args):
 
     if parts:
         # the calls need coverage, raw and smoothed values at the candidates: downloaded with the tracks that are written
-        need = tuple(dict.fromkeys(list(track_of.values()) + [L.T_NORM, L.T_SMOOTH, L.T_RAW, L.T_NUC_COV, L.T_NFR_COV]))
+        need = [L.T_NORM, L.T_SMOOTH, L.T_RAW, L.T_NUC_COV, L.T_NFR_COV]
+        if not DEVICE_WRITER:
+            need = list(dict.fromkeys(list(track_of.values()) + need))
         stages = Stages(nuc_sd=params.smooth_sd, occ=False, ins=None,
                         peaks=dict(min_signal=0, sep=params.redundant_sep, boundary=params.nonredundant_sep // 2,
-                                   order=params.redundant_sep // 2), tracks=need)
+                                   order=params.redundant_sep // 2), tracks=need,
+                        text_tracks=tuple(track_of.values()) if DEVICE_WRITER else ())
         writer = _Writer(paths, track_of, calls, len(parts), rank == world - 1)
         writer.start()
         fa_chrs = read_chrom_sizes_from_fasta(params.fasta) if params.fasta is not None else params.chrs

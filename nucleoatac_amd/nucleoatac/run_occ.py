@@ -24,7 +24,7 @@ from ..pyatac.fragmentsizes import FragmentSizes
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
 from ..shard import (balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, gather_in_chunk_order,
                      ordered_sum, shared_fragment_store)
-from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
+from ..writer import BGZF_EOF, bgzip_file, tabix_index, write_bed_rows, write_bedgraph
 from .Occupancy import FragmentMixDistribution, OccupancyParameters, occ_batch
 
 LAST_TIMINGS = {}      # phase -> seconds of the last run_occ call of this process (bench.py's cli_end_to_end reports them)
@@ -47,7 +47,9 @@ class _Phases(object):
 
 BATCH_CHUNKS = int(os.environ.get("NATAC_BATCH_CHUNKS", "4096"))   # chunks per sub-batch (the reference maps cores*5 chunks per round)
 N_CONTEXTS = int(os.environ.get("NATAC_CONTEXTS", "3"))            # contexts (streams) of the pipelined executor
-COMPRESS_LEVEL = 4     # BGZF deflate level of the track files
+COMPRESS_LEVEL = 4     # BGZF deflate level of the track files written by the host writer
+# Track.write_track + bgzip on the GPU (natac_batch_format_track); NATAC_DEVICE_WRITER=0: the native host writer formats the tracks
+DEVICE_WRITER = os.environ.get("NATAC_DEVICE_WRITER", "1") != "0"
 
 
 def _occHelper(arg):
@@ -93,8 +95,16 @@ class _Writer(threading.Thread):
                     part = r.tag
                     chroms, starts = [c.chrom for c in part], [c.start for c in part]
                     for name, path in self.paths.items():
-                        write_bedgraph(path, chroms, starts, r.packed.out_off, r.tracks[self.track_of[name]], append=r.seq > 0,
-                                       compress=COMPRESS_LEVEL, finish=(r.seq == self.nb - 1 and self.last_rank))
+                        t = self.track_of[name]
+                        z = r.text.get(t) if r.text else None
+                        if z is not None:       # finished BGZF members from the device: append them (+ the EOF marker at the very end)
+                            with open(path, "ab" if r.seq > 0 else "wb") as fh:
+                                fh.write(memoryview(z))
+                                if r.seq == self.nb - 1 and self.last_rank:
+                                    fh.write(BGZF_EOF)
+                        else:
+                            write_bedgraph(path, chroms, starts, r.packed.out_off, r.tracks[t], append=r.seq > 0,
+                                           compress=COMPRESS_LEVEL, finish=(r.seq == self.nb - 1 and self.last_rank))
                     self.extra(r)
                     self.seconds += time.perf_counter() - t0
             except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
@@ -191,7 +201,8 @@ def run_occ(args):
 
     if parts:
         stages = Stages(nuc_sd=None, occ=True, ins=None, occ_peaks=dict(min_occ=params.min_occ, sep=params.sep),
-                        tracks=tuple(track_of.values()))
+                        tracks=() if DEVICE_WRITER else tuple(track_of.values()),
+                        text_tracks=tuple(track_of.values()) if DEVICE_WRITER else ())
         writer = _Writer(paths, track_of, peaks_and_dists, len(parts), rank == world - 1)
         writer.start()
 
