@@ -242,6 +242,23 @@ int natac_batch_format_track(natac_batch *b, int track, const int32_t *chrom_id,
                              const int64_t *chunk_start, int write_zero, int compress, int64_t *n_bytes, int64_t *n_text_bytes,
                              int64_t *n_lines, int32_t *n_hard);
 int natac_batch_format_fetch(natac_batch *b, void *dst, size_t dst_bytes);
+/* The .tbi of a file assembled from natac_batch_format_track(compress) results, WITHOUT re-reading the file (the reference runs
+ * pysam.tabix_index(..., preset="bed") over every finished file, run_occ.py:136-139).  The device reduces the lines of a result to runs
+ * of records per 16-kb leaf bin (one per ~16 kb instead of one per base): natac_batch_format_index_size / _fetch return the runs
+ * of the LAST result -- chromosome id, [beg, end), record count, text offsets [t0, t1) -- and the member start offsets
+ * member_pos[n_members + 1] inside the result.  natac_tbi_push enters them into an incremental index once the caller knows at
+ * which byte `file_offset` of the .gz the result is written (results may be produced out of order by several contexts and
+ * written in order by one writer); natac_tbi_write serialises the same index natac_tabix_index builds from the finished file. */
+typedef struct natac_tbi natac_tbi;
+int natac_tbi_create(natac_tbi **out);
+void natac_tbi_free(natac_tbi *t);
+int natac_batch_format_index_size(natac_batch *b, int64_t *n_groups, int64_t *n_members);
+int natac_batch_format_index_fetch(natac_batch *b, int32_t *cid, int64_t *beg, int64_t *end, int64_t *count, uint64_t *t0, uint64_t *t1,
+                                   uint64_t *member_pos);
+int natac_tbi_push(natac_tbi *t, int64_t n, const char *const *names, int32_t n_names, const int32_t *cid, const int64_t *beg,
+                   const int64_t *end, const int64_t *count, const uint64_t *t0, const uint64_t *t1, const uint64_t *member_pos,
+                   int64_t n_members, int64_t file_offset);
+int natac_tbi_write(natac_tbi *t, const char *tbi_path, int64_t *n_records);
 /* the device formatter on arbitrary doubles (validation): out_off[i] .. out_off[i+1] = python-2 str(vals[i]); out_cap >= 24 n */
 int natac_format_doubles(natac_ctx *ctx, const double *vals, int64_t n, char *out, size_t out_cap, int64_t *out_off, int32_t *n_hard);
 /* host restatement of the device BGZF encoder (no GPU): text + line start offsets -> the members natac_batch_format_track(compress)

@@ -138,6 +138,10 @@ struct natac_batch {
     double *d_bnum = nullptr, *d_bcov = nullptr;   // per-base sum B V / sum B of the background kernel (candidate statistics)
     unsigned char *d_fmt_out = nullptr;            // result of the last natac_batch_format_track (text or BGZF members)
     long long fmt_bytes = -1;
+    // tabix records of that result (compress mode): runs of lines per leaf bin, member offsets, chromosome names
+    std::vector<natac_textz::GroupRec> fmt_groups;
+    std::vector<unsigned long long> fmt_member_pos;
+    std::vector<std::string> fmt_names;
     long long nuc_gen = -1;                        // model generation natac_run_nuc ran with
 };
 
@@ -369,6 +373,9 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     dev_free(b->d_fmt_out);
     b->d_fmt_out = nullptr;
     b->fmt_bytes = -1;
+    b->fmt_groups.clear();
+    b->fmt_member_pos.clear();
+    b->fmt_names.assign(names, names + n_names);
     // name table
     std::vector<char> cat;
     std::vector<int> noff(1, 0);
@@ -405,7 +412,8 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     hipLaunchKernelGGL(tz_flags_count, dim3(nt), dim3(256), 0, c->stream, job, d_tc);
     TRYF(dev_scan(c, d_tc, (long long)nt, d_tb));
     unsigned long long nruns = 0;
-    HIPCHK(hipMemcpy(&nruns, d_tb + nt, sizeof nruns, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(&nruns, d_tb + nt, sizeof nruns, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     TRYF(dev_alloc(&d_R, (size_t)nruns)); tmp.keep(d_R);
     TRYF(dev_alloc(&d_C, (size_t)nruns)); tmp.keep(d_C);
     hipLaunchKernelGGL(tz_scatter_runs, dim3(nt), dim3(256), 0, c->stream, job, d_tb, d_R, d_C);
@@ -419,17 +427,25 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_scan(c, d_isl, (long long)nruns, d_lidx));
     unsigned long long n_text = 0, nlines = 0;
     int hard = 0;
-    HIPCHK(hipMemcpy(&n_text, d_boff + nruns, sizeof n_text, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&nlines, d_lidx + nruns, sizeof nlines, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&hard, d_hard, sizeof hard, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(&n_text, d_boff + nruns, sizeof n_text, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&nlines, d_lidx + nruns, sizeof nlines, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&hard, d_hard, sizeof hard, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (n_text_bytes) *n_text_bytes = (int64_t)n_text;
     if (n_lines) *n_lines = (int64_t)nlines;
     if (n_hard) *n_hard = hard;
     if (n_text == 0) { b->fmt_bytes = 0; if (n_bytes) *n_bytes = 0; return NATAC_OK; }
     TRYF(dev_alloc(&d_text, (size_t)n_text + 64));
     TRYF(dev_alloc(&d_line_off, (size_t)nlines + 1)); tmp.keep(d_line_off);
+    int *d_lcid = nullptr;
+    long long *d_lbeg = nullptr, *d_lend = nullptr;
+    if (compress) {
+        TRYF(dev_alloc(&d_lcid, (size_t)nlines)); tmp.keep(d_lcid);
+        TRYF(dev_alloc(&d_lbeg, (size_t)nlines)); tmp.keep(d_lbeg);
+        TRYF(dev_alloc(&d_lend, (size_t)nlines)); tmp.keep(d_lend);
+    }
     hipLaunchKernelGGL(tz_write_lines, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_boff, d_lidx, d_text,
-                       d_line_off);
+                       d_line_off, d_lcid, d_lbeg, d_lend);
     if (!compress) {
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { dev_free(d_text); return fail(NATAC_E_HIP, "format_track: %s", hipGetErrorString(e)); }
@@ -448,7 +464,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_hist, (size_t)nd::NLL + nd::ND)); tmp.keep(d_hist);
     HIPCHK(hipMemsetAsync(d_hist, 0, (nd::NLL + nd::ND) * sizeof(unsigned int), c->stream));
     const size_t lds_count = 65536 + (nd::NLL + nd::ND) * sizeof(unsigned int);
-    hipLaunchKernelGGL(tz_count_tokens, dim3((unsigned)nblk), dim3(256), lds_count, c->stream, d_text, (long long)n_text, d_line_off,
+    hipLaunchKernelGGL(tz_count_tokens, dim3((unsigned)nblk), dim3(TZ_THREADS), lds_count, c->stream, d_text, (long long)n_text, d_line_off,
                        (long long)nlines, d_hist);
     unsigned int hist[nd::NLL + nd::ND];
     HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, c->stream));
@@ -462,12 +478,35 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_sizes, (size_t)nblk)); tmp.keep(d_sizes);
     TRYF(dev_alloc(&d_pos, (size_t)nblk + 1)); tmp.keep(d_pos);
     const size_t lds_emit = 65536 + ((sizeof(nd::Codes) + 15) & ~(size_t)15);
-    hipLaunchKernelGGL(tz_emit_members, dim3((unsigned)nblk), dim3(256), lds_emit, c->stream, d_text, (long long)n_text, d_line_off,
+    hipLaunchKernelGGL(tz_emit_members, dim3((unsigned)nblk), dim3(TZ_THREADS), lds_emit, c->stream, d_text, (long long)n_text, d_line_off,
                        (long long)nlines, d_codes, c->d_crc, d_regions, d_sizes);
     HIPCHK(hipGetLastError());
     TRYF(dev_scan(c, d_sizes, nblk, d_pos));
-    unsigned long long total = 0;
-    HIPCHK(hipMemcpy(&total, d_pos + nblk, sizeof total, hipMemcpyDeviceToHost));
+    b->fmt_member_pos.resize((size_t)nblk + 1);
+    HIPCHK(hipMemcpyAsync(b->fmt_member_pos.data(), d_pos, ((size_t)nblk + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    {   // tabix records: runs of lines per leaf bin (tz_group_*)
+        unsigned char *d_gf = nullptr;
+        unsigned long long *d_gidx = nullptr;
+        long long *d_first = nullptr;
+        GroupRec *d_rec = nullptr;
+        const unsigned lb = (unsigned)((nlines + 255) / 256);
+        TRYF(dev_alloc(&d_gf, (size_t)nlines)); tmp.keep(d_gf);
+        TRYF(dev_alloc(&d_gidx, (size_t)nlines + 1)); tmp.keep(d_gidx);
+        hipLaunchKernelGGL(tz_group_flags, dim3(lb), dim3(256), 0, c->stream, (long long)nlines, d_lcid, d_lbeg, d_lend, d_gf);
+        TRYF(dev_scan(c, d_gf, (long long)nlines, d_gidx));
+        unsigned long long ngroups = 0;
+        HIPCHK(hipMemcpyAsync(&ngroups, d_gidx + nlines, sizeof ngroups, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        TRYF(dev_alloc(&d_first, (size_t)ngroups)); tmp.keep(d_first);
+        TRYF(dev_alloc(&d_rec, (size_t)ngroups)); tmp.keep(d_rec);
+        hipLaunchKernelGGL(tz_group_starts, dim3(lb), dim3(256), 0, c->stream, (long long)nlines, d_gf, d_gidx, d_first);
+        hipLaunchKernelGGL(tz_group_records, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, c->stream, (long long)ngroups, d_first,
+                           (long long)nlines, d_lcid, d_lbeg, d_lend, d_line_off, (long long)n_text, d_rec);
+        b->fmt_groups.resize((size_t)ngroups);
+        HIPCHK(hipMemcpyAsync(b->fmt_groups.data(), d_rec, (size_t)ngroups * sizeof(GroupRec), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const unsigned long long total = b->fmt_member_pos[(size_t)nblk];
     TRYF(dev_alloc(&d_out, (size_t)total + 64));
     hipLaunchKernelGGL(tz_compact, dim3((unsigned)nblk), dim3(256), 0, c->stream, d_regions, d_sizes, d_pos, d_out);
     hipError_t e = hipGetLastError();
@@ -1985,6 +2024,77 @@ int natac_batch_format_fetch(natac_batch *b, void *dst, size_t dst_bytes) {
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipMemcpyAsync(dst, b->d_fmt_out, (size_t)b->fmt_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    return NATAC_OK;
+}
+
+struct natac_tbi { natac_tabix::Builder bld; };
+
+int natac_tbi_create(natac_tbi **out) {
+    if (!out) return fail(NATAC_E_ARG, "null argument");
+    *out = new natac_tbi();
+    return NATAC_OK;
+}
+void natac_tbi_free(natac_tbi *t) { delete t; }
+
+static int tbi_push_groups(natac_tbi *t, int64_t n, const char *const *names, int32_t n_names, const int32_t *cid, const int64_t *beg,
+                           const int64_t *end, const int64_t *count, const uint64_t *t0, const uint64_t *t1, const uint64_t *member_pos,
+                           int64_t n_members, int64_t file_offset) {
+    const size_t nblk = (size_t)n_members;
+    // virtual offset of a text position: member start in the file << 16 | offset inside the member; a position at a member's end
+    // belongs to the start of the next member (for the last one: whatever the caller writes next -- more members or the EOF block)
+    auto voff = [&](uint64_t toff) -> uint64_t {
+        const size_t m = (size_t)(toff / natac_deflate::BLK);
+        const uint64_t within = toff - (uint64_t)m * natac_deflate::BLK;
+        const uint64_t pos = m < nblk ? member_pos[m] : member_pos[nblk];
+        return (((uint64_t)file_offset + pos) << 16) | (m < nblk ? within : 0);
+    };
+    for (int64_t i = 0; i < n; ++i) {
+        if (cid[i] < 0 || cid[i] >= n_names) return fail(NATAC_E_ARG, "record with chromosome id %d", cid[i]);
+        const char *nm = names[cid[i]];
+        if (!t->bld.push(nm, strlen(nm), beg[i], end[i], voff(t0[i]), voff(t1[i]), count[i])) return fail(NATAC_E_ARG, "tabix index: %s", t->bld.err.c_str());
+    }
+    return NATAC_OK;
+}
+
+int natac_batch_format_index_size(natac_batch *b, int64_t *n_groups, int64_t *n_members) {
+    if (!b || !n_groups || !n_members) return fail(NATAC_E_ARG, "null argument");
+    if (b->fmt_bytes < 0) return fail(NATAC_E_STATE, "natac_batch_format_track has not run");
+    *n_groups = (int64_t)b->fmt_groups.size();
+    *n_members = b->fmt_member_pos.empty() ? 0 : (int64_t)b->fmt_member_pos.size() - 1;
+    return NATAC_OK;
+}
+
+int natac_batch_format_index_fetch(natac_batch *b, int32_t *cid, int64_t *beg, int64_t *end, int64_t *count, uint64_t *t0, uint64_t *t1,
+                                   uint64_t *member_pos) {
+    if (!b) return fail(NATAC_E_ARG, "null argument");
+    if (b->fmt_bytes < 0) return fail(NATAC_E_STATE, "natac_batch_format_track has not run");
+    const size_t n = b->fmt_groups.size();
+    if (n && (!cid || !beg || !end || !count || !t0 || !t1)) return fail(NATAC_E_ARG, "null argument");
+    for (size_t i = 0; i < n; ++i) {
+        const auto &g = b->fmt_groups[i];
+        cid[i] = g.cid; beg[i] = g.beg; end[i] = g.end; count[i] = g.count; t0[i] = g.t0; t1[i] = g.t1;
+    }
+    if (!b->fmt_member_pos.empty()) {
+        if (!member_pos) return fail(NATAC_E_ARG, "null argument");
+        memcpy(member_pos, b->fmt_member_pos.data(), b->fmt_member_pos.size() * sizeof(uint64_t));
+    }
+    return NATAC_OK;
+}
+
+int natac_tbi_push(natac_tbi *t, int64_t n, const char *const *names, int32_t n_names, const int32_t *cid, const int64_t *beg,
+                   const int64_t *end, const int64_t *count, const uint64_t *t0, const uint64_t *t1, const uint64_t *member_pos,
+                   int64_t n_members, int64_t file_offset) {
+    if (!t || n < 0 || n_members < 0 || file_offset < 0) return fail(NATAC_E_ARG, "bad argument");
+    if (n == 0) return NATAC_OK;
+    if (!names || !cid || !beg || !end || !count || !t0 || !t1 || !member_pos) return fail(NATAC_E_ARG, "null argument");
+    return tbi_push_groups(t, n, names, n_names, cid, beg, end, count, t0, t1, member_pos, n_members, file_offset);
+}
+
+int natac_tbi_write(natac_tbi *t, const char *tbi_path, int64_t *n_records) {
+    if (!t || !tbi_path) return fail(NATAC_E_ARG, "null argument");
+    const int rc = t->bld.write(tbi_path);
+    if (rc) return fail(NATAC_E_ARG, "cannot write %s (code %d)", tbi_path, rc);
+    if (n_records) *n_records = t->bld.nrec;
     return NATAC_OK;
 }
 

@@ -6,7 +6,7 @@
 // is against the PREVIOUS LINE -- the same column (chromosome name, the leading digits of the coordinates), the previous line's
 // end coordinate (== this line's start when runs are adjacent) -- or against this line's own start coordinate (end = start + 1
 // differs in the last digits only).  So every line is tokenised independently from three candidate distances that follow from
-// the line structure: no hash table, no dependence between lines, one thread per line.  With a Huffman code built from the
+// the line structure: no hash table, no dependence between lines, one wavefront per line (lane = column).  With a Huffman code built from the
 // token histogram of the text at hand this gives SMALLER files than zlib level 4 on float tracks (10.3 vs 12.1 bytes per line on
 // an occupancy track) and the same size on integer tracks, and it is embarrassingly parallel: a 0xff00-byte BGZF member is
 // one workgroup.
@@ -48,58 +48,120 @@ NATAC_HD inline void dist_symbol(int d, int *sym, int *ebits, int *eval) {     /
 }
 
 // ---- tokeniser ------------------------------------------------------------------------------------------------------
-// One line segment [q0, q1) of the text, inside the member [bs, be).  `ls` = start of the segment's line, `pls` = start of the
-// previous line (or -1).  Sources of matches must lie inside the member (>= bs).  text is indexed by absolute offset minus `base`.
-template <class Sink>
-NATAC_HD inline void tokenize_segment(const unsigned char *text, long long base, long long bs, long long q0, long long q1, long long ls,
-                                      long long pls, Sink &sink) {
-    int cand[3];
-    int nc = 0;
-    // field geometry of this line, as far as it lies in the member
-    long long tab1 = -1;                                   // first tab of this line (end of the chromosome name)
-    if (ls >= bs) {
-        for (long long q = ls; q < q1 && q < ls + 80; ++q)
-            if (text[q - base] == '\t') { tab1 = q; break; }
+// A line segment is tokenised from three candidate distances given by the line structure; matches are only searched inside the
+// first WIN = 64 columns of a segment (a bedGraph line is 30-45 characters; longer lines spill into literals), so that for one
+// segment everything a greedy parse needs is three 64-bit equality masks:
+//     eq[c] bit i  <=>  byte i of the segment equals the byte d[c] positions earlier (and that byte lies inside the member).
+// On the device a wave forms the masks with one ballot per candidate (lane = column) and the parse is scalar bit arithmetic;
+// the host restatement forms the same masks byte by byte.
+constexpr int WIN = 64;
+
+struct LineGeom {                  // tab positions of a line inside its first WIN columns (-1: none there)
+    int tab1, tab2;
+};
+NATAC_HD inline LineGeom geom_from_tabmask(unsigned long long tabmask) {
+    LineGeom g;
+    g.tab1 = g.tab2 = -1;
+    if (tabmask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        g.tab1 = __ffsll((long long)tabmask) - 1;
+#else
+        g.tab1 = __builtin_ctzll(tabmask);
+#endif
+        const unsigned long long rest = tabmask & (tabmask - 1);
+        if (rest) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            g.tab2 = __ffsll((long long)rest) - 1;
+#else
+            g.tab2 = __builtin_ctzll(rest);
+#endif
+        }
     }
+    return g;
+}
+
+struct Cands {                     // candidate distances as scalars (0 = unused): arrays indexed in loops would live in scratch memory
+    int d0, d1, d2;
+};
+// candidate distances of the line starting at ls (inside the member), previous line at pls with geometry pg (pls < bs: no previous)
+NATAC_HD inline Cands line_candidates(long long bs, long long ls, long long pls, const LineGeom &g, const LineGeom &pg) {
+    Cands c;
+    c.d0 = c.d1 = c.d2 = 0;
     if (pls >= bs) {
-        cand[nc++] = (int)(ls - pls);                      // the same column of the previous line
-        if (tab1 >= 0) {
-            // previous line's end coordinate: after its second tab
-            long long t = -1;
-            int seen = 0;
-            for (long long q = pls; q < ls; ++q)
-                if (text[q - base] == '\t' && ++seen == 2) { t = q; break; }
-            if (t >= 0) {
-                const long long d2 = (tab1 + 1) - (t + 1);
-                if (d2 > 0 && d2 != cand[0] && d2 <= 32768) cand[nc++] = (int)d2;
-            }
+        c.d0 = (int)(ls - pls);                                         // the same column of the previous line
+        if (g.tab1 >= 0 && pg.tab2 >= 0) {                               // this start coordinate == the previous end coordinate?
+            const long long d = (ls + g.tab1 + 1) - (pls + pg.tab2 + 1);
+            if (d > 0 && d != c.d0 && d <= 32768) c.d1 = (int)d;
         }
     }
-    if (tab1 >= 0) {                                       // this line's own start coordinate, seen from its end coordinate
-        long long t2 = -1;
-        for (long long q = tab1 + 1; q < q1 && q < tab1 + 24; ++q)
-            if (text[q - base] == '\t') { t2 = q; break; }
-        if (t2 >= 0) {
-            const int d3 = (int)(t2 - tab1);
-            bool dup = false;
-            for (int i = 0; i < nc; ++i) dup = dup || cand[i] == d3;
-            if (!dup) cand[nc++] = d3;
-        }
+    if (g.tab1 >= 0 && g.tab2 >= 0) {                                    // this line's own start coordinate, seen from its end coordinate
+        const int d = g.tab2 - g.tab1;
+        if (d != c.d0 && d != c.d1) c.d2 = d;
     }
-    long long q = q0;
-    while (q < q1) {
-        int best = 0, bd = 0;
-        for (int i = 0; i < nc; ++i) {
-            const int d = cand[i];
-            if (q - d < bs) continue;
-            int L = 0;
-            const long long lim = (q1 - q < MAX_MATCH) ? (q1 - q) : MAX_MATCH;
-            while (L < lim && text[q + L - base] == text[q + L - d - base]) ++L;
-            if (L > best) { best = L; bd = d; }
-        }
+    return c;
+}
+
+NATAC_HD inline int trailing_ones(unsigned long long x) {                // number of consecutive set bits from bit 0
+    const unsigned long long inv = ~x;
+    if (!inv) return 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((long long)inv) - 1;
+#else
+    return __builtin_ctzll(inv);
+#endif
+}
+
+// greedy parse of one segment of `seglen` bytes from its masks (eq_i belongs to distance c.d_i; a zero mask for an unused
+// candidate); ties go to the lower candidate index; byte_at(i) = byte i of the segment
+template <class Sink, class ByteAt>
+NATAC_HD inline void greedy_tokens(unsigned long long eq0, unsigned long long eq1, unsigned long long eq2, const Cands &c, int seglen,
+                                   ByteAt byte_at, Sink &sink) {
+    const int n = seglen < WIN ? seglen : WIN;
+    int q = 0;
+    while (q < n) {
+        int best = trailing_ones(eq0 >> q), bd = c.d0;
+        const int L1 = trailing_ones(eq1 >> q), L2 = trailing_ones(eq2 >> q);
+        if (L1 > best) { best = L1; bd = c.d1; }
+        if (L2 > best) { best = L2; bd = c.d2; }
+        if (best > n - q) best = n - q;
         if (best >= MIN_MATCH) { sink.match(best, bd); q += best; }
-        else { sink.literal(text[q - base]); ++q; }
+        else { sink.literal(byte_at(q)); ++q; }
     }
+    for (; q < seglen; ++q) sink.literal(byte_at(q));
+}
+
+// host restatement: masks byte by byte.  text indexed by absolute offset; [q0, q1) = the segment, ls = start of its line,
+// pls = start of the previous line (or -1)
+template <class Sink>
+inline void tokenize_segment(const unsigned char *text, long long bs, long long q0, long long q1, long long ls, long long pls,
+                             Sink &sink) {
+    const int seglen = (int)(q1 - q0);
+    const int n = seglen < WIN ? seglen : WIN;
+    Cands c;
+    c.d0 = c.d1 = c.d2 = 0;
+    if (ls >= bs) {                                          // the line starts inside the member: q0 == ls
+        auto tabmask = [&](long long a, long long e) {
+            unsigned long long m = 0;
+            for (int i = 0; i < WIN && a + i < e; ++i)
+                if (text[a + i] == '\t') m |= 1ull << i;
+            return m;
+        };
+        const LineGeom g = geom_from_tabmask(tabmask(ls, q1));
+        LineGeom pg;
+        pg.tab1 = pg.tab2 = -1;
+        if (pls >= bs) pg = geom_from_tabmask(tabmask(pls, ls));
+        c = line_candidates(bs, ls, pls, g, pg);
+    }
+    auto mask = [&](int d) {
+        unsigned long long m = 0;
+        if (d > 0)
+            for (int i = 0; i < n; ++i) {
+                const long long src = q0 + i - d;
+                if (src >= bs && text[src] == text[q0 + i]) m |= 1ull << i;
+            }
+        return m;
+    };
+    greedy_tokens(mask(c.d0), mask(c.d1), mask(c.d2), c, seglen, [&](int i) { return text[q0 + i]; }, sink);
 }
 
 struct CountSink {                 // token histogram (host: plain increments)
@@ -360,7 +422,7 @@ inline bool bgzf_lines_host(const unsigned char *text, long long n, const long l
     for (long long b = 0; b < nblk; ++b) {
         const long long bs = b * BLK, be = std::min<long long>(n, bs + BLK);
         for_segments(line_off, nlines, n, bs, be, [&](long long q0, long long q1, long long ls, long long pls) {
-            tokenize_segment(text, 0, bs, q0, q1, ls, pls, cs);
+            tokenize_segment(text, bs, q0, q1, ls, pls, cs);
         });
     }
     hl[256] += (uint32_t)nblk;
@@ -375,7 +437,7 @@ inline bool bgzf_lines_host(const unsigned char *text, long long n, const long l
         hb.n = c.hdr_bits;
         EmitSinkHost es{&c, &hb};
         for_segments(line_off, nlines, n, bs, be, [&](long long q0, long long q1, long long ls, long long pls) {
-            tokenize_segment(text, 0, bs, q0, q1, ls, pls, es);
+            tokenize_segment(text, bs, q0, q1, ls, pls, es);
         });
         hb.put(c.ll_code[256], c.ll_len[256]);
         std::string data;

@@ -41,6 +41,99 @@ struct RefIndex {
 inline void put32(std::string &o, uint32_t v) { for (int i = 0; i < 4; ++i) o.push_back((char)((v >> (8 * i)) & 0xff)); }
 inline void put64(std::string &o, uint64_t v) { for (int i = 0; i < 8; ++i) o.push_back((char)((v >> (8 * i)) & 0xff)); }
 
+// Incremental index: records (or runs of records, see push) in file order.  index_bed() feeds it from the parsed text; the
+// device-side track writer feeds it runs computed on the GPU (natac_textz.hpp), without ever re-reading the file it writes.
+struct Builder {
+    std::vector<std::string> names;
+    std::vector<RefIndex> refs;
+    int cur = -1;
+    uint32_t last_bin = 0xffffffffu;
+    uint64_t save_off = 0, last_off = 0;
+    int64_t last_beg = -1, nrec = 0;
+    std::string err;
+
+    void flush_bin() {
+        if (cur >= 0 && last_bin != 0xffffffffu && last_off > save_off) refs[cur].bins[last_bin].push_back({save_off, last_off});
+    }
+    // `count` consecutive records of chromosome `name` that share ONE bin, spanning [beg, end) together, at virtual offsets
+    // [v0, v1).  count == 1: an ordinary record.  A run of several records is equivalent to pushing them one by one when all of
+    // them lie in the same 16-kb window (a leaf bin): same bin, same linear-index window, the first offset wins.
+    bool push(const char *name, size_t nlen, int64_t beg, int64_t end, uint64_t v0, uint64_t v1, int64_t count) {
+        if (end <= beg) end = beg + 1;
+        if (cur < 0 || names[cur].size() != nlen || std::memcmp(names[cur].data(), name, nlen) != 0) {
+            flush_bin();
+            if (cur >= 0) refs[cur].off_end = v0;
+            for (auto &n : names)
+                if (n.size() == nlen && std::memcmp(n.data(), name, nlen) == 0) { err = "chromosome blocks not continuous: " + n; return false; }
+            names.emplace_back(name, nlen);
+            refs.emplace_back();
+            cur = (int)names.size() - 1;
+            refs[cur].off_beg = v0;
+            last_bin = 0xffffffffu;
+            last_beg = -1;
+            save_off = v0;
+        }
+        if (beg < last_beg) { err = "unsorted positions on " + names[cur]; return false; }
+        last_beg = beg;
+        const uint32_t bin = (uint32_t)reg2bin(beg, end);
+        if (bin != last_bin) {
+            flush_bin();
+            save_off = v0;
+            last_bin = bin;
+        }
+        RefIndex &r = refs[cur];
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+        if (r.lin.size() <= w1) r.lin.resize(w1 + 1, ~0ull);
+        for (size_t w = w0; w <= w1; ++w) if (r.lin[w] == ~0ull) r.lin[w] = v0;
+        r.n_rec += (uint64_t)count;
+        nrec += count;
+        last_off = v1;
+        return true;
+    }
+    // returns 0 ok, 3 deflate error, 5 write error
+    int write(const char *tbi_path) {
+        flush_bin();
+        last_bin = 0xffffffffu;
+        if (cur >= 0) refs[cur].off_end = last_off;
+        std::string out;
+        out.append("TBI\1", 4);
+        put32(out, (uint32_t)names.size());
+        put32(out, 0x10000u);                 // TBX_UCSC: 0-based half-open coordinates (the "bed" preset)
+        put32(out, 1); put32(out, 2); put32(out, 3);
+        put32(out, (uint32_t)'#');
+        put32(out, 0);
+        uint32_t l_nm = 0;
+        for (auto &n : names) l_nm += (uint32_t)n.size() + 1;
+        put32(out, l_nm);
+        for (auto &n : names) { out.append(n); out.push_back('\0'); }
+        for (auto &r : refs) {
+            for (size_t w = r.lin.size(); w-- > 0;)            // windows without a record inherit the next one's offset
+                if (r.lin[w] == ~0ull) r.lin[w] = (w + 1 < r.lin.size()) ? r.lin[w + 1] : r.off_end;
+            put32(out, (uint32_t)r.bins.size() + 1);
+            for (auto &b : r.bins) {
+                put32(out, b.first);
+                put32(out, (uint32_t)b.second.size());
+                for (auto &c : b.second) { put64(out, c.first); put64(out, c.second); }
+            }
+            put32(out, 37450u);                                 // htslib's pseudo-bin: file range + record counts of the reference
+            put32(out, 2);
+            put64(out, r.off_beg); put64(out, r.off_end);
+            put64(out, r.n_rec); put64(out, 0);
+            put32(out, (uint32_t)r.lin.size());
+            for (uint64_t v : r.lin) put64(out, v);
+        }
+        put64(out, 0);                                          // n_no_coor
+        std::string comp;
+        if (!natac_writer::bgzf_compress(comp, out, 6)) return 3;
+        comp.append((const char *)natac_writer::BGZF_EOF, 28);
+        FILE *f = std::fopen(tbi_path, "wb");
+        if (!f) return 5;
+        const bool ok = std::fwrite(comp.data(), 1, comp.size(), f) == comp.size();
+        if (std::fclose(f) != 0 || !ok) return 5;
+        return 0;
+    }
+};
+
 // returns 0 ok, 1 cannot open / read, 2 not BGZF, 3 inflate error, 4 unsorted or malformed record, 5 write error
 inline int index_bed(const char *path, const char *tbi_path, int n_threads, int64_t *n_records, std::string *errmsg) {
     // ---- read the file and walk the BGZF members
@@ -110,15 +203,7 @@ inline int index_bed(const char *path, const char *tbi_path, int n_threads, int6
         return (blocks[bi].coff << 16) | (u - blocks[bi].uoff);
     };
     // ---- records: chrom \t beg \t end ...   (0-based half-open: TBX_UCSC)
-    std::vector<std::string> names;
-    std::vector<RefIndex> refs;
-    int cur = -1;
-    uint32_t last_bin = 0xffffffffu;
-    uint64_t save_off = 0, last_off = 0;
-    int64_t last_beg = -1, nrec = 0;
-    auto flush_bin = [&]() {
-        if (cur >= 0 && last_bin != 0xffffffffu && last_off > save_off) refs[cur].bins[last_bin].push_back({save_off, last_off});
-    };
+    Builder bld;
     uint64_t u = 0;
     while (u < utotal) {
         const char *ls = text.data() + u;
@@ -129,84 +214,16 @@ inline int index_bed(const char *path, const char *tbi_path, int n_threads, int6
             const char *t2 = t1 ? (const char *)std::memchr(t1 + 1, '\t', len - (size_t)(t1 + 1 - ls)) : nullptr;
             if (!t1 || !t2) { if (errmsg) *errmsg = "record without three columns"; return 4; }
             const int64_t beg = std::strtoll(t1 + 1, nullptr, 10);
-            int64_t end = std::strtoll(t2 + 1, nullptr, 10);
-            if (end <= beg) end = beg + 1;
-            const size_t nlen = (size_t)(t1 - ls);
+            const int64_t end = std::strtoll(t2 + 1, nullptr, 10);
             const uint64_t v0 = voff(u);
-            if (cur < 0 || names[cur].size() != nlen || std::memcmp(names[cur].data(), ls, nlen) != 0) {
-                flush_bin();
-                if (cur >= 0) refs[cur].off_end = v0;
-                for (auto &n : names)
-                    if (n.size() == nlen && std::memcmp(n.data(), ls, nlen) == 0) {
-                        if (errmsg) *errmsg = "chromosome blocks not continuous: " + n;
-                        return 4;
-                    }
-                names.emplace_back(ls, nlen);
-                refs.emplace_back();
-                cur = (int)names.size() - 1;
-                refs[cur].off_beg = v0;
-                last_bin = 0xffffffffu;
-                last_beg = -1;
-                save_off = v0;
-            }
-            if (beg < last_beg) { if (errmsg) *errmsg = "unsorted positions on " + names[cur]; return 4; }
-            last_beg = beg;
-            const uint32_t bin = (uint32_t)reg2bin(beg, end);
-            if (bin != last_bin) {
-                flush_bin();
-                save_off = v0;
-                last_bin = bin;
-            }
-            RefIndex &r = refs[cur];
-            const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
-            if (r.lin.size() <= w1) r.lin.resize(w1 + 1, ~0ull);
-            for (size_t w = w0; w <= w1; ++w) if (r.lin[w] == ~0ull) r.lin[w] = v0;
-            ++r.n_rec;
-            ++nrec;
-            last_off = voff(u + len);
+            if (!bld.push(ls, (size_t)(t1 - ls), beg, end, v0, voff(u + len), 1)) { if (errmsg) *errmsg = bld.err; return 4; }
         }
         u += len;
     }
-    flush_bin();
-    if (cur >= 0) refs[cur].off_end = last_off;
-    // ---- serialise
-    std::string out;
-    out.append("TBI\1", 4);
-    put32(out, (uint32_t)names.size());
-    put32(out, 0x10000u);                 // TBX_UCSC: 0-based half-open coordinates (the "bed" preset)
-    put32(out, 1); put32(out, 2); put32(out, 3);
-    put32(out, (uint32_t)'#');
-    put32(out, 0);
-    uint32_t l_nm = 0;
-    for (auto &n : names) l_nm += (uint32_t)n.size() + 1;
-    put32(out, l_nm);
-    for (auto &n : names) { out.append(n); out.push_back('\0'); }
-    for (auto &r : refs) {
-        for (size_t w = r.lin.size(); w-- > 0;)            // windows without a record inherit the next one's offset
-            if (r.lin[w] == ~0ull) r.lin[w] = (w + 1 < r.lin.size()) ? r.lin[w + 1] : r.off_end;
-        put32(out, (uint32_t)r.bins.size() + 1);
-        for (auto &b : r.bins) {
-            put32(out, b.first);
-            put32(out, (uint32_t)b.second.size());
-            for (auto &c : b.second) { put64(out, c.first); put64(out, c.second); }
-        }
-        put32(out, 37450u);                                 // htslib's pseudo-bin: file range + record counts of the reference
-        put32(out, 2);
-        put64(out, r.off_beg); put64(out, r.off_end);
-        put64(out, r.n_rec); put64(out, 0);
-        put32(out, (uint32_t)r.lin.size());
-        for (uint64_t v : r.lin) put64(out, v);
-    }
-    put64(out, 0);                                          // n_no_coor
-    std::string comp;
-    if (!natac_writer::bgzf_compress(comp, out, 6)) return 3;
-    comp.append((const char *)natac_writer::BGZF_EOF, 28);
     const std::string tp = tbi_path ? std::string(tbi_path) : std::string(path) + ".tbi";
-    FILE *f = std::fopen(tp.c_str(), "wb");
-    if (!f) return 5;
-    const bool ok = std::fwrite(comp.data(), 1, comp.size(), f) == comp.size();
-    if (std::fclose(f) != 0 || !ok) return 5;
-    if (n_records) *n_records = nrec;
+    const int wrc = bld.write(tp.c_str());
+    if (wrc) return wrc;
+    if (n_records) *n_records = bld.nrec;
     return 0;
 }
 

@@ -203,7 +203,8 @@ __global__ void __launch_bounds__(256) tz_line_len(TextJob job, long long nruns,
 __global__ void __launch_bounds__(256) tz_write_lines(TextJob job, long long nruns, const unsigned int *__restrict__ R, const int *__restrict__ C,
                                                        const unsigned char *__restrict__ len8, const unsigned long long *__restrict__ byte_off,
                                                        const unsigned long long *__restrict__ line_idx, unsigned char *__restrict__ text,
-                                                       long long *__restrict__ line_off) {
+                                                       long long *__restrict__ line_off, int *__restrict__ l_cid, long long *__restrict__ l_beg,
+                                                       long long *__restrict__ l_end) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= nruns || !len8[k]) return;
     const RunInfo r = run_info(job, k, nruns, R, C);
@@ -212,7 +213,60 @@ __global__ void __launch_bounds__(256) tz_write_lines(TextJob job, long long nru
     const int n = (int)(format_line(buf, job, r, &hard) - buf);
     unsigned char *dst = text + byte_off[k];
     for (int i = 0; i < n; ++i) dst[i] = (unsigned char)buf[i];
-    line_off[line_idx[k]] = (long long)byte_off[k];
+    const unsigned long long j = line_idx[k];
+    line_off[j] = (long long)byte_off[k];
+    if (l_cid) {                                     // the record of this line, for the tabix index (tz_group_*)
+        const long long s = job.chunk_start[r.chunk];
+        l_cid[j] = job.chrom_id[r.chunk];
+        l_beg[j] = s + r.a_rel;
+        l_end[j] = s + r.b_rel;
+    }
+}
+
+// ---- tabix records without re-reading the file ----------------------------------------------------------------------------
+// The index needs, in file order, every record's bin (binning scheme of the tabix specification, min_shift 14, depth 5), its
+// 16-kb windows and its virtual offsets.  Consecutive records of one chromosome inside ONE 16-kb window share a leaf bin and a
+// window: such a run enters the index exactly like its records one by one (natac_tabix::Builder::push), so the device reduces
+// the (tens of millions of) lines to runs -- about one per 16 kb -- and the host index builder only sees those.
+__device__ __forceinline__ int tbx_reg2bin(long long beg, long long end) {
+    --end;
+    if (beg >> 14 == end >> 14) return ((1 << 15) - 1) / 7 + (int)(beg >> 14);
+    if (beg >> 17 == end >> 17) return ((1 << 12) - 1) / 7 + (int)(beg >> 17);
+    if (beg >> 20 == end >> 20) return ((1 << 9) - 1) / 7 + (int)(beg >> 20);
+    if (beg >> 23 == end >> 23) return ((1 << 6) - 1) / 7 + (int)(beg >> 23);
+    if (beg >> 26 == end >> 26) return ((1 << 3) - 1) / 7 + (int)(beg >> 26);
+    return 0;
+}
+__global__ void __launch_bounds__(256) tz_group_flags(long long nlines, const int *__restrict__ l_cid, const long long *__restrict__ l_beg,
+                                                       const long long *__restrict__ l_end, unsigned char *__restrict__ flag) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nlines) return;
+    bool start = true;
+    if (j > 0) {
+        const int b1 = tbx_reg2bin(l_beg[j], l_end[j]), b0 = tbx_reg2bin(l_beg[j - 1], l_end[j - 1]);
+        start = l_cid[j] != l_cid[j - 1] || b1 != b0 || b1 < 4681 || l_beg[j] < l_beg[j - 1];    // 4681 = first leaf bin; unsorted input stays visible
+    }
+    flag[j] = start ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) tz_group_starts(long long nlines, const unsigned char *__restrict__ flag,
+                                                        const unsigned long long *__restrict__ gidx, long long *__restrict__ first) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j < nlines && flag[j]) first[gidx[j]] = j;
+}
+struct GroupRec { int cid; int pad; long long beg, end, count; unsigned long long t0, t1; };
+__global__ void __launch_bounds__(256) tz_group_records(long long ngroups, const long long *__restrict__ first, long long nlines,
+                                                         const int *__restrict__ l_cid, const long long *__restrict__ l_beg,
+                                                         const long long *__restrict__ l_end, const long long *__restrict__ line_off,
+                                                         long long n_text, GroupRec *__restrict__ out) {
+    const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const long long j0 = first[gi], j1 = (gi + 1 < ngroups ? first[gi + 1] : nlines) - 1;
+    GroupRec r;
+    r.cid = l_cid[j0]; r.pad = 0;
+    r.beg = l_beg[j0]; r.end = l_end[j1]; r.count = j1 - j0 + 1;
+    r.t0 = (unsigned long long)line_off[j0];
+    r.t1 = (unsigned long long)(j1 + 1 < nlines ? line_off[j1 + 1] : n_text);
+    out[gi] = r;
 }
 
 // python-2 str(float) of arbitrary doubles, MAX_VALUE_CHARS bytes reserved per value (test entry natac_format_doubles)
@@ -229,6 +283,13 @@ __global__ void __launch_bounds__(256) tz_format_values(const double *__restrict
 }
 
 // ---- deflate ------------------------------------------------------------------------------------------------------------
+// One workgroup of TZ_THREADS (16 waves) per member.  A wave takes 64 consecutive lines at a time, in two phases:
+//   masks   the wave visits the 64 lines one after the other with lane = column: the tab positions and the three equality masks
+//           of natac_deflate.hpp are ballots; lane j keeps the masks / candidate distances of line j;
+//   parse   every lane runs the greedy parse of ITS line from its masks (bit arithmetic + one LDS byte per literal), so the
+//           token loop -- the bulk of the instructions -- runs 64 lines wide.
+constexpr int TZ_THREADS = 1024, TZ_WAVES = TZ_THREADS / 64;
+
 struct DevCountSink {              // LDS histogram
     unsigned int *ll, *d;
     __device__ void literal(unsigned char c) { atomicAdd(&ll[c], 1u); }
@@ -268,15 +329,80 @@ __device__ __forceinline__ MemberGeom member_geom(const long long *line_off, lon
     return g;
 }
 
-template <class Sink>
-__device__ __forceinline__ void tokenize_my_segments(const unsigned char *lds_text, const MemberGeom &g, const long long *line_off,
-                                                     long long nlines, long long n_text, long long s0, long long s1, Sink &sink) {
-    for (long long s = s0; s < s1; ++s) {
-        const long long k = g.k0 + s;
-        const long long ls = line_off[k], le = (k + 1 < nlines) ? line_off[k + 1] : n_text;
+struct LaneLine {                  // what a lane needs to parse its line
+    bool valid;
+    int q0rel, seglen;             // segment start relative to the member start, length
+    nd::Cands c;
+    unsigned long long eq0, eq1, eq2;
+};
+
+__device__ __forceinline__ long long shfl_i64(long long v, int src) {
+    const int lo = __shfl((int)(v & 0xffffffffll), src), hi = __shfl((int)(v >> 32), src);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// masks phase for the segments [base_s, base_s + cnt) (cnt <= 64) of the member: returns this lane's line
+__device__ __forceinline__ LaneLine group_masks(const unsigned char *lds_text, const MemberGeom &g, const long long *line_off, long long nlines,
+                                                long long n_text, long long base_s, int cnt, int lane) {
+    // line starts of the group: lane j holds line (k0 + base_s + j); lane 63's successor and lane 0's predecessor come from memory
+    const long long kk = g.k0 + base_s + lane;
+    const long long my_ls = lane < cnt ? line_off[kk] : 0;
+    const long long my_le = lane < cnt ? ((kk + 1 < nlines) ? line_off[kk + 1] : n_text) : 0;
+    const long long first_k = g.k0 + base_s;
+    const long long pls0 = first_k > 0 ? line_off[first_k - 1] : (long long)-1;
+    LaneLine me;
+    me.valid = false;
+    me.q0rel = me.seglen = 0;
+    me.c.d0 = me.c.d1 = me.c.d2 = 0;
+    me.eq0 = me.eq1 = me.eq2 = 0;
+    nd::LineGeom pg;
+    pg.tab1 = pg.tab2 = -1;
+    bool have_pg = false;
+    long long pls = pls0;
+    for (int j = 0; j < cnt; ++j) {
+        const long long ls = shfl_i64(my_ls, j), le = shfl_i64(my_le, j);
         const long long q0 = ls > g.bs ? ls : g.bs, q1 = le < g.be ? le : g.be;
-        if (q1 > q0) nd::tokenize_segment(lds_text, g.bs, g.bs, q0, q1, ls, k > 0 ? line_off[k - 1] : (long long)-1, sink);
+        const int seglen = (int)(q1 - q0);
+        const int n = seglen < nd::WIN ? seglen : nd::WIN;
+        const unsigned char mine = lane < n ? lds_text[q0 + lane - g.bs] : 0;
+        nd::Cands c;
+        c.d0 = c.d1 = c.d2 = 0;
+        nd::LineGeom lg;
+        lg.tab1 = lg.tab2 = -1;
+        if (ls >= g.bs) {
+            lg = nd::geom_from_tabmask(__ballot(lane < n && mine == '\t'));
+            if (pls >= g.bs) {
+                if (!have_pg) {
+                    const bool in = pls + lane < ls && lane < nd::WIN;
+                    const unsigned char ch = in ? lds_text[pls + lane - g.bs] : 0;
+                    pg = nd::geom_from_tabmask(__ballot(in && ch == '\t'));
+                }
+            } else pg.tab1 = pg.tab2 = -1;
+            c = nd::line_candidates(g.bs, ls, pls, lg, pg);
+        }
+        const long long s0r = q0 + lane - c.d0, s1r = q0 + lane - c.d1, s2r = q0 + lane - c.d2;
+        const bool ok0 = c.d0 > 0 && lane < n && s0r >= g.bs, ok1 = c.d1 > 0 && lane < n && s1r >= g.bs, ok2 = c.d2 > 0 && lane < n && s2r >= g.bs;
+        const unsigned char o0 = ok0 ? lds_text[s0r - g.bs] : 0, o1 = ok1 ? lds_text[s1r - g.bs] : 0, o2 = ok2 ? lds_text[s2r - g.bs] : 0;
+        const unsigned long long e0 = __ballot(ok0 && o0 == mine), e1 = __ballot(ok1 && o1 == mine), e2 = __ballot(ok2 && o2 == mine);
+        if (lane == j) {
+            me.valid = seglen > 0;
+            me.q0rel = (int)(q0 - g.bs);
+            me.seglen = seglen;
+            me.c = c;
+            me.eq0 = e0; me.eq1 = e1; me.eq2 = e2;
+        }
+        pg = lg;
+        have_pg = true;
+        pls = ls;
     }
+    return me;
+}
+
+template <class Sink>
+__device__ __forceinline__ void parse_lane_line(const unsigned char *lds_text, const LaneLine &me, Sink &sink) {
+    if (!me.valid) return;
+    const unsigned char *seg = lds_text + me.q0rel;
+    nd::greedy_tokens(me.eq0, me.eq1, me.eq2, me.c, me.seglen, [&](int i) -> unsigned char { return seg[i]; }, sink);
 }
 
 __device__ __forceinline__ void load_member_text(unsigned char *lds_text, const unsigned char *text, const MemberGeom &g) {
@@ -289,23 +415,33 @@ __device__ __forceinline__ void load_member_text(unsigned char *lds_text, const 
     for (int i = (n16 << 4) + threadIdx.x; i < n; i += blockDim.x) lds_text[i] = src[i];
 }
 
-__global__ void __launch_bounds__(256) tz_count_tokens(const unsigned char *__restrict__ text, long long n_text,
-                                                        const long long *__restrict__ line_off, long long nlines,
-                                                        unsigned int *__restrict__ hist /* [NLL + ND] */) {
+__device__ __forceinline__ void wave_range(const MemberGeom &g, int wave, long long *s0, long long *s1) {
+    const long long per = (g.nseg + TZ_WAVES - 1) / TZ_WAVES;
+    *s0 = per * wave < g.nseg ? per * wave : g.nseg;
+    *s1 = *s0 + per < g.nseg ? *s0 + per : g.nseg;
+}
+
+__global__ void __launch_bounds__(TZ_THREADS) tz_count_tokens(const unsigned char *__restrict__ text, long long n_text,
+                                                               const long long *__restrict__ line_off, long long nlines,
+                                                               unsigned int *__restrict__ hist /* [NLL + ND] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_text = smem;
     unsigned int *h = (unsigned int *)(smem + 65536);
     const MemberGeom g = member_geom(line_off, nlines, n_text, blockIdx.x);
-    for (int i = threadIdx.x; i < nd::NLL + nd::ND; i += 256) h[i] = 0;
+    for (int i = threadIdx.x; i < nd::NLL + nd::ND; i += TZ_THREADS) h[i] = 0;
     load_member_text(lds_text, text, g);
     __syncthreads();
-    const long long per = (g.nseg + 255) / 256;
-    const long long s0 = per * threadIdx.x < g.nseg ? per * threadIdx.x : g.nseg;
-    const long long s1 = s0 + per < g.nseg ? s0 + per : g.nseg;
+    long long s0, s1;
+    wave_range(g, threadIdx.x >> 6, &s0, &s1);
+    const int lane = threadIdx.x & 63;
     DevCountSink sink{h, h + nd::NLL};
-    tokenize_my_segments(lds_text, g, line_off, nlines, n_text, s0, s1, sink);
+    for (long long base = s0; base < s1; base += 64) {
+        const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
+        const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
+        parse_lane_line(lds_text, me, sink);
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < nd::NLL + nd::ND; i += 256)
+    for (int i = threadIdx.x; i < nd::NLL + nd::ND; i += TZ_THREADS)
         if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
@@ -314,13 +450,12 @@ struct DevBitWriter {              // LSB-first bit stream into zero-initialised
     long long bitpos;              // next bit to write
     unsigned long long acc;        // pending bits, acc bit 0 = stream bit (bitpos - nacc)
     int nacc;
-    bool first;                    // the next flushed word is the first one of this writer (may be shared with the previous thread)
+    bool first;                    // the next flushed word is the first one of this writer (may be shared with the previous line)
     __device__ void init(unsigned int *w, long long start_bit) {
         words = w;
-        const int sh = (int)(start_bit & 31);
         bitpos = start_bit;
         acc = 0;
-        nacc = sh;                 // pretend the low `sh` bits of the first word are pending zeros: OR-ing zeros is harmless
+        nacc = (int)(start_bit & 31);   // the bits below the start in the first word are pending zeros: OR-ing zeros is harmless
         first = true;
     }
     __device__ void put(unsigned int v, int nb) {
@@ -360,56 +495,69 @@ __device__ __forceinline__ void or_bytes(unsigned int *words, long long byte_off
     }
 }
 
+__device__ __forceinline__ unsigned long long wave_excl_scan(unsigned long long v, int lane, unsigned long long *total) {
+    unsigned long long inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    *total = __shfl(inc, 63);
+    return inc - v;
+}
+
 // One workgroup per member.  out_regions: nd::REGION bytes per member, zeroed; the member occupies bytes [2, 2 + size) of its
 // region (so that the deflate payload, 18 bytes later, starts on a 32-bit word).  sizes[b] = member size in bytes.
-__global__ void __launch_bounds__(256) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
-                                                        const long long *__restrict__ line_off, long long nlines,
-                                                        const nd::Codes *__restrict__ codes_g, const nd::CrcTables *__restrict__ crc_g,
-                                                        unsigned char *__restrict__ out_regions, unsigned int *__restrict__ sizes) {
+__global__ void __launch_bounds__(TZ_THREADS) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
+                                                               const long long *__restrict__ line_off, long long nlines,
+                                                               const nd::Codes *__restrict__ codes_g, const nd::CrcTables *__restrict__ crc_g,
+                                                               unsigned char *__restrict__ out_regions, unsigned int *__restrict__ sizes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_text = smem;
     nd::Codes *codes = (nd::Codes *)(smem + 65536);
-    __shared__ unsigned long long tbits[256];
-    __shared__ unsigned int crc_v[256];
-    __shared__ int crc_n[256];
+    __shared__ unsigned long long wbits[TZ_WAVES];
+    __shared__ unsigned int crc_v[TZ_THREADS];
+    __shared__ int crc_n[TZ_THREADS];
     __shared__ unsigned int crc_tab[256 + 32];
     const MemberGeom g = member_geom(line_off, nlines, n_text, blockIdx.x);
     {
         const unsigned int *src = (const unsigned int *)codes_g;
         unsigned int *dst = (unsigned int *)codes;
-        for (int i = threadIdx.x; i < (int)(sizeof(nd::Codes) / 4); i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(nd::Codes) / 4); i += TZ_THREADS) dst[i] = src[i];
         const unsigned int *ct = (const unsigned int *)crc_g;
-        for (int i = threadIdx.x; i < 256 + 32; i += 256) crc_tab[i] = ct[i];
+        for (int i = threadIdx.x; i < 256 + 32; i += TZ_THREADS) crc_tab[i] = ct[i];
     }
     load_member_text(lds_text, text, g);
     __syncthreads();
     const int n = (int)(g.be - g.bs);
-    const long long per = (g.nseg + 255) / 256;
-    const long long s0 = per * threadIdx.x < g.nseg ? per * threadIdx.x : g.nseg;
-    const long long s1 = s0 + per < g.nseg ? s0 + per : g.nseg;
-    // pass A: bits of my segments
-    nd::BitCountSink bc{codes, 0};
-    tokenize_my_segments(lds_text, g, line_off, nlines, n_text, s0, s1, bc);
-    tbits[threadIdx.x] = (unsigned long long)bc.bits;
-    // CRC-32 of my 255-byte slice of the member
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long s0, s1;
+    wave_range(g, wave, &s0, &s1);
+    // pass A: bits of this wave's lines
+    unsigned long long wave_bits = 0;
+    for (long long base = s0; base < s1; base += 64) {
+        const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
+        const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
+        nd::BitCountSink bc{codes, 0};
+        parse_lane_line(lds_text, me, bc);
+        unsigned long long tot;
+        (void)wave_excl_scan((unsigned long long)bc.bits, lane, &tot);
+        wave_bits += tot;
+    }
+    if (lane == 0) wbits[wave] = wave_bits;
+    // CRC-32 of my 64-byte slice of the member
     {
-        const int c0 = threadIdx.x * 255 < n ? threadIdx.x * 255 : n;
-        const int c1 = c0 + 255 < n ? c0 + 255 : n;
+        const int c0 = threadIdx.x * 64 < n ? threadIdx.x * 64 : n;
+        const int c1 = c0 + 64 < n ? c0 + 64 : n;
         crc_v[threadIdx.x] = nd::crc_bytes(crc_tab, lds_text + c0, c1 - c0);
         crc_n[threadIdx.x] = c1 - c0;
     }
     __syncthreads();
-    // exclusive scan of tbits (256 values) + tree combination of the slice CRCs
-    unsigned long long mine = tbits[threadIdx.x];
-    for (int off = 1; off < 256; off <<= 1) {
-        const unsigned long long add = threadIdx.x >= off ? tbits[threadIdx.x - off] : 0;
-        __syncthreads();
-        tbits[threadIdx.x] += add;
-        __syncthreads();
+    unsigned long long my_start = 0, total_tok_bits = 0;
+    for (int w = 0; w < TZ_WAVES; ++w) {
+        if (w < wave) my_start += wbits[w];
+        total_tok_bits += wbits[w];
     }
-    const unsigned long long total_tok_bits = tbits[255];
-    const unsigned long long my_start = tbits[threadIdx.x] - mine;
-    for (int step = 1; step < 256; step <<= 1) {
+    for (int step = 1; step < TZ_THREADS; step <<= 1) {
         if ((threadIdx.x & (2 * step - 1)) == 0) {
             const int o = threadIdx.x + step;
             crc_v[threadIdx.x] = nd::crc_combine(crc_tab + 256, crc_v[threadIdx.x], crc_v[o], crc_n[o]);
@@ -427,15 +575,31 @@ __global__ void __launch_bounds__(256) tz_emit_members(const unsigned char *__re
     if (!stored) {
         // shared header: whole words by the first threads, the ragged last word OR-ed (the token stream continues in it)
         const int hw = codes->hdr_bits >> 5, hr = codes->hdr_bits & 31;
-        for (int i = threadIdx.x; i < hw; i += 256) words[5 + i] = codes->hdr[i];
+        for (int i = threadIdx.x; i < hw; i += TZ_THREADS) words[5 + i] = codes->hdr[i];
         if (threadIdx.x == 0 && hr) atomicOr(&words[5 + hw], codes->hdr[hw]);
-        DevBitWriter bw;
-        bw.init(words + 5, (long long)codes->hdr_bits + (long long)my_start);
-        // init() treats the bits below the start as pending zeros; the first flushed word is OR-ed
-        DevEmitSink es{codes, &bw};
-        tokenize_my_segments(lds_text, g, line_off, nlines, n_text, s0, s1, es);
-        if (threadIdx.x == 255) bw.put(codes->ll_code[256], eob_len);
-        bw.finish();
+        unsigned long long pos = (unsigned long long)codes->hdr_bits + my_start;      // bit position of this wave's next group
+        for (long long base = s0; base < s1; base += 64) {
+            const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
+            const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
+            nd::BitCountSink bc{codes, 0};
+            parse_lane_line(lds_text, me, bc);
+            unsigned long long tot;
+            const unsigned long long mine = wave_excl_scan((unsigned long long)bc.bits, lane, &tot);
+            if (me.valid) {
+                DevBitWriter bw;
+                bw.init(words + 5, (long long)(pos + mine));
+                DevEmitSink es{codes, &bw};
+                parse_lane_line(lds_text, me, es);
+                bw.finish();
+            }
+            pos += tot;
+        }
+        if (threadIdx.x == 0) {                               // end of block after the last token
+            DevBitWriter bw;
+            bw.init(words + 5, (long long)((unsigned long long)codes->hdr_bits + total_tok_bits));
+            bw.put(codes->ll_code[256], eob_len);
+            bw.finish();
+        }
     } else {
         payload = 5 + n;
         if (threadIdx.x == 0) {
@@ -443,7 +607,7 @@ __global__ void __launch_bounds__(256) tz_emit_members(const unsigned char *__re
             region[21] = (unsigned char)(n & 0xff); region[22] = (unsigned char)(n >> 8);
             region[23] = (unsigned char)(~n & 0xff); region[24] = (unsigned char)((~n >> 8) & 0xff);
         }
-        for (int i = threadIdx.x; i < n; i += 256) region[25 + i] = lds_text[i];
+        for (int i = threadIdx.x; i < n; i += TZ_THREADS) region[25 + i] = lds_text[i];
     }
     __threadfence();
     __syncthreads();

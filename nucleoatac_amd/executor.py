@@ -99,13 +99,13 @@ class ResidentShard(object):
 
 class Result(object):
     """outputs of one sub-batch in page-locked host memory; `release()` hands the buffers back to the executor"""
-    __slots__ = ("seq", "packed", "tag", "tracks", "text", "peaks", "occ_peaks", "status", "_slot", "_ex")
+    __slots__ = ("seq", "packed", "tag", "tracks", "text", "text_index", "peaks", "occ_peaks", "status", "_slot", "_ex")
 
     def release(self):
         if self._slot is not None:
             self._ex._free_slot(self._slot)
             self._slot = None
-        self.tracks = self.text = self.peaks = self.occ_peaks = None
+        self.tracks = self.text = self.text_index = self.peaks = self.occ_peaks = None
 
 
 class _Slot(object):
@@ -178,7 +178,7 @@ class PipelinedExecutor(object):
             for t in st.tracks:
                 dt = np.int32 if t == L.T_INS else np.float64
                 r.tracks[t] = b.track(t, out=slot.view(t, b.total_bp, dt))
-            r.text = {}
+            r.text, r.text_index = {}, {}
             for t in st.text_tracks:
                 # Track.write_track + bgzip on the device: BGZF members straight into the pinned slot
                 buf, info = b.format_track(t, packed.chroms, packed.chunk_start, compress=True,
@@ -190,6 +190,7 @@ class PipelinedExecutor(object):
                     r.text[t] = None
                 else:
                     r.text[t] = buf
+                    r.text_index[t] = info["index"]      # tabix records of these members (writer.TbiBuilder)
             r.peaks = b.download_peaks(n) if st.peaks is not None else None
             r.occ_peaks = b.run_occ_peaks(**st.occ_peaks) if st.occ_peaks is not None else None
             r.status = b.status()

@@ -21,7 +21,7 @@ from ..pyatac.VMat import VMat
 from ..shard import balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, shared_fragment_store
 from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
 from .NucleosomeCalling import NucParameters, fit_fuzz_chunk, nuc_batch, occ_reader_pool, read_occ_tracks
-from .run_occ import DEVICE_WRITER, _Phases, _Writer
+from .run_occ import DEVICE_WRITER, _Phases, _Writer, finish_indexes
 
 LAST_TIMINGS = {}
 
@@ -225,6 +225,7 @@ def run_nuc(args):
         LAST_TIMINGS["calls_and_fits_inside_writer"] = round(calls_s[0], 3)
     if pool is not None:
         pool.shutdown()
+    to_index = finish_indexes(writer if parts else None, list(track_of), lambda n: args.out + "." + n + ".bedgraph.gz")
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
     if rank == 0:
         for n in outputs:
@@ -239,6 +240,6 @@ def run_nuc(args):
             if n.startswith("nucpos"):
                 bgzip_file(base, level=COMPRESS_LEVEL)
                 tabix_index(base + ".gz")
-            else:
+            elif base in to_index:
                 tabix_index(base)
     ph.mark("merge_bgzip_tabix")

@@ -72,9 +72,11 @@ def _occHelperBatch(chunks, params):
 
 
 class _Writer(threading.Thread):
-    """consumes finished sub-batches in order on its own thread: native run-length bedGraph + BGZF for every track
-    (Track.write_track, pyatac/tracks.py:37-74; run_occ.py:41-59 are the reference's writer processes), then `extra(result)`,
-    then the result's pinned buffers go back to the executor"""
+    """consumes finished sub-batches in order on its own thread (run_occ.py:41-59 are the reference's writer processes): every
+    track is appended to its file -- finished BGZF members when Track.write_track + bgzip ran on the device, else through the
+    native host writer (pyatac/tracks.py:37-74) --, then `extra(result)`, then the result's pinned buffers go back to the executor.
+    For device-written tracks the tabix records of every result are logged with the byte offset they were written at, so that the
+    .tbi can be built without reading the file again (finish_indexes)."""
 
     def __init__(self, paths, track_of, extra, n_batches, last_rank):
         threading.Thread.__init__(self, daemon=True)
@@ -82,6 +84,9 @@ class _Writer(threading.Thread):
         self.q = queue.Queue(maxsize=2)
         self.err = None
         self.seconds = 0.0
+        self.offset = {n: 0 for n in paths}          # bytes of members written so far (without the EOF marker)
+        self.index_log = {n: [] for n in paths}      # (tabix records of a result, offset it was written at)
+        self.index_ok = {n: True for n in paths}
 
     def run(self):
         import time
@@ -97,14 +102,18 @@ class _Writer(threading.Thread):
                     for name, path in self.paths.items():
                         t = self.track_of[name]
                         z = r.text.get(t) if r.text else None
+                        last = r.seq == self.nb - 1 and self.last_rank
                         if z is not None:       # finished BGZF members from the device: append them (+ the EOF marker at the very end)
                             with open(path, "ab" if r.seq > 0 else "wb") as fh:
                                 fh.write(memoryview(z))
-                                if r.seq == self.nb - 1 and self.last_rank:
+                                if last:
                                     fh.write(BGZF_EOF)
+                            self.index_log[name].append((r.text_index[t], self.offset[name]))
+                            self.offset[name] += len(z)
                         else:
                             write_bedgraph(path, chroms, starts, r.packed.out_off, r.tracks[t], append=r.seq > 0,
-                                           compress=COMPRESS_LEVEL, finish=(r.seq == self.nb - 1 and self.last_rank))
+                                           compress=COMPRESS_LEVEL, finish=last)
+                            self.index_ok[name] = False
                     self.extra(r)
                     self.seconds += time.perf_counter() - t0
             except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
@@ -122,6 +131,33 @@ class _Writer(threading.Thread):
         self.join()
         if self.err is not None:
             raise self.err
+
+
+def finish_indexes(writer, names, base_of):
+    """.tbi of every track file on rank 0.  `writer`: this rank's _Writer (None without sub-batches).  Files assembled from
+    device-formatted members get their index from the logged tabix records -- gathered from all ranks, shifted by the sizes of
+    the part files in front --, without being read again; files the host writer touched are indexed by natac_tabix_index."""
+    from ..writer import TbiBuilder
+    log = dict(index_log=writer.index_log if writer else {n: [] for n in names}, ok=writer.index_ok if writer else {n: True for n in names},
+               size=writer.offset if writer else {n: 0 for n in names})
+    logs = gather_in_chunk_order([log], dst=0)
+    pending = []                # files that need the file-based indexer once rank 0 has assembled them
+    if logs is None:
+        return pending
+    for n in names:
+        path = base_of(n)
+        if all(l["ok"][n] for l in logs) and DEVICE_WRITER and any(l["index_log"][n] for l in logs):
+            tb = TbiBuilder()
+            base = 0
+            for l in logs:                      # rank order == file order
+                for idx, off in l["index_log"][n]:
+                    tb.push(idx, base + off)
+                base += l["size"][n]
+            tb.write(path + ".tbi")
+            tb.close()
+        else:
+            pending.append(path)
+    return pending
 
 
 def run_occ(args):
@@ -234,6 +270,7 @@ def run_occ(args):
         LAST_TIMINGS["pack_inside_pipeline"] = round(pack_s[0], 3)
         LAST_TIMINGS["writer_inside_pipeline"] = round(writer.seconds, 3)
     dists = gather_in_chunk_order(dists, dst=0)
+    to_index = finish_indexes(writer if parts else None, list(track_of), lambda n: args.out + "." + n + ".bedgraph.gz")
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
     if rank == 0:
         if world > 1:   # BGZF members / text lines concatenate: rank order == chunk order
@@ -247,8 +284,8 @@ def run_occ(args):
         # bgzip + tabix of every output like the reference (run_occ.py:130-136)
         bgzip_file(args.out + ".occpeaks.bed", level=COMPRESS_LEVEL)
         tabix_index(args.out + ".occpeaks.bed.gz")
-        for n in track_of:
-            tabix_index(args.out + "." + n + ".bedgraph.gz")
+        for path in to_index:
+            tabix_index(path)
         nuc_dist = ordered_sum(dists) if dists else np.zeros(args.upper)
         FragmentSizes(0, args.upper, vals=nuc_dist).save(args.out + ".nuc_dist.txt")
     ph.mark("merge_bgzip_tabix")

@@ -77,3 +77,42 @@ def bgzf_lines_host(text):
 
 
 BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+class TbiBuilder(object):
+    """incremental tabix index (natac_tbi) of a bedGraph.gz assembled from device-formatted results: push(index, file_offset) for
+    every result in file order (`index` = info["index"] of DeviceBatch.format_track, `file_offset` = byte at which the result's
+    first member sits in the file), then write(path + ".tbi") -- the file itself is never read again"""
+
+    def __init__(self):
+        self._lib = L.load()
+        h = C.c_void_p()
+        L.check(self._lib.natac_tbi_create(C.byref(h)))
+        self._h = h
+
+    def push(self, index, file_offset):
+        n = len(index["cid"])
+        if n == 0:
+            return
+        names = index["names"]
+        arr = (C.c_char_p * len(names))(*[c.encode("ascii") for c in names])
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.check(self._lib.natac_tbi_push(self._h, n, arr, len(names), vp(index["cid"]), vp(index["beg"]), vp(index["end"]), vp(index["count"]),
+                                         vp(index["t0"]), vp(index["t1"]), vp(index["member_pos"]), len(index["member_pos"]) - 1,
+                                         int(file_offset)))
+
+    def write(self, tbi_path):
+        n = C.c_int64(0)
+        L.check(self._lib.natac_tbi_write(self._h, str(tbi_path).encode(), C.byref(n)))
+        return n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.natac_tbi_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

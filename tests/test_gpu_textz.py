@@ -165,3 +165,37 @@ def test_device_writer_at_scale(ctx):
     first = ("%s\t%d\t%d\t%s\n" % (chroms[k], int(pk.chunk_start[k]), int(pk.chunk_start[k]) + 1, f2s(float(seg[0])))).encode()
     assert first in raw
     b.free()
+
+
+def test_index_from_device_records_equals_index_from_the_file(ctx, tmp_path):
+    """the .tbi built from the device's per-leaf-bin runs (natac_batch_format_index_*, writer.TbiBuilder) while the file is being
+    assembled out of several results is byte-identical to the one natac_tabix_index builds by reading the finished file --
+    float tracks (one record per base), integer tracks (long zero runs that span 16-kb windows: records in inner bins), several
+    chromosomes, members that end inside records"""
+    from nucleoatac_amd.writer import TbiBuilder
+    subs = [make_synthetic_chunks(700, 2120, 500, seed=20 + i, first_chunk=700 * i) for i in range(3)]
+    # sparse sub-batch: few fragments -> insertion track mostly zero, runs of equal values tens of kb long across chunk... (runs stop at chunk ends)
+    sparse = make_synthetic_chunks(40, 60000, 30, seed=99, first_chunk=4000)
+    subs.append(sparse)
+    chrom_of = lambda i, pk: ["chr%d" % (1 + i)] * pk.n_chunks
+    for track in (L.T_OCC, L.T_INS, L.T_SMOOTH):
+        path = str(tmp_path / ("t%d.bedgraph.gz" % track))
+        tb = TbiBuilder()
+        off = 0
+        with open(path, "wb") as fh:
+            for i, pk in enumerate(subs):
+                b = ctx.upload(pk)
+                b.run_nuc(10)
+                b.run_occ()
+                b.run_ins(0, 2000)
+                z, info = b.format_track(track, chrom_of(i, pk), pk.chunk_start, compress=True)
+                fh.write(z.tobytes())
+                tb.push(info["index"], off)
+                off += len(z)
+                assert len(info["index"]["cid"]) < info["lines"] / 50 + 2000     # runs, not lines
+                b.free()
+            fh.write(BGZF_EOF)
+        n_dev = tb.write(path + ".dev.tbi")
+        n_file = tabix_index(path)
+        assert n_dev == n_file > 100000
+        assert open(path + ".dev.tbi", "rb").read() == open(path + ".tbi", "rb").read(), track
