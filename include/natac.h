@@ -246,18 +246,18 @@ int natac_batch_format_fetch(natac_batch *b, void *dst, size_t dst_bytes);
  * pysam.tabix_index(..., preset="bed") over every finished file, run_occ.py:136-139).  The device reduces the lines of a result to runs
  * of records per 16-kb leaf bin (one per ~16 kb instead of one per base): natac_batch_format_index_size / _fetch return the runs
  * of the LAST result -- chromosome id, [beg, end), record count, text offsets [t0, t1) -- and the member start offsets
- * member_pos[n_members + 1] inside the result.  natac_tbi_push enters them into an incremental index once the caller knows at
+ * member_pos[n_members + 1] inside the result (n_text = bytes of text in it: the last member is partial).  natac_tbi_push enters them into an incremental index once the caller knows at
  * which byte `file_offset` of the .gz the result is written (results may be produced out of order by several contexts and
  * written in order by one writer); natac_tbi_write serialises the same index natac_tabix_index builds from the finished file. */
 typedef struct natac_tbi natac_tbi;
 int natac_tbi_create(natac_tbi **out);
 void natac_tbi_free(natac_tbi *t);
-int natac_batch_format_index_size(natac_batch *b, int64_t *n_groups, int64_t *n_members);
+int natac_batch_format_index_size(natac_batch *b, int64_t *n_groups, int64_t *n_members, int64_t *n_text);
 int natac_batch_format_index_fetch(natac_batch *b, int32_t *cid, int64_t *beg, int64_t *end, int64_t *count, uint64_t *t0, uint64_t *t1,
                                    uint64_t *member_pos);
 int natac_tbi_push(natac_tbi *t, int64_t n, const char *const *names, int32_t n_names, const int32_t *cid, const int64_t *beg,
                    const int64_t *end, const int64_t *count, const uint64_t *t0, const uint64_t *t1, const uint64_t *member_pos,
-                   int64_t n_members, int64_t file_offset);
+                   int64_t n_members, int64_t n_text, int64_t file_offset);
 int natac_tbi_write(natac_tbi *t, const char *tbi_path, int64_t *n_records);
 /* the device formatter on arbitrary doubles (validation): out_off[i] .. out_off[i+1] = python-2 str(vals[i]); out_cap >= 24 n */
 int natac_format_doubles(natac_ctx *ctx, const double *vals, int64_t n, char *out, size_t out_cap, int64_t *out_off, int32_t *n_hard);

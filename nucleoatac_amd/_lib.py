@@ -68,9 +68,9 @@ SIGNATURES = {
     "natac_batch_format_fetch": (C.c_int, [_vp, _vp, _sz]),
     "natac_tbi_create": (C.c_int, [_pp]),
     "natac_tbi_free": (None, [_vp]),
-    "natac_batch_format_index_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "natac_batch_format_index_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "natac_batch_format_index_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "natac_tbi_push": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "natac_tbi_push": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "natac_tbi_write": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "natac_format_doubles": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp, C.POINTER(_i32)]),
     "natac_bgzf_lines_host": (C.c_int, [C.c_char_p, _i64, _vp, _i64, _vp, _sz, C.POINTER(_i64)]),

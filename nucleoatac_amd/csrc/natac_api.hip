@@ -142,6 +142,7 @@ struct natac_batch {
     std::vector<natac_textz::GroupRec> fmt_groups;
     std::vector<unsigned long long> fmt_member_pos;
     std::vector<std::string> fmt_names;
+    long long fmt_text_bytes = 0;
     long long nuc_gen = -1;                        // model generation natac_run_nuc ran with
 };
 
@@ -431,6 +432,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     HIPCHK(hipMemcpyAsync(&nlines, d_lidx + nruns, sizeof nlines, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&hard, d_hard, sizeof hard, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    b->fmt_text_bytes = (long long)n_text;
     if (n_text_bytes) *n_text_bytes = (int64_t)n_text;
     if (n_lines) *n_lines = (int64_t)nlines;
     if (n_hard) *n_hard = hard;
@@ -2038,15 +2040,14 @@ void natac_tbi_free(natac_tbi *t) { delete t; }
 
 static int tbi_push_groups(natac_tbi *t, int64_t n, const char *const *names, int32_t n_names, const int32_t *cid, const int64_t *beg,
                            const int64_t *end, const int64_t *count, const uint64_t *t0, const uint64_t *t1, const uint64_t *member_pos,
-                           int64_t n_members, int64_t file_offset) {
+                           int64_t n_members, int64_t n_text, int64_t file_offset) {
     const size_t nblk = (size_t)n_members;
     // virtual offset of a text position: member start in the file << 16 | offset inside the member; a position at a member's end
     // belongs to the start of the next member (for the last one: whatever the caller writes next -- more members or the EOF block)
     auto voff = [&](uint64_t toff) -> uint64_t {
+        if (toff >= (uint64_t)n_text) return ((uint64_t)file_offset + member_pos[nblk]) << 16;      // the end of the last (partial) member
         const size_t m = (size_t)(toff / natac_deflate::BLK);
-        const uint64_t within = toff - (uint64_t)m * natac_deflate::BLK;
-        const uint64_t pos = m < nblk ? member_pos[m] : member_pos[nblk];
-        return (((uint64_t)file_offset + pos) << 16) | (m < nblk ? within : 0);
+        return (((uint64_t)file_offset + member_pos[m]) << 16) | (toff - (uint64_t)m * natac_deflate::BLK);
     };
     for (int64_t i = 0; i < n; ++i) {
         if (cid[i] < 0 || cid[i] >= n_names) return fail(NATAC_E_ARG, "record with chromosome id %d", cid[i]);
@@ -2056,8 +2057,9 @@ static int tbi_push_groups(natac_tbi *t, int64_t n, const char *const *names, in
     return NATAC_OK;
 }
 
-int natac_batch_format_index_size(natac_batch *b, int64_t *n_groups, int64_t *n_members) {
-    if (!b || !n_groups || !n_members) return fail(NATAC_E_ARG, "null argument");
+int natac_batch_format_index_size(natac_batch *b, int64_t *n_groups, int64_t *n_members, int64_t *n_text) {
+    if (!b || !n_groups || !n_members || !n_text) return fail(NATAC_E_ARG, "null argument");
+    *n_text = b->fmt_text_bytes;
     if (b->fmt_bytes < 0) return fail(NATAC_E_STATE, "natac_batch_format_track has not run");
     *n_groups = (int64_t)b->fmt_groups.size();
     *n_members = b->fmt_member_pos.empty() ? 0 : (int64_t)b->fmt_member_pos.size() - 1;
@@ -2083,11 +2085,11 @@ int natac_batch_format_index_fetch(natac_batch *b, int32_t *cid, int64_t *beg, i
 
 int natac_tbi_push(natac_tbi *t, int64_t n, const char *const *names, int32_t n_names, const int32_t *cid, const int64_t *beg,
                    const int64_t *end, const int64_t *count, const uint64_t *t0, const uint64_t *t1, const uint64_t *member_pos,
-                   int64_t n_members, int64_t file_offset) {
-    if (!t || n < 0 || n_members < 0 || file_offset < 0) return fail(NATAC_E_ARG, "bad argument");
+                   int64_t n_members, int64_t n_text, int64_t file_offset) {
+    if (!t || n < 0 || n_members < 0 || file_offset < 0 || n_text < 0) return fail(NATAC_E_ARG, "bad argument");
     if (n == 0) return NATAC_OK;
     if (!names || !cid || !beg || !end || !count || !t0 || !t1 || !member_pos) return fail(NATAC_E_ARG, "null argument");
-    return tbi_push_groups(t, n, names, n_names, cid, beg, end, count, t0, t1, member_pos, n_members, file_offset);
+    return tbi_push_groups(t, n, names, n_names, cid, beg, end, count, t0, t1, member_pos, n_members, n_text, file_offset);
 }
 
 int natac_tbi_write(natac_tbi *t, const char *tbi_path, int64_t *n_records) {

@@ -81,6 +81,9 @@ inline Bam *decode(const char *path, int n_threads, std::string &err, size_t bat
             if (!bsize || bsize < 12 + (size_t)xlen + 8) return fail("truncated BGZF block");
             if (o + bsize > raw_len) break;                       // the rest of this block comes with the next window
             const uint32_t isize = rd32(h + bsize - 4);
+            // a BGZF member inflates to at most 64 KiB (SAM spec 4.1): a larger ISIZE is a corrupt or hostile file and would
+            // otherwise size the window buffer (the bounded-memory guarantee of this decoder rests on this check)
+            if (isize > 65536) return fail("corrupt BGZF block (ISIZE > 65536)");
             blks.push_back({o + 12 + xlen, bsize - 12 - xlen - 8, isize, utotal});
             utotal += isize;
             o += bsize;

@@ -438,10 +438,10 @@ class DeviceBatch(object):
         info = dict(bytes=nb.value, text_bytes=nt.value, lines=nl.value, hard=hard.value)
         if compress:
             # tabix records of this result (runs of lines per 16-kb leaf bin) for writer.TbiBuilder.push
-            ng, nm = C.c_int64(0), C.c_int64(0)
-            L.check(self._lib.natac_batch_format_index_size(self._h, C.byref(ng), C.byref(nm)))
+            ng, nm, ntx = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            L.check(self._lib.natac_batch_format_index_size(self._h, C.byref(ng), C.byref(nm), C.byref(ntx)))
             ng, nm = ng.value, nm.value
-            rec = dict(names=names, cid=np.empty(ng, np.int32), beg=np.empty(ng, np.int64), end=np.empty(ng, np.int64),
+            rec = dict(names=names, n_text=ntx.value, cid=np.empty(ng, np.int32), beg=np.empty(ng, np.int64), end=np.empty(ng, np.int64),
                        count=np.empty(ng, np.int64), t0=np.empty(ng, np.uint64), t1=np.empty(ng, np.uint64),
                        member_pos=np.zeros(nm + 1, np.uint64))
             L.check(self._lib.natac_batch_format_index_fetch(self._h, _ptr(rec["cid"]), _ptr(rec["beg"]), _ptr(rec["end"]), _ptr(rec["count"]),

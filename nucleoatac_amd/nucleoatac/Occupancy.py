@@ -48,9 +48,23 @@ class FragmentMixDistribution(object):
         score = np.ones(lo + 1) * float("inf")
         param = [0] * (lo + 1)
         pranges = ((0.01, 10), (0.01, 150), (0.01, 1))
+        # scipy.optimize.brute(f, pranges, finish=fmin) of the reference (Occupancy.py:48-53), with its 20 x 20 x 20 grid evaluated
+        # in one vectorised pass per offset instead of 8,000 Python calls (168,000 in total: ~2 s of a run's fixed cost): the same
+        # grid (np.mgrid with complex steps, as brute builds it), the same element-wise formula, the first minimum, then brute's
+        # own finisher from that grid point.
+        grid = np.mgrid[tuple(slice(a, b, complex(20)) for a, b in pranges)]
+        K, TH, A = (g.ravel()[:, None] for g in grid)
+        norm_c = TH ** K * gamma(K)
         for i in range(15, lo + 1):
-            res = optimize.brute(lambda p: np.sum((gamma_fit(x, i, p) - y) ** 2), pranges, full_output=True,
-                                 finish=optimize.fmin)
+            f = lambda p: np.sum((gamma_fit(x, i, p) - y) ** 2)      # noqa: E731
+            xm = (x - i)[None, :].astype(np.float64)
+            nz = np.where(K >= 1, xm >= 0, xm > 0)
+            with np.errstate(all="ignore"):
+                vals = A * np.where(nz, xm, 1.0) ** (K - 1) * np.exp(-xm / TH) / norm_c
+            J = np.sum((np.where(nz, vals, 0.0) - y[None, :]) ** 2, axis=1)
+            j0 = int(np.argmin(J))
+            x0 = np.array([K[j0, 0], TH[j0, 0], A[j0, 0]])
+            res = optimize.fmin(f, x0, full_output=1, disp=0)
             score[i], param[i] = res[1], res[0]
         best = int(np.argmin(score))
         self.nfr_fit0 = FragmentSizes(self.lower, self.upper, vals=gamma_fit(np.arange(self.lower, self.upper), best, param[best]))

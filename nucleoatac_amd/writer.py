@@ -99,7 +99,7 @@ class TbiBuilder(object):
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         L.check(self._lib.natac_tbi_push(self._h, n, arr, len(names), vp(index["cid"]), vp(index["beg"]), vp(index["end"]), vp(index["count"]),
                                          vp(index["t0"]), vp(index["t1"]), vp(index["member_pos"]), len(index["member_pos"]) - 1,
-                                         int(file_offset)))
+                                         int(index["n_text"]), int(file_offset)))
 
     def write(self, tbi_path):
         n = C.c_int64(0)

@@ -97,3 +97,19 @@ def test_streaming_rejects_truncated_files(tmp_path, monkeypatch):
         open(bad, "wb").write(raw[:cut])
         with pytest.raises(L.NatacError):
             FragmentStore.from_bam(bad)
+
+
+def test_corrupt_isize_is_rejected_before_allocation(tmp_path):
+    """a BGZF member whose ISIZE field claims gigabytes must be rejected ("corrupt BGZF block"), not used to size the buffer"""
+    import struct
+    refs = [("chrA", 50000)]
+    path = str(tmp_path / "ok.bam")
+    _write_bam(path, refs, [(0, 100 + i, 0x63, 200) for i in range(300)])
+    raw = bytearray(open(path, "rb").read())
+    bsize = struct.unpack_from("<H", raw, 16)[0] + 1                 # first member: overwrite its ISIZE with 3 GB
+    struct.pack_into("<I", raw, bsize - 4, 3000000000)
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(Exception) as e:
+        FragmentStore.from_bam(bad)
+    assert "corrupt BGZF block" in str(e.value)
