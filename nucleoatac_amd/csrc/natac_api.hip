@@ -2201,8 +2201,10 @@ int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads)
     std::vector<int> bad(n_threads, 0);
     auto work = [&](int t) {   // contiguous block ranges so that the parts concatenate in file order
         const size_t b0 = nblk * t / n_threads, b1 = nblk * (t + 1) / n_threads;
+        natac_writer::Deflater df;                // one z_stream per thread, deflateReset per member
+        parts[t].reserve((b1 - b0) * 24000);
         for (size_t b = b0; b < b1; ++b)
-            if (!natac_writer::bgzf_block(parts[t], (const unsigned char *)text.data() + b * BLK, std::min(BLK, text.size() - b * BLK), level)) {
+            if (!natac_writer::bgzf_block(parts[t], (const unsigned char *)text.data() + b * BLK, std::min(BLK, text.size() - b * BLK), level, &df)) {
                 bad[t] = 1;
                 return;
             }

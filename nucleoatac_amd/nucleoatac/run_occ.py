@@ -271,6 +271,7 @@ def run_occ(args):
         LAST_TIMINGS["writer_inside_pipeline"] = round(writer.seconds, 3)
     dists = gather_in_chunk_order(dists, dst=0)
     to_index = finish_indexes(writer if parts else None, list(track_of), lambda n: args.out + "." + n + ".bedgraph.gz")
+    ph.mark("gather_and_track_indexes")
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
     if rank == 0:
         if world > 1:   # BGZF members / text lines concatenate: rank order == chunk order
@@ -282,10 +283,12 @@ def run_occ(args):
                             shutil.copyfileobj(fi, fo)
                         os.remove(base + ".rank%d" % r)
         # bgzip + tabix of every output like the reference (run_occ.py:130-136)
+        ph.mark("merge_part_files")
         bgzip_file(args.out + ".occpeaks.bed", level=COMPRESS_LEVEL)
         tabix_index(args.out + ".occpeaks.bed.gz")
+        ph.mark("occpeaks_bgzip_tabix")
         for path in to_index:
             tabix_index(path)
         nuc_dist = ordered_sum(dists) if dists else np.zeros(args.upper)
         FragmentSizes(0, args.upper, vals=nuc_dist).save(args.out + ".nuc_dist.txt")
-    ph.mark("merge_bgzip_tabix")
+    ph.mark("nuc_dist_and_rest")
