@@ -224,7 +224,10 @@ class Context(object):
 
     def pwm_bias(self, sequence, pwm_mat, nucleotides):
         """InsertionBiasTrack.computeBias (pyatac/bias.py:85-92): log-bias of every position of `sequence`."""
-        seq = np.frombuffer(sequence.encode("ascii") if isinstance(sequence, str) else bytes(sequence), dtype=np.uint8)
+        if isinstance(sequence, np.ndarray) and sequence.dtype == np.uint8:
+            seq = np.ascontiguousarray(sequence)              # already upper-case ASCII codes (FastaStore)
+        else:
+            seq = np.frombuffer(sequence.encode("ascii") if isinstance(sequence, str) else bytes(sequence), dtype=np.uint8)
         logp = _f64(np.log(np.asarray(pwm_mat, dtype=np.float64)))
         lens = set(len(x) for x in nucleotides)
         if len(lens) != 1:     # the reference's seq_to_mat check (pyatac/seq.py:39-41)

@@ -7,7 +7,6 @@ import numpy as np
 from . import _lib as L
 from . import get_context
 from .packing import BIAS_LEFT, BIAS_RIGHT, PackedChunks, sort_by_centre
-from .pyatac.bias import InsertionBiasTrack
 from .pyatac.fragments import FragmentStore
 
 # fragments attached to a chunk: l in [start - MARGIN, end + MARGIN) -- covers every fragment that can put a centre
@@ -54,11 +53,7 @@ def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN,
     offs, lpos, ilen = _pack_fragments(st, chroms, starts, ends, margin, atac)
     boffs = bias = None
     if fasta is not None:
-        bias_of = _bias_spans(chunks, fasta, chrs, pwm, bias_left=bl, bias_right=br)
-        bvals = [bias_of(ch) for ch in chunks]
-        boffs = np.zeros(nc + 1, np.int64)
-        np.cumsum([len(v) for v in bvals], out=boffs[1:])
-        bias = np.concatenate(bvals).astype(np.float64) if bvals else np.zeros(0, np.float64)
+        boffs, bias = _bias_batch(chunks, starts, ends, fasta, pwm, bl, br)
     return PackedChunks(chunk_start=starts, chunk_len=(ends - starts).astype(np.int32), frag_off=offs, frag_lpos=lpos,
                         frag_ilen=ilen, bias_off=boffs, bias_log=bias, chroms=chroms, bias_left=bl, bias_right=br)
 
@@ -87,41 +82,30 @@ def _pack_fragments(st, chroms, starts, ends, margin, atac):
     return offs, lpos, ilen
 
 
-def _bias_spans(chunks, fasta, chrs, pwm, max_gap=4096, bias_left=BIAS_LEFT, bias_right=BIAS_RIGHT):
-    """PWM log-bias for [start-246, end+247) of every chunk (InsertionBiasTrack.computeBias, pyatac/bias.py:85-92).
-    Windows of nearby chunks are merged into spans that are scored with ONE natac_pwm_bias launch each and then sliced,
-    instead of one sequence fetch + launch per chunk as in the reference (Occupancy.py:212-214)."""
-    by_chrom = {}
-    for ch in chunks:
-        by_chrom.setdefault(ch.chrom, []).append((ch.start - bias_left, ch.end + bias_right))
-    spans = {}
-    for chrom, iv in by_chrom.items():
-        iv.sort()
-        cur = list(iv[0])
-        merged = []
-        for a, b in iv[1:]:
-            if a <= cur[1] + max_gap:
-                cur[1] = max(cur[1], b)
-            else:
-                merged.append(cur)
-                cur = [a, b]
-        merged.append(cur)
-        tracks = []
-        for a, b in merged:
-            bt = InsertionBiasTrack(chrom, a, b, log=True)
-            bt.computeBias(fasta, chrs, pwm)
-            tracks.append((bt.start, bt.end, bt.vals))
-        spans[chrom] = (np.array([t[0] for t in tracks]), tracks)
-
-    def lookup(ch):
-        a, b = ch.start - bias_left, ch.end + bias_right
-        s0, tracks = spans[ch.chrom]
-        t = tracks[int(np.searchsorted(s0, a, "right")) - 1]
-        if a < t[0] or b > t[1]:
+def _bias_batch(chunks, starts, ends, fasta, pwm, bias_left, bias_right):
+    """PWM log-bias of [start - bias_left, end + bias_right) for every chunk of a sub-batch with ONE natac_pwm_bias launch
+    (InsertionBiasTrack.computeBias, pyatac/bias.py:85-92, per chunk in the reference, Occupancy.py:212-214): the sequence windows
+    [start - bias_left - pwm.up, end + bias_right + pwm.down] of all chunks are laid end to end, scored in one pass, and the
+    K - 1 scores that straddle two windows are dropped by the gather that forms the packed bias array."""
+    from . import get_context
+    from .pyatac.seq import FastaStore
+    fs = FastaStore.open(fasta)
+    K = pwm.up + pwm.down + 1
+    a = starts - bias_left - pwm.up
+    b = ends + bias_right + pwm.down + 1
+    segs = []
+    for k, ch in enumerate(chunks):
+        s = fs.seqs.get(ch.chrom)
+        if s is None or a[k] < 0 or b[k] > len(s):
             raise Exception("chunk %s too close to the chromosome end for the bias window" % ch.asBed())
-        return t[2][a - t[0]:b - t[0]]
-
-    return lookup
+        segs.append(s[int(a[k]):int(b[k])])
+    cat = np.concatenate(segs) if segs else np.zeros(0, np.uint8)
+    scores = get_context().pwm_bias(cat, pwm.mat, pwm.nucleotides)
+    lens = (ends - starts) + bias_left + bias_right                  # scores kept per chunk
+    boffs = np.zeros(len(chunks) + 1, np.int64)
+    np.cumsum(lens, out=boffs[1:])
+    idx = np.arange(int(boffs[-1]), dtype=np.int64) + np.repeat(np.arange(len(chunks), dtype=np.int64) * (K - 1), lens)
+    return boffs, scores[idx]
 
 
 def window_size_hist(pk, k, pos, flank, upper):

@@ -210,6 +210,8 @@ def my_shard(packed, rank=None, world=None, kappa=4.0):
 def gather_in_chunk_order(local_items, dst=0):
     """Gather per-chunk python objects / arrays from every rank to `dst`, concatenated in rank (== chunk) order.
     Works with any initialised torch.distributed backend (nccl on GPUs, gloo on CPU); no-op without one."""
+    if env_rank_world()[1] <= 1 and "torch.distributed" not in __import__("sys").modules:
+        return list(local_items)             # single process: do not pay the 1 s `import torch` for a no-op
     try:
         import torch.distributed as dist
     except Exception:  # pragma: no cover
