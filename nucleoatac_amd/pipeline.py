@@ -85,14 +85,14 @@ def _pack_fragments(st, chroms, starts, ends, margin, atac):
 def _bias_batch(chunks, starts, ends, fasta, pwm, bias_left, bias_right):
     """PWM log-bias of [start - bias_left, end + bias_right) for every chunk of a sub-batch with ONE natac_pwm_bias launch
     (InsertionBiasTrack.computeBias, pyatac/bias.py:85-92, per chunk in the reference, Occupancy.py:212-214): the sequence windows
-    [start - bias_left - pwm.up, end + bias_right + pwm.down] of all chunks are laid end to end, scored in one pass, and the
+    [start - bias_left - pwm.up, end + bias_right + pwm.down) of all chunks are laid end to end, scored in one pass, and the
     K - 1 scores that straddle two windows are dropped by the gather that forms the packed bias array."""
     from . import get_context
     from .pyatac.seq import FastaStore
     fs = FastaStore.open(fasta)
     K = pwm.up + pwm.down + 1
     a = starts - bias_left - pwm.up
-    b = ends + bias_right + pwm.down + 1
+    b = ends + bias_right + pwm.down          # computeBias: [a - up, b + down) gives exactly b - a scores
     segs = []
     for k, ch in enumerate(chunks):
         s = fs.seqs.get(ch.chrom)
