@@ -110,6 +110,14 @@ int natac_set_occ_model(natac_ctx *ctx, const double *nuc_probs, const double *n
 int natac_batch_create(natac_ctx *ctx, int32_t n_chunks, const int32_t *chunk_len, const int64_t *frag_off,
                        const int32_t *frag_lpos, const int32_t *frag_ilen, const int64_t *bias_off,
                        const double *bias_log, int32_t bias_left, int32_t bias_right, natac_batch **out);
+/* The same batch with the Tn5 bias scored ON THE DEVICE from the genome sequence (InsertionBiasTrack.computeBias, pyatac/bias.py:85-92, as
+ * the reference calls it per chunk, Occupancy.py:212-214 / NucleosomeCalling.py:246-248): seq[seq_off[i] .. seq_off[i+1]) = the upper-case
+ * bases of [start - bias_left - up, end + bias_right + down) of chunk i (up + down + 1 = K, the PWM width); log_pwm[nrow x K] = log(PWM.mat),
+ * nucleotides[nrow] its row letters (natac_pwm_bias).  One byte per base crosses PCIe instead of a float64 score down and up again. */
+int natac_batch_create_from_seq(natac_ctx *ctx, int32_t n_chunks, const int32_t *chunk_len, const int64_t *frag_off,
+                                const int32_t *frag_lpos, const int32_t *frag_ilen, const int64_t *seq_off, const uint8_t *seq,
+                                const double *log_pwm, const uint8_t *nucleotides, int nrow, int K, int32_t bias_left,
+                                int32_t bias_right, natac_batch **out);
 void natac_batch_free(natac_batch *b);
 int natac_batch_info(natac_batch *b, int64_t *total_bp, int64_t *total_grid, int64_t *n_frags);
 /* Drop every output of the batch (per-base tracks, grid arrays, candidate / peak arrays) but keep its packed inputs resident:

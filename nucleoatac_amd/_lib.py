@@ -33,6 +33,7 @@ SIGNATURES = {
     "natac_set_sizes": (C.c_int, [_vp, _vp, C.c_int]),
     "natac_set_occ_model": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _f64, C.c_int, C.c_int]),
     "natac_batch_create": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _pp]),
+    "natac_batch_create_from_seq": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i32, _i32, _pp]),
     "natac_batch_free": (None, [_vp]),
     "natac_batch_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "natac_batch_release_outputs": (C.c_int, [_vp]),

@@ -857,7 +857,7 @@ int natac_batch_create(natac_ctx *c, int32_t nc, const int32_t *chunk_len, const
     if (!c || !out || !chunk_len || !frag_off) return fail(NATAC_E_ARG, "null argument");
     *out = nullptr;
     if (nc <= 0) return fail(NATAC_E_ARG, "n_chunks must be positive");
-    if ((bias_off == nullptr) != (bias_log == nullptr)) return fail(NATAC_E_ARG, "bias_off and bias_log must both be given or both NULL");
+    if (bias_log && !bias_off) return fail(NATAC_E_ARG, "bias_log without bias_off");
     if (frag_off[0] != 0) return fail(NATAC_E_ARG, "frag_off[0] must be 0");
     const long long nf = frag_off[nc];
     if (nf > 0 && (!frag_lpos || !frag_ilen)) return fail(NATAC_E_ARG, "fragment arrays are NULL");
@@ -889,7 +889,8 @@ int natac_batch_create(natac_ctx *c, int32_t nc, const int32_t *chunk_len, const
     TRY(dev_upload(c, &b->d_out_off, b->h_out_off.data(), (size_t)nc + 1));
     if (bias_off) {
         TRY(dev_upload(c, (long long **)&b->d_bias_off, (const long long *)bias_off, (size_t)nc + 1));
-        TRY(dev_upload(c, &b->d_bias, bias_log, (size_t)b->nb));
+        if (bias_log) TRY(dev_upload(c, &b->d_bias, bias_log, (size_t)b->nb));
+        else TRY(dev_alloc(&b->d_bias, (size_t)b->nb));           // filled on the device (natac_batch_create_from_seq)
     }
     TRY(dev_alloc(&b->d_status, (size_t)nc));
     hipError_t e = hipMemsetAsync(b->d_status, 0, (size_t)nc * sizeof(int), c->stream);
@@ -904,6 +905,44 @@ int natac_batch_create(natac_ctx *c, int32_t nc, const int32_t *chunk_len, const
 #undef TRY
     *out = b;
     return NATAC_OK;
+}
+
+int natac_batch_create_from_seq(natac_ctx *c, int32_t nc, const int32_t *chunk_len, const int64_t *frag_off, const int32_t *frag_lpos,
+                                const int32_t *frag_ilen, const int64_t *seq_off, const uint8_t *seq, const double *log_pwm,
+                                const uint8_t *nucleotides, int nrow, int K, int32_t bias_left, int32_t bias_right, natac_batch **out) {
+    if (!c || !out || !chunk_len || !seq_off || !seq || !log_pwm || !nucleotides) return fail(NATAC_E_ARG, "null argument");
+    if (nc <= 0 || nrow < 1 || K < 1) return fail(NATAC_E_ARG, "bad argument");
+    std::vector<int64_t> boff((size_t)nc + 1, 0);
+    for (int i = 0; i < nc; ++i) {
+        const int64_t nb = (int64_t)chunk_len[i] + bias_left + bias_right;
+        if (seq_off[i + 1] - seq_off[i] != nb + K - 1)
+            return fail(NATAC_E_ARG, "sequence window of chunk %d must hold %lld bases ([start-%d-up, end+%d+down))", i, (long long)(nb + K - 1),
+                        bias_left, bias_right);
+        boff[(size_t)i + 1] = boff[(size_t)i] + nb;
+    }
+    int rc = natac_batch_create(c, nc, chunk_len, frag_off, frag_lpos, frag_ilen, boff.data(), nullptr, bias_left, bias_right, out);
+    if (rc) return rc;
+    natac_batch *b = *out;
+    unsigned char *d_s = nullptr, *d_n = nullptr;
+    long long *d_so = nullptr;
+    double *d_p = nullptr;
+    const size_t nseq = (size_t)seq_off[nc];
+    if ((rc = dev_upload(c, &d_s, (const unsigned char *)seq, nseq)) == NATAC_OK &&
+        (rc = dev_upload(c, (long long **)&d_so, (const long long *)seq_off, (size_t)nc + 1)) == NATAC_OK &&
+        (rc = dev_upload(c, &d_n, (const unsigned char *)nucleotides, (size_t)nrow)) == NATAC_OK &&
+        (rc = dev_upload(c, &d_p, log_pwm, (size_t)nrow * K)) == NATAC_OK) {
+        int maxlen = 0;
+        for (int i = 0; i < nc; ++i) maxlen = std::max(maxlen, chunk_len[i] + bias_left + bias_right);
+        const unsigned gx = (unsigned)std::min(16, (maxlen + 1023) / 1024);
+        hipLaunchKernelGGL(natac_pwm_score_chunks, dim3(gx, (unsigned)nc), dim3(256), 0, c->stream, d_s, d_so, b->d_bias_off, d_p, d_n, nrow, K,
+                           b->d_bias);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(NATAC_E_HIP, "pwm score: %s", hipGetErrorString(e));
+    }
+    dev_free(d_s); dev_free(d_so); dev_free(d_n); dev_free(d_p);
+    if (rc) { natac_batch_free(b); *out = nullptr; }
+    return rc;
 }
 
 void natac_batch_free(natac_batch *b) {

@@ -2333,6 +2333,28 @@ __global__ void __launch_bounds__(256) natac_bias_mat_dense(const double *__rest
 
 // InsertionBiasTrack.computeBias (pyatac/bias.py:85-92) + seq_to_mat (pyatac/seq.py:37-45):
 // out[x] = sum_k logpwm[row(seq[x+k]), k]; characters that are not one of the PWM's nucleotides add 0.
+// the same score for the packed bias array of a batch: chunk k's sequence window starts at seq_off[k] and holds its
+// bias_off[k+1] - bias_off[k] + K - 1 bases; one workgroup per 1024 positions of a chunk (grid.y = chunk)
+__global__ void __launch_bounds__(256) natac_pwm_score_chunks(const unsigned char *__restrict__ seq, const long long *__restrict__ seq_off,
+                                                                const long long *__restrict__ bias_off, const double *__restrict__ logpwm,
+                                                                const unsigned char *__restrict__ nucs, int nrow, int K,
+                                                                double *__restrict__ bias) {
+    const int chunk = blockIdx.y;
+    const long long nb = bias_off[chunk + 1] - bias_off[chunk];
+    const unsigned char *s = seq + seq_off[chunk];
+    double *o = bias + bias_off[chunk];
+    for (long long x = (long long)blockIdx.x * 256 + threadIdx.x; x < nb; x += (long long)gridDim.x * 256) {
+        double acc = 0.0;
+        for (int r = 0; r < nrow; ++r) {
+            double rs = 0.0;
+            const unsigned char c = nucs[r];
+            for (int k = 0; k < K; ++k) if (s[x + k] == c) rs += logpwm[r * K + k];
+            acc += rs;
+        }
+        o[x] = acc;
+    }
+}
+
 __global__ void __launch_bounds__(256) natac_pwm_score(const unsigned char *__restrict__ seq, long long n,
                                                          const double *__restrict__ logpwm, const unsigned char *__restrict__ nucs,
                                                          int nrow, int K, double *__restrict__ out) {

@@ -311,10 +311,16 @@ class DeviceBatch(object):
         self._lib = ctx._lib
         self.packed = packed
         h = C.c_void_p()
-        L.check(self._lib.natac_batch_create(
-            ctx._h, packed.n_chunks, _ptr(packed.chunk_len), _ptr(packed.frag_off), _ptr(packed.frag_lpos),
-            _ptr(packed.frag_ilen), _ptr(packed.bias_off) if packed.bias_log is not None else None,
-            _ptr(packed.bias_log), int(packed.bias_left), int(packed.bias_right), C.byref(h)))
+        if getattr(packed, "seq", None) is not None:        # Tn5 bias scored on the device from the sequence windows
+            L.check(self._lib.natac_batch_create_from_seq(
+                ctx._h, packed.n_chunks, _ptr(packed.chunk_len), _ptr(packed.frag_off), _ptr(packed.frag_lpos), _ptr(packed.frag_ilen),
+                _ptr(packed.seq_off), _ptr(packed.seq), _ptr(packed.pwm_log), _ptr(packed.pwm_nucs), packed.pwm_log.shape[0],
+                packed.pwm_log.shape[1], int(packed.bias_left), int(packed.bias_right), C.byref(h)))
+        else:
+            L.check(self._lib.natac_batch_create(
+                ctx._h, packed.n_chunks, _ptr(packed.chunk_len), _ptr(packed.frag_off), _ptr(packed.frag_lpos),
+                _ptr(packed.frag_ilen), _ptr(packed.bias_off) if packed.bias_log is not None else None,
+                _ptr(packed.bias_log), int(packed.bias_left), int(packed.bias_right), C.byref(h)))
         self._h = h
         self.total_bp = packed.total_bp
         ctx._batches.add(self)

@@ -12,7 +12,7 @@ import numpy as np
 
 from .. import _lib as L
 from ..executor import PipelinedExecutor, Stages
-from ..pipeline import pack
+from ..pipeline import pack, prefetch_map
 from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
@@ -206,9 +206,9 @@ def run_nuc(args):
         writer.start()
         fa_chrs = read_chrom_sizes_from_fasta(params.fasta) if params.fasta is not None else params.chrs
 
-        def items():
-            for part in parts:
-                yield pack(part, st, params.fasta, fa_chrs, params.pwm, atac=params.atac, window=params.window, upper=params.upper), part
+        def items():       # sub-batches packed up to three ahead of the GPU, on their own threads
+            return prefetch_map(lambda part: (pack(part, st, params.fasta, fa_chrs, params.pwm, atac=params.atac, window=params.window,
+                                                   upper=params.upper, bias_on_device=True), part), parts, depth=3)
 
         device = int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         try:

@@ -17,7 +17,7 @@ import numpy as np
 
 from .. import _lib as L
 from ..executor import PipelinedExecutor, Stages
-from ..pipeline import chunk_fragment_counts, pack
+from ..pipeline import chunk_fragment_counts, pack, prefetch_map
 from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
@@ -244,14 +244,16 @@ def run_occ(args):
 
         pack_s = [0.0]
 
-        def items():
+        def pack_part(part):
             import time
-            for part in parts:
-                t0 = time.perf_counter()
-                pk = pack(part, st, params.fasta, params.chrs, params.pwm if params.fasta is not None else None,
-                          window=params.window, upper=params.upper)
-                pack_s[0] += time.perf_counter() - t0
-                yield pk, part
+            t0 = time.perf_counter()
+            pk = pack(part, st, params.fasta, params.chrs, params.pwm if params.fasta is not None else None,
+                      window=params.window, upper=params.upper, bias_on_device=True)
+            pack_s[0] += time.perf_counter() - t0
+            return pk, part
+
+        def items():       # sub-batches packed up to three ahead of the GPU, on their own threads
+            return prefetch_map(pack_part, parts, depth=3)
 
         device = int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         try:

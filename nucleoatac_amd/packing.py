@@ -41,6 +41,12 @@ class PackedChunks:
     bias_right: int = BIAS_RIGHT
     chroms: List[str] = field(default_factory=list)
     out_off: np.ndarray = None
+    # alternative to bias_log: the genome sequence of every chunk's bias window, scored on the device when the batch is uploaded
+    # (natac_batch_create_from_seq): seq[seq_off[i]:seq_off[i+1]] = bases of [start - bias_left - up, end + bias_right + down)
+    seq_off: Optional[np.ndarray] = None
+    seq: Optional[np.ndarray] = None
+    pwm_log: Optional[np.ndarray] = None       # log(PWM.mat), (nrow, K)
+    pwm_nucs: Optional[np.ndarray] = None      # uint8 row letters
 
     def __post_init__(self):
         self.chunk_start = np.ascontiguousarray(self.chunk_start, dtype=np.int64)
@@ -51,6 +57,13 @@ class PackedChunks:
         if self.bias_log is not None:
             self.bias_off = np.ascontiguousarray(self.bias_off, dtype=np.int64)
             self.bias_log = np.ascontiguousarray(self.bias_log, dtype=np.float64)
+        if self.seq is not None:
+            if self.bias_log is not None:
+                raise ValueError("give either bias_log or seq, not both")
+            self.seq_off = np.ascontiguousarray(self.seq_off, dtype=np.int64)
+            self.seq = np.ascontiguousarray(self.seq, dtype=np.uint8)
+            self.pwm_log = np.ascontiguousarray(self.pwm_log, dtype=np.float64)
+            self.pwm_nucs = np.ascontiguousarray(self.pwm_nucs, dtype=np.uint8)
         if self.out_off is None:
             self.out_off = np.zeros(self.n_chunks + 1, dtype=np.int64)
             np.cumsum(self.chunk_len, out=self.out_off[1:])
@@ -80,6 +93,11 @@ class PackedChunks:
             want = self.chunk_len.astype(np.int64) + self.bias_left + self.bias_right
             if self.bias_off.shape[0] != nc + 1 or np.any(np.diff(self.bias_off) != want):
                 raise ValueError("bias_log must cover [start-bias_left, end+bias_right) for every chunk")
+        if self.seq is not None:
+            K = self.pwm_log.shape[1]
+            want = self.chunk_len.astype(np.int64) + self.bias_left + self.bias_right + K - 1
+            if self.seq_off.shape[0] != nc + 1 or np.any(np.diff(self.seq_off) != want) or self.seq_off[-1] != self.seq.shape[0]:
+                raise ValueError("seq must hold [start-bias_left-up, end+bias_right+down) for every chunk")
         if np.any(self.chunk_len <= 0):
             raise ValueError("empty chunk")
 
@@ -104,6 +122,9 @@ class PackedChunks:
             ba, bb = int(self.bias_off[lo]), int(self.bias_off[hi])
             kw["bias_off"] = self.bias_off[lo:hi + 1] - ba
             kw["bias_log"] = self.bias_log[ba:bb]
+        if self.seq is not None:
+            sa, sb = int(self.seq_off[lo]), int(self.seq_off[hi])
+            kw.update(seq_off=self.seq_off[lo:hi + 1] - sa, seq=self.seq[sa:sb], pwm_log=self.pwm_log, pwm_nucs=self.pwm_nucs)
         return PackedChunks(**kw)
 
 

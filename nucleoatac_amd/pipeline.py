@@ -14,6 +14,23 @@ from .pyatac.fragments import FragmentStore
 MARGIN = 2000 + 126
 
 
+def prefetch_map(fn, items, depth=3):
+    """fn(item) for every item, in order, computed up to `depth` items ahead on a small thread pool: host-side packing of the
+    next sub-batches (numpy + the native packer, both release the GIL) overlaps with each other and with the consumer"""
+    import collections
+    import itertools
+    from concurrent.futures import ThreadPoolExecutor
+    it = iter(items)
+    with ThreadPoolExecutor(max(1, depth), thread_name_prefix="natac-pack") as ex:
+        futs = collections.deque(ex.submit(fn, x) for x in itertools.islice(it, max(1, depth)))
+        while futs:
+            res = futs.popleft().result()
+            nxt = next(it, None)
+            if nxt is not None:
+                futs.append(ex.submit(fn, nxt))
+            yield res
+
+
 def bias_window(window, upper):
     """(left, right) extent of the reference's bias track around a chunk: [start - window - upper//2, end + window +
     upper//2 + 1) with window = 2*flank+1 (occ, Occupancy.py:184, 212-213) or the V-plot width (nuc,
@@ -40,7 +57,7 @@ def chunk_fragment_counts(st, chunks):
     return n
 
 
-def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN, window=None, upper=None):
+def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN, window=None, upper=None, bias_on_device=False):
     """PackedChunks for a list of Chunk objects.  The log-bias slice of every chunk is the PWM score of
     [start-246, end+247) (InsertionBiasTrack.computeBias, as in nucleoatac/Occupancy.py:212-214) or None; `window` /
     `upper` (OccupancyParameters.window / NucParameters.window and .upper) widen it for non-default parameters."""
@@ -52,10 +69,19 @@ def pack(chunks, bam, fasta=None, chrs=None, pwm=None, atac=True, margin=MARGIN,
     ends = np.array([ch.end for ch in chunks], np.int64)
     offs, lpos, ilen = _pack_fragments(st, chroms, starts, ends, margin, atac)
     boffs = bias = None
-    if fasta is not None:
+    extra = {}
+    if fasta is not None and bias_on_device:
+        # hand the sequence windows to the device: the PWM score lands in the batch's bias array without a round trip
+        seq_off, seq = _seq_windows(chunks, starts, ends, fasta, pwm, bl, br)
+        lens = set(len(x) for x in pwm.nucleotides)
+        if lens != {1}:
+            raise NotImplementedError("k-mer PWMs are not supported on the device (single-nucleotide PWMs only)")
+        extra = dict(seq_off=seq_off, seq=seq, pwm_log=np.log(np.asarray(pwm.mat, dtype=np.float64)),
+                     pwm_nucs=np.frombuffer("".join(pwm.nucleotides).encode("ascii"), dtype=np.uint8))
+    elif fasta is not None:
         boffs, bias = _bias_batch(chunks, starts, ends, fasta, pwm, bl, br)
     return PackedChunks(chunk_start=starts, chunk_len=(ends - starts).astype(np.int32), frag_off=offs, frag_lpos=lpos,
-                        frag_ilen=ilen, bias_off=boffs, bias_log=bias, chroms=chroms, bias_left=bl, bias_right=br)
+                        frag_ilen=ilen, bias_off=boffs, bias_log=bias, chroms=chroms, bias_left=bl, bias_right=br, **extra)
 
 
 def _pack_fragments(st, chroms, starts, ends, margin, atac):
@@ -82,24 +108,31 @@ def _pack_fragments(st, chroms, starts, ends, margin, atac):
     return offs, lpos, ilen
 
 
-def _bias_batch(chunks, starts, ends, fasta, pwm, bias_left, bias_right):
-    """PWM log-bias of [start - bias_left, end + bias_right) for every chunk of a sub-batch with ONE natac_pwm_bias launch
-    (InsertionBiasTrack.computeBias, pyatac/bias.py:85-92, per chunk in the reference, Occupancy.py:212-214): the sequence windows
-    [start - bias_left - pwm.up, end + bias_right + pwm.down) of all chunks are laid end to end, scored in one pass, and the
-    K - 1 scores that straddle two windows are dropped by the gather that forms the packed bias array."""
-    from . import get_context
+def _seq_windows(chunks, starts, ends, fasta, pwm, bias_left, bias_right):
+    """(seq_off, seq): the sequence windows [start - bias_left - pwm.up, end + bias_right + pwm.down) of the chunks laid end to end"""
     from .pyatac.seq import FastaStore
     fs = FastaStore.open(fasta)
-    K = pwm.up + pwm.down + 1
     a = starts - bias_left - pwm.up
-    b = ends + bias_right + pwm.down          # computeBias: [a - up, b + down) gives exactly b - a scores
+    b = ends + bias_right + pwm.down
     segs = []
     for k, ch in enumerate(chunks):
         s = fs.seqs.get(ch.chrom)
         if s is None or a[k] < 0 or b[k] > len(s):
             raise Exception("chunk %s too close to the chromosome end for the bias window" % ch.asBed())
         segs.append(s[int(a[k]):int(b[k])])
-    cat = np.concatenate(segs) if segs else np.zeros(0, np.uint8)
+    off = np.zeros(len(chunks) + 1, np.int64)
+    np.cumsum(b - a, out=off[1:])
+    return off, (np.concatenate(segs) if segs else np.zeros(0, np.uint8))
+
+
+def _bias_batch(chunks, starts, ends, fasta, pwm, bias_left, bias_right):
+    """PWM log-bias of [start - bias_left, end + bias_right) for every chunk of a sub-batch with ONE natac_pwm_bias launch
+    (InsertionBiasTrack.computeBias, pyatac/bias.py:85-92, per chunk in the reference, Occupancy.py:212-214): the sequence windows
+    [start - bias_left - pwm.up, end + bias_right + pwm.down) of all chunks are laid end to end, scored in one pass, and the
+    K - 1 scores that straddle two windows are dropped by the gather that forms the packed bias array."""
+    from . import get_context
+    K = pwm.up + pwm.down + 1
+    _, cat = _seq_windows(chunks, starts, ends, fasta, pwm, bias_left, bias_right)
     scores = get_context().pwm_bias(cat, pwm.mat, pwm.nucleotides)
     lens = (ends - starts) + bias_left + bias_right                  # scores kept per chunk
     boffs = np.zeros(len(chunks) + 1, np.int64)

@@ -199,3 +199,31 @@ def test_index_from_device_records_equals_index_from_the_file(ctx, tmp_path):
         n_file = tabix_index(path)
         assert n_dev == n_file > 100000
         assert open(path + ".dev.tbi", "rb").read() == open(path + ".tbi", "rb").read(), track
+
+
+def test_bias_scored_on_the_device_equals_host_packed_bias(ctx):
+    """natac_batch_create_from_seq: the batch's Tn5 bias computed on the device from the sequence windows gives bit-identical
+    tracks to the batch whose bias array was scored through natac_pwm_bias and uploaded (InsertionBiasTrack.computeBias,
+    pyatac/bias.py:85-92)"""
+    from helpers import synth_stores
+    from nucleoatac_amd import set_context
+    from nucleoatac_amd.pipeline import pack
+    from nucleoatac_amd.pyatac.bias import PWM
+    from nucleoatac_amd.pyatac.chunk import Chunk
+    set_context(ctx)
+    frags, fasta = synth_stores(11)
+    chunks = [Chunk("chrS", s, s + 900 + 37 * i) for i, s in enumerate(range(1200, 11000, 1400))]
+    pwm = PWM.open("Human")
+    host = pack(chunks, frags, fasta, fasta.chrom_sizes(), pwm, window=121, upper=251)
+    dev = pack(chunks, frags, fasta, fasta.chrom_sizes(), pwm, window=121, upper=251, bias_on_device=True)
+    assert dev.bias_log is None and dev.seq is not None and host.bias_log is not None
+    outs = []
+    for pk in (host, dev):
+        b = ctx.upload(pk)
+        b.run_nuc(10)
+        b.run_occ()
+        outs.append([b.track(t) for t in (L.T_BACKGROUND, L.T_NORM, L.T_OCC, L.T_OCC_LOWER)])
+        b.free()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert np.abs(outs[0][0]).max() > 0
