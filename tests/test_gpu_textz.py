@@ -210,12 +210,15 @@ def test_bias_scored_on_the_device_equals_host_packed_bias(ctx):
     from nucleoatac_amd.pipeline import pack
     from nucleoatac_amd.pyatac.bias import PWM
     from nucleoatac_amd.pyatac.chunk import Chunk
-    set_context(ctx)
+    import nucleoatac_amd
+    prev = nucleoatac_amd._default_ctx
+    set_context(ctx)                       # pack() scores the host-side bias through the default context
     frags, fasta = synth_stores(11)
     chunks = [Chunk("chrS", s, s + 900 + 37 * i) for i, s in enumerate(range(1200, 11000, 1400))]
     pwm = PWM.open("Human")
     host = pack(chunks, frags, fasta, fasta.chrom_sizes(), pwm, window=121, upper=251)
     dev = pack(chunks, frags, fasta, fasta.chrom_sizes(), pwm, window=121, upper=251, bias_on_device=True)
+    set_context(prev)
     assert dev.bias_log is None and dev.seq is not None and host.bias_log is not None
     outs = []
     for pk in (host, dev):
