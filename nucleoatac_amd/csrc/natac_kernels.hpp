@@ -1509,8 +1509,10 @@ __device__ __forceinline__ int wave_lower_bound(const int *__restrict__ a, int l
 // Lanes without a template column (c >= W) read the zeros block instead of branching: their products are exactly 0.
 // USEBG: sum B and sum B V of a candidate's window are the per-base values the background kernel already formed at that
 // position (bcov / bnum of natac_run_nuc); the sweep then keeps two accumulators per candidate instead of four.
+// USEBG keeps two accumulators per candidate and column and fits three waves per SIMD (168 VGPRs); the four-accumulator form
+// needs ~230 VGPRs: it is compiled for two waves per SIMD instead of spilling 196 registers to scratch (round 2's build)
 template <bool USEBG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) natac_candidates4(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(USEBG ? 3 : 2, USEBG ? 3 : 2))) natac_candidates4(ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk,
                                                            const int *__restrict__ cand_pos, int ncand,
                                                            const double *__restrict__ nuc_cov, const double *__restrict__ norm,
                                                            const double *__restrict__ bnum, const double *__restrict__ bcov,
