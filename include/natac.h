@@ -176,6 +176,9 @@ int natac_download_nuc_dist(natac_batch *b, double *dst, size_t dst_bytes);
 int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes);
 /* copy one per-grid-point array to host (float64[total_grid]). */
 int natac_batch_download_grid(natac_batch *b, int which, double *dst, size_t dst_bytes);
+/* overwrite one float64 per-base track of the batch with host values (total_bp doubles, chunk order): lets any track -- an
+ * externally computed one, or a test pattern -- go through the device-side writer (natac_batch_format_track) */
+int natac_batch_set_track(natac_batch *b, int track, const double *vals, size_t n);
 /* per-chunk status flags (int32[n_chunks]; 0 = ok, bit0 = occupancy likelihood undefined at some grid point
  * -- the reference would raise ValueError at Occupancy.py:118). */
 int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes);

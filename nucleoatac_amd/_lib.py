@@ -50,6 +50,7 @@ SIGNATURES = {
     "natac_download_nuc_dist": (C.c_int, [_vp, _vp, _sz]),
     "natac_batch_download": (C.c_int, [_vp, C.c_int, _vp, _sz]),
     "natac_batch_download_grid": (C.c_int, [_vp, C.c_int, _vp, _sz]),
+    "natac_batch_set_track": (C.c_int, [_vp, C.c_int, _vp, _sz]),
     "natac_batch_status": (C.c_int, [_vp, _vp, _sz]),
     "natac_batch_track_ptr": (C.c_int, [_vp, C.c_int, _pp]),
     "natac_make_fragment_mat": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp]),

@@ -1723,6 +1723,22 @@ int natac_batch_download_grid(natac_batch *b, int which, double *dst, size_t dst
     return NATAC_OK;
 }
 
+int natac_batch_set_track(natac_batch *b, int track, const double *vals, size_t n) {
+    if (!b || !vals) return fail(NATAC_E_ARG, "null argument");
+    if (track < 0 || track >= NATAC_T_COUNT || track == NATAC_T_INS) return fail(NATAC_E_ARG, "bad track id %d (float64 tracks only)", track);
+    if (n != (size_t)b->total_bp) return fail(NATAC_E_ARG, "track needs %lld values, got %zu", b->total_bp, n);
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_all(c));
+    int rc = ensure_track(b, track);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(b->d_track[track], vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (track <= NATAC_T_SMOOTH) b->nuc_done = true;            // the stage flags only gate downloads / the writer
+    else { b->occ_done = true; if (track == NATAC_T_OCC_PREFILL) b->prefill_valid = true; }
+    return NATAC_OK;
+}
+
 int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes) {
     if (!b || !dst) return fail(NATAC_E_ARG, "null argument");
     if (dst_bytes != (size_t)b->nc * sizeof(int)) return fail(NATAC_E_ARG, "status buffer must hold n_chunks int32");

@@ -458,6 +458,12 @@ class DeviceBatch(object):
             info["index"] = rec
         return buf[:nb.value], info
 
+    def set_track(self, t, vals):
+        """overwrite float64 per-base track `t` with host values (natac_batch_set_track), e.g. to send an externally computed
+        track through the device-side writer"""
+        v = _f64(vals)
+        L.check(self._lib.natac_batch_set_track(self._h, int(t), _ptr(v), v.shape[0]))
+
     def track(self, t, out=None):
         """download one per-base track (concatenated over chunks); `out`: destination array (e.g. pinned_empty)"""
         dt = np.int32 if t == L.T_INS else np.float64

@@ -230,3 +230,55 @@ def test_bias_scored_on_the_device_equals_host_packed_bias(ctx):
     for x, y in zip(*outs):
         assert np.array_equal(x, y, equal_nan=True)
     assert np.abs(outs[0][0]).max() > 0
+
+
+def test_device_writer_on_random_tracks(ctx, tmp_path):
+    """arbitrary values through the device writer (natac_batch_set_track): NaN runs of every length and position, runs of equal
+    values (incl. +0 / -0, which compare equal and form one run), zeros, negative and tiny / huge magnitudes, integers, ragged
+    chunk lengths, chromosome names of 1..64 characters, coordinates up to 2^40: text == native host writer for every
+    write_zero / keep-runs-before-NaN mode, BGZF members inflate to it and equal the host restatement"""
+    rng = np.random.default_rng(77)
+    for rnd in range(6):
+        nc = int(rng.integers(1, 40))
+        lens = rng.integers(121, 3000, size=nc)
+        nb = lens + 493
+        pk = PackedChunks(np.sort(rng.integers(0, 2 ** 40 if rnd == 5 else 10 ** 9, size=nc)), lens, np.zeros(nc + 1, np.int64), np.zeros(0, np.int32),
+                          np.zeros(0, np.int32), np.concatenate(([0], np.cumsum(nb))), np.zeros(int(nb.sum())))
+        names = ["".join(rng.choice(list("abcXYZ_0123456789."), size=int(rng.integers(1, 65)))) for _ in range(4)]
+        chroms = [names[int(i)] for i in np.sort(rng.integers(0, 4, size=nc))]
+        n = int(lens.sum())
+        kind = rng.integers(0, 6, size=n)
+        v = np.where(kind == 0, rng.normal(0, 1, n), 0.0)
+        v = np.where(kind == 1, rng.integers(-3, 50, n).astype(float), v)
+        v = np.where(kind == 2, rng.normal(0, 1, n) * 10.0 ** rng.integers(-30, 11, n), v)
+        v = np.where(kind == 3, np.round(rng.random(n), 2), v)
+        v = np.where(kind == 4, -0.0, v)
+        # runs: repeat values over random stretches; NaN stretches
+        i = 0
+        while i < n:
+            ln = int(rng.integers(1, 60))
+            mode = rng.integers(0, 5)
+            if mode == 0:
+                v[i:i + ln] = v[i]
+            elif mode == 1:
+                v[i:i + ln] = np.nan
+            i += ln
+        b = ctx.upload(pk)
+        b.set_track(L.T_SMOOTH, v)
+        for wz, keep in ((True, False), (False, False), (True, True), (False, True)):
+            text, info = b.format_track(L.T_SMOOTH, chroms, pk.chunk_start, write_zero=wz, keep_runs_before_nan=keep, compress=False)
+            want = _native_text(tmp_path, chroms, pk.chunk_start, pk.out_off, v, write_zero=wz, keep_runs_before_nan=keep)
+            assert info["hard"] == 0 and text.tobytes() == want, (rnd, wz, keep)
+        z, zi = b.format_track(L.T_SMOOTH, chroms, pk.chunk_start, compress=True)
+        text, _ = b.format_track(L.T_SMOOTH, chroms, pk.chunk_start, compress=False)
+        assert gzip.GzipFile(fileobj=io.BytesIO(z.tobytes() + BGZF_EOF)).read() == text.tobytes()
+        assert z.tobytes() == bgzf_lines_host(text.tobytes())
+        b.free()
+    # an all-NaN track: nothing to write
+    pk = make_synthetic_chunks(3, 500, 0, seed=1, counts=np.zeros(3, np.int64))
+    b = ctx.upload(pk)
+    b.set_track(L.T_OCC, np.full(pk.total_bp, np.nan))
+    for comp in (False, True):
+        out, info = b.format_track(L.T_OCC, ["c"] * 3, pk.chunk_start, compress=comp)
+        assert len(out) == 0 and info["lines"] == 0
+    b.free()
