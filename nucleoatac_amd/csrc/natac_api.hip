@@ -465,9 +465,19 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     unsigned long long *d_pos = nullptr;
     TRYF(dev_alloc(&d_hist, (size_t)nd::NLL + nd::ND)); tmp.keep(d_hist);
     HIPCHK(hipMemsetAsync(d_hist, 0, (nd::NLL + nd::ND) * sizeof(unsigned int), c->stream));
+    // line segments per member -> offsets of the per-segment records the histogram pass leaves for the emit pass
+    unsigned int *d_nseg = nullptr;
+    unsigned long long *d_segbase = nullptr;
+    LaneRec *d_recs = nullptr;
+    TRYF(dev_alloc(&d_nseg, (size_t)nblk)); tmp.keep(d_nseg);
+    TRYF(dev_alloc(&d_segbase, (size_t)nblk + 1)); tmp.keep(d_segbase);
+    hipLaunchKernelGGL(tz_member_nseg, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->stream, d_line_off, (long long)nlines,
+                       (long long)n_text, nblk, d_nseg);
+    TRYF(dev_scan(c, d_nseg, nblk, d_segbase));
+    TRYF(dev_alloc(&d_recs, (size_t)nlines + (size_t)nblk + 64)); tmp.keep(d_recs);      // every line once + one more per straddled member border
     const size_t lds_count = 65536 + (nd::NLL + nd::ND) * sizeof(unsigned int);
     hipLaunchKernelGGL(tz_count_tokens, dim3((unsigned)nblk), dim3(TZ_THREADS), lds_count, c->stream, d_text, (long long)n_text, d_line_off,
-                       (long long)nlines, d_hist);
+                       (long long)nlines, d_segbase, d_recs, d_hist);
     unsigned int hist[nd::NLL + nd::ND];
     HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -481,7 +491,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_pos, (size_t)nblk + 1)); tmp.keep(d_pos);
     const size_t lds_emit = 65536 + ((sizeof(nd::Codes) + 15) & ~(size_t)15);
     hipLaunchKernelGGL(tz_emit_members, dim3((unsigned)nblk), dim3(TZ_THREADS), lds_emit, c->stream, d_text, (long long)n_text, d_line_off,
-                       (long long)nlines, d_codes, c->d_crc, d_regions, d_sizes);
+                       (long long)nlines, d_segbase, d_recs, d_codes, c->d_crc, d_regions, d_sizes);
     HIPCHK(hipGetLastError());
     TRYF(dev_scan(c, d_sizes, nblk, d_pos));
     b->fmt_member_pos.resize((size_t)nblk + 1);

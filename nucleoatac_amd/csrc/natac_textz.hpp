@@ -405,6 +405,34 @@ __device__ __forceinline__ void parse_lane_line(const unsigned char *lds_text, c
     nd::greedy_tokens(me.eq0, me.eq1, me.eq2, me.c, me.seglen, [&](int i) -> unsigned char { return seg[i]; }, sink);
 }
 
+// what tz_count_tokens leaves per line segment for tz_emit_members (40 bytes): the masks phase runs once per track
+struct LaneRec {
+    unsigned long long eq0, eq1, eq2;
+    unsigned short d0, d1, d2, q0rel, seglen, pad0, pad1, pad2;
+};
+__device__ __forceinline__ LaneRec pack_rec(const LaneLine &me) {
+    LaneRec r;
+    r.eq0 = me.eq0; r.eq1 = me.eq1; r.eq2 = me.eq2;
+    r.d0 = (unsigned short)me.c.d0; r.d1 = (unsigned short)me.c.d1; r.d2 = (unsigned short)me.c.d2;     // distances <= 32768
+    r.q0rel = (unsigned short)me.q0rel; r.seglen = (unsigned short)(me.valid ? me.seglen : 0);
+    r.pad0 = r.pad1 = r.pad2 = 0;
+    return r;
+}
+__device__ __forceinline__ LaneLine unpack_rec(const LaneRec &r) {
+    LaneLine me;
+    me.valid = r.seglen > 0;
+    me.q0rel = r.q0rel; me.seglen = r.seglen;
+    me.c.d0 = r.d0; me.c.d1 = r.d1; me.c.d2 = r.d2;
+    me.eq0 = r.eq0; me.eq1 = r.eq1; me.eq2 = r.eq2;
+    return me;
+}
+// number of line segments of every member (for the offsets of the records above)
+__global__ void __launch_bounds__(256) tz_member_nseg(const long long *__restrict__ line_off, long long nlines, long long n_text,
+                                                       long long nblk, unsigned int *__restrict__ nseg) {
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (b < nblk) nseg[b] = (unsigned int)member_geom(line_off, nlines, n_text, b).nseg;
+}
+
 __device__ __forceinline__ void load_member_text(unsigned char *lds_text, const unsigned char *text, const MemberGeom &g) {
     const int n = (int)(g.be - g.bs);
     const unsigned char *src = text + g.bs;      // bs is a multiple of 0xff00: 256-byte aligned
@@ -423,6 +451,7 @@ __device__ __forceinline__ void wave_range(const MemberGeom &g, int wave, long l
 
 __global__ void __launch_bounds__(TZ_THREADS) tz_count_tokens(const unsigned char *__restrict__ text, long long n_text,
                                                                const long long *__restrict__ line_off, long long nlines,
+                                                               const unsigned long long *__restrict__ seg_base, LaneRec *__restrict__ recs,
                                                                unsigned int *__restrict__ hist /* [NLL + ND] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_text = smem;
@@ -438,6 +467,7 @@ __global__ void __launch_bounds__(TZ_THREADS) tz_count_tokens(const unsigned cha
     for (long long base = s0; base < s1; base += 64) {
         const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
         const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
+        if (lane < cnt) recs[seg_base[blockIdx.x] + base + lane] = pack_rec(me);
         parse_lane_line(lds_text, me, sink);
     }
     __syncthreads();
@@ -509,6 +539,7 @@ __device__ __forceinline__ unsigned long long wave_excl_scan(unsigned long long 
 // region (so that the deflate payload, 18 bytes later, starts on a 32-bit word).  sizes[b] = member size in bytes.
 __global__ void __launch_bounds__(TZ_THREADS) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
                                                                const long long *__restrict__ line_off, long long nlines,
+                                                               const unsigned long long *__restrict__ seg_base, const LaneRec *__restrict__ recs,
                                                                const nd::Codes *__restrict__ codes_g, const nd::CrcTables *__restrict__ crc_g,
                                                                unsigned char *__restrict__ out_regions, unsigned int *__restrict__ sizes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -532,16 +563,26 @@ __global__ void __launch_bounds__(TZ_THREADS) tz_emit_members(const unsigned cha
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long s0, s1;
     wave_range(g, wave, &s0, &s1);
-    // pass A: bits of this wave's lines
+    // pass A: bits of this wave's lines, from the records tz_count_tokens left (a wave holds at most 8 groups of 64 lines: a
+    // member has <= 8,161 segments); the per-lane counts stay in registers for pass B
+    const LaneRec *myrecs = recs + seg_base[blockIdx.x];
+    unsigned int lbits[8];
     unsigned long long wave_bits = 0;
-    for (long long base = s0; base < s1; base += 64) {
-        const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
-        const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
-        nd::BitCountSink bc{codes, 0};
-        parse_lane_line(lds_text, me, bc);
-        unsigned long long tot;
-        (void)wave_excl_scan((unsigned long long)bc.bits, lane, &tot);
-        wave_bits += tot;
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi) {
+        const long long base = s0 + 64 * gi;
+        lbits[gi] = 0;
+        if (base < s1) {
+            if (base + lane < s1) {
+                const LaneLine me = unpack_rec(myrecs[base + lane]);
+                nd::BitCountSink bc{codes, 0};
+                parse_lane_line(lds_text, me, bc);
+                lbits[gi] = (unsigned int)bc.bits;
+            }
+            unsigned long long tot;
+            (void)wave_excl_scan((unsigned long long)lbits[gi], lane, &tot);
+            wave_bits += tot;
+        }
     }
     if (lane == 0) wbits[wave] = wave_bits;
     // CRC-32 of my 64-byte slice of the member
@@ -578,21 +619,24 @@ __global__ void __launch_bounds__(TZ_THREADS) tz_emit_members(const unsigned cha
         for (int i = threadIdx.x; i < hw; i += TZ_THREADS) words[5 + i] = codes->hdr[i];
         if (threadIdx.x == 0 && hr) atomicOr(&words[5 + hw], codes->hdr[hw]);
         unsigned long long pos = (unsigned long long)codes->hdr_bits + my_start;      // bit position of this wave's next group
-        for (long long base = s0; base < s1; base += 64) {
-            const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
-            const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
-            nd::BitCountSink bc{codes, 0};
-            parse_lane_line(lds_text, me, bc);
-            unsigned long long tot;
-            const unsigned long long mine = wave_excl_scan((unsigned long long)bc.bits, lane, &tot);
-            if (me.valid) {
-                DevBitWriter bw;
-                bw.init(words + 5, (long long)(pos + mine));
-                DevEmitSink es{codes, &bw};
-                parse_lane_line(lds_text, me, es);
-                bw.finish();
+#pragma unroll
+        for (int gi = 0; gi < 8; ++gi) {
+            const long long base = s0 + 64 * gi;
+            if (base < s1) {
+                unsigned long long tot;
+                const unsigned long long mine = wave_excl_scan((unsigned long long)lbits[gi], lane, &tot);
+                if (base + lane < s1) {
+                    const LaneLine me = unpack_rec(myrecs[base + lane]);
+                    if (me.valid) {
+                        DevBitWriter bw;
+                        bw.init(words + 5, (long long)(pos + mine));
+                        DevEmitSink es{codes, &bw};
+                        parse_lane_line(lds_text, me, es);
+                        bw.finish();
+                    }
+                }
+                pos += tot;
             }
-            pos += tot;
         }
         if (threadIdx.x == 0) {                               // end of block after the last token
             DevBitWriter bw;
