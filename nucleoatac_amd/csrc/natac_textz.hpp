@@ -537,7 +537,7 @@ __device__ __forceinline__ unsigned long long wave_excl_scan(unsigned long long 
 
 // One workgroup per member.  out_regions: nd::REGION bytes per member, zeroed; the member occupies bytes [2, 2 + size) of its
 // region (so that the deflate payload, 18 bytes later, starts on a 32-bit word).  sizes[b] = member size in bytes.
-__global__ void __launch_bounds__(TZ_THREADS) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
+__global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
                                                                const long long *__restrict__ line_off, long long nlines,
                                                                const unsigned long long *__restrict__ seg_base, const LaneRec *__restrict__ recs,
                                                                const nd::Codes *__restrict__ codes_g, const nd::CrcTables *__restrict__ crc_g,
@@ -566,21 +566,22 @@ __global__ void __launch_bounds__(TZ_THREADS) tz_emit_members(const unsigned cha
     // pass A: bits of this wave's lines, from the records tz_count_tokens left (a wave holds at most 8 groups of 64 lines: a
     // member has <= 8,161 segments); the per-lane counts stay in registers for pass B
     const LaneRec *myrecs = recs + seg_base[blockIdx.x];
-    unsigned int lbits[8];
+    unsigned int lb[4] = {0, 0, 0, 0};              // eight 16-bit counts (a line is <= 160 characters x 15 bits)
     unsigned long long wave_bits = 0;
 #pragma unroll
     for (int gi = 0; gi < 8; ++gi) {
         const long long base = s0 + 64 * gi;
-        lbits[gi] = 0;
         if (base < s1) {
+            unsigned int nbits = 0;
             if (base + lane < s1) {
                 const LaneLine me = unpack_rec(myrecs[base + lane]);
                 nd::BitCountSink bc{codes, 0};
                 parse_lane_line(lds_text, me, bc);
-                lbits[gi] = (unsigned int)bc.bits;
+                nbits = (unsigned int)bc.bits;
             }
+            lb[gi >> 1] |= nbits << (16 * (gi & 1));
             unsigned long long tot;
-            (void)wave_excl_scan((unsigned long long)lbits[gi], lane, &tot);
+            (void)wave_excl_scan((unsigned long long)nbits, lane, &tot);
             wave_bits += tot;
         }
     }
@@ -624,7 +625,7 @@ __global__ void __launch_bounds__(TZ_THREADS) tz_emit_members(const unsigned cha
             const long long base = s0 + 64 * gi;
             if (base < s1) {
                 unsigned long long tot;
-                const unsigned long long mine = wave_excl_scan((unsigned long long)lbits[gi], lane, &tot);
+                const unsigned long long mine = wave_excl_scan((unsigned long long)((lb[gi >> 1] >> (16 * (gi & 1))) & 0xffffu), lane, &tot);
                 if (base + lane < s1) {
                     const LaneLine me = unpack_rec(myrecs[base + lane]);
                     if (me.valid) {
