@@ -125,3 +125,65 @@ class NFRChunk(Chunk):
 
     def removeData(self):
         self.__dict__.clear()
+
+
+def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
+    """NFRChunk.process for a list of chunks with the per-chunk work batched: ONE PWM launch for the bias of all chunks
+    (pipeline._bias_batch), the occupancy tracks and the dyad positions read through the persistent native tabix readers on
+    the reader pool (three region reads per chunk, GIL released), then the interval statistics of NFR.__init__ with the
+    reference's own numpy expressions per gap.  Returns (chunk index, left, right, values[n, 4]) of the NFRs that pass, in
+    chunk / position order -- what the per-chunk loop writes."""
+    from ..pipeline import _bias_batch
+    from ..pyatac.tracks import _tabix
+    from .NucleosomeCalling import occ_reader_pool
+    n = len(chunks)
+    starts = np.array([c.start for c in chunks], dtype=np.int64)
+    ends = np.array([c.end for c in chunks], dtype=np.int64)
+    boff = bias = None
+    if params.fasta is not None:
+        boff, bias = _bias_batch(chunks, starts, ends, params.fasta, params.pwm, 0, 0)
+    upper = params.upper_bound_track()
+
+    def track(path, ch):             # Track.read_track: the native tabix reader when the file is indexed, else a linear scan
+        t = Track(ch.chrom, ch.start, ch.end)
+        t.read_track(path)
+        return t.vals
+
+    def read(k):
+        ch = chunks[k]
+        occ, up = track(params.occ_track, ch), track(upper, ch)
+        rd = _tabix(params.calls)         # the calls file is tabix-indexed, like the reference requires
+        if hasattr(rd, "read_values"):    # record starts (column 2) at their own positions
+            dy = rd.read_values(ch.chrom, ch.start, ch.end, value_col=2)
+            nucs = np.flatnonzero(~np.isnan(dy)) + ch.start
+        else:
+            nucs = np.array([int(row.split("\t")[1]) for row in rd.fetch(ch.chrom, ch.start, ch.end)] if ch.chrom in rd.contigs else [],
+                            dtype=np.int64)
+        ins = track(params.ins_track, ch) if params.ins_track is not None else None
+        return occ, up, nucs, ins
+
+    reads = list(occ_reader_pool().map(read, range(n))) if n > 1 else [read(0)] if n else []
+    kc, lefts, rights, vals = [], [], [], []
+    for k, (occ, up, nucs, ins) in enumerate(reads):
+        s = int(starts[k])
+        if ins is None:
+            if ins_flat is not None:
+                ins = ins_flat[int(ins_off[k]):int(ins_off[k + 1])]
+            else:
+                t = InsertionTrack(chunks[k].chrom, s, int(ends[k]))
+                t.calculateInsertions(params.bam)
+                ins = t.vals
+        b = None if bias is None else bias[int(boff[k]):int(boff[k + 1])]
+        for a, c in zip(nucs[:-1], nucs[1:]):
+            left, right = int(a) + DYAD_LEFT, int(c) - DYAD_RIGHT
+            if right > left:
+                o = float(np.mean(occ[left - s:right - s]))
+                mu = float(np.min(up[left - s:right - s]))
+                if mu < params.max_occ_upper and o < params.max_occ:
+                    kc.append(k)
+                    lefts.append(left)
+                    rights.append(right)
+                    vals.append((o, mu, float(np.mean(ins[left - s:right - s])),
+                                 float(np.mean(np.exp(b[left - s:right - s]))) if b is not None else float("nan")))
+    return (np.array(kc, dtype=np.int64), np.array(lefts, dtype=np.int64), np.array(rights, dtype=np.int64),
+            np.array(vals, dtype=np.float64).reshape(-1, 4))

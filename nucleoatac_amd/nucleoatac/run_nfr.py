@@ -13,8 +13,8 @@ from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fasta
 from ..shard import barrier, ensure_distributed, env_rank_world
-from ..writer import bgzip_file, tabix_index, write_bedgraph
-from .NFRCalling import NFRChunk, NFRParameters
+from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
+from .NFRCalling import NFRChunk, NFRParameters, nfr_batch
 
 BATCH_CHUNKS = 4096
 COMPRESS_LEVEL = 4
@@ -72,30 +72,30 @@ def run_nfr(args):
     suffix = "" if world == 1 else ".rank%d" % rank
     ins_path = args.out + ".ins.bedgraph.gz" + suffix
     nb = max(1, (len(chunks) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
-    with open(args.out + ".nfrpos.bed" + suffix, "w") as nfr_handle:
-        for bi in range(nb):
-            part = chunks[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
-            if not part:
-                if make_ins:
-                    write_bedgraph(ins_path, [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL,
-                                   finish=(rank == world - 1))
-                break
-            off = flat = None
+    nfr_path = args.out + ".nfrpos.bed" + suffix
+    open(nfr_path, "w").close()
+    for bi in range(nb):
+        part = chunks[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
+        if not part:
             if make_ins:
-                off, flat = _batch_insertions(part, args.bam)
-            for k, ch in enumerate(part):
-                nfr = NFRChunk(ch)
-                try:
-                    nfr.process(params, ins_vals=None if flat is None else flat[int(off[k]):int(off[k + 1])])
-                except Exception:
-                    print("Caught exception when processing:\n" + ch.asBed() + "\n")
-                    raise
-                for pos in nfr.nfrs:
-                    pos.write(nfr_handle)
-                nfr.removeData()
-            if make_ins:      # Track.write_track of every chunk's insertion track (run_nfr.py:55-67) through the native writer
-                write_bedgraph(ins_path, [c.chrom for c in part], [c.start for c in part], off, flat, append=bi > 0,
-                               compress=COMPRESS_LEVEL, finish=(bi == nb - 1 and rank == world - 1))
+                write_bedgraph(ins_path, [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL,
+                               finish=(rank == world - 1))
+            break
+        off = flat = None
+        if make_ins:
+            off, flat = _batch_insertions(part, args.bam)
+        try:
+            kc, left, right, vals = nfr_batch(part, params, off, flat)
+        except Exception:
+            print("Caught exception when processing:\n" + "\n".join(c.asBed() for c in part[:3]) + "\n")
+            raise
+        if len(kc):        # NFR.asBed rows of the whole sub-batch, python-2 float text, natively
+            names = sorted(set(c.chrom for c in part))
+            idx = {c: i for i, c in enumerate(names)}
+            write_bed_rows(nfr_path, names, np.array([idx[c.chrom] for c in part], dtype=np.int32)[kc], left, right, vals)
+        if make_ins:      # Track.write_track of every chunk's insertion track (run_nfr.py:55-67) through the native writer
+            write_bedgraph(ins_path, [c.chrom for c in part], [c.start for c in part], off, flat, append=bi > 0,
+                           compress=COMPRESS_LEVEL, finish=(bi == nb - 1 and rank == world - 1))
     barrier()          # every rank has closed its part files
     if rank != 0:
         return
