@@ -34,7 +34,8 @@ def env_rank_world():
 
 
 _STATE = {"gpu_group": None, "backend": None}
-GROUP_TIMEOUT_S = 12 * 3600      # single-rank phases (merge, a slow shard) may hold the others in a barrier for a long time
+GROUP_TIMEOUT_S = 12 * 3600      # control plane (gloo): single-rank phases (merge, a slow shard) may hold the others for a long time
+RCCL_TIMEOUT_S = 600             # RCCL group: only the benchmark's timing barrier runs over it (ranks arrive together)
 
 
 def ensure_distributed(prefer=None, device=None):
@@ -46,8 +47,9 @@ def ensure_distributed(prefer=None, device=None):
     group (CPU, always available) with a long timeout; there is no data-path collective.  When `prefer` (default: the
     NATAC_DIST_BACKEND environment variable, else "nccl") is "nccl", an RCCL subgroup is created on top of it and probed; whether
     it is used is decided COLLECTIVELY (a MIN all-reduce of the per-rank probe results over gloo), so one rank with a broken
-    RCCL cannot leave the others waiting in an RCCL collective.  `barrier()` then synchronises over RCCL when all ranks have
-    it, over gloo otherwise.  Returns (dist module or None, True if this call created the group)."""
+    RCCL cannot leave the others waiting in an RCCL collective for long (its own timeout is 10 minutes).  The drivers' barriers
+    always use gloo; `barrier(sync_cuda=True)` -- the benchmark's timing barrier -- synchronises over RCCL when all ranks have
+    it.  Returns (dist module or None, True if this call created the group)."""
     rank, world, local = env_rank_world()
     if world <= 1:
         return None, False
@@ -81,7 +83,7 @@ def ensure_distributed(prefer=None, device=None):
                 ok, why = 0, "ranks share GPUs %s" % devs
             else:
                 try:
-                    grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=GROUP_TIMEOUT_S))
+                    grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=RCCL_TIMEOUT_S))
                     probe = torch.ones(1, device="cuda")
                     dist.all_reduce(probe, group=grp)
                     torch.cuda.synchronize()
@@ -104,13 +106,14 @@ def control_backend():
 
 
 def barrier(sync_cuda=False):
-    """all ranks reach this point (no-op on one rank; raises if WORLD_SIZE > 1 without a process group)"""
+    """all ranks reach this point (no-op on one rank; raises if WORLD_SIZE > 1 without a process group).  sync_cuda: the
+    benchmark's form -- torch.cuda.synchronize() + a barrier over the RCCL group when the ranks agreed on one; the drivers'
+    plain barriers run over gloo, whose timeout allows for ranks that arrive minutes apart."""
     dist, _ = ensure_distributed()
     if dist is not None:
-        if _STATE["gpu_group"] is not None:
-            if sync_cuda:
-                import torch
-                torch.cuda.synchronize()
+        if sync_cuda and _STATE["gpu_group"] is not None:
+            import torch
+            torch.cuda.synchronize()
             dist.barrier(group=_STATE["gpu_group"])
         else:
             dist.barrier()
