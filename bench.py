@@ -9,6 +9,10 @@ Workloads (--workload):
   cfg3 (default)  BASELINE.json configs[2]: 100k windows x 2 kb (2,120 bp after the +-60 slop), 50 M fragments, default
                   VMat (146 x 121).  With N > 1 every rank owns its own shard of the same shape (weak scaling).
   cfg3-heavy      the same windows with Poisson fragment counts and 1 % of the chunks 10x denser (heavy-tailed load).
+  cfg5            BASELINE.json configs[4]: 8 independent samples, one per GPU (every rank its own 12,500-chunk configs[2]-like set
+                  with its own seed: replicas, weak scaling); after the timed steps every rank runs the multinomial_cov tolerance
+                  sweep (literal O(N^2) fp64 / closed form fp64 / closed form fp32 at the candidates of 200 chunks) and rank 0
+                  reports the worst relative errors over all samples.
   cfg4            BASELINE.json configs[3]: ~300k tiles x 10 kb (10,120 bp), ~200 M fragments, the chunk list sharded across
                   the N ranks by sum(L) + kappa sum(F) (nucleoatac_amd/shard.py): STRONG scaling, total work fixed.  Every
                   rank draws the same cheap per-chunk count vector, balances, and generates only its own shard in
@@ -34,7 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_BYTES_PER_BP = {"cfg3": 79.8, "cfg3-heavy": 79.8, "cfg4": 76.9}   # 76 L + 8 F + 3,944 B per chunk
+ALG_BYTES_PER_BP = {"cfg3": 79.8, "cfg3-heavy": 79.8, "cfg4": 76.9, "cfg5": 79.8}   # 76 L + 8 F + 3,944 B per chunk
 FLOP_PER_BP_BG = 2 * 146 * 121   # fp64 flop per base of the background correlation evaluated directly (R x W FMA)
 # executed by the FFT kernel: 73 row pairs x 364 flop per lane (172 add + 72 mul + 60 fma) x 64 lanes per 392-base tile
 FLOP_PER_BP_BG_FFT = 73 * 364 * 64 / 392.0
@@ -52,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg3", "cfg3-heavy", "cfg4"], default="cfg3")
+    ap.add_argument("--workload", choices=["cfg3", "cfg3-heavy", "cfg4", "cfg5"], default="cfg3")
     ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU (cfg3: 100000) / in total (cfg4: 300000)")
     ap.add_argument("--chunk-len", type=int, default=0)
     ap.add_argument("--frags-per-chunk", type=int, default=0)
@@ -253,11 +257,15 @@ def make_workload(a, rank, world):
     """list of PackedChunks sub-batches of this rank + description"""
     from nucleoatac_amd.shard import balanced_ranges
     from nucleoatac_amd.synth import fragment_counts, make_synthetic_chunks
-    if a.workload in ("cfg3", "cfg3-heavy"):
-        nc = a.chunks or 100000
+    if a.workload in ("cfg3", "cfg3-heavy", "cfg5"):
+        nc = a.chunks or (12500 if a.workload == "cfg5" else 100000)
         L = a.chunk_len or 2120
         F = a.frags_per_chunk or 500
-        if a.workload == "cfg3":
+        if a.workload == "cfg5":
+            pk = make_synthetic_chunks(nc, L, F, seed=a.seed + 1000 + rank)
+            desc = ("configs[4]: one independent synthetic sample per rank (own seed), %d windows x 2 kb (L=%d), %d fragments, default VMat; "
+                    "fp64 multinomial_cov tolerance sweep at the candidates of 200 chunks after the timed steps")
+        elif a.workload == "cfg3":
             pk = make_synthetic_chunks(nc, L, F, seed=a.seed + 1000 * rank)
             desc = "configs[2]: synthetic %d windows x 2 kb (L=%d after slop), %d fragments, default VMat 146x121, 1 GPU-shard per rank"
         else:
@@ -523,6 +531,31 @@ def main():
         cand = batches[0].download_peaks(last_n[0])
         t_dn = time.time() - t_dn
         assert np.isfinite(cand[4][:1000]).any()
+    cov_sweep = None
+    if a.workload == "cfg5" and batches:
+        # calculateCov variants (nucleoatac/multinomial_cov.pyx:20-31) at every candidate of 200 chunks of this rank's sample
+        b0 = batches[0]
+        cc, cp, _lr, var, _z = b0.run_peaks(min_signal=0, sep=25, boundary=60, order=12)
+        ks = np.sort(np.random.default_rng(a.seed + rank).choice(subs[0].n_chunks, size=min(200, subs[0].n_chunks), replace=False))
+        first, last = np.searchsorted(cc, ks, "left"), np.searchsorted(cc, ks, "right")
+        sel = np.concatenate([np.arange(x, y) for x, y in zip(first, last)]) if len(ks) else np.zeros(0, np.int64)
+        t0 = time.perf_counter()
+        lit = b0.run_candidates_cov(cc[sel], cp[sel], "literal")
+        t_lit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        clo = b0.run_candidates_cov(cc[sel], cp[sel], "closed")
+        t_clo = time.perf_counter() - t0
+        f32 = b0.run_candidates_cov(cc[sel], cp[sel], "fp32")
+        ok = lit > 0
+        rel = lambda x: float(np.max(np.abs(x[ok] - lit[ok]) / lit[ok])) if ok.any() else 0.0
+        mine = dict(rank=rank, candidates=int(len(sel)), closed_fp64=rel(clo), fp32=rel(f32), run_peaks_var=rel(var[sel]),
+                    literal_s=round(t_lit, 3), closed_s=round(t_clo, 3))
+        rows = [mine]
+        if dist is not None:
+            rows = [None] * world
+            dist.all_gather_object(rows, mine)
+        cov_sweep = dict(samples=rows, worst_closed_fp64=max(r["closed_fp64"] for r in rows), worst_fp32=max(r["fp32"] for r in rows),
+                         reference="the device's literal O(N^2) fp64 pair sum (the .pyx's own terms); tests pin it to the oracle's C restatement")
     shard.close()
     h2h = None
     if rank == 0 and world == 1 and not a.no_h2h and a.workload != "cfg4":
@@ -593,6 +626,8 @@ def main():
             out["host_to_host"] = h2h
         if e2e is not None:
             out["cli_end_to_end"] = e2e
+        if cov_sweep is not None:
+            out["multinomial_cov_sweep"] = cov_sweep
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

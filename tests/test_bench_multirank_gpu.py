@@ -107,3 +107,18 @@ def test_eight_ranks_share_device_cfg4():
     assert [r["rank"] for r in rows] == list(range(8)) and sum(r["bp"] for r in rows) == c8["bp_total"]
     assert all(r["ms_per_step"] > 0 and r["generate_s"] >= 0 for r in rows)
     assert c8["shard_imbalance"]["bp_max_over_mean"] < 1.05 and len(c8["shard_imbalance"]["bp_per_rank"]) == 8
+
+
+def test_cfg5_independent_samples_with_cov_sweep():
+    """--workload cfg5 (BASELINE configs[4]): one independent sample per rank + the multinomial_cov tolerance sweep, 2 ranks on GPU 0"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29539", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg5", "--chunks", "1500", "--steps", "1",
+           "--warmup", "1", "--share-device", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["chunks_total"] == 3000
+    s = d["multinomial_cov_sweep"]
+    assert [r["rank"] for r in s["samples"]] == [0, 1] and all(r["candidates"] > 2000 for r in s["samples"])
+    assert s["worst_closed_fp64"] < 1e-9 and 1e-8 < s["worst_fp32"] < 1e-2
+    assert s["samples"][0]["closed_fp64"] != s["samples"][1]["closed_fp64"]        # two different samples
