@@ -3,6 +3,8 @@
 Sub-packages mirror the reference's module names for the hot path:
   nucleoatac_amd.pyatac      chunk, tracks, chunkmat2d, fragments, fragmentsizes, bias, seq, VMat, utils
   nucleoatac_amd.nucleoatac  Occupancy, NucleosomeCalling, run_occ, run_nuc, cli
+  nucleoatac_amd.executor    how sub-batches move through one GPU: ResidentShard, PipelinedExecutor (the CLI drivers and bench.py)
+  nucleoatac_amd.shard       chunk-list sharding over the GPUs of a node, control-plane group, shared BAM decode
 All numerics run in libnatac_hip.so (include/natac.h); there is no CPU fallback.
 """
 import os

@@ -96,3 +96,45 @@ def test_native_pack_matches_per_chunk_fetch():
         assert pk.chroms == [c.chrom for c in chunks]
         pk.validate()
     assert pipeline.pack([], st).n_chunks == 0
+
+
+def test_sequence_windows_pack_and_host_helpers():
+    """pack(bias_on_device=True): sequence windows instead of a scored bias array (natac_batch_create_from_seq), their validation and
+    subsets; chunk_fragment_counts == the per-chunk fetch it replaced; prefetch_map keeps order and forwards exceptions"""
+    from helpers import synth_stores
+    from nucleoatac_amd.pipeline import chunk_fragment_counts, pack, prefetch_map
+    from nucleoatac_amd.pyatac.bias import PWM
+    from nucleoatac_amd.pyatac.chunk import Chunk
+    frags, fasta = synth_stores(11)
+    chunks = [Chunk("chrS", s, s + 700 + 13 * i) for i, s in enumerate(range(1200, 11000, 1400))]
+    pwm = PWM.open("Human")
+    K = pwm.up + pwm.down + 1
+    pk = pack(chunks, frags, fasta, fasta.chrom_sizes(), pwm, window=121, upper=251, bias_on_device=True)
+    assert pk.bias_log is None and pk.bias_off is None and pk.seq.dtype == np.uint8 and pk.pwm_log.shape == (4, K)
+    for k, ch in enumerate(chunks):
+        a, b = int(pk.seq_off[k]), int(pk.seq_off[k + 1])
+        assert b - a == ch.length() + 246 + 247 + K - 1
+        assert pk.seq[a:b].tobytes() == fasta.seqs["chrS"][ch.start - 246 - pwm.up:ch.end + 247 + pwm.down].tobytes()
+    sub = pk.subset(2, 5)
+    assert sub.n_chunks == 3 and sub.seq[:10].tobytes() == pk.seq[int(pk.seq_off[2]):int(pk.seq_off[2]) + 10].tobytes()
+    with pytest.raises(ValueError):
+        PackedChunks(pk.chunk_start, pk.chunk_len, pk.frag_off, pk.frag_lpos, pk.frag_ilen, None, None, seq_off=pk.seq_off,
+                     seq=pk.seq[:-1], pwm_log=pk.pwm_log, pwm_nucs=pk.pwm_nucs)
+    with pytest.raises(Exception) as e:
+        pack([Chunk("chrS", 100, 900)], frags, fasta, fasta.chrom_sizes(), pwm, window=121, upper=251, bias_on_device=True)
+    assert "too close to the chromosome end" in str(e.value)
+    # shard-balance counts: one searchsorted per chromosome == FragmentStore.fetch per chunk
+    want = [len(frags.fetch(c.chrom, c.start, c.end)[0]) for c in chunks] + [0]
+    assert list(chunk_fragment_counts(frags, chunks + [Chunk("chrNone", 5, 50)])) == want
+    # prefetch_map: order, laziness bounded by depth, exceptions
+    seen = []
+    def f(x):
+        seen.append(x)
+        if x == 7:
+            raise KeyError("boom")
+        return x * x
+    it = prefetch_map(f, range(20), depth=3)
+    assert [next(it) for _ in range(5)] == [0, 1, 4, 9, 16] and len(seen) <= 8
+    with pytest.raises(KeyError):
+        list(it)
+    assert list(prefetch_map(lambda x: x + 1, [], depth=2)) == []
