@@ -105,7 +105,7 @@ def csrc_sha16():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".inc")))
     files.append(os.path.join(os.path.dirname(_HERE), "include", "natac.h"))
     for f in files:
         with open(f, "rb") as fh:
