@@ -87,6 +87,8 @@ class _Writer(threading.Thread):
         self.offset = {n: 0 for n in paths}          # bytes of members written so far (without the EOF marker)
         self.index_log = {n: [] for n in paths}      # (tabix records of a result, offset it was written at)
         self.index_ok = {n: True for n in paths}
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max(1, len(paths)), thread_name_prefix="natac-track-file")
 
     def run(self):
         import time
@@ -99,8 +101,9 @@ class _Writer(threading.Thread):
                     t0 = time.perf_counter()
                     part = r.tag
                     chroms, starts = [c.chrom for c in part], [c.start for c in part]
-                    for name, path in self.paths.items():
-                        t = self.track_of[name]
+
+                    def write_one(name):
+                        path, t = self.paths[name], self.track_of[name]
                         z = r.text.get(t) if r.text else None
                         last = r.seq == self.nb - 1 and self.last_rank
                         if z is not None:       # finished BGZF members from the device: append them (+ the EOF marker at the very end)
@@ -114,6 +117,9 @@ class _Writer(threading.Thread):
                             write_bedgraph(path, chroms, starts, r.packed.out_off, r.tracks[t], append=r.seq > 0,
                                            compress=COMPRESS_LEVEL, finish=last)
                             self.index_ok[name] = False
+
+                    # one file per track: the appends run side by side (write() releases the GIL), every file still in order
+                    list(self.pool.map(write_one, list(self.paths)))
                     self.extra(r)
                     self.seconds += time.perf_counter() - t0
             except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
@@ -129,6 +135,7 @@ class _Writer(threading.Thread):
     def finish(self):
         self.q.put(None)
         self.join()
+        self.pool.shutdown()
         if self.err is not None:
             raise self.err
 
