@@ -156,7 +156,7 @@ def fit_fuzz_one(vals, allnucs, index, nonredundant_sep, smooth_sd):
         res = optimize.minimize(err, guess, bounds=bounds, method="L-BFGS-B")
         return np.sqrt(res["x"][0]), res["x"][1], res["x"][2] + left
 
-    # The reference lets scipy difference `err` numerically: n + 1 Python calls per gradient.  `grad` forms the SAME 2-point
+    # The reference lets scipy difference `err` numerically: n + 1 Python calls per gradient.  `fun_and_grad` forms the SAME 2-point
     # differences (absolute step 1e-8, flipped at an upper bound: scipy.optimize._numdiff.approx_derivative as L-BFGS-B
     # calls it) from one batched evaluation of the n shifted parameter vectors; every element goes through the same numpy
     # operations as in `err`, so the optimiser sees bit-identical values and takes the same path (tests/test_host_logic.py).
@@ -165,7 +165,9 @@ def fit_fuzz_one(vals, allnucs, index, nonredundant_sep, smooth_sd):
     n = len(guess)
     idx = np.arange(n)
 
-    def grad(pars):
+    def fun_and_grad(pars):
+        """(err(pars), its 2-point finite differences): one evaluation of the objective at pars shared by both -- L-BFGS-B always
+        asks for the pair"""
         x0 = np.asarray(pars, dtype=np.float64)
         h = np.full(n, 1e-8)
         lower_dist, upper_dist = x0 - lb, ub - x0
@@ -187,9 +189,10 @@ def fit_fuzz_one(vals, allnucs, index, nonredundant_sep, smooth_sd):
             fit += y * (w / y.max(axis=1)[:, None])
         r = (fit - sig[None, :]) ** 2
         f1 = np.array([np.sum(r[i]) for i in range(n)])
-        return (f1 - err(x0)) / dx
+        f0 = err(x0)
+        return f0, (f1 - f0) / dx
 
-    res = optimize.minimize(err, guess, jac=grad, bounds=bounds, method="L-BFGS-B")
+    res = optimize.minimize(fun_and_grad, guess, jac=True, bounds=bounds, method="L-BFGS-B")
     return np.sqrt(res["x"][0]), res["x"][1], res["x"][2] + left
 
 
