@@ -54,6 +54,9 @@ def run_nfr(args):
         pwm = PWM.open(args.pwm)
         chunks = ChunkList.read(args.bed, chromDict=chrs_fasta, min_offset=max(pwm.up, pwm.down))
     else:
+        import warnings
+        warnings.warn("nfr without --fasta: the bias column of nfrpos.bed is written as 'nan' (the reference raises here; see "
+                      "INTEGRATION.md section 6)")
         chunks = ChunkList.read(args.bed)
     ensure_distributed()
     if args.bam is not None:
