@@ -124,3 +124,32 @@ def test_rank0_failure_ends_every_rank(tmp_path):
                        cwd=ROOT)
     assert r.returncode != 0 and time.time() - t0 < 120
     assert "rank 0 failed" in r.stderr or "No such file" in r.stderr or "Error" in r.stderr
+
+
+def test_device_writer_and_host_writer_give_the_same_files(tmp_path):
+    """`occ` + `nuc` with the tracks formatted / compressed / indexed on the GPU (default) and with the native host writer
+    (NATAC_DEVICE_WRITER=0): the text inside every .bedgraph.gz is identical, both sets of .tbi answer region reads identically"""
+    from nucleoatac_amd.pyatac.tracks import Track
+    bed, bam, fa, sizes, vm = _inputs(tmp_path)
+    outs = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / ("w" + mode))
+        common = ["--bed", bed, "--bam", bam, "--fasta", fa, "--sizes", sizes, "--out", out]
+        for sub in (["occ"] + common, ["nuc"] + common + ["--vmat", vm, "--write_all"]):
+            r = subprocess.run([sys.executable, "-m", "nucleoatac_amd.nucleoatac.cli"] + sub, capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, NATAC_DEVICE_WRITER=mode, NATAC_BATCH_CHUNKS="3"), cwd=ROOT)   # several sub-batches
+            assert r.returncode == 0, r.stderr[-3000:]
+        outs[mode] = out
+    for n in ("occ", "occ.lower_bound", "occ.upper_bound", "nucleoatac_signal", "nucleoatac_signal.smooth", "nucleoatac_raw",
+              "nucleoatac_background"):
+        a, b = outs["1"] + "." + n + ".bedgraph.gz", outs["0"] + "." + n + ".bedgraph.gz"
+        ta, tb = gzip.open(a, "rt").read(), gzip.open(b, "rt").read()
+        assert ta == tb and len(ta) > 1000, n
+        assert os.path.getsize(a) < 1.05 * os.path.getsize(b), n          # the device's members are not larger than zlib level 4's
+        for s in (1300, 5600, 10300):
+            x, y = Track("chrS", s, s + 700), Track("chrS", s, s + 700)
+            x.read_track(a)
+            y.read_track(b)
+            assert np.array_equal(x.vals, y.vals, equal_nan=True), (n, s)
+    for n in ("occpeaks.bed.gz", "nucpos.bed.gz"):
+        assert gzip.open(outs["1"] + "." + n, "rt").read() == gzip.open(outs["0"] + "." + n, "rt").read()
