@@ -88,3 +88,41 @@ def test_errors_surface_on_the_consumer_thread():
             n += 1
             r.release()
         assert n == len(subs)
+
+
+def test_writer_mixes_device_members_and_host_written_batches(tmp_path):
+    """a sub-batch whose track holds a value the device formatter cannot decide (n_hard > 0) is formatted by the native host
+    writer instead; its members are appended between the device's, the file stays one valid BGZF stream with the same text, and
+    the index falls back to the file-based indexer (the device's record log no longer covers the whole file)"""
+    import gzip
+    import types
+    from nucleoatac_amd.nucleoatac.run_occ import _Writer, finish_indexes
+    from nucleoatac_amd.pyatac.chunk import Chunk
+    from nucleoatac_amd.pyatac.tracks import Track
+    from nucleoatac_amd.writer import tabix_index, write_bedgraph
+    subs = _subs(5)
+    stages = Stages(nuc_sd=None, occ=True, ins=None, tracks=(L.T_OCC,), text_tracks=(L.T_OCC,))
+    path = str(tmp_path / "mixed.bedgraph.gz")
+    ref_path = str(tmp_path / "host.bedgraph.gz")
+    parts = [[Chunk(c, int(s), int(s) + int(n)) for c, s, n in zip(pk.chroms, pk.chunk_start, pk.chunk_len)] for pk in subs]
+    w = _Writer({"occ": path}, {"occ": L.T_OCC}, lambda r: None, len(subs), True)
+    w.start()
+    with PipelinedExecutor(0, _configure, stages, n_contexts=2) as ex:
+        for r in ex.map((pk, part) for pk, part in zip(subs, parts)):
+            write_bedgraph(ref_path, pk_chroms := r.packed.chroms, r.packed.chunk_start, r.packed.out_off, r.tracks[L.T_OCC].copy(),
+                           append=r.seq > 0, compress=4, finish=r.seq == len(subs) - 1)
+            if r.seq in (1, 3):                    # what executor._process does when info["hard"] > 0
+                r.text[L.T_OCC] = None
+            w.put(r)
+    w.finish()
+    assert not w.index_ok["occ"] and len(w.index_log["occ"]) == 3
+    ws = types.SimpleNamespace(index_log=w.index_log, index_ok=w.index_ok, offset=w.offset)
+    assert finish_indexes(ws, ["occ"], lambda n: path) == [path]
+    tabix_index(path)
+    tabix_index(ref_path)
+    assert gzip.open(path, "rt").read() == gzip.open(ref_path, "rt").read()
+    pk = subs[3]
+    a, b = Track(pk.chroms[5], int(pk.chunk_start[5]), int(pk.chunk_start[5]) + 300), Track(pk.chroms[5], int(pk.chunk_start[5]), int(pk.chunk_start[5]) + 300)
+    a.read_track(path)
+    b.read_track(ref_path)
+    assert np.array_equal(a.vals, b.vals, equal_nan=True) and np.isfinite(a.vals).any()
