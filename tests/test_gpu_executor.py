@@ -101,6 +101,8 @@ def test_writer_mixes_device_members_and_host_written_batches(tmp_path):
     from nucleoatac_amd.pyatac.tracks import Track
     from nucleoatac_amd.writer import tabix_index, write_bedgraph
     subs = _subs(5)
+    for i, pk in enumerate(subs):                  # one sorted file: chromosome blocks contiguous, positions ascending
+        pk.chroms = ["chr%d" % (1 + i // 2)] * pk.n_chunks
     stages = Stages(nuc_sd=None, occ=True, ins=None, tracks=(L.T_OCC,), text_tracks=(L.T_OCC,))
     path = str(tmp_path / "mixed.bedgraph.gz")
     ref_path = str(tmp_path / "host.bedgraph.gz")
@@ -109,7 +111,7 @@ def test_writer_mixes_device_members_and_host_written_batches(tmp_path):
     w.start()
     with PipelinedExecutor(0, _configure, stages, n_contexts=2) as ex:
         for r in ex.map((pk, part) for pk, part in zip(subs, parts)):
-            write_bedgraph(ref_path, pk_chroms := r.packed.chroms, r.packed.chunk_start, r.packed.out_off, r.tracks[L.T_OCC].copy(),
+            write_bedgraph(ref_path, r.packed.chroms, r.packed.chunk_start, r.packed.out_off, r.tracks[L.T_OCC].copy(),
                            append=r.seq > 0, compress=4, finish=r.seq == len(subs) - 1)
             if r.seq in (1, 3):                    # what executor._process does when info["hard"] > 0
                 r.text[L.T_OCC] = None
