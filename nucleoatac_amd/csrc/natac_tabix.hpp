@@ -238,7 +238,23 @@ struct Reader {
     std::vector<std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins;
     std::vector<std::vector<uint64_t>> lin;
     int col_seq = 1, col_beg = 2, col_end = 3;
-    std::string buf, block;
+    std::string buf;
+    // The last inflated members with their lines split and their coordinates parsed once: a driver reads neighbouring regions
+    // one after the other (three tracks per chunk in `nuc` / `nfr`), a region read starts at the beginning of its 16-kb index
+    // window, so consecutive reads walk over the same ~5 members; without the cache each read inflated and parsed them again.
+    struct Line { uint32_t off, len; int32_t tid; int32_t nf; int64_t b0, e0; };
+    struct Block {
+        uint64_t coff = ~0ull, stamp = 0;
+        uint32_t bsize = 0;
+        uint32_t head_end = 0;          // bytes [0, head_end) finish the line the previous member ended in (or are a line of their own)
+        uint32_t tail_off = 0;          // bytes [tail_off, size) start a line that ends in the next member
+        std::string text;
+        std::vector<Line> lines;        // the complete lines that start after the first newline, in order
+    };
+    static constexpr int CACHE_BLOCKS = 24;
+    std::vector<Block> cache;
+    uint64_t clock = 0;
+    int last_tid = 0;
 };
 
 // inflate a whole BGZF file into memory (the .tbi itself)
@@ -347,15 +363,51 @@ inline void close_reader(Reader *r) {
     delete r;
 }
 
-// inflate the member at compressed offset coff into r->block; returns its compressed size (0 at EOF / error)
-inline uint32_t read_block(Reader *r, uint64_t coff) {
+// split [p, p + len) at tabs into at most 8 fields; returns the count
+inline int split_fields(const char *p, size_t len, const char *fld[8]) {
+    int nf = 0;
+    fld[nf++] = p;
+    for (const char *t = p, *le = p + len; t < le && nf < 8; ++t) if (*t == '\t') fld[nf++] = t + 1;
+    return nf;
+}
+
+// coordinates of one text line: reference index (-1: comment, too few columns or a name the index does not hold), begin, end
+inline void parse_line(Reader *r, const char *ls, size_t ll, Reader::Line &ln) {
+    ln.tid = -1; ln.nf = 0; ln.b0 = ln.e0 = 0;
+    if (ll == 0 || ls[0] == '#') return;
+    const char *fld[8];
+    const int nf = split_fields(ls, ll, fld);
+    ln.nf = nf;
+    if (nf < std::max(r->col_seq, r->col_end)) return;
+    const char *sq = fld[r->col_seq - 1];
+    const size_t sl = (size_t)((r->col_seq < nf ? fld[r->col_seq] - 1 : ls + ll) - sq);
+    auto same = [&](int t) { return r->names[t].size() == sl && std::memcmp(r->names[t].data(), sq, sl) == 0; };
+    if (r->last_tid < (int)r->names.size() && same(r->last_tid)) ln.tid = r->last_tid;
+    else
+        for (int t = 0; t < (int)r->names.size(); ++t) if (same(t)) { ln.tid = r->last_tid = t; break; }
+    ln.b0 = std::strtoll(fld[r->col_beg - 1], nullptr, 10);
+    ln.e0 = std::strtoll(fld[r->col_end - 1], nullptr, 10);
+    if (ln.e0 <= ln.b0) ln.e0 = ln.b0 + 1;
+}
+
+// the member at compressed offset coff, inflated and split into lines (from the cache when it was read recently);
+// nullptr at EOF / on a read or inflate error
+inline Reader::Block *get_block(Reader *r, uint64_t coff) {
+    if (r->cache.empty()) r->cache.resize(Reader::CACHE_BLOCKS);
+    Reader::Block *slot = &r->cache[0];
+    for (auto &b : r->cache) {
+        if (b.coff == coff) { b.stamp = ++r->clock; return &b; }
+        if (b.stamp < slot->stamp) slot = &b;
+    }
+    slot->coff = ~0ull;
+    slot->stamp = 0;
     unsigned char head[18];
-    if (std::fseek(r->f, (long)coff, SEEK_SET) != 0 || std::fread(head, 1, 18, r->f) != 18) return 0;
-    if (head[0] != 0x1f || head[1] != 0x8b) return 0;
+    if (std::fseek(r->f, (long)coff, SEEK_SET) != 0 || std::fread(head, 1, 18, r->f) != 18) return nullptr;
+    if (head[0] != 0x1f || head[1] != 0x8b) return nullptr;
     const uint32_t xlen = head[10] | (head[11] << 8);
     r->buf.resize(xlen + 12);
     std::memcpy(&r->buf[0], head, 18);
-    if (xlen > 6 && std::fread(&r->buf[18], 1, xlen - 6, r->f) != xlen - 6) return 0;
+    if (xlen > 6 && std::fread(&r->buf[18], 1, xlen - 6, r->f) != xlen - 6) return nullptr;
     uint32_t bsize = 0;
     const unsigned char *x = (const unsigned char *)r->buf.data() + 12;
     for (uint32_t q = 0; q + 4 <= xlen;) {
@@ -363,26 +415,50 @@ inline uint32_t read_block(Reader *r, uint64_t coff) {
         if (x[q] == 'B' && x[q + 1] == 'C' && slen == 2) bsize = (x[q + 4] | (x[q + 5] << 8)) + 1u;
         q += 4 + slen;
     }
-    if (!bsize) return 0;
+    if (!bsize) return nullptr;
     const uint32_t clen = bsize - 12 - xlen;
     r->buf.resize(clen);
-    if (std::fread(&r->buf[0], 1, clen, r->f) != clen) return 0;
+    if (std::fread(&r->buf[0], 1, clen, r->f) != clen) return nullptr;
     const unsigned char *b = (const unsigned char *)r->buf.data();
     const uint32_t isize = b[clen - 4] | (b[clen - 3] << 8) | (b[clen - 2] << 16) | ((uint32_t)b[clen - 1] << 24);
-    r->block.resize(isize);
+    slot->text.resize(isize);
     if (isize) {
         z_stream zs;
         std::memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, -15) != Z_OK) return 0;
+        if (inflateInit2(&zs, -15) != Z_OK) return nullptr;
         zs.next_in = (Bytef *)b;
         zs.avail_in = clen - 8;
-        zs.next_out = (Bytef *)&r->block[0];
+        zs.next_out = (Bytef *)&slot->text[0];
         zs.avail_out = isize;
         const int rc = inflate(&zs, Z_FINISH);
         inflateEnd(&zs);
-        if (rc != Z_STREAM_END) return 0;
+        if (rc != Z_STREAM_END) return nullptr;
     }
-    return bsize;
+    // line table: [0, head_end) belongs to the line the previous member ended in (or is a whole line when that member ended on
+    // a newline: the reader decides from its carry), complete lines follow, [tail_off, size) continues in the next member
+    slot->lines.clear();
+    const char *t0 = slot->text.data(), *te = t0 + isize;
+    const char *nl = isize ? (const char *)std::memchr(t0, '\n', isize) : nullptr;
+    if (!nl) { slot->head_end = isize + 1; slot->tail_off = isize; }       // no newline at all: everything continues
+    else {
+        slot->head_end = (uint32_t)(nl + 1 - t0);
+        const char *p = nl + 1;
+        while (p < te) {
+            const char *e = (const char *)std::memchr(p, '\n', (size_t)(te - p));
+            if (!e) break;
+            Reader::Line ln;
+            ln.off = (uint32_t)(p - t0);
+            ln.len = (uint32_t)(e - p);
+            parse_line(r, p, ln.len, ln);
+            slot->lines.push_back(ln);
+            p = e + 1;
+        }
+        slot->tail_off = (uint32_t)(p - t0);
+    }
+    slot->bsize = bsize;
+    slot->coff = coff;
+    slot->stamp = ++r->clock;
+    return slot;
 }
 
 // out[x - start] = value (column value_col) of every record of `chrom` overlapping [start, end), later records overwrite
@@ -419,53 +495,64 @@ inline int64_t read_values(Reader *r, const char *chrom, int64_t start, int64_t 
         else merged.push_back(c);
     }
     int64_t used = 0;
-    const size_t clen = std::strlen(chrom);
-    std::string line;
+    bool done = false;
+    // one record: skipped unless it is on `chrom` and overlaps [qs, qe); the first record at or past qe ends the chunk
+    auto record = [&](const Reader::Line &ln, const char *ls) {
+        if (ln.tid != tid || ln.nf < value_col) return;
+        if (ln.b0 >= qe) { done = true; return; }
+        if (ln.e0 > qs) {
+            const char *fld[8];
+            split_fields(ls, ln.len, fld);
+            const double v = std::strtod(fld[value_col - 1], nullptr);
+            const int64_t a = std::max(ln.b0, start) - start, z = std::min(ln.e0, end) - start;
+            for (int64_t i = a; i < z; ++i) out[i] = v;
+            ++used;
+        }
+    };
+    auto loose = [&](const char *ls, size_t ll) {                  // a line outside a member's table: parsed here
+        Reader::Line ln;
+        ln.off = 0;
+        ln.len = (uint32_t)ll;
+        parse_line(r, ls, ll, ln);
+        record(ln, ls);
+    };
+    std::string carry;
     for (auto &c : merged) {
         uint64_t coff = c.first >> 16;
         uint32_t uoff = (uint32_t)(c.first & 0xffff);
-        line.clear();
-        bool done = false;
+        carry.clear();
+        done = false;
         while (!done && (coff < (c.second >> 16) || (coff == (c.second >> 16) && uoff < (c.second & 0xffff)))) {
-            const uint32_t bsize = read_block(r, coff);
-            if (!bsize) return -1;
-            const uint32_t stop = (coff == (c.second >> 16)) ? (uint32_t)(c.second & 0xffff) : (uint32_t)r->block.size();
-            const char *p = r->block.data() + uoff, *pe = r->block.data() + std::min<size_t>(stop, r->block.size());
-            while (p < pe) {
-                const char *nl = (const char *)std::memchr(p, '\n', (size_t)(pe - p));
-                if (!nl) { line.append(p, (size_t)(pe - p)); break; }       // record continues in the next member
-                const char *ls = p;
-                size_t ll = (size_t)(nl - p);
-                if (!line.empty()) { line.append(p, ll); ls = line.data(); ll = line.size(); }
-                if (ll > 0 && ls[0] != '#') {
-                    // columns (1-based): seq, beg, end, value
-                    const char *cp = ls, *le = ls + ll;
-                    const char *fld[8];
-                    int nf = 0;
-                    fld[nf++] = cp;
-                    for (const char *t = cp; t < le && nf < 8; ++t) if (*t == '\t') fld[nf++] = t + 1;
-                    const int need = std::max(std::max(r->col_seq, r->col_end), value_col);
-                    if (nf >= need) {
-                        const char *sq = fld[r->col_seq - 1];
-                        const size_t sl = (size_t)((r->col_seq < nf ? fld[r->col_seq] - 1 : le) - sq);
-                        if (sl == clen && std::memcmp(sq, chrom, clen) == 0) {
-                            const int64_t b0 = std::strtoll(fld[r->col_beg - 1], nullptr, 10);
-                            int64_t e0 = std::strtoll(fld[r->col_end - 1], nullptr, 10);
-                            if (e0 <= b0) e0 = b0 + 1;
-                            if (b0 >= qe) { done = true; break; }
-                            if (e0 > qs) {
-                                const double v = std::strtod(fld[value_col - 1], nullptr);
-                                const int64_t a = std::max(b0, start) - start, z = std::min(e0, end) - start;
-                                for (int64_t i = a; i < z; ++i) out[i] = v;
-                                ++used;
-                            }
-                        }
-                    }
+            Reader::Block *blk = get_block(r, coff);
+            if (!blk) return -1;
+            const uint32_t size = (uint32_t)blk->text.size();
+            const uint32_t stop = (coff == (c.second >> 16)) ? std::min<uint32_t>((uint32_t)(c.second & 0xffff), size) : size;
+            const char *t0 = blk->text.data();
+            uint32_t pos = uoff;
+            if (pos < blk->head_end && pos < stop) {
+                // up to the first newline: the end of the carried line, or a line that starts at `pos`
+                if (blk->head_end > stop) {                            // no newline before `stop`: continues in the next member
+                    carry.append(t0 + pos, stop - pos);
+                    pos = stop;
+                } else {
+                    if (!carry.empty()) { carry.append(t0 + pos, blk->head_end - 1 - pos); loose(carry.data(), carry.size()); carry.clear(); }
+                    else loose(t0 + pos, blk->head_end - 1 - pos);
+                    pos = blk->head_end;
                 }
-                line.clear();
-                p = nl + 1;
             }
-            coff += bsize;
+            if (!done && pos < stop) {
+                // table lines from `pos` on (index offsets are record starts, i.e. line starts)
+                size_t lo = 0, hi = blk->lines.size();
+                while (lo < hi) { const size_t mid = (lo + hi) / 2; if (blk->lines[mid].off < pos) lo = mid + 1; else hi = mid; }
+                for (size_t k = lo; k < blk->lines.size() && !done; ++k) {
+                    const Reader::Line &ln = blk->lines[k];
+                    if (ln.off + ln.len >= stop) break;               // its newline is not before `stop`
+                    record(ln, t0 + ln.off);
+                    pos = ln.off + ln.len + 1;
+                }
+                if (!done && pos < stop) { carry.append(t0 + pos, stop - pos); pos = stop; }
+            }
+            coff += blk->bsize;
             uoff = 0;
         }
     }

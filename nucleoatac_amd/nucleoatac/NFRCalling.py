@@ -130,12 +130,12 @@ class NFRChunk(Chunk):
 def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
     """NFRChunk.process for a list of chunks with the per-chunk work batched: ONE PWM launch for the bias of all chunks
     (pipeline._bias_batch), the occupancy tracks and the dyad positions read through the persistent native tabix readers on
-    the reader pool (three region reads per chunk, GIL released), then the interval statistics of NFR.__init__ with the
+    the reader pool (three region reads per chunk, GIL released, neighbouring chunks on the same thread), then the interval statistics of NFR.__init__ with the
     reference's own numpy expressions per gap.  Returns (chunk index, left, right, values[n, 4]) of the NFRs that pass, in
     chunk / position order -- what the per-chunk loop writes."""
     from ..pipeline import _bias_batch
     from ..pyatac.tracks import _tabix
-    from .NucleosomeCalling import occ_reader_pool
+    from .NucleosomeCalling import map_in_slices
     n = len(chunks)
     starts = np.array([c.start for c in chunks], dtype=np.int64)
     ends = np.array([c.end for c in chunks], dtype=np.int64)
@@ -162,7 +162,7 @@ def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
         ins = track(params.ins_track, ch) if params.ins_track is not None else None
         return occ, up, nucs, ins
 
-    reads = list(occ_reader_pool().map(read, range(n))) if n > 1 else [read(0)] if n else []
+    reads = map_in_slices(read, range(n))
     kc, lefts, rights, vals = [], [], [], []
     for k, (occ, up, nucs, ins) in enumerate(reads):
         s = int(starts[k])

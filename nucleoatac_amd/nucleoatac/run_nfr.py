@@ -18,6 +18,7 @@ from .NFRCalling import NFRChunk, NFRParameters, nfr_batch
 
 BATCH_CHUNKS = 4096
 COMPRESS_LEVEL = 4
+LAST_TIMINGS = {}      # phase -> seconds of the last run_nfr call of this process (bench.py's cli_end_to_end reports them)
 
 
 def _nfrHelper(arg):
@@ -45,6 +46,8 @@ def _batch_insertions(chunks, bam):
 
 
 def run_nfr(args):
+    from .run_occ import _Phases
+    ph = _Phases(LAST_TIMINGS)
     if args.bam is None and args.ins_track is None:
         raise Exception("Must supply either bam file or insertion track")
     if not args.out:
@@ -77,6 +80,7 @@ def run_nfr(args):
     nb = max(1, (len(chunks) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
     nfr_path = args.out + ".nfrpos.bed" + suffix
     open(nfr_path, "w").close()
+    ph.mark("read_inputs")
     for bi in range(nb):
         part = chunks[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
         if not part:
@@ -87,11 +91,13 @@ def run_nfr(args):
         off = flat = None
         if make_ins:
             off, flat = _batch_insertions(part, args.bam)
+            ph.mark("insertions_gpu")
         try:
             kc, left, right, vals = nfr_batch(part, params, off, flat)
         except Exception:
             print("Caught exception when processing:\n" + "\n".join(c.asBed() for c in part[:3]) + "\n")
             raise
+        ph.mark("reads_bias_statistics")
         if len(kc):        # NFR.asBed rows of the whole sub-batch, python-2 float text, natively
             names = sorted(set(c.chrom for c in part))
             idx = {c: i for i, c in enumerate(names)}
@@ -99,6 +105,7 @@ def run_nfr(args):
         if make_ins:      # Track.write_track of every chunk's insertion track (run_nfr.py:55-67) through the native writer
             write_bedgraph(ins_path, [c.chrom for c in part], [c.start for c in part], off, flat, append=bi > 0,
                            compress=COMPRESS_LEVEL, finish=(bi == nb - 1 and rank == world - 1))
+        ph.mark("write_rows_and_ins_track")
     barrier()          # every rank has closed its part files
     if rank != 0:
         return
@@ -114,3 +121,4 @@ def run_nfr(args):
     tabix_index(args.out + ".nfrpos.bed.gz")
     if make_ins:
         tabix_index(ins_path)
+    ph.mark("bgzip_tabix")

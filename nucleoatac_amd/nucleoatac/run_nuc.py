@@ -20,7 +20,7 @@ from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fast
 from ..pyatac.VMat import VMat
 from ..shard import balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, shared_fragment_store
 from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
-from .NucleosomeCalling import NucParameters, fit_fuzz_chunk, nuc_batch, occ_reader_pool, read_occ_tracks
+from .NucleosomeCalling import NucParameters, fit_fuzz_tasks, map_in_slices, nuc_batch, read_occ_tracks
 from .run_occ import DEVICE_WRITER, _Phases, _Writer, finish_indexes
 
 LAST_TIMINGS = {}
@@ -81,7 +81,7 @@ def batch_calls(r, params, pool=None, pool_workers=1):
                 return read_occ_tracks(params.occ_track, ch.chrom, ch.start, ch.end)
             except Exception:      # noqa: BLE001 -- Nucleosome.getOcc: any failure gives NaN (NucleosomeCalling.py:128-135)
                 return None
-        for k, res in zip(called, occ_reader_pool().map(occ_of, called)):
+        for k, res in zip(called, map_in_slices(occ_of, called)):
             if res is not None:
                 a, e = int(bounds[k]), int(bounds[k + 1])
                 for j in range(3):
@@ -90,10 +90,7 @@ def batch_calls(r, params, pool=None, pool_workers=1):
     sm = tr[L.T_SMOOTH]
     tasks = [(sm[int(pk.out_off[k]):int(pk.out_off[k + 1])].copy(), kp[int(bounds[k]):int(bounds[k + 1])].astype(np.int64),
               params.nonredundant_sep, params.smooth_sd) for k in called]
-    if pool is None or len(tasks) < 2:
-        fits = [fit_fuzz_chunk(t) for t in tasks]
-    else:
-        fits = list(pool.map(fit_fuzz_chunk, tasks, chunksize=max(1, len(tasks) // (4 * pool_workers))))
+    fits = fit_fuzz_tasks(tasks, pool, pool_workers)
     nonred = np.zeros(len(kc), dtype=bool)
     for k, f in zip(called, fits):
         a, e = int(bounds[k]), int(bounds[k + 1])

@@ -178,10 +178,57 @@ def test_batched_finite_differences_reproduce_scipys_gradient():
         tasks.append((v, keys, 120, 10))
     res = {}
     try:
+        N.LOCKSTEP = False
         for fast in (False, True):
             N.FAST_FD = fast
             res[fast] = np.array([r for tk in tasks for r in N.fit_fuzz_chunk(tk)])
     finally:
-        N.FAST_FD = True
+        N.FAST_FD = N.LOCKSTEP = True
     assert res[True].shape == (6 * 14, 3)
     assert np.array_equal(res[False], res[True])
+
+
+def test_lockstep_fits_take_the_optimisers_own_steps():
+    """fuzzfit.fit_many advances many L-BFGS-B runs together through scipy's reverse-communication routine and evaluates
+    their objectives in one set of numpy calls: every fit must end on the bits scipy.optimize.minimize gives one at a time
+    (1-, 2- and 3-Gaussian fits, windows of every length, fits ending on a bound, flat and negative signal)"""
+    from nucleoatac_amd.nucleoatac import NucleosomeCalling as N, fuzzfit
+    assert fuzzfit.available(), "this scipy's private setulb no longer matches: the per-call path is used (slower, same values)"
+    rng = np.random.default_rng(7)
+    tasks = []
+    for i in range(40):
+        Lc = int(rng.integers(400, 2500))
+        x = np.arange(Lc)
+        nk = int(rng.integers(1, 18))
+        keys = np.sort(rng.choice(np.arange(60, Lc - 60, 25), size=min(nk, (Lc - 120) // 25), replace=False))
+        sd = rng.uniform(2.5, 45, size=len(keys))
+        v = sum(rng.uniform(0.2, 3) * np.exp(-0.5 * ((x - k) / s) ** 2) for k, s in zip(keys, sd)) + rng.normal(0, 0.03, Lc)
+        if i % 7 == 0:
+            v -= 0.1                                   # parts of the window clamp at 0
+        tasks.append((v, keys, 120, int(rng.choice([10, 25]))))
+    try:
+        N.LOCKSTEP = False
+        one = [N.fit_fuzz_chunk(tk) for tk in tasks]
+    finally:
+        N.LOCKSTEP = True
+    for group in (3, 64):
+        old, fuzzfit.GROUP = fuzzfit.GROUP, group
+        try:
+            many = N.fit_fuzz_chunks(tasks)
+        finally:
+            fuzzfit.GROUP = old
+        assert [len(m) for m in many] == [len(tk[1]) for tk in tasks]
+        assert np.array_equal(np.array([r for c in one for r in c], dtype=np.float64),
+                              np.array([r for c in many for r in c], dtype=np.float64))
+    flat = (np.zeros(300), np.array([150]), 120, 10)   # an all-zero window has no valid weight bound: both paths refuse it
+    for lock in (False, True):
+        N.LOCKSTEP = lock
+        try:
+            with pytest.raises(ValueError, match="upper bound is less"):
+                N.fit_fuzz_chunk(flat)
+        finally:
+            N.LOCKSTEP = True
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:                # the slicing over a --cores pool keeps the task order
+        sliced = N.fit_fuzz_tasks(tasks, pool, 2)
+    assert np.array_equal(np.array([r for c in many for r in c]), np.array([r for c in sliced for r in c]))

@@ -169,3 +169,40 @@ def test_read_track_through_index_equals_linear_scan(tmp_path):
     t = Track("chr1", -40, 30)                                           # negative start: bases before 0 stay empty
     t.read_track(path)
     assert np.isnan(t.vals).all()
+
+
+@pytest.mark.parametrize("blk", [37, 700, 5000, 65280])
+def test_region_reads_with_cached_members_equal_a_linear_scan(tmp_path, blk):
+    """The native reader keeps the last inflated members with their lines split (natac_tabix.hpp: Reader::Block).  Members
+    that end anywhere -- in the middle of a line, of a number, with no newline at all (37-byte members) -- and reads in
+    ascending, repeated and random order must give what a scan of the text gives; also the record-start column of a BED file
+    (value_col 2, the dyads of `nfr`), comment lines and overlapping records (later records overwrite earlier ones)."""
+    from helpers import bgzf_bytes
+    from nucleoatac_amd.tabix import NativeTabix
+    rng = np.random.default_rng(blk)
+    recs = []
+    for c, n in (("chrA", 3000), ("chrB", 40), ("chrC_long_name", 1500)):
+        pos = np.sort(rng.integers(0, 60000, n))
+        for p in pos:
+            recs.append((c, int(p), int(p) + int(rng.choice([1, 1, 1, 7, 300, 20000], p=[.5, .2, .1, .1, .09, .01])), float(rng.normal())))
+    text = "#comment line\n" + "".join("%s\t%d\t%d\t%r\n" % r for r in recs)
+    path = str(tmp_path / "r.bed.gz")
+    open(path, "wb").write(bgzf_bytes(text.encode(), blk))
+    tabix_index(path)
+
+    def brute(chrom, s, e, col):
+        out = np.full(e - s, np.nan)
+        for c, b0, e0, v in recs:
+            if c == chrom and b0 < e and e0 > max(s, 0):
+                out[max(b0, s) - s:min(e0, e) - s] = v if col == 4 else b0
+        return out
+
+    rd = NativeTabix(path)
+    regions = [(c, s, s + w) for c in ("chrA", "chrC_long_name", "chrB") for s, w in zip(range(0, 60000, 4100), [2120] * 15)]
+    regions += [("chrA", int(s), int(s) + int(w)) for s, w in zip(rng.integers(-50, 61000, 40), rng.integers(1, 9000, 40))]
+    regions += regions[:10]                                             # again, now from the cache
+    for chrom, s, e in regions:
+        for col in (4, 2):
+            assert np.array_equal(rd.read_values(chrom, s, e, value_col=col), brute(chrom, s, e, col), equal_nan=True), (chrom, s, e, col)
+    assert np.isnan(rd.read_values("chrNone", 0, 100)).all()
+    rd.close()
