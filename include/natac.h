@@ -299,6 +299,13 @@ int natac_tbx_open(const char *path, natac_tbx **out);
 void natac_tbx_close(natac_tbx *t);
 int natac_tbx_read_values(natac_tbx *t, const char *chrom, int64_t start, int64_t end, int value_col, double empty, double *out,
                           int64_t *n_records);
+/* the same for n regions in one call (the three occupancy tracks of every chunk of a batch: NucChunk.getOcc,
+ * nucleoatac/NucleosomeCalling.py:284-293, NFRChunk.getOcc, NFRCalling.py:63-68): region i = names[chrom_id[i]]:[start[i], end[i]),
+ * written to out[out_off[i] ...].  n_threads cursors of the handle take contiguous runs of the list (0 = up to 16); a cursor keeps
+ * the members it inflated last, so position-sorted lists inflate and parse every member once. */
+int natac_tbx_read_regions(natac_tbx *t, int64_t n, const int32_t *chrom_id, const char *const *names, int32_t n_names,
+                           const int64_t *start, const int64_t *end, int value_col, double empty, double *out, const int64_t *out_off,
+                           int n_threads, int64_t *n_records);
 
 /* ---- host-side packing of a chunk list (what replaces the per-chunk bamHandle.fetch of pyatac/fragments.pyx:21-36) ---- */
 /* pos[c] / tlen[c]: the forward proper-pair reads of chromosome c (natac_bam_ref_reads), pos ascending.  chrom_id[i] < 0: a

@@ -82,6 +82,7 @@ SIGNATURES = {
     "natac_tbx_open": (C.c_int, [C.c_char_p, _pp]),
     "natac_tbx_close": (None, [_vp]),
     "natac_tbx_read_values": (C.c_int, [_vp, C.c_char_p, _i64, _i64, C.c_int, _f64, _vp, C.POINTER(_i64)]),
+    "natac_tbx_read_regions": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int32, _vp, _vp, C.c_int, _f64, _vp, _vp, C.c_int, C.POINTER(_i64)]),
     "natac_pack_chunks": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "natac_bam_open": (C.c_int, [C.c_char_p, C.c_int, _pp]),
     "natac_bam_close": (None, [_vp]),

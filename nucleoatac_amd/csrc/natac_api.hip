@@ -2357,6 +2357,21 @@ int natac_tbx_read_values(natac_tbx *t, const char *chrom, int64_t start, int64_
     return NATAC_OK;
 }
 
+int natac_tbx_read_regions(natac_tbx *t, int64_t n, const int32_t *chrom_id, const char *const *names, int32_t n_names,
+                           const int64_t *start, const int64_t *end, int value_col, double empty, double *out, const int64_t *out_off,
+                           int n_threads, int64_t *n_records) {
+    if (!t || n < 0 || (n > 0 && (!chrom_id || !names || !start || !end || !out_off))) return fail(NATAC_E_ARG, "null argument");
+    if (value_col < 1 || value_col > 8) return fail(NATAC_E_ARG, "value_col must be 1..8");
+    for (int64_t i = 0; i < n; ++i) {
+        if (chrom_id[i] < 0 || chrom_id[i] >= n_names) return fail(NATAC_E_ARG, "region %lld: chromosome index out of range", (long long)i);
+        if (end[i] > start[i] && !out) return fail(NATAC_E_ARG, "null output");
+    }
+    const int64_t u = natac_tabix::read_regions(t->impl, n, chrom_id, names, n_names, start, end, value_col, empty, out, out_off, n_threads);
+    if (u < 0) return fail(NATAC_E_ARG, "read error in the indexed file");
+    if (n_records) *n_records = u;
+    return NATAC_OK;
+}
+
 /* ---------------- native BAM extractor ---------------- */
 
 int natac_bam_open(const char *path, int n_threads, natac_bam **out) {

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -232,12 +233,19 @@ inline int index_bed(const char *path, const char *tbi_path, int n_threads, int6
 // ---- reader: values of a tabix-indexed bedGraph over a region (Track.read_track, pyatac/tracks.py:75-87) ----
 namespace natac_tabix {
 
-struct Reader {
-    FILE *f = nullptr;
+// the parsed .tbi: immutable after open_reader, shared by the cursors of one handle
+struct Index {
     std::vector<std::string> names;
     std::vector<std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins;
     std::vector<std::vector<uint64_t>> lin;
     int col_seq = 1, col_beg = 2, col_end = 3;
+};
+
+struct Reader {
+    FILE *f = nullptr;
+    std::shared_ptr<const Index> ix;
+    std::string path;
+    std::vector<std::unique_ptr<Reader>> workers;     // further cursors on the same file for read_regions (own FILE, own cache)
     std::string buf;
     // The last inflated members with their lines split and their coordinates parsed once: a driver reads neighbouring regions
     // one after the other (three tracks per chunk in `nuc` / `nfr`), a region read starts at the beginning of its 16-kb index
@@ -255,6 +263,7 @@ struct Reader {
     std::vector<Block> cache;
     uint64_t clock = 0;
     int last_tid = 0;
+    ~Reader() { if (f) std::fclose(f); }
 };
 
 // inflate a whole BGZF file into memory (the .tbi itself)
@@ -320,14 +329,15 @@ inline int open_reader(const char *path, Reader **out) {
     const int rc = inflate_all((std::string(path) + ".tbi").c_str(), raw);
     if (rc) return rc;
     if (raw.size() < 36 || std::memcmp(raw.data(), "TBI\1", 4) != 0) return 2;
-    Reader *r = new Reader();
+    auto ixp = std::make_shared<Index>();
+    Index *r = ixp.get();
     size_t p = 4;
     const uint32_t n_ref = rd32(raw, p);
     rd32(raw, p);
     r->col_seq = (int)rd32(raw, p); r->col_beg = (int)rd32(raw, p); r->col_end = (int)rd32(raw, p);
     rd32(raw, p); rd32(raw, p);
     const uint32_t l_nm = rd32(raw, p);
-    if (p + l_nm > raw.size()) { delete r; return 2; }
+    if (p + l_nm > raw.size()) return 2;
     for (size_t q = p; q < p + l_nm;) {
         const size_t e = raw.find('\0', q);
         r->names.emplace_back(raw.substr(q, e - q));
@@ -337,31 +347,30 @@ inline int open_reader(const char *path, Reader **out) {
     r->bins.resize(n_ref);
     r->lin.resize(n_ref);
     for (uint32_t t = 0; t < n_ref; ++t) {
-        if (p + 4 > raw.size()) { delete r; return 2; }
+        if (p + 4 > raw.size()) return 2;
         const uint32_t n_bin = rd32(raw, p);
         for (uint32_t b = 0; b < n_bin; ++b) {
             const uint32_t bin = rd32(raw, p), n_chunk = rd32(raw, p);
-            if (p + 16ull * n_chunk > raw.size()) { delete r; return 2; }
+            if (p + 16ull * n_chunk > raw.size()) return 2;
             std::vector<std::pair<uint64_t, uint64_t>> cs(n_chunk);
             for (auto &c : cs) { c.first = rd64(raw, p); c.second = rd64(raw, p); }
             if (bin != 37450u) r->bins[t][bin] = std::move(cs);
         }
         const uint32_t n_intv = rd32(raw, p);
-        if (p + 8ull * n_intv > raw.size()) { delete r; return 2; }
+        if (p + 8ull * n_intv > raw.size()) return 2;
         r->lin[t].resize(n_intv);
         for (auto &v : r->lin[t]) v = rd64(raw, p);
     }
-    r->f = std::fopen(path, "rb");
-    if (!r->f) { delete r; return 1; }
-    *out = r;
+    Reader *rd = new Reader();
+    rd->ix = ixp;
+    rd->path = path;
+    rd->f = std::fopen(path, "rb");
+    if (!rd->f) { delete rd; return 1; }
+    *out = rd;
     return 0;
 }
 
-inline void close_reader(Reader *r) {
-    if (!r) return;
-    if (r->f) std::fclose(r->f);
-    delete r;
-}
+inline void close_reader(Reader *r) { delete r; }
 
 // split [p, p + len) at tabs into at most 8 fields; returns the count
 inline int split_fields(const char *p, size_t len, const char *fld[8]) {
@@ -371,6 +380,50 @@ inline int split_fields(const char *p, size_t len, const char *fld[8]) {
     return nf;
 }
 
+// decimal text -> double, correctly rounded like strtod: up to 15 significant digits and a decimal exponent within +-22 are one
+// exact integer and one exactly representable power of ten, so a single multiplication or division rounds correctly (Clinger
+// 1990); anything else ("nan", "inf", 17-digit reprs, 1e-300) goes to strtod.  The tracks the writer produces are 12 digits.
+inline double parse_double(const char *p) {
+    static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18,
+                                   1e19, 1e20, 1e21, 1e22};
+    const char *s = p;
+    bool neg = false, any = false, ok = true;
+    if (*s == '-') { neg = true; ++s; } else if (*s == '+') ++s;
+    uint64_t m = 0;
+    int nd = 0, frac = 0, ex = 0;
+    for (; *s >= '0' && *s <= '9'; ++s) { any = true; if (m || *s != '0') { if (++nd > 15) ok = false; else m = m * 10 + (uint64_t)(*s - '0'); } }
+    if (*s == '.') {
+        for (++s; *s >= '0' && *s <= '9'; ++s) { any = true; ++frac; if (m || *s != '0') { if (++nd > 15) ok = false; else m = m * 10 + (uint64_t)(*s - '0'); } }
+    }
+    if (any && (*s == 'e' || *s == 'E')) {
+        const char *q = s + 1;
+        bool eneg = false;
+        if (*q == '-') { eneg = true; ++q; } else if (*q == '+') ++q;
+        if (*q >= '0' && *q <= '9') {
+            int nde = 0;
+            for (; *q >= '0' && *q <= '9'; ++q) { if (++nde > 4) ok = false; else ex = ex * 10 + (*q - '0'); }
+            if (eneg) ex = -ex;
+            s = q;
+        }
+    }
+    const int e10 = ex - frac;
+    if (!any || !ok || e10 < -22 || e10 > 22 || !(*s == '\t' || *s == '\n' || *s == '\0' || *s == '\r' || *s == ' '))
+        return std::strtod(p, nullptr);
+    double v = (double)m;
+    v = e10 < 0 ? v / P10[-e10] : v * P10[e10];
+    return neg ? -v : v;
+}
+
+// non-negative decimal integer (coordinates); anything else goes to strtoll
+inline int64_t parse_int(const char *p) {
+    const char *s = p;
+    int64_t v = 0;
+    int nd = 0;
+    for (; *s >= '0' && *s <= '9' && nd < 18; ++s, ++nd) v = v * 10 + (*s - '0');
+    if (nd == 0 || (*s >= '0' && *s <= '9')) return std::strtoll(p, nullptr, 10);
+    return v;
+}
+
 // coordinates of one text line: reference index (-1: comment, too few columns or a name the index does not hold), begin, end
 inline void parse_line(Reader *r, const char *ls, size_t ll, Reader::Line &ln) {
     ln.tid = -1; ln.nf = 0; ln.b0 = ln.e0 = 0;
@@ -378,15 +431,15 @@ inline void parse_line(Reader *r, const char *ls, size_t ll, Reader::Line &ln) {
     const char *fld[8];
     const int nf = split_fields(ls, ll, fld);
     ln.nf = nf;
-    if (nf < std::max(r->col_seq, r->col_end)) return;
-    const char *sq = fld[r->col_seq - 1];
-    const size_t sl = (size_t)((r->col_seq < nf ? fld[r->col_seq] - 1 : ls + ll) - sq);
-    auto same = [&](int t) { return r->names[t].size() == sl && std::memcmp(r->names[t].data(), sq, sl) == 0; };
-    if (r->last_tid < (int)r->names.size() && same(r->last_tid)) ln.tid = r->last_tid;
+    if (nf < std::max(r->ix->col_seq, r->ix->col_end)) return;
+    const char *sq = fld[r->ix->col_seq - 1];
+    const size_t sl = (size_t)((r->ix->col_seq < nf ? fld[r->ix->col_seq] - 1 : ls + ll) - sq);
+    auto same = [&](int t) { return r->ix->names[t].size() == sl && std::memcmp(r->ix->names[t].data(), sq, sl) == 0; };
+    if (r->last_tid < (int)r->ix->names.size() && same(r->last_tid)) ln.tid = r->last_tid;
     else
-        for (int t = 0; t < (int)r->names.size(); ++t) if (same(t)) { ln.tid = r->last_tid = t; break; }
-    ln.b0 = std::strtoll(fld[r->col_beg - 1], nullptr, 10);
-    ln.e0 = std::strtoll(fld[r->col_end - 1], nullptr, 10);
+        for (int t = 0; t < (int)r->ix->names.size(); ++t) if (same(t)) { ln.tid = r->last_tid = t; break; }
+    ln.b0 = parse_int(fld[r->ix->col_beg - 1]);
+    ln.e0 = parse_int(fld[r->ix->col_end - 1]);
     if (ln.e0 <= ln.b0) ln.e0 = ln.b0 + 1;
 }
 
@@ -467,19 +520,19 @@ inline int64_t read_values(Reader *r, const char *chrom, int64_t start, int64_t 
     const int64_t n = end - start;
     for (int64_t i = 0; i < n; ++i) out[i] = empty;
     int tid = -1;
-    for (size_t i = 0; i < r->names.size(); ++i) if (r->names[i] == chrom) tid = (int)i;
+    for (size_t i = 0; i < r->ix->names.size(); ++i) if (r->ix->names[i] == chrom) tid = (int)i;
     if (tid < 0 || n <= 0) return 0;
     const int64_t qs = std::max<int64_t>(0, start), qe = end;
     if (qe <= qs) return 0;
-    const auto &lin = r->lin[tid];
+    const auto &lin = r->ix->lin[tid];
     const size_t w = (size_t)(qs >> 14);
     const uint64_t min_off = lin.empty() ? 0 : (w < lin.size() ? lin[w] : lin.back());
     std::vector<std::pair<uint64_t, uint64_t>> chunks;
     {
         const int64_t b = qs, e = qe - 1;
         auto add = [&](uint32_t bin) {
-            auto it = r->bins[tid].find(bin);
-            if (it == r->bins[tid].end()) return;
+            auto it = r->ix->bins[tid].find(bin);
+            if (it == r->ix->bins[tid].end()) return;
             for (auto &c : it->second) if (c.second > min_off) chunks.push_back({std::max(c.first, min_off), c.second});
         };
         add(0);
@@ -503,7 +556,7 @@ inline int64_t read_values(Reader *r, const char *chrom, int64_t start, int64_t 
         if (ln.e0 > qs) {
             const char *fld[8];
             split_fields(ls, ln.len, fld);
-            const double v = std::strtod(fld[value_col - 1], nullptr);
+            const double v = parse_double(fld[value_col - 1]);
             const int64_t a = std::max(ln.b0, start) - start, z = std::min(ln.e0, end) - start;
             for (int64_t i = a; i < z; ++i) out[i] = v;
             ++used;
@@ -557,6 +610,40 @@ inline int64_t read_values(Reader *r, const char *chrom, int64_t start, int64_t 
         }
     }
     return used;
+}
+
+// read_values of n regions into out[out_off[i] .. out_off[i] + end[i] - start[i]): contiguous runs of the region list per thread (each
+// with its own cursor and member cache, so neighbouring regions share the members they inflate).  Returns #records, -1 on IO error.
+inline int64_t read_regions(Reader *r, int64_t n, const int32_t *chrom_id, const char *const *names, int32_t n_names, const int64_t *start,
+                            const int64_t *end, int value_col, double empty, double *out, const int64_t *out_off, int n_threads) {
+    int T = n_threads > 0 ? n_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(T, n / 4));
+    while ((int)r->workers.size() < T - 1) {
+        std::unique_ptr<Reader> w(new Reader());
+        w->ix = r->ix;
+        w->path = r->path;
+        w->f = std::fopen(r->path.c_str(), "rb");
+        if (!w->f) return -1;
+        r->workers.push_back(std::move(w));
+    }
+    std::vector<int64_t> used((size_t)T, 0);
+    auto work = [&](int t) {
+        Reader *rd = t == 0 ? r : r->workers[(size_t)t - 1].get();
+        for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+            const int32_t c = chrom_id[i];
+            if (c < 0 || c >= n_names) { used[(size_t)t] = -1; return; }
+            const int64_t u = read_values(rd, names[c], start[i], end[i], value_col, empty, out + out_off[i]);
+            if (u < 0) { used[(size_t)t] = -1; return; }
+            used[(size_t)t] += u;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    int64_t total = 0;
+    for (auto u : used) { if (u < 0) return -1; total += u; }
+    return total;
 }
 
 }  // namespace natac_tabix

@@ -129,13 +129,13 @@ class NFRChunk(Chunk):
 
 def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
     """NFRChunk.process for a list of chunks with the per-chunk work batched: ONE PWM launch for the bias of all chunks
-    (pipeline._bias_batch), the occupancy tracks and the dyad positions read through the persistent native tabix readers on
-    the reader pool (three region reads per chunk, GIL released, neighbouring chunks on the same thread), then the interval statistics of NFR.__init__ with the
-    reference's own numpy expressions per gap.  Returns (chunk index, left, right, values[n, 4]) of the NFRs that pass, in
+    (pipeline._bias_batch), the occupancy tracks and the dyad positions of the whole batch read with one native call per file
+    (natac_tbx_read_regions: every BGZF member inflated and parsed once), then the interval statistics of NFR.__init__ with
+    the reference's own numpy expressions per gap.  Returns (chunk index, left, right, values[n, 4]) of the NFRs that pass, in
     chunk / position order -- what the per-chunk loop writes."""
     from ..pipeline import _bias_batch
     from ..pyatac.tracks import _tabix
-    from .NucleosomeCalling import map_in_slices
+    from .NucleosomeCalling import map_in_slices, read_regions_of
     n = len(chunks)
     starts = np.array([c.start for c in chunks], dtype=np.int64)
     ends = np.array([c.end for c in chunks], dtype=np.int64)
@@ -149,20 +149,28 @@ def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
         t.read_track(path)
         return t.vals
 
-    def read(k):
-        ch = chunks[k]
-        occ, up = track(params.occ_track, ch), track(upper, ch)
-        rd = _tabix(params.calls)         # the calls file is tabix-indexed, like the reference requires
-        if hasattr(rd, "read_values"):    # record starts (column 2) at their own positions
-            dy = rd.read_values(ch.chrom, ch.start, ch.end, value_col=2)
-            nucs = np.flatnonzero(~np.isnan(dy)) + ch.start
-        else:
-            nucs = np.array([int(row.split("\t")[1]) for row in rd.fetch(ch.chrom, ch.start, ch.end)] if ch.chrom in rd.contigs else [],
-                            dtype=np.int64)
-        ins = track(params.ins_track, ch) if params.ins_track is not None else None
-        return occ, up, nucs, ins
+    def column(path, value_col=4):   # per chunk values of one file: one native call for the batch, else chunk by chunk
+        got = read_regions_of(path, chunks, value_col)
+        if got is not None:
+            flat, off = got
+            return [flat[int(off[k]):int(off[k + 1])] for k in range(n)]
+        if value_col == 2:           # record starts (the dyads) through the line reader
+            def starts_of(ch):
+                rd = _tabix(path)
+                out = np.full(ch.end - ch.start, np.nan)
+                if ch.chrom in rd.contigs:
+                    for row in rd.fetch(ch.chrom, ch.start, ch.end):
+                        p = int(row.split("\t")[1])
+                        if ch.start <= p < ch.end:
+                            out[p - ch.start] = p
+                return out
+            return map_in_slices(starts_of, chunks)
+        return map_in_slices(lambda ch: track(path, ch), chunks)
 
-    reads = map_in_slices(read, range(n))
+    occs, ups = column(params.occ_track), column(upper)
+    dyads = column(params.calls, 2)      # the calls file is tabix-indexed, like the reference requires
+    inss = column(params.ins_track) if params.ins_track is not None else [None] * n
+    reads = [(occs[k], ups[k], np.flatnonzero(~np.isnan(dyads[k])) + chunks[k].start, inss[k]) for k in range(n)]
     kc, lefts, rights, vals = [], [], [], []
     for k, (occ, up, nucs, ins) in enumerate(reads):
         s = int(starts[k])

@@ -130,6 +130,37 @@ def read_occ_tracks(occ_track, chrom, start, end):
     return out
 
 
+def read_regions_of(path, chunks, value_col=4):
+    """Track.read_track of every chunk from ONE indexed file in one native call (natac_tbx_read_regions: the chunks of a batch
+    are position-sorted, its cursors inflate and parse every BGZF member once): (flat values, offsets), or None when the file
+    has no index / the native reader is not there (the callers then read chunk by chunk)"""
+    from ..pyatac.tracks import _tabix
+    if not (path.endswith(".gz") and os.path.exists(path + ".tbi")):
+        return None
+    rd = _tabix(path)
+    if not hasattr(rd, "read_regions"):
+        return None
+    return rd.read_regions([c.chrom for c in chunks], [c.start for c in chunks], [c.end for c in chunks], value_col=value_col)
+
+
+def read_occ_tracks_many(occ_track, chunks):
+    """read_occ_tracks for a list of chunks: per chunk [occ, lower, upper], or None where the read failed (Nucleosome.getOcc
+    turns any failure into NaN, NucleosomeCalling.py:128-135)"""
+    base = occ_track[:-11]
+    try:
+        three = [read_regions_of(f, chunks) for f in (occ_track, base + "lower_bound.bedgraph.gz", base + "upper_bound.bedgraph.gz")]
+    except Exception:      # noqa: BLE001 -- e.g. one damaged member: find out chunk by chunk which reads still work
+        three = [None]
+    if any(t is None for t in three):
+        def one(ch):
+            try:
+                return read_occ_tracks(occ_track, ch.chrom, ch.start, ch.end)
+            except Exception:      # noqa: BLE001
+                return None
+        return map_in_slices(one, chunks)
+    return [[flat[int(off[k]):int(off[k + 1])] for flat, off in three] for k in range(len(chunks))]
+
+
 FAST_FD = True    # batched finite differences in fit_fuzz_one (False: scipy's own numerical gradient)
 
 
@@ -238,14 +269,17 @@ def fit_fuzz_chunks(tasks):
     return out
 
 
-def fit_fuzz_tasks(tasks, pool=None, pool_workers=1):
+def fit_fuzz_tasks(tasks, pool=None, pool_workers=1, start_only=False):
     """fit_fuzz_chunks over a list of per-chunk tasks, in slices over the process pool when there is one (4 slices per
-    worker: the lockstep groups stay full, the tail of slow fits stays short); results in task order"""
+    worker: the lockstep groups stay full, the tail of slow fits stays short); results in task order.  start_only: submit
+    the slices and return a function that waits for the results (the caller reads its occupancy tracks meanwhile)."""
     if pool is None or len(tasks) < 2:
-        return fit_fuzz_chunks(tasks)
+        res = fit_fuzz_chunks(tasks)
+        return (lambda: res) if start_only else res
     per = max(1, -(-len(tasks) // (4 * pool_workers)))
-    slices = [tasks[a:a + per] for a in range(0, len(tasks), per)]
-    return [r for part in pool.map(fit_fuzz_chunks, slices) for r in part]
+    parts = pool.map(fit_fuzz_chunks, [tasks[a:a + per] for a in range(0, len(tasks), per)])   # submitted here
+    collect = lambda: [r for part in parts for r in part]      # noqa: E731
+    return collect if start_only else collect()
 
 
 class Nucleosome(Chunk):

@@ -20,7 +20,7 @@ from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fast
 from ..pyatac.VMat import VMat
 from ..shard import balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, shared_fragment_store
 from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
-from .NucleosomeCalling import NucParameters, fit_fuzz_tasks, map_in_slices, nuc_batch, read_occ_tracks
+from .NucleosomeCalling import NucParameters, fit_fuzz_tasks, nuc_batch, read_occ_tracks_many
 from .run_occ import DEVICE_WRITER, _Phases, _Writer, finish_indexes
 
 LAST_TIMINGS = {}
@@ -73,24 +73,20 @@ def batch_calls(r, params, pool=None, pool_workers=1):
     vals[:, 7], vals[:, 8] = nuc_cov[keep], tr[L.T_NFR_COV][kidx]
     bounds = np.searchsorted(kc, np.arange(len(part) + 1))
     called = [k for k in range(len(part)) if bounds[k + 1] > bounds[k]]
+    # fuzziness fits: one task per chunk with calls (the smoothed values are copied out of the pinned slot), started on the pool
+    sm = tr[L.T_SMOOTH]
+    tasks = [(sm[int(pk.out_off[k]):int(pk.out_off[k + 1])].copy(), kp[int(bounds[k]):int(bounds[k + 1])].astype(np.int64),
+              params.nonredundant_sep, params.smooth_sd) for k in called]
+    fits = fit_fuzz_tasks(tasks, pool, pool_workers, start_only=True)
     if params.occ_track is not None and called:
-        # three tabix region reads per chunk with calls (NucChunk.getOcc, NucleosomeCalling.py:284-293) on the persistent reader pool
-        def occ_of(k):
-            ch = part[k]
-            try:
-                return read_occ_tracks(params.occ_track, ch.chrom, ch.start, ch.end)
-            except Exception:      # noqa: BLE001 -- Nucleosome.getOcc: any failure gives NaN (NucleosomeCalling.py:128-135)
-                return None
-        for k, res in zip(called, map_in_slices(occ_of, called)):
+        # meanwhile the three occupancy tracks of every chunk with calls (NucChunk.getOcc, NucleosomeCalling.py:284-293): one native
+        # call per file
+        for k, res in zip(called, read_occ_tracks_many(params.occ_track, [part[k] for k in called])):
             if res is not None:
                 a, e = int(bounds[k]), int(bounds[k + 1])
                 for j in range(3):
                     vals[a:e, 1 + j] = res[j][kp[a:e]]
-    # fuzziness fits: one task per chunk with calls (the smoothed values are copied out of the pinned slot)
-    sm = tr[L.T_SMOOTH]
-    tasks = [(sm[int(pk.out_off[k]):int(pk.out_off[k + 1])].copy(), kp[int(bounds[k]):int(bounds[k + 1])].astype(np.int64),
-              params.nonredundant_sep, params.smooth_sd) for k in called]
-    fits = fit_fuzz_tasks(tasks, pool, pool_workers)
+    fits = fits()
     nonred = np.zeros(len(kc), dtype=bool)
     for k, f in zip(called, fits):
         a, e = int(bounds[k]), int(bounds[k + 1])

@@ -218,6 +218,25 @@ class NativeTabix(object):
                                                       float(empty), out.ctypes.data_as(C.c_void_p), C.byref(n)))
         return out
 
+    def read_regions(self, chroms, starts, ends, empty=np.nan, value_col=4, n_threads=0):
+        """read_values of many regions in one call (natac_tbx_read_regions): (flat values, offsets); region i is
+        flat[off[i]:off[i + 1]].  Contiguous runs of the list go to the handle's cursors, so a position-sorted list inflates
+        and parses every BGZF member once."""
+        C = self._C
+        names = sorted(set(chroms))
+        idx = {c: i for i, c in enumerate(names)}
+        cid = np.array([idx[c] for c in chroms], dtype=np.int32)
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        ends = np.ascontiguousarray(ends, dtype=np.int64)
+        off = np.concatenate(([0], np.cumsum(np.maximum(ends - starts, 0)))).astype(np.int64)
+        out = np.empty(int(off[-1]), np.float64)
+        arr = (C.c_char_p * max(1, len(names)))(*[str(c).encode() for c in names])
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        n = C.c_int64(0)
+        self._L.check(self._lib.natac_tbx_read_regions(self._h, len(cid), vp(cid), arr, len(names), vp(starts), vp(ends), int(value_col),
+                                                       float(empty), vp(out), vp(off), int(n_threads), C.byref(n)))
+        return out, off
+
     def close(self):
         if self._h:
             self._lib.natac_tbx_close(self._h)

@@ -206,3 +206,47 @@ def test_region_reads_with_cached_members_equal_a_linear_scan(tmp_path, blk):
             assert np.array_equal(rd.read_values(chrom, s, e, value_col=col), brute(chrom, s, e, col), equal_nan=True), (chrom, s, e, col)
     assert np.isnan(rd.read_values("chrNone", 0, 100)).all()
     rd.close()
+
+
+def test_read_regions_equals_single_reads_and_parses_numbers_like_float(tmp_path):
+    """natac_tbx_read_regions (many regions per call, contiguous runs per cursor) against read_values per region; the value
+    parser (one exact multiplication / division for <= 15 digits and |exponent| <= 22, strtod otherwise) against python's float()
+    on 12-digit track values, reprs, exponent forms, integers, nan, inf, denormals"""
+    from helpers import bgzf_bytes
+    from nucleoatac_amd.tabix import NativeTabix
+    rng = np.random.default_rng(11)
+    n = 120000
+    x = rng.normal(size=n) * 10.0 ** rng.integers(-30, 30, n)
+    forms = ["%.12g", "%r", "%e", "%.15g", "%.16g", "%d", "%.3f", "%.12g"]
+    texts = []
+    for i, v in enumerate(x):
+        f = forms[i % len(forms)]
+        texts.append(f % (int(v % 1e15) if f == "%d" else float(v)))
+    special = ["nan", "inf", "-inf", "-0.0", "0", "1e22", "1e23", "1e-22", "1e-23", "123456789012345", "1234567890123456", "4.9e-324",
+               "2.2250738585072014e-308", "1.7976931348623157e308", "+5.5", "0.000000000000000000001", "9007199254740993", ".5", "5.",
+               "1E5", "12345678901234567890123", "0.1e-21", "1e+5"]
+    texts[:len(special)] = special
+    text = "".join("c1\t%d\t%d\t%s\n" % (i, i + 1, t) for i, t in enumerate(texts))
+    path = str(tmp_path / "v.bed.gz")
+    open(path, "wb").write(bgzf_bytes(text.encode(), 60000))
+    tabix_index(path)
+    rd = NativeTabix(path)
+    want = np.array([float(t) for t in texts])
+    starts = np.arange(0, n, 997)
+    ends = np.minimum(starts + 997, n)
+    flat, off = rd.read_regions(["c1"] * len(starts), starts, ends, n_threads=5)
+    assert np.array_equal(off, np.r_[0, np.cumsum(ends - starts)])
+    same = (flat == want) | (np.isnan(flat) & np.isnan(want))
+    assert same.all(), [texts[i] for i in np.flatnonzero(~same)[:10]]
+    assert np.array_equal(np.signbit(flat), np.signbit(want))
+    # arbitrary (overlapping, unsorted, empty, other-chromosome) region lists: the same values as one read per region
+    chroms = ["c1"] * 60 + ["cX"] * 3
+    s2 = np.r_[rng.integers(-100, n, 60), [5, 10, 15]]
+    e2 = s2 + np.r_[rng.integers(0, 5000, 60), [100, 0, 7]]
+    for threads in (1, 4):
+        flat, off = rd.read_regions(chroms, s2, e2, n_threads=threads, empty=-7.0)
+        for i in range(len(chroms)):
+            assert np.array_equal(flat[off[i]:off[i + 1]], rd.read_values(chroms[i], int(s2[i]), int(e2[i]), empty=-7.0), equal_nan=True), i
+    flat, off = rd.read_regions([], [], [])
+    assert len(flat) == 0 and list(off) == [0]
+    rd.close()
