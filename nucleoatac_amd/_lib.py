@@ -89,6 +89,8 @@ SIGNATURES = {
     "natac_bam_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
     "natac_bam_ref_info": (C.c_int, [_vp, _i32, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(_i64)]),
     "natac_bam_ref_reads": (C.c_int, [_vp, _i32, _vp, _vp, _i64]),
+    "natac_bam_open_device": (C.c_int, [_vp, C.c_char_p, _pp, C.POINTER(C.c_int)]),
+    "natac_inflate_raw_host": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t]),
     "natac_host_alloc": (C.c_int, [_sz, _pp]),
     "natac_host_free": (C.c_int, [_vp]),
     "natac_pool_trim": (C.c_int, []),

@@ -12,6 +12,7 @@
 #include "natac_tabix.hpp"
 #include "natac_pack.hpp"
 #include "natac_bam.hpp"
+#include "natac_bam_dev.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -2386,6 +2387,33 @@ int natac_bam_open(const char *path, int n_threads, natac_bam **out) {
     h->impl = impl;
     *out = h;
     return NATAC_OK;
+}
+
+int natac_bam_open_device(natac_ctx *c, const char *path, natac_bam **out, int *on_device) {
+    if (!c || !path || !out) return fail(NATAC_E_ARG, "null argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(c->device));
+    std::string err;
+    size_t window = (size_t)1 << 30;                  // compressed bytes per device window; NATAC_BAM_DEV_WINDOW overrides (tests)
+    if (const char *e = getenv("NATAC_BAM_DEV_WINDOW")) { const long long v = atoll(e); if (v > 0) window = (size_t)v; }
+    bool undecided = false;
+    natac_bamio::Bam *impl = natac_bamdev::decode_device(path, c->stream, err, &undecided, window);
+    if (on_device) *on_device = impl ? 1 : 0;
+    if (!impl && undecided) {                         // the chain of record starts was not confirmed: the host decoder answers
+        size_t hw = (size_t)48 << 20;
+        if (const char *e = getenv("NATAC_BAM_WINDOW")) { const long long v = atoll(e); if (v > 0) hw = (size_t)v; }
+        impl = natac_bamio::decode(path, 0, err, hw);
+    }
+    if (!impl) return fail(NATAC_E_ARG, "%s: %s", path, err.c_str());
+    natac_bam *h = new natac_bam();
+    h->impl = impl;
+    *out = h;
+    return NATAC_OK;
+}
+
+int natac_inflate_raw_host(const void *src, size_t csize, void *out, size_t isize) {
+    if ((!src && csize) || (!out && isize) || csize > 0xffffffffull || isize > 0xffffffffull) return -1;
+    return natac_bamdev::inflate_member((const unsigned char *)src, (unsigned int)csize, (unsigned char *)out, (unsigned int)isize);
 }
 
 void natac_bam_close(natac_bam *bam) {

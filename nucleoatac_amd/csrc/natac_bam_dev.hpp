@@ -1,0 +1,508 @@
+// natac_bam_dev.hpp -- BAM -> fragment arrays on the GPU: BGZF members inflated by the device, records walked by the device.
+//
+// The host extractor (natac_bam.hpp) spends its time in zlib: ~180 MB/s of inflated data per core, 9-18 s for the 100 M
+// records behind configs[2] -- several times the whole `occ` run on the accelerated path.  A BGZF file is a sequence of
+// INDEPENDENT raw-deflate members of <= 64 KiB (SAM spec 4.1), tens of thousands per gigabyte: here one LANE inflates one
+// member (RFC 1951: stored, fixed and dynamic blocks, canonical Huffman decode without tables larger than the code itself), so
+// a window of the file keeps every SIMD of the chip busy with serial decoders.
+//
+// Records chain through their block_size fields and may start anywhere in a member.  Each lane of the walk kernel finds the
+// first record start of ITS member by validation (a chain of plausible records: reference ids, name length and terminator,
+// field sizes against block_size), walks to the end of the member and reports where it stopped.  The host then follows
+// first/exit through the member table from the one start that is known (the end of the header / of the previous window's
+// carry): every link must agree, otherwise the guess was wrong and the file goes to the host decoder.  Agreement makes the
+// result exact by induction, not heuristic: a walk that starts at a true record start only visits true record starts.
+// Kept reads (proper pair, forward strand: pyatac/fragments.pyx:24-38) are written in file order after a scan of the counts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "natac_bam.hpp"
+
+namespace natac_bamdev {
+
+struct Member { unsigned long long coff; unsigned int csize, isize; unsigned long long uoff; };   // payload offset / sizes / output offset
+struct WalkOut { unsigned long long first, exit; unsigned int n_rec, n_kept; };
+
+// ---- raw deflate (RFC 1951), one stream, serial; the same code runs on the host in the CPU test suite ----------------------
+struct BitIn {
+    const unsigned char *p;
+    unsigned int n, pos;
+    unsigned long long buf;
+    int cnt;
+    __host__ __device__ void init(const unsigned char *src, unsigned int len) { p = src; n = len; pos = 0; buf = 0; cnt = 0; }
+    __host__ __device__ void need(int k) {
+        while (cnt < k) {
+            const unsigned int b = pos < n ? p[pos] : 0u;    // reading past the end yields zeros; consumed() exposes it
+            ++pos;
+            buf |= (unsigned long long)b << cnt;
+            cnt += 8;
+        }
+    }
+    __host__ __device__ unsigned int bits(int k) {
+        need(k);
+        const unsigned int v = (unsigned int)(buf & ((1ull << k) - 1ull));
+        buf >>= k;
+        cnt -= k;
+        return v;
+    }
+    __host__ __device__ unsigned int consumed() const { return pos - (unsigned int)(cnt >> 3); }    // whole bytes taken from the input
+};
+
+// canonical Huffman code: count[len] codes of each length, symbols in code order.  Returns the number of unused code points
+// (0: complete, > 0: incomplete, < 0: over-subscribed).
+__host__ __device__ inline int build_code(unsigned short *count, unsigned short *symbol, const unsigned char *length, int n) {
+    for (int l = 0; l <= 15; ++l) count[l] = 0;
+    for (int s = 0; s < n; ++s) ++count[length[s]];
+    if (count[0] == n) return 0;                        // no codes at all: complete by convention, decoding any symbol fails
+    int left = 1;
+    for (int l = 1; l <= 15; ++l) {
+        left <<= 1;
+        left -= count[l];
+        if (left < 0) return left;
+    }
+    unsigned short offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = (unsigned short)(offs[l] + count[l]);
+    for (int s = 0; s < n; ++s)
+        if (length[s] != 0) symbol[offs[length[s]]++] = (unsigned short)s;
+    return left;
+}
+
+// next symbol of a canonical code, bit by bit (codes are sent most significant bit first); -1: no such code
+__host__ __device__ inline int decode_symbol(BitIn &in, const unsigned short *count, const unsigned short *symbol) {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; ++l) {
+        code |= (int)in.bits(1);
+        const int c = count[l];
+        if (code - c < first) return symbol[index + (code - first)];
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+// inflate one member's payload into out[0, isize); 0 ok, otherwise an error code (1 bad block type, 2 stored length, 3 code
+// lengths, 4 bad symbol, 5 distance too far, 6 output overrun / short, 7 input overrun)
+__host__ __device__ inline int inflate_member(const unsigned char *src, unsigned int csize, unsigned char *out, unsigned int isize) {
+    const unsigned short LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    const unsigned char LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    const unsigned short DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+                                      8193, 12289, 16385, 24577};
+    const unsigned char DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    const unsigned char ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    unsigned short lcount[16], lsym[288], dcount[16], dsym[30];
+    unsigned char lengths[320];
+    BitIn in;
+    in.init(src, csize);
+    unsigned int o = 0;
+    for (;;) {
+        const unsigned int last = in.bits(1), type = in.bits(2);
+        if (type == 0) {
+            in.bits(in.cnt & 7);                                  // to the byte boundary
+            const unsigned int len = in.bits(16), nlen = in.bits(16);
+            if ((len ^ 0xffffu) != nlen) return 2;
+            unsigned int q = in.consumed();
+            if (q + len > csize) return 7;
+            if (o + len > isize) return 6;
+            for (unsigned int i = 0; i < len; ++i) out[o + i] = src[q + i];
+            o += len;
+            in.pos = q + len;
+            in.buf = 0;
+            in.cnt = 0;
+        } else if (type == 1 || type == 2) {
+            if (type == 1) {
+                for (int s = 0; s < 144; ++s) lengths[s] = 8;
+                for (int s = 144; s < 256; ++s) lengths[s] = 9;
+                for (int s = 256; s < 280; ++s) lengths[s] = 7;
+                for (int s = 280; s < 288; ++s) lengths[s] = 8;
+                build_code(lcount, lsym, lengths, 288);
+                for (int s = 0; s < 30; ++s) lengths[s] = 5;
+                build_code(dcount, dsym, lengths, 30);
+            } else {
+                const int nlen = (int)in.bits(5) + 257, ndist = (int)in.bits(5) + 1, ncode = (int)in.bits(4) + 4;
+                if (nlen > 286 || ndist > 30) return 3;
+                for (int i = 0; i < 19; ++i) lengths[i] = 0;
+                for (int i = 0; i < ncode; ++i) lengths[ORDER[i]] = (unsigned char)in.bits(3);
+                if (build_code(lcount, lsym, lengths, 19) != 0) return 3;      // the code-length code must be complete
+                int idx = 0;
+                while (idx < nlen + ndist) {
+                    int sym = decode_symbol(in, lcount, lsym);
+                    if (sym < 0) return 4;
+                    if (sym < 16) lengths[idx++] = (unsigned char)sym;
+                    else {
+                        int rep, val = 0;
+                        if (sym == 16) {
+                            if (idx == 0) return 3;
+                            val = lengths[idx - 1];
+                            rep = 3 + (int)in.bits(2);
+                        } else if (sym == 17) rep = 3 + (int)in.bits(3);
+                        else rep = 11 + (int)in.bits(7);
+                        if (idx + rep > nlen + ndist) return 3;
+                        while (rep--) lengths[idx++] = (unsigned char)val;
+                    }
+                }
+                if (lengths[256] == 0) return 3;                  // no end-of-block code
+                unsigned char dl[30];
+                for (int i = 0; i < ndist; ++i) dl[i] = lengths[nlen + i];
+                int left = build_code(lcount, lsym, lengths, nlen);
+                if (left < 0 || (left > 0 && nlen - lcount[0] != 1)) return 3;     // incomplete only with a single code
+                left = build_code(dcount, dsym, dl, ndist);
+                if (left < 0 || (left > 0 && ndist - dcount[0] != 1)) return 3;
+            }
+            for (;;) {
+                int sym = decode_symbol(in, lcount, lsym);
+                if (sym < 0) return 4;
+                if (sym < 256) {
+                    if (o >= isize) return 6;
+                    out[o++] = (unsigned char)sym;
+                } else if (sym == 256) break;
+                else {
+                    sym -= 257;
+                    if (sym >= 29) return 4;
+                    const unsigned int len = LBASE[sym] + in.bits(LEXT[sym]);
+                    const int ds = decode_symbol(in, dcount, dsym);
+                    if (ds < 0 || ds >= 30) return 4;
+                    const unsigned int dist = DBASE[ds] + in.bits(DEXT[ds]);
+                    if (dist > o) return 5;
+                    if (o + len > isize) return 6;
+                    for (unsigned int i = 0; i < len; ++i) out[o + i] = out[o + i - dist];
+                    o += len;
+                }
+                if (in.consumed() > csize) return 7;
+            }
+        } else return 1;
+        if (in.consumed() > csize) return 7;
+        if (last) break;
+    }
+    return o == isize ? 0 : 6;
+}
+
+// ---- kernels -------------------------------------------------------------------------------------------------------------
+// one lane per member; status[0] = first error code (0 = none), status[1] = its member
+__global__ void __launch_bounds__(64) bamdev_inflate(const unsigned char *__restrict__ raw, const Member *__restrict__ mem, int n_members,
+                                                     unsigned char *__restrict__ data, int *__restrict__ status) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= n_members) return;
+    const Member mb = mem[m];
+    if (mb.isize == 0) return;
+    const int rc = inflate_member(raw + mb.coff, mb.csize, data + mb.uoff, mb.isize);
+    if (rc != 0 && atomicCAS(&status[0], 0, rc) == 0) status[1] = m;
+}
+
+__device__ __forceinline__ unsigned int ld32(const unsigned char *p) {
+    return (unsigned int)p[0] | ((unsigned int)p[1] << 8) | ((unsigned int)p[2] << 16) | ((unsigned int)p[3] << 24);
+}
+
+// is [o, ...) a plausible alignment record (SAM spec 4.2)?  n: valid bytes of data.  *next = start of the following record.
+__device__ __forceinline__ bool plausible(const unsigned char *data, unsigned long long o, unsigned long long n, int n_ref, unsigned long long *next) {
+    if (o + 36 > n) return false;
+    const unsigned char *r = data + o;
+    const int bs = (int)ld32(r);
+    if (bs < 32 || bs > (1 << 28)) return false;
+    const int ref = (int)ld32(r + 4), pos = (int)ld32(r + 8);
+    const int lname = r[12];
+    const int ncig = r[16] | (r[17] << 8);
+    const int lseq = (int)ld32(r + 20);
+    const int nref = (int)ld32(r + 24), npos = (int)ld32(r + 28);
+    if (ref < -1 || ref >= n_ref || nref < -1 || nref >= n_ref || pos < -1 || npos < -1 || lname < 1 || lseq < 0) return false;
+    const long long fixed = 32ll + lname + 4ll * ncig + ((long long)lseq + 1) / 2 + lseq;
+    if (fixed > bs) return false;
+    const unsigned long long nul = o + 36 + (unsigned long long)lname - 1;
+    if (nul < n && data[nul] != 0) return false;
+    *next = o + 4 + (unsigned long long)bs;
+    return true;
+}
+
+// pass 0 (write == 0): first record start of every member (member 0: q0, the others by validation), walk to the member's end:
+// counts and the exit offset.  pass 1 (write == 1): the same walk from wo[m].first, kept reads written at kept_base[m] + i.
+// A member the host marked void (first == ~0) owns no record.  The walk stops at the first record that is not complete
+// inside [0, n): that offset is the carry into the next window.
+__global__ void __launch_bounds__(64) bamdev_walk(const unsigned char *__restrict__ data, unsigned long long n, const Member *__restrict__ mem,
+                                                  int n_members, unsigned long long q0, int n_ref, int write, const unsigned long long *__restrict__ kept_base,
+                                                  WalkOut *__restrict__ wo, int *__restrict__ o_ref, int *__restrict__ o_pos, int *__restrict__ o_tlen) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= n_members) return;
+    const Member mb = mem[m];
+    const unsigned long long ustart = mb.uoff, uend = mb.uoff + mb.isize;
+    unsigned long long q;
+    if (write) {
+        q = wo[m].first;
+        if (q == ~0ull) return;
+    } else {
+        WalkOut w;
+        w.first = w.exit = ~0ull;
+        w.n_rec = w.n_kept = 0;
+        if (m == 0) q = q0;
+        else {
+            // the first offset in the member from which CHAIN records validate (or validate up to the end of the data)
+            const int CHAIN = 8;
+            q = ~0ull;
+            for (unsigned long long o = ustart; o < uend && q == ~0ull; ++o) {
+                unsigned long long c = o, nx = 0;
+                int ok = 0;
+                while (ok < CHAIN && plausible(data, c, n, n_ref, &nx)) { c = nx; ++ok; }
+                if (ok == CHAIN || (ok > 0 && c + 36 > n)) q = o;
+            }
+        }
+        w.first = w.exit = q;                                   // no start found: ~0 (the host decides whether that matters)
+        wo[m] = w;
+        if (q == ~0ull) return;
+    }
+    unsigned int n_rec = 0, n_kept = 0;
+    const unsigned long long base = write ? kept_base[m] : 0ull;
+    while (q < uend) {
+        if (q + 4 > n) break;
+        const int bs = (int)ld32(data + q);
+        if (bs < 32) { q = ~0ull - 1; break; }                  // malformed: reported through exit, the host rejects the file
+        if (q + 4 + (unsigned long long)bs > n) break;          // incomplete inside this window: the carry starts here
+        const unsigned char *r = data + q + 4;
+        const int ref = (int)ld32(r);
+        const unsigned int flag = r[14] | ((unsigned int)r[15] << 8);
+        ++n_rec;
+        if (ref >= 0 && ref < n_ref && (flag & 0x2u) && !(flag & 0x10u)) {
+            if (write) {
+                const int tl = (int)ld32(r + 28);
+                o_ref[base + n_kept] = ref;
+                o_pos[base + n_kept] = (int)ld32(r + 4);
+                o_tlen[base + n_kept] = tl < 0 ? -tl : tl;
+            }
+            ++n_kept;
+        }
+        q += 4 + (unsigned long long)bs;
+    }
+    if (!write) {
+        wo[m].exit = q;
+        wo[m].n_rec = n_rec;
+        wo[m].n_kept = n_kept;
+    }
+}
+
+// ---- host driver ---------------------------------------------------------------------------------------------------------
+// The file goes through the device in windows of ~window_bytes of compressed data (pinned staging buffer); what is not a
+// complete record at the end of a window's inflated bytes is carried to the front of the next window's buffer on the device.
+// Returns the same object as natac_bamio::decode.  nullptr + err: the file is damaged (same messages as the host decoder);
+// nullptr + *undecided = true: the record chain could not be confirmed (or the header outgrew a window), the caller uses the
+// host decoder.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // at least n bytes; the first `keep` bytes survive a reallocation
+    hipError_t reserve(size_t n, size_t keep = 0, hipStream_t stream = nullptr) {
+        if (n <= cap) return hipSuccess;
+        const size_t want = n + n / 8 + 4096;
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess) return e;
+        if (p && keep) {
+            e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) { (void)hipFree(q); return e; }
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std::string &err, bool *undecided,
+                                       size_t window_bytes = (size_t)1 << 30) {
+    using natac_bamio::rd16;
+    using natac_bamio::rd32;
+    using natac_bamio::rdi32;
+    *undecided = false;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) { err = std::string("cannot open ") + path; return nullptr; }
+    window_bytes = std::max<size_t>(window_bytes, (size_t)4096);
+    const size_t raw_cap = window_bytes + ((size_t)1 << 16);
+    unsigned char *raw = nullptr;
+    natac_bamio::Bam *bam = new natac_bamio::Bam();
+    DevBuf d_raw, d_mem, d_data[2], d_wo, d_base, d_ref, d_pos, d_tlen, d_status;
+    std::vector<Member> mem;
+    std::vector<WalkOut> wo;
+    std::vector<unsigned long long> base;
+    std::vector<int> h_ref, h_pos, h_tlen;
+    std::vector<unsigned char> head;
+    int cur_buf = 0;
+    auto cleanup = [&]() { if (raw) (void)hipHostFree(raw); std::fclose(f); };
+    auto fail = [&](const std::string &msg) -> natac_bamio::Bam * { err = msg; delete bam; cleanup(); return nullptr; };
+    auto give_up = [&]() -> natac_bamio::Bam * { *undecided = true; delete bam; cleanup(); return nullptr; };
+#define BAMDEV_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+    BAMDEV_HIP(hipHostMalloc((void **)&raw, raw_cap, hipHostMallocDefault));
+    BAMDEV_HIP(d_status.reserve(2 * sizeof(int)));
+    size_t raw_len = 0;
+    unsigned long long pend = 0;       // carried bytes at the front of d_data[cur_buf]
+    bool eof = false, header_done = false, any_block = false;
+    int32_t n_ref = 0;
+    while (!eof || raw_len > 0) {
+        if (!eof) {
+            const size_t want = raw_cap - raw_len;
+            const size_t got = std::fread(raw + raw_len, 1, want, f);
+            raw_len += got;
+            if (got < want) eof = true;
+        }
+        // ---- complete BGZF members of the window (same checks as the host decoder)
+        mem.clear();
+        size_t o = 0;
+        unsigned long long utotal = pend;
+        while (o + 18 <= raw_len) {
+            const unsigned char *h = raw + o;
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail("not a BGZF file (bad block header)");
+            const unsigned xlen = rd16(h + 10);
+            if (o + 12 + xlen > raw_len) break;
+            size_t bsize = 0;
+            for (size_t x = 12; x + 4 <= 12 + (size_t)xlen;) {
+                const unsigned slen = rd16(h + x + 2);
+                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(h + x + 4) + 1;
+                x += 4 + slen;
+            }
+            if (!bsize || bsize < 12 + (size_t)xlen + 8) return fail("truncated BGZF block");
+            if (o + bsize > raw_len) break;
+            const uint32_t isize = rd32(h + bsize - 4);
+            if (isize > 65536) return fail("corrupt BGZF block (ISIZE > 65536)");
+            mem.push_back({(unsigned long long)(o + 12 + xlen), (unsigned int)(bsize - 12 - xlen - 8), isize, utotal});
+            utotal += isize;
+            o += bsize;
+            any_block = true;
+        }
+        if (mem.empty()) {
+            if (eof) {
+                if (raw_len > 0) return fail(any_block ? "trailing bytes after the last BGZF block" : "not a BGZF file (bad block header)");
+                break;
+            }
+            return fail("BGZF block larger than the read window");
+        }
+        const int M = (int)mem.size();
+        const unsigned long long n = utotal;
+        // ---- upload + inflate
+        BAMDEV_HIP(d_raw.reserve(o + 64));
+        BAMDEV_HIP(d_mem.reserve(mem.size() * sizeof(Member)));
+        BAMDEV_HIP(d_data[cur_buf].reserve((size_t)n + 64, (size_t)pend, stream));      // the carry at the front stays
+        BAMDEV_HIP(hipMemcpyAsync(d_raw.p, raw, o, hipMemcpyHostToDevice, stream));
+        BAMDEV_HIP(hipMemcpyAsync(d_mem.p, mem.data(), mem.size() * sizeof(Member), hipMemcpyHostToDevice, stream));
+        BAMDEV_HIP(hipMemsetAsync(d_status.p, 0, 2 * sizeof(int), stream));
+        unsigned char *data = (unsigned char *)d_data[cur_buf].p;
+        hipLaunchKernelGGL(bamdev_inflate, dim3((M + 63) / 64), dim3(64), 0, stream, (const unsigned char *)d_raw.p, (const Member *)d_mem.p, M, data,
+                           (int *)d_status.p);
+        int st[2] = {0, 0};
+        BAMDEV_HIP(hipMemcpyAsync(st, d_status.p, sizeof st, hipMemcpyDeviceToHost, stream));
+        BAMDEV_HIP(hipStreamSynchronize(stream));
+        if (st[0] != 0) return fail("inflate failed (corrupt BGZF block)");
+        std::memmove(raw, raw + o, raw_len - o);
+        raw_len -= o;
+        // ---- header (first window): parsed on the host from the front of the inflated bytes
+        unsigned long long q0 = 0;
+        if (!header_done) {
+            size_t have = (size_t)std::min<unsigned long long>(n, (unsigned long long)8 << 20);
+            bool complete = false;
+            for (;;) {
+                head.resize(have);
+                BAMDEV_HIP(hipMemcpy(head.data(), data, have, hipMemcpyDeviceToHost));
+                const unsigned char *p = head.data();
+                do {
+                    if (have < 12) break;
+                    if (std::memcmp(p, "BAM\1", 4) != 0) return fail("not a BAM file (bad magic)");
+                    size_t hq = 8 + (size_t)(uint32_t)rdi32(p + 4);
+                    if (hq + 4 > have) break;
+                    n_ref = rdi32(p + hq);
+                    hq += 4;
+                    if (n_ref < 0) return fail("truncated reference list");
+                    std::vector<natac_bamio::Ref> refs((size_t)n_ref);
+                    bool ok = true;
+                    for (int32_t r = 0; r < n_ref; ++r) {
+                        if (hq + 4 > have) { ok = false; break; }
+                        const int32_t ln = rdi32(p + hq);
+                        if (ln < 1) return fail("truncated reference list");
+                        if (hq + 8 + (size_t)ln > have) { ok = false; break; }
+                        refs[r].name.assign((const char *)p + hq + 4, (size_t)ln - 1);
+                        refs[r].length = rdi32(p + hq + 4 + ln);
+                        hq += 8 + (size_t)ln;
+                    }
+                    if (!ok) break;
+                    bam->refs.swap(refs);
+                    q0 = hq;
+                    complete = true;
+                } while (false);
+                if (complete || have == n) break;
+                have = (size_t)n;
+            }
+            if (!complete) {
+                if (eof && raw_len == 0) return fail(n < 12 ? "not a BAM file (bad magic)" : "truncated BAM header");
+                return give_up();          // a header larger than a window: the host decoder streams it
+            }
+            header_done = true;
+        }
+        // ---- record walk, pass 0: first / exit / counts per member
+        BAMDEV_HIP(d_wo.reserve(mem.size() * sizeof(WalkOut)));
+        hipLaunchKernelGGL(bamdev_walk, dim3((M + 63) / 64), dim3(64), 0, stream, (const unsigned char *)data, n, (const Member *)d_mem.p, M, q0, (int)n_ref, 0,
+                           (const unsigned long long *)nullptr, (WalkOut *)d_wo.p, (int *)nullptr, (int *)nullptr, (int *)nullptr);
+        wo.resize(mem.size());
+        BAMDEV_HIP(hipMemcpyAsync(wo.data(), d_wo.p, mem.size() * sizeof(WalkOut), hipMemcpyDeviceToHost, stream));
+        BAMDEV_HIP(hipStreamSynchronize(stream));
+        // ---- the chain from the one known start: every member's guess must be where the previous walk stopped
+        base.assign(mem.size(), 0);
+        unsigned long long cur = q0, kept = 0, nrec = 0;
+        bool stop = false;
+        for (int m = 0; m < M; ++m) {
+            const unsigned long long uend = mem[m].uoff + mem[m].isize;
+            if (stop || cur >= uend) { wo[m].first = ~0ull; continue; }                // owns no record
+            if (cur + 36 > n && wo[m].first != cur) { wo[m].first = ~0ull; stop = true; continue; }   // an incomplete record header: the carry
+            if (wo[m].first != cur) return give_up();
+            if (wo[m].exit == ~0ull - 1) return fail("truncated alignment record");
+            base[m] = kept;
+            kept += wo[m].n_kept;
+            nrec += wo[m].n_rec;
+            cur = wo[m].exit;
+        }
+        bam->n_records += (int64_t)nrec;
+        // ---- pass 1: the kept reads in file order
+        if (kept) {
+            BAMDEV_HIP(d_base.reserve(mem.size() * sizeof(unsigned long long)));
+            BAMDEV_HIP(d_ref.reserve(kept * sizeof(int)));
+            BAMDEV_HIP(d_pos.reserve(kept * sizeof(int)));
+            BAMDEV_HIP(d_tlen.reserve(kept * sizeof(int)));
+            BAMDEV_HIP(hipMemcpyAsync(d_wo.p, wo.data(), mem.size() * sizeof(WalkOut), hipMemcpyHostToDevice, stream));
+            BAMDEV_HIP(hipMemcpyAsync(d_base.p, base.data(), mem.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(bamdev_walk, dim3((M + 63) / 64), dim3(64), 0, stream, (const unsigned char *)data, n, (const Member *)d_mem.p, M, q0, (int)n_ref, 1,
+                               (const unsigned long long *)d_base.p, (WalkOut *)d_wo.p, (int *)d_ref.p, (int *)d_pos.p, (int *)d_tlen.p);
+            h_ref.resize(kept); h_pos.resize(kept); h_tlen.resize(kept);
+            BAMDEV_HIP(hipMemcpyAsync(h_ref.data(), d_ref.p, kept * sizeof(int), hipMemcpyDeviceToHost, stream));
+            BAMDEV_HIP(hipMemcpyAsync(h_pos.data(), d_pos.p, kept * sizeof(int), hipMemcpyDeviceToHost, stream));
+            BAMDEV_HIP(hipMemcpyAsync(h_tlen.data(), d_tlen.p, kept * sizeof(int), hipMemcpyDeviceToHost, stream));
+            BAMDEV_HIP(hipStreamSynchronize(stream));
+            for (size_t a = 0; a < kept;) {                   // runs of one reference (a sorted file has one per reference)
+                size_t b = a + 1;
+                while (b < kept && h_ref[b] == h_ref[a]) ++b;
+                natac_bamio::Ref &r = bam->refs[(size_t)h_ref[a]];
+                const size_t at = r.pos.size();
+                r.pos.resize(at + (b - a));
+                r.tlen.resize(at + (b - a));
+                for (size_t i = a; i < b; ++i) { r.pos[at + i - a] = h_pos[i]; r.tlen[at + i - a] = h_tlen[i]; }
+                a = b;
+            }
+            bam->n_kept += (int64_t)kept;
+        }
+        // ---- carry the incomplete tail to the front of the other buffer
+        pend = n - cur;
+        BAMDEV_HIP(d_data[cur_buf ^ 1].reserve((size_t)pend + 64));
+        if (pend) BAMDEV_HIP(hipMemcpyAsync(d_data[cur_buf ^ 1].p, data + cur, (size_t)pend, hipMemcpyDeviceToDevice, stream));
+        BAMDEV_HIP(hipStreamSynchronize(stream));
+        cur_buf ^= 1;
+        if (eof && raw_len == 0) break;
+    }
+#undef BAMDEV_HIP
+    cleanup();
+    if (!header_done) { err = any_block ? "truncated BAM header" : "not a BGZF file (bad block header)"; delete bam; return nullptr; }
+    if (pend != 0) { err = "truncated alignment record"; delete bam; return nullptr; }
+    return bam;
+}
+
+}  // namespace natac_bamdev

@@ -7,6 +7,7 @@ fragments.pyx:25); the extractor functions keep the reference's names and argume
 FragmentStore or a path (.bam / .npz) -- and run on the GPU through the C-ABI.
 """
 import gzip
+import os
 import struct
 
 import numpy as np
@@ -71,13 +72,26 @@ class FragmentStore(object):
         np.savez_compressed(path, **arrs)
 
     @staticmethod
-    def from_bam(path, n_threads=0):
-        """native decoder (natac_bam_open: parallel BGZF inflate + record walk in libnatac_hip.so)"""
+    def from_bam(path, n_threads=0, device=None):
+        """native decoder in libnatac_hip.so.  On a GPU box the BGZF members are inflated and the records walked on the device
+        (natac_bam_open_device, csrc/natac_bam_dev.hpp: zlib on the host cores is ~10x slower than the rest of an `occ` run);
+        without a GPU -- or with device=False / NATAC_DEVICE_BAM=0 -- natac_bam_open: parallel inflate + record walk on the
+        host.  Both give the same arrays."""
         import ctypes as C
         from .. import _lib as L
         lib = L.load()
         h = C.c_void_p()
-        L.check(lib.natac_bam_open(str(path).encode(), int(n_threads), C.byref(h)))
+        if device is None:
+            from ..device import Context
+            device = os.environ.get("NATAC_DEVICE_BAM", "1") != "0" and Context.device_count() > 0
+        if device:
+            from .. import get_context
+            on_dev = C.c_int(0)
+            L.check(lib.natac_bam_open_device(get_context()._h, str(path).encode(), C.byref(h), C.byref(on_dev)))
+            FragmentStore.last_bam_on_device = bool(on_dev.value)
+        else:
+            L.check(lib.natac_bam_open(str(path).encode(), int(n_threads), C.byref(h)))
+            FragmentStore.last_bam_on_device = False
         try:
             nref = C.c_int32(0)
             L.check(lib.natac_bam_counts(h, C.byref(nref), None, None))

@@ -113,3 +113,44 @@ def test_corrupt_isize_is_rejected_before_allocation(tmp_path):
     with pytest.raises(Exception) as e:
         FragmentStore.from_bam(bad)
     assert "corrupt BGZF block" in str(e.value)
+
+
+def test_device_inflate_algorithm_on_the_host():
+    """natac_bam_dev.hpp's raw-deflate decoder is __host__ __device__: here it runs on the CPU against zlib on stored, fixed and
+    dynamic blocks, several blocks per member, empty and maximal members; damaged input gives an error code, never a crash"""
+    import ctypes as C
+    import zlib
+    from nucleoatac_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(0)
+
+    def inflate(comp, n):
+        out = C.create_string_buffer(max(1, n))
+        return lib.natac_inflate_raw_host(comp, len(comp), out, n), out.raw[:n]
+
+    cases = []
+    for n in (0, 1, 2, 100, 3000, 65280, 65536):
+        cases += [bytes(rng.integers(0, 256, n, dtype=np.uint8)), bytes(rng.integers(0, 4, n, dtype=np.uint8)),
+                  (b"chr1\t12345\t12346\t0.123456789012\n" * (n // 30 + 1))[:n], bytes(n)]
+    for d in cases:
+        for lvl in (0, 1, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strat)
+                comp = co.compress(d) + co.flush()
+                rc, got = inflate(comp, len(d))
+                assert rc == 0 and got == d, (len(d), lvl, strat, rc)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts, data = [], b""
+    for i in range(20):
+        d = bytes(rng.integers(0, 1 + i * 12, 3000, dtype=np.uint8))
+        data += d
+        parts += [co.compress(d), co.flush(zlib.Z_FULL_FLUSH if i % 2 else zlib.Z_SYNC_FLUSH)]
+    comp = b"".join(parts) + co.flush()
+    assert inflate(comp, len(data)) == (0, data)
+    assert inflate(comp[:len(comp) // 2], len(data))[0] != 0          # truncated input
+    assert inflate(comp, len(data) - 5)[0] != 0                        # ISIZE too small
+    assert inflate(comp, len(data) + 5)[0] != 0                        # ISIZE too large
+    for k in range(0, len(comp), 97):                                  # flipped bytes: an error or other bytes, no crash
+        g = bytearray(comp)
+        g[k] ^= 0xff
+        inflate(bytes(g), len(data))
