@@ -10,8 +10,9 @@
 // first record start of ITS member by validation (a chain of plausible records: reference ids, name length and terminator,
 // field sizes against block_size), walks to the end of the member and reports where it stopped.  The host then follows
 // first/exit through the member table from the one start that is known (the end of the header / of the previous window's
-// carry): every link must agree, otherwise the guess was wrong and the file goes to the host decoder.  Agreement makes the
-// result exact by induction, not heuristic: a walk that starts at a true record start only visits true record starts.
+// carry): where a member's guess is not where the chain arrives, that member is walked again from the chain's offset (a
+// single-lane launch; more than a few thousand of those per window send the file to the host decoder).  The result is exact
+// by induction, not heuristic: a walk that starts at a true record start only visits true record starts.
 // Kept reads (proper pair, forward strand: pyatac/fragments.pyx:24-38) are written in file order after a scan of the counts.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -222,12 +223,19 @@ __device__ __forceinline__ bool plausible(const unsigned char *data, unsigned lo
 
 // pass 0 (write == 0): first record start of every member (member 0: q0, the others by validation), walk to the member's end:
 // counts and the exit offset.  pass 1 (write == 1): the same walk from wo[m].first, kept reads written at kept_base[m] + i.
+// write == 2: pass 0 for the single member `only` from the given start q0 (the host found the guess of that member wrong).
 // A member the host marked void (first == ~0) owns no record.  The walk stops at the first record that is not complete
 // inside [0, n): that offset is the carry into the next window.
 __global__ void __launch_bounds__(64) bamdev_walk(const unsigned char *__restrict__ data, unsigned long long n, const Member *__restrict__ mem,
-                                                  int n_members, unsigned long long q0, int n_ref, int write, const unsigned long long *__restrict__ kept_base,
-                                                  WalkOut *__restrict__ wo, int *__restrict__ o_ref, int *__restrict__ o_pos, int *__restrict__ o_tlen) {
-    const int m = blockIdx.x * 64 + threadIdx.x;
+                                                  int n_members, unsigned long long q0, int n_ref, int write, int only,
+                                                  const unsigned long long *__restrict__ kept_base, WalkOut *__restrict__ wo, int *__restrict__ o_ref,
+                                                  int *__restrict__ o_pos, int *__restrict__ o_tlen) {
+    int m = blockIdx.x * 64 + threadIdx.x;
+    if (write == 2) {
+        if (m != 0) return;
+        m = only;
+        write = 0;
+    } else only = 0;
     if (m >= n_members) return;
     const Member mb = mem[m];
     const unsigned long long ustart = mb.uoff, uend = mb.uoff + mb.isize;
@@ -239,16 +247,18 @@ __global__ void __launch_bounds__(64) bamdev_walk(const unsigned char *__restric
         WalkOut w;
         w.first = w.exit = ~0ull;
         w.n_rec = w.n_kept = 0;
-        if (m == 0) q = q0;
+        if (m == only) q = q0;
         else {
-            // the first offset in the member from which CHAIN records validate (or validate up to the end of the data)
+            // the first offset in the member from which CHAIN records validate, or validate exactly up to the end of the data.
+            // (A chain that jumps past the end after fewer records is what a misaligned block_size looks like; the rare true
+            // start of that kind -- the window's last, incomplete record -- is settled by the host with a write == 2 launch.)
             const int CHAIN = 8;
             q = ~0ull;
             for (unsigned long long o = ustart; o < uend && q == ~0ull; ++o) {
                 unsigned long long c = o, nx = 0;
                 int ok = 0;
                 while (ok < CHAIN && plausible(data, c, n, n_ref, &nx)) { c = nx; ++ok; }
-                if (ok == CHAIN || (ok > 0 && c + 36 > n)) q = o;
+                if (ok == CHAIN || (ok > 0 && c <= n && c + 36 > n)) q = o;
             }
         }
         w.first = w.exit = q;                                   // no start found: ~0 (the host decides whether that matters)
@@ -442,7 +452,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
         }
         // ---- record walk, pass 0: first / exit / counts per member
         BAMDEV_HIP(d_wo.reserve(mem.size() * sizeof(WalkOut)));
-        hipLaunchKernelGGL(bamdev_walk, dim3((M + 63) / 64), dim3(64), 0, stream, (const unsigned char *)data, n, (const Member *)d_mem.p, M, q0, (int)n_ref, 0,
+        hipLaunchKernelGGL(bamdev_walk, dim3((M + 63) / 64), dim3(64), 0, stream, (const unsigned char *)data, n, (const Member *)d_mem.p, M, q0, (int)n_ref, 0, 0,
                            (const unsigned long long *)nullptr, (WalkOut *)d_wo.p, (int *)nullptr, (int *)nullptr, (int *)nullptr);
         wo.resize(mem.size());
         BAMDEV_HIP(hipMemcpyAsync(wo.data(), d_wo.p, mem.size() * sizeof(WalkOut), hipMemcpyDeviceToHost, stream));
@@ -451,11 +461,22 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
         base.assign(mem.size(), 0);
         unsigned long long cur = q0, kept = 0, nrec = 0;
         bool stop = false;
+        int fixups = 0;
+        const int MAX_FIXUPS = 4096;       // per window; beyond that the guesses are systematically off: host decoder
         for (int m = 0; m < M; ++m) {
             const unsigned long long uend = mem[m].uoff + mem[m].isize;
             if (stop || cur >= uend) { wo[m].first = ~0ull; continue; }                // owns no record
             if (cur + 36 > n && wo[m].first != cur) { wo[m].first = ~0ull; stop = true; continue; }   // an incomplete record header: the carry
-            if (wo[m].first != cur) return give_up();
+            if (wo[m].first != cur) {
+                // the guess of this member is not where the chain arrives (a chance pattern before it, or the window's last,
+                // incomplete record): `cur` IS a record start, so the member is walked again from there
+                if (++fixups > MAX_FIXUPS) return give_up();
+                hipLaunchKernelGGL(bamdev_walk, dim3(1), dim3(64), 0, stream, (const unsigned char *)data, n, (const Member *)d_mem.p, M, cur, (int)n_ref, 2, m,
+                                   (const unsigned long long *)nullptr, (WalkOut *)d_wo.p, (int *)nullptr, (int *)nullptr, (int *)nullptr);
+                BAMDEV_HIP(hipMemcpyAsync(&wo[m], (const WalkOut *)d_wo.p + m, sizeof(WalkOut), hipMemcpyDeviceToHost, stream));
+                BAMDEV_HIP(hipStreamSynchronize(stream));
+                if (wo[m].first != cur) return give_up();
+            }
             if (wo[m].exit == ~0ull - 1) return fail("truncated alignment record");
             base[m] = kept;
             kept += wo[m].n_kept;
@@ -471,7 +492,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
             BAMDEV_HIP(d_tlen.reserve(kept * sizeof(int)));
             BAMDEV_HIP(hipMemcpyAsync(d_wo.p, wo.data(), mem.size() * sizeof(WalkOut), hipMemcpyHostToDevice, stream));
             BAMDEV_HIP(hipMemcpyAsync(d_base.p, base.data(), mem.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(bamdev_walk, dim3((M + 63) / 64), dim3(64), 0, stream, (const unsigned char *)data, n, (const Member *)d_mem.p, M, q0, (int)n_ref, 1,
+            hipLaunchKernelGGL(bamdev_walk, dim3((M + 63) / 64), dim3(64), 0, stream, (const unsigned char *)data, n, (const Member *)d_mem.p, M, q0, (int)n_ref, 1, 0,
                                (const unsigned long long *)d_base.p, (WalkOut *)d_wo.p, (int *)d_ref.p, (int *)d_pos.p, (int *)d_tlen.p);
             h_ref.resize(kept); h_pos.resize(kept); h_tlen.resize(kept);
             BAMDEV_HIP(hipMemcpyAsync(h_ref.data(), d_ref.p, kept * sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -38,7 +38,7 @@ def synth_bam(path, n, n_refs=4, ref_len=50_000_000, seed=0):
     a["nref"] = a["ref"]
     tl = rng.integers(40, 600, n)
     a["tlen"] = np.where(fwd, tl, -tl)
-    a["npos"] = a["pos"] + np.where(fwd, tl - seq_len, -(tl - seq_len))
+    a["npos"] = np.maximum(a["pos"] + np.where(fwd, tl - seq_len, -(tl - seq_len)), 0)
     a["name"] = np.char.add(b"read", np.arange(n).astype("S15"))
     a["cigar"] = seq_len << 4
     a["seq"] = rng.integers(0, 256, (n, (seq_len + 1) // 2), dtype=np.uint8)
