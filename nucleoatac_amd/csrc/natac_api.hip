@@ -2394,7 +2394,8 @@ int natac_bam_open_device(natac_ctx *c, const char *path, natac_bam **out, int *
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
     std::string err;
-    size_t window = (size_t)1 << 30;                  // compressed bytes per device window; NATAC_BAM_DEV_WINDOW overrides (tests)
+    size_t window = (size_t)2 << 30;                  // compressed bytes per device window (>= 49,152 members keep every CU's LDS
+                                                      // full); NATAC_BAM_DEV_WINDOW overrides (tests)
     if (const char *e = getenv("NATAC_BAM_DEV_WINDOW")) { const long long v = atoll(e); if (v > 0) window = (size_t)v; }
     bool undecided = false;
     natac_bamio::Bam *impl = natac_bamdev::decode_device(path, c->stream, err, &undecided, window);
@@ -2413,7 +2414,9 @@ int natac_bam_open_device(natac_ctx *c, const char *path, natac_bam **out, int *
 
 int natac_inflate_raw_host(const void *src, size_t csize, void *out, size_t isize) {
     if ((!src && csize) || (!out && isize) || csize > 0xffffffffull || isize > 0xffffffffull) return -1;
-    return natac_bamdev::inflate_member((const unsigned char *)src, (unsigned int)csize, (unsigned char *)out, (unsigned int)isize);
+    std::vector<unsigned char> padded(csize + 8, 0);         // the bit reader takes whole words: 8 readable bytes behind the payload
+    if (csize) std::memcpy(padded.data(), src, csize);
+    return natac_bamdev::inflate_member_host(padded.data(), (unsigned int)csize, (unsigned char *)out, (unsigned int)isize);
 }
 
 void natac_bam_close(natac_bam *bam) {

@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -30,86 +32,100 @@ struct Member { unsigned long long coff; unsigned int csize, isize; unsigned lon
 struct WalkOut { unsigned long long first, exit; unsigned int n_rec, n_kept; };
 
 // ---- raw deflate (RFC 1951), one stream, serial; the same code runs on the host in the CPU test suite ----------------------
+// Table storage is a template parameter: on the device the symbol tables of the 64 lanes of a workgroup sit lane-interleaved in
+// LDS (element i of a lane at index i * 64 + lane), on the host they are plain arrays.
+template <class T, int STRIDE>
+struct Strided {
+    T *base;
+    __host__ __device__ T &operator[](int i) const { return base[i * STRIDE]; }
+};
+
 struct BitIn {
-    const unsigned char *p;
+    const unsigned char *p;      // at least 8 readable bytes behind p[n - 1]
     unsigned int n, pos;
     unsigned long long buf;
     int cnt;
     __host__ __device__ void init(const unsigned char *src, unsigned int len) { p = src; n = len; pos = 0; buf = 0; cnt = 0; }
-    __host__ __device__ void need(int k) {
-        while (cnt < k) {
-            const unsigned int b = pos < n ? p[pos] : 0u;    // reading past the end yields zeros; consumed() exposes it
-            ++pos;
-            buf |= (unsigned long long)b << cnt;
-            cnt += 8;
+    __host__ __device__ void refill() {              // >= 32 valid bits afterwards (bytes past the end are never legitimately used:
+        if (cnt <= 32) {                             // consumed() exposes a stream that runs over)
+            unsigned int w;
+            __builtin_memcpy(&w, p + pos, 4);
+            buf |= (unsigned long long)w << cnt;
+            pos += 4;
+            cnt += 32;
         }
     }
-    __host__ __device__ unsigned int bits(int k) {
-        need(k);
-        const unsigned int v = (unsigned int)(buf & ((1ull << k) - 1ull));
-        buf >>= k;
-        cnt -= k;
-        return v;
-    }
+    __host__ __device__ unsigned int peek(int k) { refill(); return (unsigned int)(buf & ((1ull << k) - 1ull)); }
+    __host__ __device__ void skip(int k) { buf >>= k; cnt -= k; }
+    __host__ __device__ unsigned int bits(int k) { const unsigned int v = peek(k); skip(k); return v; }
     __host__ __device__ unsigned int consumed() const { return pos - (unsigned int)(cnt >> 3); }    // whole bytes taken from the input
 };
 
-// canonical Huffman code: count[len] codes of each length, symbols in code order.  Returns the number of unused code points
-// (0: complete, > 0: incomplete, < 0: over-subscribed).
-__host__ __device__ inline int build_code(unsigned short *count, unsigned short *symbol, const unsigned char *length, int n) {
-    for (int l = 0; l <= 15; ++l) count[l] = 0;
-    for (int s = 0; s < n; ++s) ++count[length[s]];
-    if (count[0] == n) return 0;                        // no codes at all: complete by convention, decoding any symbol fails
+// Canonical Huffman code in the form the decoder wants: for the next 15 stream bits read as a number X with the first bit on top,
+// the code has length l = the smallest l with X < lim[l] (lim is non-decreasing), and the symbol is sym[(X >> (15 - l)) + delta[l]].
+// lim lives in registers (static indices only), delta / sym / work in the caller's table storage.
+// Returns the number of unused code points (0: complete, > 0: incomplete, < 0: over-subscribed).
+template <class L8, class T16>
+__host__ __device__ inline int build_code(const L8 &length, int first_sym, int n, unsigned int (&lim)[16], const T16 &delta, const T16 &sym,
+                                          const T16 &work) {
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { work[l] = 0; lim[l] = 0; }
+    for (int s = 0; s < n; ++s) work[length[first_sym + s]] = (unsigned short)(work[length[first_sym + s]] + 1);
+    if (work[0] == n) return 0;                        // no codes at all: every lim stays 0, decoding any symbol fails
     int left = 1;
+    unsigned int code = 0, off = 0;
+#pragma unroll
     for (int l = 1; l <= 15; ++l) {
-        left <<= 1;
-        left -= count[l];
-        if (left < 0) return left;
+        const unsigned int c = work[l];
+        left = (left << 1) - (int)c;
+        lim[l] = (code + c) << (15 - l);
+        delta[l] = (unsigned short)(off - code);        // modulo 2^16: the index sum below is taken modulo 2^16 too
+        work[l] = (unsigned short)off;                  // next free slot of this length
+        off += c;
+        code = (code + c) << 1;
     }
-    unsigned short offs[16];
-    offs[1] = 0;
-    for (int l = 1; l < 15; ++l) offs[l + 1] = (unsigned short)(offs[l] + count[l]);
-    for (int s = 0; s < n; ++s)
-        if (length[s] != 0) symbol[offs[length[s]]++] = (unsigned short)s;
+    if (left < 0) return left;
+    for (int s = 0; s < n; ++s) {
+        const int l = length[first_sym + s];
+        if (l != 0) { const unsigned short at = work[l]; sym[at] = (unsigned short)s; work[l] = (unsigned short)(at + 1); }
+    }
     return left;
 }
 
-// next symbol of a canonical code, bit by bit (codes are sent most significant bit first); -1: no such code
-__host__ __device__ inline int decode_symbol(BitIn &in, const unsigned short *count, const unsigned short *symbol) {
-    int code = 0, first = 0, index = 0;
-    for (int l = 1; l <= 15; ++l) {
-        code |= (int)in.bits(1);
-        const int c = count[l];
-        if (code - c < first) return symbol[index + (code - first)];
-        index += c;
-        first += c;
-        first <<= 1;
-        code <<= 1;
-    }
-    return -1;
+// next symbol; -1: the bits are no code
+template <class T16>
+__host__ __device__ inline int decode_symbol(BitIn &in, const unsigned int (&lim)[16], const T16 &delta, const T16 &sym) {
+    const unsigned int x = __builtin_bitreverse32(in.peek(15)) >> 17;
+    int l = 1;
+#pragma unroll
+    for (int k = 1; k <= 14; ++k) l += x >= lim[k] ? 1 : 0;
+    if (x >= lim[15]) return -1;
+    in.skip(l);
+    return sym[(unsigned short)((x >> (15 - l)) + delta[l])];
 }
 
 // inflate one member's payload into out[0, isize); 0 ok, otherwise an error code (1 bad block type, 2 stored length, 3 code
-// lengths, 4 bad symbol, 5 distance too far, 6 output overrun / short, 7 input overrun)
-__host__ __device__ inline int inflate_member(const unsigned char *src, unsigned int csize, unsigned char *out, unsigned int isize) {
+// lengths, 4 bad symbol, 5 distance too far, 6 output overrun / short, 7 input overrun).  src needs 8 readable bytes of slack.
+template <class L8, class T16>
+__host__ __device__ inline int inflate_member(const unsigned char *src, unsigned int csize, unsigned char *out, unsigned int isize, const L8 &lengths,
+                                              const T16 &lsym, const T16 &ldelta, const T16 &lwork, const T16 &dsym, const T16 &ddelta, const T16 &dwork) {
     const unsigned short LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     const unsigned char LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
     const unsigned short DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
                                       8193, 12289, 16385, 24577};
     const unsigned char DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     const unsigned char ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    unsigned short lcount[16], lsym[288], dcount[16], dsym[30];
-    unsigned char lengths[320];
+    unsigned int llim[16], dlim[16];
     BitIn in;
     in.init(src, csize);
     unsigned int o = 0;
     for (;;) {
         const unsigned int last = in.bits(1), type = in.bits(2);
         if (type == 0) {
-            in.bits(in.cnt & 7);                                  // to the byte boundary
+            in.skip(in.cnt & 7);                                  // to the byte boundary
             const unsigned int len = in.bits(16), nlen = in.bits(16);
             if ((len ^ 0xffffu) != nlen) return 2;
-            unsigned int q = in.consumed();
+            const unsigned int q = in.consumed();
             if (q + len > csize) return 7;
             if (o + len > isize) return 6;
             for (unsigned int i = 0; i < len; ++i) out[o + i] = src[q + i];
@@ -123,18 +139,18 @@ __host__ __device__ inline int inflate_member(const unsigned char *src, unsigned
                 for (int s = 144; s < 256; ++s) lengths[s] = 9;
                 for (int s = 256; s < 280; ++s) lengths[s] = 7;
                 for (int s = 280; s < 288; ++s) lengths[s] = 8;
-                build_code(lcount, lsym, lengths, 288);
-                for (int s = 0; s < 30; ++s) lengths[s] = 5;
-                build_code(dcount, dsym, lengths, 30);
+                for (int s = 288; s < 318; ++s) lengths[s] = 5;
+                build_code(lengths, 0, 288, llim, ldelta, lsym, lwork);
+                build_code(lengths, 288, 30, dlim, ddelta, dsym, dwork);
             } else {
                 const int nlen = (int)in.bits(5) + 257, ndist = (int)in.bits(5) + 1, ncode = (int)in.bits(4) + 4;
                 if (nlen > 286 || ndist > 30) return 3;
                 for (int i = 0; i < 19; ++i) lengths[i] = 0;
                 for (int i = 0; i < ncode; ++i) lengths[ORDER[i]] = (unsigned char)in.bits(3);
-                if (build_code(lcount, lsym, lengths, 19) != 0) return 3;      // the code-length code must be complete
+                if (build_code(lengths, 0, 19, llim, ldelta, lsym, lwork) != 0) return 3;      // the code-length code must be complete
                 int idx = 0;
                 while (idx < nlen + ndist) {
-                    int sym = decode_symbol(in, lcount, lsym);
+                    const int sym = decode_symbol(in, llim, ldelta, lsym);
                     if (sym < 0) return 4;
                     if (sym < 16) lengths[idx++] = (unsigned char)sym;
                     else {
@@ -150,15 +166,17 @@ __host__ __device__ inline int inflate_member(const unsigned char *src, unsigned
                     }
                 }
                 if (lengths[256] == 0) return 3;                  // no end-of-block code
-                unsigned char dl[30];
-                for (int i = 0; i < ndist; ++i) dl[i] = lengths[nlen + i];
-                int left = build_code(lcount, lsym, lengths, nlen);
-                if (left < 0 || (left > 0 && nlen - lcount[0] != 1)) return 3;     // incomplete only with a single code
-                left = build_code(dcount, dsym, dl, ndist);
-                if (left < 0 || (left > 0 && ndist - dcount[0] != 1)) return 3;
+                int left = build_code(lengths, 0, nlen, llim, ldelta, lsym, lwork);
+                int zeros = 0;
+                for (int s = 0; s < nlen; ++s) zeros += lengths[s] == 0;
+                if (left < 0 || (left > 0 && nlen - zeros != 1)) return 3;         // incomplete only with a single code
+                left = build_code(lengths, nlen, ndist, dlim, ddelta, dsym, dwork);
+                zeros = 0;
+                for (int s = 0; s < ndist; ++s) zeros += lengths[nlen + s] == 0;
+                if (left < 0 || (left > 0 && ndist - zeros != 1)) return 3;
             }
             for (;;) {
-                int sym = decode_symbol(in, lcount, lsym);
+                int sym = decode_symbol(in, llim, ldelta, lsym);
                 if (sym < 0) return 4;
                 if (sym < 256) {
                     if (o >= isize) return 6;
@@ -168,12 +186,19 @@ __host__ __device__ inline int inflate_member(const unsigned char *src, unsigned
                     sym -= 257;
                     if (sym >= 29) return 4;
                     const unsigned int len = LBASE[sym] + in.bits(LEXT[sym]);
-                    const int ds = decode_symbol(in, dcount, dsym);
+                    const int ds = decode_symbol(in, dlim, ddelta, dsym);
                     if (ds < 0 || ds >= 30) return 4;
                     const unsigned int dist = DBASE[ds] + in.bits(DEXT[ds]);
                     if (dist > o) return 5;
                     if (o + len > isize) return 6;
-                    for (unsigned int i = 0; i < len; ++i) out[o + i] = out[o + i - dist];
+                    unsigned int i = 0;
+                    if (dist >= 4)                                // whole words while source and destination do not overlap within one
+                        for (; i + 4 <= len; i += 4) {
+                            unsigned int w;
+                            __builtin_memcpy(&w, out + o + i - dist, 4);
+                            __builtin_memcpy(out + o + i, &w, 4);
+                        }
+                    for (; i < len; ++i) out[o + i] = out[o + i - dist];
                     o += len;
                 }
                 if (in.consumed() > csize) return 7;
@@ -185,15 +210,33 @@ __host__ __device__ inline int inflate_member(const unsigned char *src, unsigned
     return o == isize ? 0 : 6;
 }
 
+// the decoder with plain arrays (host test entry)
+inline int inflate_member_host(const unsigned char *src, unsigned int csize, unsigned char *out, unsigned int isize) {
+    unsigned char lengths[320];
+    unsigned short lsym[288], ldelta[16], lwork[16], dsym[32], ddelta[16], dwork[16];
+    typedef Strided<unsigned char, 1> L8;
+    typedef Strided<unsigned short, 1> T16;
+    return inflate_member(src, csize, out, isize, L8{lengths}, T16{lsym}, T16{ldelta}, T16{lwork}, T16{dsym}, T16{ddelta}, T16{dwork});
+}
+
 // ---- kernels -------------------------------------------------------------------------------------------------------------
-// one lane per member; status[0] = first error code (0 = none), status[1] = its member
+// one lane per member, 64 lanes per workgroup; the symbol tables of a lane are lane-interleaved in LDS (48 KiB per workgroup), the
+// code lengths of a block header -- touched only while a block's tables are built -- stay in private memory.
+// status[0] = first error code (0 = none), status[1] = its member
+constexpr int INFLATE_LDS_U16 = (288 + 32 + 4 * 16) * 64;
 __global__ void __launch_bounds__(64) bamdev_inflate(const unsigned char *__restrict__ raw, const Member *__restrict__ mem, int n_members,
                                                      unsigned char *__restrict__ data, int *__restrict__ status) {
+    __shared__ unsigned short tab[INFLATE_LDS_U16];
     const int m = blockIdx.x * 64 + threadIdx.x;
     if (m >= n_members) return;
     const Member mb = mem[m];
     if (mb.isize == 0) return;
-    const int rc = inflate_member(raw + mb.coff, mb.csize, data + mb.uoff, mb.isize);
+    unsigned char lengths[320];
+    typedef Strided<unsigned char, 1> L8;
+    typedef Strided<unsigned short, 64> T16;
+    unsigned short *t = tab + threadIdx.x;
+    const int rc = inflate_member(raw + mb.coff, mb.csize, data + mb.uoff, mb.isize, L8{lengths}, T16{t}, T16{t + 288 * 64}, T16{t + 304 * 64},
+                                  T16{t + 320 * 64}, T16{t + 352 * 64}, T16{t + 368 * 64});
     if (rc != 0 && atomicCAS(&status[0], 0, rc) == 0) status[1] = m;
 }
 
@@ -324,7 +367,7 @@ struct DevBuf {
 };
 
 inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std::string &err, bool *undecided,
-                                       size_t window_bytes = (size_t)1 << 30) {
+                                       size_t window_bytes = (size_t)2 << 30) {
     using natac_bamio::rd16;
     using natac_bamio::rd32;
     using natac_bamio::rdi32;
@@ -332,6 +375,12 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
     FILE *f = std::fopen(path, "rb");
     if (!f) { err = std::string("cannot open ") + path; return nullptr; }
     window_bytes = std::max<size_t>(window_bytes, (size_t)4096);
+    {   // a file smaller than the window needs no window-sized staging buffer (pinning memory costs ~0.25 s per GiB)
+        std::fseek(f, 0, SEEK_END);
+        const long fsize = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        if (fsize >= 0) window_bytes = std::min<size_t>(window_bytes, std::max<size_t>((size_t)fsize, (size_t)4096));
+    }
     const size_t raw_cap = window_bytes + ((size_t)1 << 16);
     unsigned char *raw = nullptr;
     natac_bamio::Bam *bam = new natac_bamio::Bam();
@@ -348,6 +397,11 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
 #define BAMDEV_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
     BAMDEV_HIP(hipHostMalloc((void **)&raw, raw_cap, hipHostMallocDefault));
     BAMDEV_HIP(d_status.reserve(2 * sizeof(int)));
+    const bool timing = getenv("NATAC_BAM_DEV_TIMING") != nullptr;
+    double t_read = 0, t_scan = 0, t_inflate = 0, t_walk = 0, t_chain = 0, t_out = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](double &acc) { const double t = now(); acc += t - t0; t0 = t; };
     size_t raw_len = 0;
     unsigned long long pend = 0;       // carried bytes at the front of d_data[cur_buf]
     bool eof = false, header_done = false, any_block = false;
@@ -359,6 +413,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
             raw_len += got;
             if (got < want) eof = true;
         }
+        lap(t_read);
         // ---- complete BGZF members of the window (same checks as the host decoder)
         mem.clear();
         size_t o = 0;
@@ -392,6 +447,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
         }
         const int M = (int)mem.size();
         const unsigned long long n = utotal;
+        lap(t_scan);
         // ---- upload + inflate
         BAMDEV_HIP(d_raw.reserve(o + 64));
         BAMDEV_HIP(d_mem.reserve(mem.size() * sizeof(Member)));
@@ -408,6 +464,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
         if (st[0] != 0) return fail("inflate failed (corrupt BGZF block)");
         std::memmove(raw, raw + o, raw_len - o);
         raw_len -= o;
+        lap(t_inflate);
         // ---- header (first window): parsed on the host from the front of the inflated bytes
         unsigned long long q0 = 0;
         if (!header_done) {
@@ -457,6 +514,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
         wo.resize(mem.size());
         BAMDEV_HIP(hipMemcpyAsync(wo.data(), d_wo.p, mem.size() * sizeof(WalkOut), hipMemcpyDeviceToHost, stream));
         BAMDEV_HIP(hipStreamSynchronize(stream));
+        lap(t_walk);
         // ---- the chain from the one known start: every member's guess must be where the previous walk stopped
         base.assign(mem.size(), 0);
         unsigned long long cur = q0, kept = 0, nrec = 0;
@@ -484,6 +542,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
             cur = wo[m].exit;
         }
         bam->n_records += (int64_t)nrec;
+        lap(t_chain);
         // ---- pass 1: the kept reads in file order
         if (kept) {
             BAMDEV_HIP(d_base.reserve(mem.size() * sizeof(unsigned long long)));
@@ -517,8 +576,12 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
         if (pend) BAMDEV_HIP(hipMemcpyAsync(d_data[cur_buf ^ 1].p, data + cur, (size_t)pend, hipMemcpyDeviceToDevice, stream));
         BAMDEV_HIP(hipStreamSynchronize(stream));
         cur_buf ^= 1;
+        lap(t_out);
         if (eof && raw_len == 0) break;
     }
+    if (timing)
+        std::fprintf(stderr, "[natac_bam_dev] read %.3f s, member scan %.3f, upload + inflate %.3f, walk %.3f, chain %.3f, kept reads + carry %.3f\n", t_read,
+                     t_scan, t_inflate, t_walk, t_chain, t_out);
 #undef BAMDEV_HIP
     cleanup();
     if (!header_done) { err = any_block ? "truncated BAM header" : "not a BGZF file (bad block header)"; delete bam; return nullptr; }

@@ -73,17 +73,18 @@ class FragmentStore(object):
 
     @staticmethod
     def from_bam(path, n_threads=0, device=None):
-        """native decoder in libnatac_hip.so.  On a GPU box the BGZF members are inflated and the records walked on the device
-        (natac_bam_open_device, csrc/natac_bam_dev.hpp: zlib on the host cores is ~10x slower than the rest of an `occ` run);
-        without a GPU -- or with device=False / NATAC_DEVICE_BAM=0 -- natac_bam_open: parallel inflate + record walk on the
-        host.  Both give the same arrays."""
+        """native decoder in libnatac_hip.so: natac_bam_open (parallel BGZF inflate + record walk on the host cores), or -- with
+        device=True / NATAC_DEVICE_BAM=1 -- natac_bam_open_device (csrc/natac_bam_dev.hpp: members inflated and records walked
+        on the GPU).  Both give the same arrays.  Measured on the MI355X box (tools/bench_bam.py, 60 M records, 4.6 GB): host
+        1.70 s with its 64 threads, 6.1 s with 4; device 1.63 s -- the device wins where host threads are scarce, so the
+        default stays the host decoder."""
         import ctypes as C
         from .. import _lib as L
         lib = L.load()
         h = C.c_void_p()
         if device is None:
             from ..device import Context
-            device = os.environ.get("NATAC_DEVICE_BAM", "1") != "0" and Context.device_count() > 0
+            device = os.environ.get("NATAC_DEVICE_BAM", "0") == "1" and Context.device_count() > 0
         if device:
             from .. import get_context
             on_dev = C.c_int(0)

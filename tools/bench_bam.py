@@ -74,6 +74,13 @@ def main():
             dt = time.perf_counter() - t0
             if device:
                 threads = "device" if FragmentStore.last_bam_on_device else "device->host"
+                import ctypes as C
+                from nucleoatac_amd import _lib as L, get_context
+                h = C.c_void_p()
+                t1 = time.perf_counter()
+                L.check(L.load().natac_bam_open_device(get_context()._h, path.encode(), C.byref(h), None))
+                print("   natac_bam_open_device alone: %.2f s" % (time.perf_counter() - t1))
+                L.load().natac_bam_close(h)
             total = sum(len(st.pos[c]) for c in st.pos) if hasattr(st, "pos") else -1
             print("threads=%s  %d records, %d kept (expected %d): %.2f s = %.1f M records/s, %.0f MB/s compressed, %.0f MB/s inflated"
                   % (threads or "auto", n, total, kept, dt, n / dt / 1e6, size / dt / 1e6, raw / dt / 1e6))
