@@ -149,11 +149,10 @@ def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
         t.read_track(path)
         return t.vals
 
-    def column(path, value_col=4):   # per chunk values of one file: one native call for the batch, else chunk by chunk
+    def column(path, value_col=4):   # (flat values, offsets) of one file: one native call for the batch, else chunk by chunk
         got = read_regions_of(path, chunks, value_col)
         if got is not None:
-            flat, off = got
-            return [flat[int(off[k]):int(off[k + 1])] for k in range(n)]
+            return got
         if value_col == 2:           # record starts (the dyads) through the line reader
             def starts_of(ch):
                 rd = _tabix(path)
@@ -164,34 +163,54 @@ def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
                         if ch.start <= p < ch.end:
                             out[p - ch.start] = p
                 return out
-            return map_in_slices(starts_of, chunks)
-        return map_in_slices(lambda ch: track(path, ch), chunks)
+            parts = map_in_slices(starts_of, chunks)
+        else:
+            parts = map_in_slices(lambda ch: track(path, ch), chunks)
+        return (np.concatenate(parts) if parts else np.zeros(0)), np.concatenate(([0], np.cumsum([len(p) for p in parts]))).astype(np.int64)
 
-    occs, ups = column(params.occ_track), column(upper)
-    dyads = column(params.calls, 2)      # the calls file is tabix-indexed, like the reference requires
-    inss = column(params.ins_track) if params.ins_track is not None else [None] * n
-    reads = [(occs[k], ups[k], np.flatnonzero(~np.isnan(dyads[k])) + chunks[k].start, inss[k]) for k in range(n)]
-    kc, lefts, rights, vals = [], [], [], []
-    for k, (occ, up, nucs, ins) in enumerate(reads):
-        s = int(starts[k])
-        if ins is None:
-            if ins_flat is not None:
-                ins = ins_flat[int(ins_off[k]):int(ins_off[k + 1])]
-            else:
-                t = InsertionTrack(chunks[k].chrom, s, int(ends[k]))
-                t.calculateInsertions(params.bam)
-                ins = t.vals
-        b = None if bias is None else bias[int(boff[k]):int(boff[k + 1])]
-        for a, c in zip(nucs[:-1], nucs[1:]):
-            left, right = int(a) + DYAD_LEFT, int(c) - DYAD_RIGHT
-            if right > left:
-                o = float(np.mean(occ[left - s:right - s]))
-                mu = float(np.min(up[left - s:right - s]))
-                if mu < params.max_occ_upper and o < params.max_occ:
-                    kc.append(k)
-                    lefts.append(left)
-                    rights.append(right)
-                    vals.append((o, mu, float(np.mean(ins[left - s:right - s])),
-                                 float(np.mean(np.exp(b[left - s:right - s]))) if b is not None else float("nan")))
-    return (np.array(kc, dtype=np.int64), np.array(lefts, dtype=np.int64), np.array(rights, dtype=np.int64),
-            np.array(vals, dtype=np.float64).reshape(-1, 4))
+    (occ, off), (up, _), (dy, _) = column(params.occ_track), column(upper), column(params.calls, 2)   # calls: tabix-indexed like in the reference
+    if params.ins_track is not None:
+        ins, ioff = column(params.ins_track)
+    elif ins_flat is not None:
+        ins, ioff = ins_flat, np.asarray(ins_off, dtype=np.int64)
+    else:
+        parts = []
+        for ch in chunks:
+            t = InsertionTrack(ch.chrom, ch.start, ch.end)
+            t.calculateInsertions(params.bam)
+            parts.append(t.vals)
+        ins, ioff = np.concatenate(parts) if parts else np.zeros(0), off
+    # gaps between consecutive dyads of a chunk (NFRCalling.py:96-104), all chunks at once: the dyads are the non-NaN entries of `dy`
+    at = np.flatnonzero(~np.isnan(dy))                       # flat indices of the dyads, ascending = chunk / position order
+    ck = np.searchsorted(off, at, "right") - 1               # their chunks
+    same = ck[1:] == ck[:-1]
+    gk = ck[:-1][same]
+    rel_l = (at[:-1] - off[ck[:-1]])[same] + DYAD_LEFT       # chunk-relative [left, right)
+    rel_r = (at[1:] - off[ck[1:]])[same] - DYAD_RIGHT
+    wide = rel_r > rel_l
+    gk, rel_l, rel_r = gk[wide], rel_l[wide], rel_r[wide]
+    glen = rel_r - rel_l
+
+    def per_gap(flat, base, sel, fn):
+        """fn over flat[base[g] + rel_l[g] : base[g] + rel_r[g]] for the gaps in `sel`: gaps of equal length are gathered into one
+        2-D array and reduced along its rows -- the same pairwise sums / exact minima as numpy's 1-D reductions on each slice"""
+        out = np.empty(len(sel))
+        order = sel[np.argsort(glen[sel], kind="stable")]
+        cuts = np.concatenate(([0], np.flatnonzero(np.diff(glen[order])) + 1, [len(order)]))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            g = order[a:b]
+            rows = flat[(base[gk[g]] + rel_l[g])[:, None] + np.arange(glen[g[0]])]
+            out[np.searchsorted(sel, g)] = fn(rows)
+        return out
+
+    everything = np.arange(len(gk))
+    o = per_gap(occ, off, everything, lambda r: r.mean(axis=1))
+    mu = per_gap(up, off, everything, lambda r: r.min(axis=1))
+    with np.errstate(invalid="ignore"):
+        ok = np.flatnonzero((mu < params.max_occ_upper) & (o < params.max_occ))   # NaN statistics fail both comparisons
+    vals = np.empty((len(ok), 4))
+    vals[:, 0], vals[:, 1] = o[ok], mu[ok]
+    vals[:, 2] = per_gap(ins, ioff, ok, lambda r: r.mean(axis=1))
+    vals[:, 3] = per_gap(bias, boff, ok, lambda r: np.exp(r).mean(axis=1)) if bias is not None else np.nan
+    kc, lefts, rights = gk[ok], rel_l[ok] + starts[gk[ok]], rel_r[ok] + starts[gk[ok]]
+    return kc.astype(np.int64), lefts.astype(np.int64), rights.astype(np.int64), vals

@@ -59,8 +59,7 @@ def problem(vals, allnucs, index, nonredundant_sep, smooth_sd):
 
 class _State(object):
     """workspace of one L-BFGS-B run (the arrays _minimize_lbfgsb allocates)"""
-    __slots__ = ("x", "f", "g", "lb", "ub", "nbd", "wa", "iwa", "task", "ln_task", "lsave", "isave", "dsave", "nit", "nfev",
-                 "last_x")
+    __slots__ = ("x", "f", "g", "lb", "ub", "nbd", "wa", "iwa", "task", "ln_task", "lsave", "isave", "dsave", "nit", "nreq", "redo")
 
     def __init__(self, guess, lb, ub):
         n, m = len(guess), M_CORR
@@ -77,8 +76,8 @@ class _State(object):
         self.isave = np.zeros(44, dtype=np.int32)
         self.dsave = np.zeros(29, dtype=np.float64)
         self.nit = 0
-        self.nfev = 1                                    # ScalarFunction evaluates the start point when it is built
-        self.last_x = self.x.copy()
+        self.nreq = 0            # f, g requests so far: an upper bound of scipy's nfev (ScalarFunction does not count a repeated point)
+        self.redo = False        # the evaluation / iteration limits came into reach: this fit is repeated through scipy.optimize.minimize
 
 
 def _advance(st, setulb, factr):
@@ -88,16 +87,13 @@ def _advance(st, setulb, factr):
                st.dsave, MAXLS, st.ln_task)
         t = st.task[0]
         if t == 3:
-            if not np.array_equal(st.x, st.last_x):      # ScalarFunction counts an evaluation per new point
-                st.nfev += 1
-                st.last_x[:] = st.x
+            st.nreq += 1
             return True
         if t == 1:
             st.nit += 1
-            if st.nit >= MAXITER:
-                st.task[0], st.task[1] = 5, 504
-            elif st.nfev > MAXFUN:
-                st.task[0], st.task[1] = 5, 502
+            if st.nit >= MAXITER or st.nreq > MAXFUN:    # scipy would stop here or soon (its nfev <= nreq): let scipy decide
+                st.redo = True
+                return False
         else:
             return False
 
@@ -185,7 +181,26 @@ def _run_group(probs, setulb):
             if _advance(st, setulb, factr):
                 nxt.append(k)
         active = nxt
-    return np.array([st.x for st in states])
+    x = np.array([st.x for st in states])
+    for k, st in enumerate(states):
+        if st.redo:
+            x[k] = _public_fit(probs[k])
+    return x
+
+
+def _public_fit(prob):
+    """one fit through scipy.optimize.minimize with the batched finite differences of fit_fuzz_one (same values)"""
+    from scipy import optimize
+    sig, lb, ub, guess, _left = prob
+    vals = np.array(sig, dtype=np.float64)
+    xs = np.linspace(0, len(vals) - 1, len(vals))
+
+    def fun_and_grad(pars):
+        f, g = _evaluate(np.asarray(pars, dtype=np.float64)[None, :], lb[None, :], ub[None, :], vals[None, :], xs[None, :],
+                         np.array([len(vals)]), (np.empty(12 * len(vals)), np.empty(10 * len(vals))))
+        return f[0], g[0]
+    res = optimize.minimize(fun_and_grad, guess, jac=True, bounds=list(zip(lb, ub)), method="L-BFGS-B")
+    return res["x"]
 
 
 def fit_many(probs):

@@ -220,6 +220,12 @@ def test_lockstep_fits_take_the_optimisers_own_steps():
         assert [len(m) for m in many] == [len(tk[1]) for tk in tasks]
         assert np.array_equal(np.array([r for c in one for r in c], dtype=np.float64),
                               np.array([r for c in many for r in c], dtype=np.float64))
+    old, fuzzfit.MAXFUN = fuzzfit.MAXFUN, 25           # fits that come near scipy's evaluation limit are handed to scipy itself
+    try:
+        few = N.fit_fuzz_chunks(tasks[:6])
+    finally:
+        fuzzfit.MAXFUN = old
+    assert np.array_equal(np.array([r for c in one[:6] for r in c], dtype=np.float64), np.array([r for c in few for r in c], dtype=np.float64))
     flat = (np.zeros(300), np.array([150]), 120, 10)   # an all-zero window has no valid weight bound: both paths refuse it
     for lock in (False, True):
         N.LOCKSTEP = lock
