@@ -52,6 +52,9 @@ def run_nfr(args):
         raise Exception("Must supply either bam file or insertion track")
     if not args.out:
         args.out = ".".join(os.path.basename(args.calls).split(".")[0:-3])
+    if env_rank_world()[0] == 0 and isinstance(args.bam, str):
+        from ..pyatac.fragments import FragmentStore
+        FragmentStore.prefetch(args.bam)       # rank 0 decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
     if args.fasta is not None:
         chrs_fasta = read_chrom_sizes_from_fasta(args.fasta)
         pwm = PWM.open(args.pwm)

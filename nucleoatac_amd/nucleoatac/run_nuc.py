@@ -114,6 +114,9 @@ def batch_calls(r, params, pool=None, pool_workers=1):
 
 def run_nuc(args):
     ph = _Phases(LAST_TIMINGS)
+    if env_rank_world()[0] == 0 and isinstance(args.bam, str):
+        from ..pyatac.fragments import FragmentStore
+        FragmentStore.prefetch(args.bam)       # rank 0 decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
     vmat = VMat.open(args.vmat)
     chrs = read_chrom_sizes_from_fasta(args.fasta) if args.fasta else read_chrom_sizes_from_bam(args.bam)
     pwm = PWM.open(args.pwm)

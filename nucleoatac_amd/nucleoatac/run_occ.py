@@ -169,6 +169,9 @@ def finish_indexes(writer, names, base_of):
 
 def run_occ(args):
     ph = _Phases(LAST_TIMINGS)
+    if env_rank_world()[0] == 0 and isinstance(args.bam, str):
+        from ..pyatac.fragments import FragmentStore
+        FragmentStore.prefetch(args.bam)       # rank 0 decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
     chrs = read_chrom_sizes_from_fasta(args.fasta) if args.fasta else read_chrom_sizes_from_bam(args.bam)
     pwm = PWM.open(args.pwm)
     chunks = ChunkList.read(args.bed, chromDict=chrs,

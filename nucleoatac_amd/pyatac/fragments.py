@@ -13,6 +13,7 @@ import struct
 import numpy as np
 
 _CACHE = {}
+_PENDING = {}     # src -> (thread, result box) of FragmentStore.prefetch
 
 
 class FragmentStore(object):
@@ -38,18 +39,46 @@ class FragmentStore(object):
         return dict(zip(self.references, self.lengths))
 
     @staticmethod
+    def prefetch(src):
+        """start decoding `src` on a thread (the drivers call this first thing: the BAM decode -- native code, GIL released --
+        runs while the main thread reads the FASTA index and the BED file); FragmentStore.open(src) waits for it"""
+        if isinstance(src, FragmentStore) or src in _CACHE or src in _PENDING:
+            return
+        import threading
+        box = {}
+
+        def work():
+            try:
+                box["store"] = FragmentStore._load(src)
+            except BaseException as e:      # noqa: BLE001 -- re-raised by open() on the caller's thread
+                box["error"] = e
+        t = threading.Thread(target=work, name="natac-bam-prefetch", daemon=True)
+        _PENDING[src] = (t, box)
+        t.start()
+
+    @staticmethod
     def open(src):
         if isinstance(src, FragmentStore):
             return src
+        if src in _PENDING:
+            t, box = _PENDING.pop(src)
+            t.join()
+            if "error" in box:
+                raise box["error"]
+            _CACHE[src] = box["store"]
         if src in _CACHE:
             return _CACHE[src]
+        _CACHE[src] = st = FragmentStore._load(src)
+        return st
+
+    @staticmethod
+    def _load(src):
         if src.endswith(".npz"):
             st = FragmentStore.from_npz(src)
         elif src.endswith(".bam"):
             st = FragmentStore.from_bam(src)
         else:
             raise ValueError("unsupported alignment source %r (expected FragmentStore, .bam or .npz)" % (src,))
-        _CACHE[src] = st
         return st
 
     @staticmethod
