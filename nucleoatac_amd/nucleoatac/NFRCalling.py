@@ -195,6 +195,8 @@ def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
         """fn over flat[base[g] + rel_l[g] : base[g] + rel_r[g]] for the gaps in `sel`: gaps of equal length are gathered into one
         2-D array and reduced along its rows -- the same pairwise sums / exact minima as numpy's 1-D reductions on each slice"""
         out = np.empty(len(sel))
+        if len(sel) == 0:
+            return out
         order = sel[np.argsort(glen[sel], kind="stable")]
         cuts = np.concatenate(([0], np.flatnonzero(np.diff(glen[order])) + 1, [len(order)]))
         for a, b in zip(cuts[:-1], cuts[1:]):
