@@ -30,8 +30,7 @@ NATAC_HD inline void len_symbol(int L, int *sym, int *ebits, int *eval) {      /
     if (L == 258) { *sym = 285; *ebits = 0; *eval = 0; return; }
     const int x = L - 3;
     if (x < 8) { *sym = 257 + x; *ebits = 0; *eval = 0; return; }
-    int eb = 1;
-    while ((x >> (eb + 2)) > 1) ++eb;                  // x in [4 << eb, 8 << eb)
+    const int eb = 29 - __builtin_clz((unsigned)x);   // x in [4 << eb, 8 << eb), eb >= 1
     // groups of four codes per extra-bit count eb >= 1: codes 265 + 4 (eb - 1) + ((x >> eb) & 3)
     *sym = 265 + 4 * (eb - 1) + ((x >> eb) & 3);
     *ebits = eb;
@@ -40,8 +39,7 @@ NATAC_HD inline void len_symbol(int L, int *sym, int *ebits, int *eval) {      /
 NATAC_HD inline void dist_symbol(int d, int *sym, int *ebits, int *eval) {     // d in [1, 32768]
     const int x = d - 1;
     if (x < 4) { *sym = x; *ebits = 0; *eval = 0; return; }
-    int eb = 1;
-    while ((x >> (eb + 1)) > 1) ++eb;                  // x in [2 << eb, 4 << eb)
+    const int eb = 30 - __builtin_clz((unsigned)x);   // x in [2 << eb, 4 << eb), eb >= 1
     *sym = 2 + 2 * eb + ((x >> eb) & 1);
     *ebits = eb;
     *eval = x & ((1 << eb) - 1);
@@ -117,15 +115,30 @@ template <class Sink, class ByteAt>
 NATAC_HD inline void greedy_tokens(unsigned long long eq0, unsigned long long eq1, unsigned long long eq2, const Cands &c, int seglen,
                                    ByteAt byte_at, Sink &sink) {
     const int n = seglen < WIN ? seglen : WIN;
+    // positions where some candidate matches MIN_MATCH (= 3) bytes or more: everywhere else the greedy parse emits a literal, so the
+    // loop visits matches only and hands the literal runs between them to the sink byte by byte (a line is ~2 matches and ~17
+    // literals: with one test of all three masks per byte the lanes of a wave paid the match path on every step)
+    unsigned long long starts = (eq0 & (eq0 >> 1) & (eq0 >> 2)) | (eq1 & (eq1 >> 1) & (eq1 >> 2)) | (eq2 & (eq2 >> 1) & (eq2 >> 2));
     int q = 0;
     while (q < n) {
-        int best = trailing_ones(eq0 >> q), bd = c.d0;
-        const int L1 = trailing_ones(eq1 >> q), L2 = trailing_ones(eq2 >> q);
-        if (L1 > best) { best = L1; bd = c.d1; }
-        if (L2 > best) { best = L2; bd = c.d2; }
-        if (best > n - q) best = n - q;
-        if (best >= MIN_MATCH) { sink.match(best, bd); q += best; }
-        else { sink.literal(byte_at(q)); ++q; }
+        const unsigned long long rest = starts >> q;
+        if (rest & 1ull) {
+            int best = trailing_ones(eq0 >> q), bd = c.d0;
+            const int L1 = trailing_ones(eq1 >> q), L2 = trailing_ones(eq2 >> q);
+            if (L1 > best) { best = L1; bd = c.d1; }
+            if (L2 > best) { best = L2; bd = c.d2; }
+            if (best > n - q) best = n - q;
+            if (best >= MIN_MATCH) { sink.match(best, bd); q += best; }
+            else { sink.literal(byte_at(q)); ++q; }
+        } else {
+            int run = n - q;
+            if (rest) {
+                const int z = trailing_ones(~rest);
+                if (z < run) run = z;
+            }
+            for (int i = 0; i < run; ++i) sink.literal(byte_at(q + i));
+            q += run;
+        }
     }
     for (; q < seglen; ++q) sink.literal(byte_at(q));
 }
@@ -229,8 +242,15 @@ NATAC_HD inline uint32_t crc_bytes(const uint32_t *table, const unsigned char *p
     return c ^ 0xffffffffu;
 }
 
+// CRC of a member from the CRCs of its 64-byte slices without a combination tree: crc(A || B) = shift(crc(A), |B|) ^ crc(B) and the
+// shift (a multiplication by x^(8 |B|) mod p) is linear, so crc = XOR_i shift(crc_i, bytes after slice i).  All full slices are
+// followed by 64 k + (length of the last slice) bytes: one multiplication by slice64[k] per slice, an XOR reduction, one more
+// multiplication by bytes[last length] for everything -- instead of ten levels of two multiplications each.
 struct CrcTables {
     uint32_t table[256], x2n[32];
+    uint32_t slice64[1024];        // x^(8 * 64 * k) mod p
+    uint32_t bytes[65];            // x^(8 * r) mod p, r = 0..64
+    uint32_t pad[3];
 };
 inline void crc_init(CrcTables &t) {
     for (uint32_t i = 0; i < 256; ++i) {
@@ -241,6 +261,10 @@ inline void crc_init(CrcTables &t) {
     uint32_t p = 1u << 30;            // x^1
     t.x2n[0] = p;
     for (int n = 1; n < 32; ++n) t.x2n[n] = p = crc_multmodp(p, p);
+    for (int r = 0; r <= 64; ++r) t.bytes[r] = crc_x2nmodp(t.x2n, r, 3);
+    t.slice64[0] = 1u << 31;          // x^0
+    for (int k = 1; k < 1024; ++k) t.slice64[k] = crc_multmodp(t.slice64[k - 1], t.bytes[64]);
+    t.pad[0] = t.pad[1] = t.pad[2] = 0;
 }
 
 }  // namespace natac_deflate

@@ -546,16 +546,14 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
     unsigned char *lds_text = smem;
     nd::Codes *codes = (nd::Codes *)(smem + 65536);
     __shared__ unsigned long long wbits[TZ_WAVES];
-    __shared__ unsigned int crc_v[TZ_THREADS];
-    __shared__ int crc_n[TZ_THREADS];
-    __shared__ unsigned int crc_tab[256 + 32];
+    __shared__ unsigned int crc_w[TZ_WAVES];
+    __shared__ unsigned int crc_tab[256];
     const MemberGeom g = member_geom(line_off, nlines, n_text, blockIdx.x);
     {
         const unsigned int *src = (const unsigned int *)codes_g;
         unsigned int *dst = (unsigned int *)codes;
         for (int i = threadIdx.x; i < (int)(sizeof(nd::Codes) / 4); i += TZ_THREADS) dst[i] = src[i];
-        const unsigned int *ct = (const unsigned int *)crc_g;
-        for (int i = threadIdx.x; i < 256 + 32; i += TZ_THREADS) crc_tab[i] = ct[i];
+        for (int i = threadIdx.x; i < 256; i += TZ_THREADS) crc_tab[i] = crc_g->table[i];
     }
     load_member_text(lds_text, text, g);
     __syncthreads();
@@ -586,28 +584,30 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
         }
     }
     if (lane == 0) wbits[wave] = wave_bits;
-    // CRC-32 of my 64-byte slice of the member
+    // CRC-32: my 64-byte slice, shifted to the start of the last slice (natac_deflate.hpp: CrcTables), XOR-reduced over the workgroup
+    const int n_slices = (n + 63) >> 6;
     {
-        const int c0 = threadIdx.x * 64 < n ? threadIdx.x * 64 : n;
-        const int c1 = c0 + 64 < n ? c0 + 64 : n;
-        crc_v[threadIdx.x] = nd::crc_bytes(crc_tab, lds_text + c0, c1 - c0);
-        crc_n[threadIdx.x] = c1 - c0;
+        unsigned int v = 0;
+        if ((int)threadIdx.x < n_slices - 1) {
+            const unsigned int c = nd::crc_bytes(crc_tab, lds_text + threadIdx.x * 64, 64);
+            v = nd::crc_multmodp(crc_g->slice64[n_slices - 2 - (int)threadIdx.x], c);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v ^= __shfl_xor(v, off);
+        if (lane == 0) crc_w[wave] = v;
     }
     __syncthreads();
     unsigned long long my_start = 0, total_tok_bits = 0;
+    unsigned int crc = 0;
     for (int w = 0; w < TZ_WAVES; ++w) {
         if (w < wave) my_start += wbits[w];
         total_tok_bits += wbits[w];
+        crc ^= crc_w[w];
     }
-    for (int step = 1; step < TZ_THREADS; step <<= 1) {
-        if ((threadIdx.x & (2 * step - 1)) == 0) {
-            const int o = threadIdx.x + step;
-            crc_v[threadIdx.x] = nd::crc_combine(crc_tab + 256, crc_v[threadIdx.x], crc_v[o], crc_n[o]);
-            crc_n[threadIdx.x] += crc_n[o];
-        }
-        __syncthreads();
+    if (threadIdx.x == 0 && n_slices > 0) {     // (only thread 0 writes the trailer) the last slice follows everything reduced so far
+        const int c0 = (n_slices - 1) * 64;
+        crc = nd::crc_multmodp(crc_g->bytes[n - c0], crc) ^ nd::crc_bytes(crc_tab, lds_text + c0, n - c0);
     }
-    const unsigned int crc = crc_v[0];
     unsigned char *region = out_regions + (size_t)blockIdx.x * nd::REGION;
     unsigned int *words = (unsigned int *)region;
     const int eob_len = codes->ll_len[256];
