@@ -654,8 +654,9 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         for (int i = threadIdx.x; i < n; i += TZ_THREADS) region[25 + i] = lds_text[i];
     }
-    __threadfence();
-    __syncthreads();
+    // No fence here: every word two writers share (the ends of a line's bits, the end-of-block code, the trailer) is written with
+    // atomicOr, which commutes; the plain stores go to words / bytes with one owner.  (An agent-scope __threadfence() writes the XCD's
+    // L2 back on this part: it cost 8 of the kernel's 20 ms.)
     if (threadIdx.x == 0) {
         const long long total = 18 + payload + 8;
         for (int i = 0; i < 16; ++i) region[2 + i] = nd::bgzf_hdr_byte(i);
