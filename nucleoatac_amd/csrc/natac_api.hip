@@ -422,7 +422,9 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_len8, (size_t)nruns)); tmp.keep(d_len8);
     TRYF(dev_alloc(&d_isl, (size_t)nruns)); tmp.keep(d_isl);
     const unsigned rb = (unsigned)((nruns + 255) / 256);
-    hipLaunchKernelGGL(tz_line_len, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_isl, d_hard);
+    unsigned long long *d_vtxt = nullptr;             // text of every run's value (tz_line_len -> tz_write_lines)
+    TRYF(dev_alloc(&d_vtxt, (size_t)nruns * (natac_textz::VTXT / 8))); tmp.keep(d_vtxt);
+    hipLaunchKernelGGL(tz_line_len, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_isl, d_hard, d_vtxt);
     TRYF(dev_alloc(&d_boff, (size_t)nruns + 1)); tmp.keep(d_boff);
     TRYF(dev_alloc(&d_lidx, (size_t)nruns + 1)); tmp.keep(d_lidx);
     TRYF(dev_scan(c, d_len8, (long long)nruns, d_boff));
@@ -447,7 +449,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
         TRYF(dev_alloc(&d_lbeg, (size_t)nlines)); tmp.keep(d_lbeg);
         TRYF(dev_alloc(&d_lend, (size_t)nlines)); tmp.keep(d_lend);
     }
-    hipLaunchKernelGGL(tz_write_lines, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_boff, d_lidx, d_text,
+    hipLaunchKernelGGL(tz_write_lines, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_boff, d_lidx, d_vtxt, d_text,
                        d_line_off, d_lcid, d_lbeg, d_lend);
     if (!compress) {
         hipError_t e = hipStreamSynchronize(c->stream);

@@ -49,22 +49,33 @@ NATAC_HD inline int clz64(uint64_t x) {
 #endif
 }
 
-NATAC_HD inline char *put_u64(char *p, uint64_t v) {
-    char tmp[20];
+// decimal digits of v (1 for 0); genome coordinates fit 32 bits: that path has no 64-bit division
+NATAC_HD inline int digits_u64(uint64_t v) {
+    if (v < 4294967296ull) {
+        const uint32_t u = (uint32_t)v;
+        return u < 10u ? 1 : u < 100u ? 2 : u < 1000u ? 3 : u < 10000u ? 4 : u < 100000u ? 5 : u < 1000000u ? 6 : u < 10000000u ? 7
+               : u < 100000000u ? 8 : u < 1000000000u ? 9 : 10;
+    }
     int n = 0;
-    do { tmp[n++] = (char)('0' + (v % 10)); v /= 10; } while (v);
-    while (n) *p++ = tmp[--n];
-    return p;
+    do { ++n; v /= 10; } while (v);
+    return n;
+}
+NATAC_HD inline char *put_u64(char *p, uint64_t v) {
+    const int n = digits_u64(v);
+    if (v < 4294967296ull) {
+        uint32_t u = (uint32_t)v;
+        for (int i = n - 1; i >= 0; --i) { const uint32_t q = u / 10u; p[i] = (char)('0' + (u - q * 10u)); u = q; }
+    } else {
+        for (int i = n - 1; i >= 0; --i) { const uint64_t q = v / 10; p[i] = (char)('0' + (v - q * 10)); v = q; }
+    }
+    return p + n;
 }
 NATAC_HD inline char *put_i64(char *p, long long v) {
     if (v < 0) { *p++ = '-'; return put_u64(p, (uint64_t)(-(v + 1)) + 1); }
     return put_u64(p, (uint64_t)v);
 }
 NATAC_HD inline int digits_i64(long long v) {
-    int n = v < 0 ? 1 : 0;
-    uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v;
-    do { ++n; u /= 10; } while (u);
-    return n;
+    return v < 0 ? 1 + digits_u64((uint64_t)(-(v + 1)) + 1) : digits_u64((uint64_t)v);
 }
 
 // python-2 str(float) of a non-NaN double: '%.12g' + ".0" for integral text.  Returns the end pointer; *hard is incremented

@@ -169,58 +169,90 @@ __device__ __forceinline__ RunInfo run_info(const TextJob &job, long long k, lon
     r.emitted = !(r.v != r.v) && (r.v != 0.0 || job.write_zero) && (job.keep_before_nan || !nan_follows);
     return r;
 }
-__device__ __forceinline__ char *format_line(char *p, const TextJob &job, const RunInfo &r, int *hard) {
-    const int cid = job.chrom_id[r.chunk];
-    const int n0 = job.name_off[cid], n1 = job.name_off[cid + 1];
-    for (int i = n0; i < n1; ++i) *p++ = job.names[i];
-    *p++ = '\t';
-    const long long s = job.chunk_start[r.chunk];
-    p = natac_text::put_i64(p, s + r.a_rel);
-    *p++ = '\t';
-    p = natac_text::put_i64(p, s + r.b_rel);
-    *p++ = '\t';
-    p = natac_text::fmt_py2_float(p, r.v, job.p10, hard);
-    *p++ = '\n';
-    return p;
-}
 constexpr int MAX_LINE = 160;      // name (<= 64) + 2 coordinates (<= 20 each) + value (<= 24) + 4 separators
+constexpr int VTXT = 24;           // bytes kept per run for the text of its value ("-1.23456789012e-308" is 19)
 
+// The value's text is the expensive part of a line (exact '%.12g': ~2,000 instructions): tz_line_len forms it once and leaves it in
+// vtxt[VTXT / 8 * k ...] for tz_write_lines, which only adds the name and the two coordinates.
 __global__ void __launch_bounds__(256) tz_line_len(TextJob job, long long nruns, const unsigned int *__restrict__ R, const int *__restrict__ C,
-                                                    unsigned char *__restrict__ len8, unsigned char *__restrict__ is_line, int *__restrict__ hard_total) {
+                                                    unsigned char *__restrict__ len8, unsigned char *__restrict__ is_line, int *__restrict__ hard_total,
+                                                    unsigned long long *__restrict__ vtxt) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= nruns) return;
     const RunInfo r = run_info(job, k, nruns, R, C);
     int n = 0, hard = 0;
     if (r.emitted) {
-        char buf[MAX_LINE];
-        n = (int)(format_line(buf, job, r, &hard) - buf);
+        union { char c[VTXT]; unsigned long long w[VTXT / 8]; } v;
+#pragma unroll
+        for (int i = 0; i < VTXT / 8; ++i) v.w[i] = 0;
+        const int nv = (int)(natac_text::fmt_py2_float(v.c, r.v, job.p10, &hard) - v.c);
+#pragma unroll
+        for (int i = 0; i < VTXT / 8; ++i) vtxt[(VTXT / 8) * k + i] = v.w[i];
+        const int cid = job.chrom_id[r.chunk];
+        const long long s = job.chunk_start[r.chunk];
+        n = (job.name_off[cid + 1] - job.name_off[cid]) + natac_text::digits_i64(s + r.a_rel) + natac_text::digits_i64(s + r.b_rel) + nv + 4;
     }
     len8[k] = (unsigned char)n;
     is_line[k] = n ? 1 : 0;
     if (hard) atomicAdd(hard_total, hard);
 }
 
+// The 256 lines of a workgroup are adjacent in the output: they are assembled in LDS (byte writes are cheap there) and leave as one
+// contiguous span with 16-byte stores, instead of ~35 scattered byte stores per line.
 __global__ void __launch_bounds__(256) tz_write_lines(TextJob job, long long nruns, const unsigned int *__restrict__ R, const int *__restrict__ C,
                                                        const unsigned char *__restrict__ len8, const unsigned long long *__restrict__ byte_off,
-                                                       const unsigned long long *__restrict__ line_idx, unsigned char *__restrict__ text,
-                                                       long long *__restrict__ line_off, int *__restrict__ l_cid, long long *__restrict__ l_beg,
-                                                       long long *__restrict__ l_end) {
-    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (k >= nruns || !len8[k]) return;
-    const RunInfo r = run_info(job, k, nruns, R, C);
-    char buf[MAX_LINE];
-    int hard = 0;
-    const int n = (int)(format_line(buf, job, r, &hard) - buf);
-    unsigned char *dst = text + byte_off[k];
-    for (int i = 0; i < n; ++i) dst[i] = (unsigned char)buf[i];
-    const unsigned long long j = line_idx[k];
-    line_off[j] = (long long)byte_off[k];
-    if (l_cid) {                                     // the record of this line, for the tabix index (tz_group_*)
-        const long long s = job.chunk_start[r.chunk];
-        l_cid[j] = job.chrom_id[r.chunk];
-        l_beg[j] = s + r.a_rel;
-        l_end[j] = s + r.b_rel;
+                                                       const unsigned long long *__restrict__ line_idx, const unsigned long long *__restrict__ vtxt,
+                                                       unsigned char *__restrict__ text, long long *__restrict__ line_off, int *__restrict__ l_cid,
+                                                       long long *__restrict__ l_beg, long long *__restrict__ l_end) {
+    __shared__ __attribute__((aligned(16))) unsigned char stage[256 * MAX_LINE + 32];
+    const long long k0 = (long long)blockIdx.x * 256, k = k0 + threadIdx.x;
+    const long long k1 = k0 + 256 < nruns ? k0 + 256 : nruns;
+    const unsigned long long base = byte_off[k0], end = byte_off[k1];          // byte_off has nruns + 1 entries
+    const int shift = (int)(base & 15);                                        // LDS and global positions agree modulo 16
+    const int n = k < nruns ? len8[k] : 0;
+    if (n) {
+        const int chunk = C[k];
+        const long long cb = job.out_off[chunk], ce = job.out_off[chunk + 1];
+        const long long a = R[k];
+        const long long b = (k + 1 < nruns && C[k + 1] == chunk) ? (long long)R[k + 1] : ce;
+        const long long s = job.chunk_start[chunk];
+        const long long beg = s + (a - cb), stop = s + (b - cb);
+        const int cid = job.chrom_id[chunk];
+        unsigned long long v[VTXT / 8];
+#pragma unroll
+        for (int i = 0; i < VTXT / 8; ++i) v[i] = vtxt[(VTXT / 8) * k + i];
+        char *dst = (char *)stage + shift + (int)(byte_off[k] - base), *p = dst;
+        for (int i = job.name_off[cid]; i < job.name_off[cid + 1]; ++i) *p++ = job.names[i];
+        *p++ = '\t';
+        p = natac_text::put_i64(p, beg);
+        *p++ = '\t';
+        p = natac_text::put_i64(p, stop);
+        *p++ = '\t';
+        const int nv = n - (int)(p - dst) - 1;       // what tz_line_len counted for the value
+#pragma unroll
+        for (int w = 0; w < VTXT / 8; ++w)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (8 * w + i < nv) *p++ = (char)((v[w] >> (8 * i)) & 0xff);
+        *p = '\n';
+        const unsigned long long j = line_idx[k];
+        line_off[j] = (long long)byte_off[k];
+        if (l_cid) {                                 // the record of this line, for the tabix index (tz_group_*)
+            l_cid[j] = cid;
+            l_beg[j] = beg;
+            l_end[j] = stop;
+        }
     }
+    __syncthreads();
+    const long long total = (long long)(end - base);
+    const unsigned long long abase = (base + 15) & ~15ull;                      // first 16-byte boundary of the span in `text`
+    const long long head = (long long)(abase - base) < total ? (long long)(abase - base) : total;
+    for (long long i = threadIdx.x; i < head; i += 256) text[base + i] = stage[shift + i];
+    const long long nvec = (total - head) >> 4;
+    const uint4 *src = (const uint4 *)(stage + shift + head);
+    uint4 *out = (uint4 *)(text + abase);
+    for (long long i = threadIdx.x; i < nvec; i += 256) out[i] = src[i];
+    for (long long i = head + (nvec << 4) + threadIdx.x; i < total; i += 256) text[base + i] = stage[shift + i];
 }
 
 // ---- tabix records without re-reading the file ----------------------------------------------------------------------------
@@ -341,60 +373,84 @@ __device__ __forceinline__ long long shfl_i64(long long v, int src) {
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// masks phase for the segments [base_s, base_s + cnt) (cnt <= 64) of the member: returns this lane's line
+// 8 bytes of the member text in LDS from any byte offset: three aligned words and two byte alignments
+__device__ __forceinline__ unsigned long long lds_load8(const unsigned char *lds_text, int off) {
+    const unsigned int *w = (const unsigned int *)(lds_text + (off & ~3));
+    const unsigned int sh = (unsigned int)off & 3u;
+    const unsigned int a0 = w[0], a1 = w[1], a2 = w[2];
+    return ((unsigned long long)__builtin_amdgcn_alignbyte(a2, a1, sh) << 32) | __builtin_amdgcn_alignbyte(a1, a0, sh);
+}
+// bit i set <=> byte i of x equals byte i of y
+__device__ __forceinline__ unsigned int eq_bytes(unsigned long long x, unsigned long long y) {
+    const unsigned long long t = x ^ y, m = 0x7f7f7f7f7f7f7f7full;
+    const unsigned long long z = ~(((t & m) + m) | t | m);          // 0x80 in every byte that is zero in t
+    return (unsigned int)(((z >> 7) * 0x0102040810204080ull) >> 56);
+}
+// equality mask of the first n (<= 64) bytes at `off` against the bytes `d` earlier (positions before the member start never match)
+__device__ __forceinline__ unsigned long long eq_mask(const unsigned char *lds_text, int off, int d, int n) {
+    unsigned long long m = 0;
+    if (d <= 0 || n <= 0) return 0;
+    if (off - d >= 0) {
+        for (int w = 0; 8 * w < n; ++w)
+            m |= (unsigned long long)eq_bytes(lds_load8(lds_text, off + 8 * w), lds_load8(lds_text, off + 8 * w - d)) << (8 * w);
+    } else {
+        for (int i = 0; i < n; ++i)
+            if (off + i - d >= 0 && lds_text[off + i - d] == lds_text[off + i]) m |= 1ull << i;
+    }
+    return n < 64 ? m & ((1ull << n) - 1ull) : m;
+}
+__device__ __forceinline__ unsigned long long tab_mask(const unsigned char *lds_text, int off, int n) {
+    unsigned long long m = 0;
+    for (int w = 0; 8 * w < n; ++w) m |= (unsigned long long)eq_bytes(lds_load8(lds_text, off + 8 * w), 0x0909090909090909ull) << (8 * w);
+    return n < 64 ? (n > 0 ? m & ((1ull << n) - 1ull) : 0ull) : m;
+}
+
+// masks phase for the segments [base_s, base_s + cnt) (cnt <= 64) of the member: every lane forms the masks of ITS line, eight
+// bytes at a time (the masks are what natac_deflate.hpp's tokenize_segment forms byte by byte)
 __device__ __forceinline__ LaneLine group_masks(const unsigned char *lds_text, const MemberGeom &g, const long long *line_off, long long nlines,
                                                 long long n_text, long long base_s, int cnt, int lane) {
-    // line starts of the group: lane j holds line (k0 + base_s + j); lane 63's successor and lane 0's predecessor come from memory
-    const long long kk = g.k0 + base_s + lane;
-    const long long my_ls = lane < cnt ? line_off[kk] : 0;
-    const long long my_le = lane < cnt ? ((kk + 1 < nlines) ? line_off[kk + 1] : n_text) : 0;
-    const long long first_k = g.k0 + base_s;
-    const long long pls0 = first_k > 0 ? line_off[first_k - 1] : (long long)-1;
     LaneLine me;
     me.valid = false;
     me.q0rel = me.seglen = 0;
     me.c.d0 = me.c.d1 = me.c.d2 = 0;
     me.eq0 = me.eq1 = me.eq2 = 0;
-    nd::LineGeom pg;
-    pg.tab1 = pg.tab2 = -1;
-    bool have_pg = false;
-    long long pls = pls0;
-    for (int j = 0; j < cnt; ++j) {
-        const long long ls = shfl_i64(my_ls, j), le = shfl_i64(my_le, j);
-        const long long q0 = ls > g.bs ? ls : g.bs, q1 = le < g.be ? le : g.be;
-        const int seglen = (int)(q1 - q0);
-        const int n = seglen < nd::WIN ? seglen : nd::WIN;
-        const unsigned char mine = lane < n ? lds_text[q0 + lane - g.bs] : 0;
-        nd::Cands c;
-        c.d0 = c.d1 = c.d2 = 0;
-        nd::LineGeom lg;
-        lg.tab1 = lg.tab2 = -1;
-        if (ls >= g.bs) {
-            lg = nd::geom_from_tabmask(__ballot(lane < n && mine == '\t'));
-            if (pls >= g.bs) {
-                if (!have_pg) {
-                    const bool in = pls + lane < ls && lane < nd::WIN;
-                    const unsigned char ch = in ? lds_text[pls + lane - g.bs] : 0;
-                    pg = nd::geom_from_tabmask(__ballot(in && ch == '\t'));
-                }
-            } else pg.tab1 = pg.tab2 = -1;
-            c = nd::line_candidates(g.bs, ls, pls, lg, pg);
-        }
-        const long long s0r = q0 + lane - c.d0, s1r = q0 + lane - c.d1, s2r = q0 + lane - c.d2;
-        const bool ok0 = c.d0 > 0 && lane < n && s0r >= g.bs, ok1 = c.d1 > 0 && lane < n && s1r >= g.bs, ok2 = c.d2 > 0 && lane < n && s2r >= g.bs;
-        const unsigned char o0 = ok0 ? lds_text[s0r - g.bs] : 0, o1 = ok1 ? lds_text[s1r - g.bs] : 0, o2 = ok2 ? lds_text[s2r - g.bs] : 0;
-        const unsigned long long e0 = __ballot(ok0 && o0 == mine), e1 = __ballot(ok1 && o1 == mine), e2 = __ballot(ok2 && o2 == mine);
-        if (lane == j) {
-            me.valid = seglen > 0;
-            me.q0rel = (int)(q0 - g.bs);
-            me.seglen = seglen;
-            me.c = c;
-            me.eq0 = e0; me.eq1 = e1; me.eq2 = e2;
-        }
-        pg = lg;
-        have_pg = true;
-        pls = ls;
+    const long long kk = g.k0 + base_s + lane;
+    const long long ls = lane < cnt ? line_off[kk] : 0;
+    const long long le = lane < cnt ? ((kk + 1 < nlines) ? line_off[kk + 1] : n_text) : 0;
+    // start of the previous line: the neighbouring lane's, for lane 0 from memory
+    long long pls = shfl_i64(ls, lane > 0 ? lane - 1 : 0);
+    if (lane == 0) pls = kk > 0 ? line_off[kk - 1] : (long long)-1;
+    const long long q0 = ls > g.bs ? ls : g.bs, q1 = le < g.be ? le : g.be;
+    const int seglen = lane < cnt ? (int)(q1 - q0) : 0;
+    const int n = seglen < nd::WIN ? seglen : nd::WIN;
+    const int off = (int)(q0 - g.bs);
+    const bool whole = lane < cnt && ls >= g.bs;                               // the line starts inside the member: q0 == ls
+    const unsigned long long tabs = whole ? tab_mask(lds_text, off, n) : 0ull;
+    // tab positions of the previous line (inside its first WIN columns): the neighbouring lane's mask, for lane 0 from the text
+    unsigned long long ptabs;
+    {
+        const unsigned int lo = __shfl((unsigned int)(tabs & 0xffffffffull), lane > 0 ? lane - 1 : 0);
+        const unsigned int hi = __shfl((unsigned int)(tabs >> 32), lane > 0 ? lane - 1 : 0);
+        ptabs = ((unsigned long long)hi << 32) | lo;
     }
+    if (lane == 0 && whole && pls >= g.bs) {
+        const int pn = (int)(ls - pls) < nd::WIN ? (int)(ls - pls) : nd::WIN;
+        ptabs = tab_mask(lds_text, (int)(pls - g.bs), pn);
+    }
+    if (whole) {
+        const nd::LineGeom lg = nd::geom_from_tabmask(tabs);
+        nd::LineGeom pg;
+        pg.tab1 = pg.tab2 = -1;
+        if (pls >= g.bs) pg = nd::geom_from_tabmask(ptabs);
+        me.c = nd::line_candidates(g.bs, ls, pls, lg, pg);
+        me.eq0 = eq_mask(lds_text, off, me.c.d0, n);
+        me.eq1 = eq_mask(lds_text, off, me.c.d1, n);
+        me.eq2 = eq_mask(lds_text, off, me.c.d2, n);
+    }
+    me.valid = seglen > 0;
+    me.q0rel = off;
+    me.seglen = seglen;
+    if (lane >= cnt) { me.valid = false; me.q0rel = me.seglen = 0; }
     return me;
 }
 
