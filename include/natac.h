@@ -335,6 +335,15 @@ int natac_bam_open_device(natac_ctx *ctx, const char *path, natac_bam **out, int
 /* test entry: the device's raw-deflate decoder run on the host (one BGZF member payload -> isize bytes); returns its error code */
 int natac_inflate_raw_host(const void *src, size_t csize, void *out, size_t isize);
 
+/* ---- native FASTA loader (host side): the genome as one upper-case byte array per record, what pyatac/seq.py:11-22 /
+ * pyatac/bias.py:85-92 fetch region by region through pysam.FastaFile.  Plain-text FASTA; record names end at the first blank. */
+typedef struct natac_fasta natac_fasta;
+int natac_fasta_open(const char *path, int n_threads, natac_fasta **out);
+void natac_fasta_close(natac_fasta *fa);
+int natac_fasta_count(natac_fasta *fa, int32_t *n_records);
+int natac_fasta_info(natac_fasta *fa, int32_t record, char *name, size_t name_len, int64_t *length);
+int natac_fasta_read(natac_fasta *fa, int32_t record, void *out, int64_t n);     /* n must equal the record's length */
+
 /* ---- pinned host memory + device memory pool ---------------------------------------------------------- */
 /* Page-locked host buffers (hipHostMalloc): uploads from / downloads into them run at full PCIe rate and asynchronously to
  * the host.  Any caller-owned host pointer of this ABI may be pinned or pageable; results are identical. */

@@ -13,6 +13,7 @@
 #include "natac_pack.hpp"
 #include "natac_bam.hpp"
 #include "natac_bam_dev.hpp"
+#include "natac_fasta.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -2372,6 +2373,54 @@ int natac_tbx_read_regions(natac_tbx *t, int64_t n, const int32_t *chrom_id, con
     const int64_t u = natac_tabix::read_regions(t->impl, n, chrom_id, names, n_names, start, end, value_col, empty, out, out_off, n_threads);
     if (u < 0) return fail(NATAC_E_ARG, "read error in the indexed file");
     if (n_records) *n_records = u;
+    return NATAC_OK;
+}
+
+/* ---------------- native FASTA loader ---------------- */
+
+struct natac_fasta { natac_fastaio::Fasta *impl = nullptr; };
+
+int natac_fasta_open(const char *path, int n_threads, natac_fasta **out) {
+    if (!path || !out) return fail(NATAC_E_ARG, "null argument");
+    *out = nullptr;
+    std::string err;
+    natac_fastaio::Fasta *impl = natac_fastaio::load(path, n_threads, err);
+    if (!impl) return fail(NATAC_E_ARG, "%s: %s", path, err.c_str());
+    natac_fasta *h = new natac_fasta();
+    h->impl = impl;
+    *out = h;
+    return NATAC_OK;
+}
+
+void natac_fasta_close(natac_fasta *fa) {
+    if (!fa) return;
+    delete fa->impl;
+    delete fa;
+}
+
+int natac_fasta_count(natac_fasta *fa, int32_t *n_records) {
+    if (!fa || !n_records) return fail(NATAC_E_ARG, "null argument");
+    *n_records = (int32_t)fa->impl->recs.size();
+    return NATAC_OK;
+}
+
+int natac_fasta_info(natac_fasta *fa, int32_t record, char *name, size_t name_len, int64_t *length) {
+    if (!fa) return fail(NATAC_E_ARG, "fasta is NULL");
+    if (record < 0 || (size_t)record >= fa->impl->recs.size()) return fail(NATAC_E_ARG, "record out of range");
+    const natac_fastaio::Record &r = fa->impl->recs[(size_t)record];
+    if (name && name_len) {
+        if (r.name.size() + 1 > name_len) return fail(NATAC_E_ARG, "record name longer than the buffer");
+        std::memcpy(name, r.name.c_str(), r.name.size() + 1);
+    }
+    if (length) *length = r.length;
+    return NATAC_OK;
+}
+
+int natac_fasta_read(natac_fasta *fa, int32_t record, void *out, int64_t n) {
+    if (!fa) return fail(NATAC_E_ARG, "fasta is NULL");
+    if (record < 0 || (size_t)record >= fa->impl->recs.size()) return fail(NATAC_E_ARG, "record out of range");
+    if (n != fa->impl->recs[(size_t)record].length || (n > 0 && !out)) return fail(NATAC_E_ARG, "buffer does not match the record's length");
+    natac_fastaio::read_record(fa->impl, (size_t)record, (unsigned char *)out);
     return NATAC_OK;
 }
 

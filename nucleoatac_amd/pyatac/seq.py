@@ -24,8 +24,15 @@ class FastaStore(object):
             return _CACHE[src]
         if src.endswith(".npz"):
             d = np.load(src, allow_pickle=False)
-            st = FastaStore({str(c): np.frombuffer(d["seq_" + str(c)].tobytes().upper(), dtype=np.uint8)
-                             for c in d["chrom_names"]})
+            seqs = {}
+            for c in d["chrom_names"]:
+                a = d["seq_" + str(c)]
+                if a.dtype != np.uint8 or (a >= 97).any():          # lower case somewhere: upper-case a copy
+                    a = np.frombuffer(a.tobytes().upper(), dtype=np.uint8)
+                seqs[str(c)] = a
+            st = FastaStore(seqs)
+        elif not src.endswith(".gz") and FastaStore._native_ok():
+            st = FastaStore(FastaStore._load_native(src))
         else:
             opener = gzip.open if src.endswith(".gz") else open
             seqs, name, parts = {}, None, []
@@ -42,6 +49,39 @@ class FastaStore(object):
             st = FastaStore(seqs)
         _CACHE[src] = st
         return st
+
+    @staticmethod
+    def _native_ok():
+        try:
+            from .. import _lib as L
+            L.load()
+            return True
+        except (ImportError, OSError, AttributeError):
+            return False
+
+    @staticmethod
+    def _load_native(path):
+        """plain-text FASTA through natac_fasta_* (csrc/natac_fasta.hpp: multi-threaded, memory speed) instead of a Python line
+        loop over the whole genome"""
+        import ctypes as C
+        from .. import _lib as L
+        lib = L.load()
+        h = C.c_void_p()
+        L.check(lib.natac_fasta_open(str(path).encode(), 0, C.byref(h)))
+        try:
+            n = C.c_int32(0)
+            L.check(lib.natac_fasta_count(h, C.byref(n)))
+            seqs = {}
+            for r in range(n.value):
+                name = C.create_string_buffer(4096)
+                ln = C.c_int64(0)
+                L.check(lib.natac_fasta_info(h, r, name, 4096, C.byref(ln)))
+                a = np.empty(ln.value, dtype=np.uint8)
+                L.check(lib.natac_fasta_read(h, r, a.ctypes.data_as(C.c_void_p), ln.value))
+                seqs[name.value.decode()] = a
+        finally:
+            lib.natac_fasta_close(h)
+        return seqs
 
     def fetch(self, chrom, start, end):
         return self.seqs[chrom][start:end].tobytes().decode("ascii")

@@ -238,3 +238,32 @@ def test_lockstep_fits_take_the_optimisers_own_steps():
     with ThreadPoolExecutor(2) as pool:                # the slicing over a --cores pool keeps the task order
         sliced = N.fit_fuzz_tasks(tasks, pool, 2)
     assert np.array_equal(np.array([r for c in many for r in c]), np.array([r for c in sliced for r in c]))
+
+
+def test_native_fasta_loader_equals_the_line_loop(tmp_path):
+    """natac_fasta_* (csrc/natac_fasta.hpp: header scan, counts and copies on threads) against the Python line loop of
+    FastaStore.open: names up to the first blank, lower case, CRLF, empty records, no final newline, a record > 1 MiB"""
+    import gzip
+    from nucleoatac_amd.pyatac import seq as S
+    rng = np.random.default_rng(3)
+    letters = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
+    recs = [("chr1 some description", 2_500_000, 60, "\n"), ("chrEmpty", 0, 60, "\n"), ("chr2\tx", 70_001, 80, "\r\n"),
+            ("scaffold_3", 59, 60, "\n"), ("chrLast", 1234, 50, "\n")]
+    text, want = [], {}
+    for name, n, width, eol in recs:
+        s = letters[rng.integers(0, len(letters), n)].tobytes().decode()
+        want[name.split()[0]] = s.upper()
+        text.append(">" + name + eol + "".join(s[i:i + width] + eol for i in range(0, n, width)))
+    body = "".join(text)
+    body = body[:-1]                                       # no newline at the end of the file
+    plain, gz = str(tmp_path / "g.fa"), str(tmp_path / "g.fa.gz")
+    open(plain, "w", newline="").write(body)
+    gzip.open(gz, "wt", newline="").write(body)
+    assert S.FastaStore._native_ok()
+    nat = S.FastaStore.open(plain)                         # native loader
+    py = S.FastaStore.open(gz)                             # the line loop (gzip)
+    assert nat.references == py.references == [r[0].split()[0] for r in recs]
+    assert list(nat.lengths) == list(py.lengths) == [r[1] for r in recs]
+    for c in nat.references:
+        assert nat.seqs[c].tobytes().decode() == want[c] == py.seqs[c].tobytes().decode(), c
+    assert nat.fetch("chr2", 100, 130) == want["chr2"][100:130]
