@@ -253,6 +253,7 @@ def run_occ(args):
         writer.start()
 
         pack_s = [0.0]
+        arrivals = []
 
         def pack_part(part):
             import time
@@ -269,7 +270,10 @@ def run_occ(args):
         try:
             with PipelinedExecutor(device, lambda ctx: params.occ_calc_params.install(ctx, step=params.step, flank=params.flank),
                                    stages, n_contexts=min(N_CONTEXTS, len(parts))) as ex:
+                import time
+                t_start, arrivals = time.perf_counter(), []
                 for r in ex.map(items()):
+                    arrivals.append(time.perf_counter() - t_start)
                     if (r.status & 1).any():
                         k = int(np.flatnonzero(r.status & 1)[0])
                         print("Caught exception when processing:\n" + r.tag[k].asBed() + "\n")
@@ -279,6 +283,9 @@ def run_occ(args):
         finally:
             writer.finish()
         ph.mark("pipeline_wall")
+        if arrivals:       # when the results of the sub-batches reached the writer (seconds after the executor started)
+            LAST_TIMINGS["results_first_median_gap_last"] = [round(arrivals[0], 3), round(float(np.median(np.diff(arrivals))) if len(arrivals) > 1 else 0.0, 4),
+                                                             round(arrivals[-1], 3)]
         LAST_TIMINGS["pack_inside_pipeline"] = round(pack_s[0], 3)
         LAST_TIMINGS["writer_inside_pipeline"] = round(writer.seconds, 3)
     dists = gather_in_chunk_order(dists, dst=0)

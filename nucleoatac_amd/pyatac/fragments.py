@@ -45,6 +45,11 @@ class FragmentStore(object):
         if isinstance(src, FragmentStore) or src in _CACHE or src in _PENDING:
             return
         import threading
+        if os.environ.get("NATAC_DEVICE_BAM", "0") == "1" and str(src).endswith(".bam"):
+            from .. import get_context
+            from ..device import Context
+            if Context.device_count() > 0:
+                get_context()               # the process-wide context is created on the caller's thread, not raced for
         box = {}
 
         def work():
