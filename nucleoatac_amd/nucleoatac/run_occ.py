@@ -84,6 +84,7 @@ class _Writer(threading.Thread):
         self.q = queue.Queue(maxsize=2)
         self.err = None
         self.seconds = 0.0
+        self.seconds_files = 0.0
         self.offset = {n: 0 for n in paths}          # bytes of members written so far (without the EOF marker)
         self.index_log = {n: [] for n in paths}      # (tabix records of a result, offset it was written at)
         self.index_ok = {n: True for n in paths}
@@ -120,6 +121,7 @@ class _Writer(threading.Thread):
 
                     # one file per track: the appends run side by side (write() releases the GIL), every file still in order
                     list(self.pool.map(write_one, list(self.paths)))
+                    self.seconds_files += time.perf_counter() - t0
                     self.extra(r)
                     self.seconds += time.perf_counter() - t0
             except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
@@ -288,6 +290,7 @@ def run_occ(args):
                                                              round(arrivals[-1], 3)]
         LAST_TIMINGS["pack_inside_pipeline"] = round(pack_s[0], 3)
         LAST_TIMINGS["writer_inside_pipeline"] = round(writer.seconds, 3)
+        LAST_TIMINGS["file_appends_inside_writer"] = round(writer.seconds_files, 3)
     dists = gather_in_chunk_order(dists, dst=0)
     to_index = finish_indexes(writer if parts else None, list(track_of), lambda n: args.out + "." + n + ".bedgraph.gz")
     ph.mark("gather_and_track_indexes")
