@@ -55,6 +55,9 @@ def run_nfr(args):
     if env_rank_world()[0] == 0 and isinstance(args.bam, str):
         from ..pyatac.fragments import FragmentStore
         FragmentStore.prefetch(args.bam)       # rank 0 decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
+    if getattr(args, "fasta", None):
+        from ..pyatac.seq import FastaStore
+        FastaStore.prefetch(args.fasta)        # the genome loads on its own thread; the BED file only needs the record lengths
     if args.fasta is not None:
         chrs_fasta = read_chrom_sizes_from_fasta(args.fasta)
         pwm = PWM.open(args.pwm)

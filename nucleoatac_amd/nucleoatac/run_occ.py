@@ -174,6 +174,9 @@ def run_occ(args):
     if env_rank_world()[0] == 0 and isinstance(args.bam, str):
         from ..pyatac.fragments import FragmentStore
         FragmentStore.prefetch(args.bam)       # rank 0 decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
+    if getattr(args, "fasta", None):
+        from ..pyatac.seq import FastaStore
+        FastaStore.prefetch(args.fasta)        # the genome loads on its own thread; the BED file only needs the record lengths
     chrs = read_chrom_sizes_from_fasta(args.fasta) if args.fasta else read_chrom_sizes_from_bam(args.bam)
     pwm = PWM.open(args.pwm)
     chunks = ChunkList.read(args.bed, chromDict=chrs,

@@ -1,10 +1,12 @@
 """Sequence access (API of the reference's pyatac/seq.py:11-45) without pysam: FastaStore reads a (gzipped)
 FASTA once, or an .npz of per-chromosome byte arrays."""
 import gzip
+import os
 
 import numpy as np
 
 _CACHE = {}
+_PENDING = {}     # src -> (thread, result box) of FastaStore.prefetch
 
 
 class FastaStore(object):
@@ -17,11 +19,72 @@ class FastaStore(object):
         return dict(zip(self.references, self.lengths))
 
     @staticmethod
+    def sizes(src):
+        """{record: length} without loading the sequence when that is possible: the .npy headers inside a .npz, the .fai next to a
+        text FASTA (what pysam.FastaFile reads, pyatac/utils.py:33-40); otherwise the lengths of the loaded store"""
+        if isinstance(src, FastaStore):
+            return src.chrom_sizes()
+        if src in _CACHE and src not in _PENDING:
+            return _CACHE[src].chrom_sizes()
+        try:
+            if src.endswith(".npz"):
+                import zipfile
+                out = {}
+                with zipfile.ZipFile(src) as z:
+                    with z.open("chrom_names.npy") as fh:
+                        names = [str(c) for c in np.lib.format.read_array(fh, allow_pickle=False)]
+                    for c in names:
+                        with z.open("seq_%s.npy" % c) as fh:
+                            major, _minor = np.lib.format.read_magic(fh)
+                            shape = (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(fh)[0]
+                            out[c] = int(shape[0])
+                return out
+            if os.path.exists(src + ".fai"):
+                out = {}
+                with open(src + ".fai") as fh:
+                    for line in fh:
+                        f = line.split("\t")
+                        if len(f) >= 2:
+                            out[f[0]] = int(f[1])
+                return out
+        except Exception:      # noqa: BLE001 -- any surprise in the shortcut: the loaded store answers
+            pass
+        return FastaStore.open(src).chrom_sizes()
+
+    @staticmethod
+    def prefetch(src):
+        """start loading `src` on a thread (native loader / zlib: the GIL is released); FastaStore.open(src) waits for it"""
+        if isinstance(src, FastaStore) or src is None or src in _CACHE or src in _PENDING:
+            return
+        import threading
+        box = {}
+
+        def work():
+            try:
+                box["store"] = FastaStore._load(src)
+            except BaseException as e:      # noqa: BLE001 -- re-raised by open() on the caller's thread
+                box["error"] = e
+        t = threading.Thread(target=work, name="natac-fasta-prefetch", daemon=True)
+        _PENDING[src] = (t, box)
+        t.start()
+
+    @staticmethod
     def open(src):
         if isinstance(src, FastaStore):
             return src
+        if src in _PENDING:
+            t, box = _PENDING.pop(src)
+            t.join()
+            if "error" in box:
+                raise box["error"]
+            _CACHE[src] = box["store"]
         if src in _CACHE:
             return _CACHE[src]
+        _CACHE[src] = st = FastaStore._load(src)
+        return st
+
+    @staticmethod
+    def _load(src):
         if src.endswith(".npz"):
             d = np.load(src, allow_pickle=False)
             seqs = {}
@@ -47,7 +110,6 @@ class FastaStore(object):
             if name is not None:
                 seqs[name] = np.frombuffer("".join(parts).upper().encode("ascii"), dtype=np.uint8)
             st = FastaStore(seqs)
-        _CACHE[src] = st
         return st
 
     @staticmethod

@@ -67,7 +67,7 @@ def read_chrom_sizes(sizesFile):
 
 def read_chrom_sizes_from_fasta(fastafile):
     from .seq import FastaStore
-    return FastaStore.open(fastafile).chrom_sizes()
+    return FastaStore.sizes(fastafile)
 
 
 def read_chrom_sizes_from_bam(bamfile):

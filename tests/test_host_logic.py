@@ -267,3 +267,25 @@ def test_native_fasta_loader_equals_the_line_loop(tmp_path):
     for c in nat.references:
         assert nat.seqs[c].tobytes().decode() == want[c] == py.seqs[c].tobytes().decode(), c
     assert nat.fetch("chr2", 100, 130) == want["chr2"][100:130]
+
+
+def test_fasta_sizes_without_loading_and_prefetch(tmp_path):
+    """FastaStore.sizes reads the record lengths from the .npy headers of an .npz / from a .fai, and falls back to the loaded
+    store; FastaStore.prefetch + open give the store a plain open gives"""
+    from nucleoatac_amd.pyatac import seq as S
+    rng = np.random.default_rng(1)
+    seqs = {"chrI": rng.integers(65, 70, 5000).astype(np.uint8), "chrII_b": rng.integers(65, 70, 123).astype(np.uint8)}
+    npz = str(tmp_path / "g.npz")
+    np.savez(npz, chrom_names=np.array(list(seqs)), **{"seq_" + c: a for c, a in seqs.items()})
+    assert S.FastaStore.sizes(npz) == {"chrI": 5000, "chrII_b": 123}
+    assert npz not in S._CACHE                              # nothing was loaded for that
+    S.FastaStore.prefetch(npz)
+    st = S.FastaStore.open(npz)
+    assert st.chrom_sizes() == {"chrI": 5000, "chrII_b": 123} and np.array_equal(st.seqs["chrI"], seqs["chrI"])
+    fa = str(tmp_path / "t.fa")
+    open(fa, "w").write(">a x\nACGTAC\nGT\n>b\nAC\n")
+    assert S.FastaStore.sizes(fa) == {"a": 8, "b": 2}       # no .fai: the loaded store answers
+    fa2 = str(tmp_path / "u.fa")
+    open(fa2, "w").write(">a x\nACGTAC\nGT\n>b\nAC\n")
+    open(fa2 + ".fai", "w").write("a\t8\t5\t6\t7\nb\t2\t18\t2\t3\n")
+    assert S.FastaStore.sizes(fa2) == {"a": 8, "b": 2} and fa2 not in S._CACHE
