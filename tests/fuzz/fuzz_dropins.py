@@ -1,13 +1,13 @@
 """Randomised sweep over the single-region drop-ins (the Cython functions' replacements and the operator-level helpers) against
 the CPU oracle: makeFragmentMat, getInsertions, getFragmentSizesFromChunkList, calculateCov (closed + literal), smooth in
-every mode, makeBiasMat, the PWM score, correlate 'valid', calculateOccupancy.   usage: python tools/fuzz_dropins.py [rounds] [seed]"""
+every mode, makeBiasMat, the PWM score, correlate 'valid', calculateOccupancy.   usage: python tests/fuzz/fuzz_dropins.py [rounds] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from nucleoatac_amd.device import Context  # noqa: E402

@@ -1,14 +1,14 @@
 """Randomised parity sweep over MODEL geometries (development / release check): per round a random V-plot (lower bound, even /
 odd row count, width), smoothing width, occupancy window / step / size range / alpha grid -- so the fallback kernels run
 (generic smoothing, natac_occ_mle, natac_candidates4, the FFT kernel's odd-row loop, natac_background_generic) -- on a
-few ragged chunks, against the CPU oracle.   usage: python tools/fuzz_generic.py [n_rounds] [seed]"""
+few ragged chunks, against the CPU oracle.   usage: python tests/fuzz/fuzz_generic.py [n_rounds] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import assert_track, expand_grid, golden  # noqa: E402

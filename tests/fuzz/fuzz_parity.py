@@ -1,14 +1,14 @@
 """Randomised parity sweep on the GPU (development / release check): random ragged chunk sets -- lengths 121..9000, fragment
 densities 0..12 per base, fragment-free stretches (NaN occupancy), with / without a bias track, odd sizes -- every track, the
 occupancy grid, insertion counts and the candidate search against the CPU oracle.
-usage: python tools/fuzz_parity.py [n_rounds] [seed]"""
+usage: python tests/fuzz/fuzz_parity.py [n_rounds] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import assert_track, golden  # noqa: E402

@@ -3,7 +3,7 @@ the encoder: random chunk geometries and chromosome names, tracks built from val
 runs and NaN stretches of every length (set through natac_batch_set_track), every write_zero / keep_runs_before_nan combination.
 Checked per case: text == natac_write_bedgraph's bytes; the BGZF members inflate to that text and equal natac_bgzf_lines_host byte for
 byte; the .tbi from the device's records == the .tbi natac_tabix_index builds from the file.
-usage: python tools/fuzz_writer.py [rounds] [seed]   (FUZZ_SECONDS bounds the run)"""
+usage: python tests/fuzz/fuzz_writer.py [rounds] [seed]   (FUZZ_SECONDS bounds the run)"""
 import gzip
 import io
 import os
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from nucleoatac_amd import _lib as L                                   # noqa: E402
@@ -49,8 +49,10 @@ def random_track(rng, n):
 
 
 def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def run(rounds, seed):
     rng = np.random.default_rng(seed)
     t0 = time.time()
     lines = 0
@@ -110,6 +112,7 @@ def main():
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     print("writer fuzz ok: %d rounds, %d lines, %.0f s" % (done, lines, time.time() - t0))
+    return done, lines
 
 
 if __name__ == "__main__":

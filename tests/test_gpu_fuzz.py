@@ -1,4 +1,4 @@
-"""GPU: a short run of tools/fuzz_parity.py -- random ragged chunk sets (lengths 121..9000, densities 0..12 fragments per base,
+"""GPU: a short run of tests/fuzz/fuzz_parity.py -- random ragged chunk sets (lengths 121..9000, densities 0..12 fragments per base,
 fragment-free stretches, with / without bias, sizes at the model's edges): every track, insertion counts and the candidate
 search against the CPU oracle.  (The release check ran ~2,400 rounds / 10 M bases of the same generator.)"""
 import os
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_random_chunk_sets_match_the_oracle():
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
     import fuzz_parity as F
     from helpers import golden
     from nucleoatac_amd.device import Context
@@ -33,9 +33,9 @@ def test_random_chunk_sets_match_the_oracle():
 
 
 def test_random_model_geometries_match_the_oracle():
-    """a short run of tools/fuzz_generic.py: random V-plot bounds / row counts / widths (incl. narrower than a wave: the paired
+    """a short run of tests/fuzz/fuzz_generic.py: random V-plot bounds / row counts / widths (incl. narrower than a wave: the paired
     candidate kernel must hand over), smoothing widths, occupancy window / step / size range / alpha grids"""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
     import fuzz_generic as G
     from helpers import golden
     par = golden("params_example")
@@ -45,9 +45,9 @@ def test_random_model_geometries_match_the_oracle():
 
 
 def test_random_dropin_calls_match_the_oracle():
-    """a short run of tools/fuzz_dropins.py: the Cython functions' replacements and the operator-level helpers on random
+    """a short run of tests/fuzz/fuzz_dropins.py: the Cython functions' replacements and the operator-level helpers on random
     regions / fragment sets / chunk lists / windows / PWMs"""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
     import fuzz_dropins as D
     from nucleoatac_amd.device import Context
     from nucleoatac_amd.synth import synth_occ_distributions
@@ -57,3 +57,12 @@ def test_random_dropin_calls_match_the_oracle():
         c.set_occ_model(*D.one_round.model, step=5, flank=60)
         for _ in range(150):
             D.one_round(c, rng)
+
+
+def test_writer_fuzz_slice():
+    """a short run of tests/fuzz/fuzz_writer.py: the device track writer on random geometries, names and tracks (runs, zero runs,
+    NaN stretches, values of every scale) in every flag combination -- text, members and index against the host side"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
+    import fuzz_writer
+    done, lines = fuzz_writer.run(12, 21)
+    assert done == 12 and lines > 100000
