@@ -329,8 +329,9 @@ int natac_bam_ref_info(natac_bam *bam, int32_t ref, char *name, size_t name_len,
 int natac_bam_ref_reads(natac_bam *bam, int32_t ref, int64_t *pos, int64_t *tlen, int64_t n);
 /* The same extraction with the BGZF members inflated and the records walked ON THE DEVICE (csrc/natac_bam_dev.hpp: one lane per
  * member; the record chain through the members is confirmed link by link from the end of the header, so the result is exactly
- * natac_bam_open's).  A file whose chain cannot be confirmed goes through the host decoder inside this call; *on_device (may be
- * NULL) tells which one answered.  Damaged files fail with the host decoder's messages. */
+ * natac_bam_open's).  A file whose chain cannot be confirmed -- or a HIP failure such as no memory for a window -- sends the file
+ * through the host decoder inside this call; *on_device (may be NULL) tells which one answered.  Damaged files fail with the host
+ * decoder's messages. */
 int natac_bam_open_device(natac_ctx *ctx, const char *path, natac_bam **out, int *on_device);
 /* test entry: the device's raw-deflate decoder run on the host (one BGZF member payload -> isize bytes); returns its error code */
 int natac_inflate_raw_host(const void *src, size_t csize, void *out, size_t isize);

@@ -2445,8 +2445,7 @@ int natac_bam_open_device(natac_ctx *c, const char *path, natac_bam **out, int *
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
     std::string err;
-    size_t window = (size_t)2 << 30;                  // compressed bytes per device window (>= 49,152 members keep every CU's LDS
-                                                      // full); NATAC_BAM_DEV_WINDOW overrides (tests)
+    size_t window = (size_t)8 << 30;                  // compressed bytes per device window; NATAC_BAM_DEV_WINDOW overrides (tests)
     if (const char *e = getenv("NATAC_BAM_DEV_WINDOW")) { const long long v = atoll(e); if (v > 0) window = (size_t)v; }
     bool undecided = false;
     natac_bamio::Bam *impl = natac_bamdev::decode_device(path, c->stream, err, &undecided, window);

@@ -18,8 +18,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -224,20 +229,25 @@ inline int inflate_member_host(const unsigned char *src, unsigned int csize, uns
 // code lengths of a block header -- touched only while a block's tables are built -- stay in private memory.
 // status[0] = first error code (0 = none), status[1] = its member
 constexpr int INFLATE_LDS_U16 = (288 + 32 + 4 * 16) * 64;
-__global__ void __launch_bounds__(64) bamdev_inflate(const unsigned char *__restrict__ raw, const Member *__restrict__ mem, int n_members,
-                                                     unsigned char *__restrict__ data, int *__restrict__ status) {
+// A launch covers the members [m_begin, n_members) whose bytes have arrived; it fills the chip at most once (3 workgroups per CU: the
+// LDS tables) and every lane takes members from the launch's queue until it is empty: a serial decoder needs ~85 ms per 64-KiB member, so with one member per lane a launch of 55 k members took two rounds
+// of 49 k lanes, the second nearly empty.
+__global__ void __launch_bounds__(64) bamdev_inflate(const unsigned char *__restrict__ raw, const Member *__restrict__ mem, int m_begin, int n_members,
+                                                     unsigned char *__restrict__ data, int *__restrict__ status, int *__restrict__ queue) {
     __shared__ unsigned short tab[INFLATE_LDS_U16];
-    const int m = blockIdx.x * 64 + threadIdx.x;
-    if (m >= n_members) return;
-    const Member mb = mem[m];
-    if (mb.isize == 0) return;
     unsigned char lengths[320];
     typedef Strided<unsigned char, 1> L8;
     typedef Strided<unsigned short, 64> T16;
     unsigned short *t = tab + threadIdx.x;
-    const int rc = inflate_member(raw + mb.coff, mb.csize, data + mb.uoff, mb.isize, L8{lengths}, T16{t}, T16{t + 288 * 64}, T16{t + 304 * 64},
-                                  T16{t + 320 * 64}, T16{t + 352 * 64}, T16{t + 368 * 64});
-    if (rc != 0 && atomicCAS(&status[0], 0, rc) == 0) status[1] = m;
+    for (;;) {
+        const int m = m_begin + atomicAdd(queue, 1);
+        if (m >= n_members) break;
+        const Member mb = mem[m];
+        if (mb.isize == 0) continue;
+        const int rc = inflate_member(raw + mb.coff, mb.csize, data + mb.uoff, mb.isize, L8{lengths}, T16{t}, T16{t + 288 * 64}, T16{t + 304 * 64},
+                                      T16{t + 320 * 64}, T16{t + 352 * 64}, T16{t + 368 * 64});
+        if (rc != 0 && atomicCAS(&status[0], 0, rc) == 0) status[1] = m;
+    }
 }
 
 __device__ __forceinline__ unsigned int ld32(const unsigned char *p) {
@@ -341,8 +351,8 @@ __global__ void __launch_bounds__(64) bamdev_walk(const unsigned char *__restric
 // The file goes through the device in windows of ~window_bytes of compressed data (pinned staging buffer); what is not a
 // complete record at the end of a window's inflated bytes is carried to the front of the next window's buffer on the device.
 // Returns the same object as natac_bamio::decode.  nullptr + err: the file is damaged (same messages as the host decoder);
-// nullptr + *undecided = true: the record chain could not be confirmed (or the header outgrew a window), the caller uses the
-// host decoder.
+// nullptr + *undecided = true: the record chain could not be confirmed, the header outgrew a window or a HIP call failed (no
+// memory for a window on a shared GPU): the caller uses the host decoder.
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -366,104 +376,212 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+// The BGZF chain of a file (where every member starts, its payload and inflated sizes), walked with one small pread per member on a
+// thread of its own while the bulk of the file goes to the device; the same checks and messages as the host decoder's window scan.
+struct Chain {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Member> members;          // coff = ABSOLUTE file offset of the deflate payload; uoff unused here
+    std::vector<unsigned long long> ends;  // absolute end offset of every member
+    bool done = false;
+    std::string error;
+};
+
+inline void walk_chain(int fd, unsigned long long fsize, Chain *ch) {
+    using natac_bamio::rd16;
+    using natac_bamio::rd32;
+    std::vector<Member> part;
+    std::vector<unsigned long long> part_end;
+    auto publish = [&](bool done, const std::string &error) {
+        std::lock_guard<std::mutex> lk(ch->mu);
+        ch->members.insert(ch->members.end(), part.begin(), part.end());
+        ch->ends.insert(ch->ends.end(), part_end.begin(), part_end.end());
+        part.clear(); part_end.clear();
+        if (done) { ch->done = true; ch->error = error; }
+        ch->cv.notify_all();
+    };
+    unsigned long long off = 0;
+    bool any = false;
+    unsigned char h[4 + 1024];
+    while (off < fsize) {
+        if (off + 18 > fsize) return publish(true, any ? "trailing bytes after the last BGZF block" : "not a BGZF file (bad block header)");
+        // the last four bytes of the previous member (its ISIZE) and this member's header in one read
+        const unsigned long long from = off >= 4 ? off - 4 : 0;
+        const size_t want = (size_t)std::min<unsigned long long>(sizeof h, fsize - from);
+        if (pread(fd, h, want, (off_t)from) != (ssize_t)want) return publish(true, "read error");
+        const unsigned char *g = h + (off - from);
+        const size_t have = want - (size_t)(off - from);
+        if (any) {
+            const uint32_t isize = rd32(g - 4);
+            if (isize > 65536) return publish(true, "corrupt BGZF block (ISIZE > 65536)");
+            part.back().isize = isize;
+        }
+        if (g[0] != 0x1f || g[1] != 0x8b || g[2] != 8 || !(g[3] & 4)) return publish(true, "not a BGZF file (bad block header)");
+        const unsigned xlen = rd16(g + 10);
+        if (12 + (size_t)xlen > have) {
+            if (off + 12 + xlen > fsize) return publish(true, any ? "trailing bytes after the last BGZF block" : "not a BGZF file (bad block header)");
+            return publish(true, "BGZF extra field longer than 1 KiB");      // never written by samtools / htslib / this writer
+        }
+        size_t bsize = 0;
+        for (size_t x = 12; x + 4 <= 12 + (size_t)xlen;) {
+            const unsigned slen = rd16(g + x + 2);
+            if (g[x] == 'B' && g[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(g + x + 4) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || bsize < 12 + (size_t)xlen + 8) return publish(true, "truncated BGZF block");
+        if (off + bsize > fsize) return publish(true, any ? "trailing bytes after the last BGZF block" : "not a BGZF file (bad block header)");
+        if (part.size() >= 4096) publish(false, "");
+        part.push_back({off + 12 + xlen, (unsigned int)(bsize - 12 - xlen - 8), 0u, 0ull});
+        part_end.push_back(off + bsize);
+        off += bsize;
+        any = true;
+    }
+    if (any) {
+        unsigned char t[4];
+        if (pread(fd, t, 4, (off_t)(fsize - 4)) != 4) return publish(true, "read error");
+        const uint32_t isize = rd32(t);
+        if (isize > 65536) return publish(true, "corrupt BGZF block (ISIZE > 65536)");
+        part.back().isize = isize;
+    }
+    publish(true, any ? "" : "not a BGZF file (bad block header)");
+}
+
 inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std::string &err, bool *undecided,
-                                       size_t window_bytes = (size_t)2 << 30) {
+                                       size_t window_bytes = (size_t)8 << 30) {
     using natac_bamio::rd16;
     using natac_bamio::rd32;
     using natac_bamio::rdi32;
     *undecided = false;
-    FILE *f = std::fopen(path, "rb");
-    if (!f) { err = std::string("cannot open ") + path; return nullptr; }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { err = std::string("cannot open ") + path; return nullptr; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); err = "cannot size the file"; return nullptr; }
+    const unsigned long long fsize = (unsigned long long)sb.st_size;
     window_bytes = std::max<size_t>(window_bytes, (size_t)4096);
-    {   // a file smaller than the window needs no window-sized staging buffer (pinning memory costs ~0.25 s per GiB)
-        std::fseek(f, 0, SEEK_END);
-        const long fsize = std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        if (fsize >= 0) window_bytes = std::min<size_t>(window_bytes, std::max<size_t>((size_t)fsize, (size_t)4096));
-    }
-    const size_t raw_cap = window_bytes + ((size_t)1 << 16);
-    unsigned char *raw = nullptr;
+    // staging: the file goes to the device through two small pinned buffers (pinning memory costs ~0.25 s per GiB: a window-sized
+    // pinned buffer took longer to allocate than the whole decode), the read of one overlapping the upload of the other
+    const size_t STAGE = (size_t)std::min<unsigned long long>((unsigned long long)32 << 20, std::max<unsigned long long>(fsize, 4096));
+    unsigned char *stage[2] = {nullptr, nullptr};
+    hipEvent_t staged[2] = {nullptr, nullptr};
     natac_bamio::Bam *bam = new natac_bamio::Bam();
-    DevBuf d_raw, d_mem, d_data[2], d_wo, d_base, d_ref, d_pos, d_tlen, d_status;
+    DevBuf d_raw, d_mem, d_data[2], d_wo, d_base, d_ref, d_pos, d_tlen, d_status, d_queue;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     std::vector<Member> mem;
     std::vector<WalkOut> wo;
     std::vector<unsigned long long> base;
     std::vector<int> h_ref, h_pos, h_tlen;
     std::vector<unsigned char> head;
     int cur_buf = 0;
-    auto cleanup = [&]() { if (raw) (void)hipHostFree(raw); std::fclose(f); };
+    Chain chain;
+    std::thread walker(walk_chain, fd, fsize, &chain);
+    auto cleanup = [&]() {
+        if (walker.joinable()) walker.join();
+        for (int i = 0; i < 2; ++i) { if (stage[i]) (void)hipHostFree(stage[i]); if (staged[i]) (void)hipEventDestroy(staged[i]); }
+        for (int i = 0; i < 3; ++i) if (aux[i]) { (void)hipStreamSynchronize(aux[i]); (void)hipStreamDestroy(aux[i]); }
+        close(fd);
+    };
     auto fail = [&](const std::string &msg) -> natac_bamio::Bam * { err = msg; delete bam; cleanup(); return nullptr; };
     auto give_up = [&]() -> natac_bamio::Bam * { *undecided = true; delete bam; cleanup(); return nullptr; };
-#define BAMDEV_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
-    BAMDEV_HIP(hipHostMalloc((void **)&raw, raw_cap, hipHostMallocDefault));
-    BAMDEV_HIP(d_status.reserve(2 * sizeof(int)));
+// a HIP failure (typically: no memory left for a window on a shared GPU) is not the file's fault: the host decoder answers
+#define BAMDEV_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); *undecided = true; return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    for (int i = 0; i < 2; ++i) {
+        BAMDEV_HIP(hipHostMalloc((void **)&stage[i], STAGE, hipHostMallocDefault));
+        BAMDEV_HIP(hipEventCreateWithFlags(&staged[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < 3; ++i) BAMDEV_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+    BAMDEV_HIP(d_status.reserve(4 * sizeof(int)));
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    }
     const bool timing = getenv("NATAC_BAM_DEV_TIMING") != nullptr;
     double t_read = 0, t_scan = 0, t_inflate = 0, t_walk = 0, t_chain = 0, t_out = 0;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     auto lap = [&](double &acc) { const double t = now(); acc += t - t0; t0 = t; };
-    size_t raw_len = 0;
     unsigned long long pend = 0;       // carried bytes at the front of d_data[cur_buf]
-    bool eof = false, header_done = false, any_block = false;
+    bool header_done = false;
     int32_t n_ref = 0;
-    while (!eof || raw_len > 0) {
-        if (!eof) {
-            const size_t want = raw_cap - raw_len;
-            const size_t got = std::fread(raw + raw_len, 1, want, f);
-            raw_len += got;
-            if (got < want) eof = true;
+    unsigned long long win_start = 0;  // file offset of the window = start of its first member
+    size_t m0 = 0;                     // its first member in the chain
+    for (;;) {
+        // ---- the members of this window: as many as fit window_bytes (at least one), once the chain walk has got that far
+        size_t m1 = m0;
+        {
+            std::unique_lock<std::mutex> lk(chain.mu);
+            chain.cv.wait(lk, [&]() { return chain.done || (!chain.ends.empty() && chain.ends.back() >= win_start + window_bytes); });
+            if (!chain.error.empty()) { const std::string e = chain.error; lk.unlock(); return fail(e); }
+            while (m1 < chain.ends.size() && (m1 == m0 || chain.ends[m1] <= win_start + window_bytes)) ++m1;
+            if (!chain.done && m1 == chain.ends.size()) --m1;          // the last one seen so far still lacks its ISIZE
+            mem.assign(chain.members.begin() + (long)m0, chain.members.begin() + (long)m1);
         }
-        lap(t_read);
-        // ---- complete BGZF members of the window (same checks as the host decoder)
-        mem.clear();
-        size_t o = 0;
+        if (mem.empty()) break;                                         // the whole chain is done
+        unsigned long long win_end;
+        { std::lock_guard<std::mutex> lk(chain.mu); win_end = chain.ends[m1 - 1]; }
         unsigned long long utotal = pend;
-        while (o + 18 <= raw_len) {
-            const unsigned char *h = raw + o;
-            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail("not a BGZF file (bad block header)");
-            const unsigned xlen = rd16(h + 10);
-            if (o + 12 + xlen > raw_len) break;
-            size_t bsize = 0;
-            for (size_t x = 12; x + 4 <= 12 + (size_t)xlen;) {
-                const unsigned slen = rd16(h + x + 2);
-                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)rd16(h + x + 4) + 1;
-                x += 4 + slen;
-            }
-            if (!bsize || bsize < 12 + (size_t)xlen + 8) return fail("truncated BGZF block");
-            if (o + bsize > raw_len) break;
-            const uint32_t isize = rd32(h + bsize - 4);
-            if (isize > 65536) return fail("corrupt BGZF block (ISIZE > 65536)");
-            mem.push_back({(unsigned long long)(o + 12 + xlen), (unsigned int)(bsize - 12 - xlen - 8), isize, utotal});
-            utotal += isize;
-            o += bsize;
-            any_block = true;
-        }
-        if (mem.empty()) {
-            if (eof) {
-                if (raw_len > 0) return fail(any_block ? "trailing bytes after the last BGZF block" : "not a BGZF file (bad block header)");
-                break;
-            }
-            return fail("BGZF block larger than the read window");
-        }
+        for (auto &mb : mem) { mb.coff -= win_start; mb.uoff = utotal; utotal += mb.isize; }
         const int M = (int)mem.size();
         const unsigned long long n = utotal;
+        const size_t o = (size_t)(win_end - win_start);
         lap(t_scan);
-        // ---- upload + inflate
+        // ---- upload (read of one staging buffer next to the copy of the other) + inflate: the members of every SUBWIN bytes that
+        // have arrived are launched on a side stream while the rest of the window is still being read
         BAMDEV_HIP(d_raw.reserve(o + 64));
         BAMDEV_HIP(d_mem.reserve(mem.size() * sizeof(Member)));
         BAMDEV_HIP(d_data[cur_buf].reserve((size_t)n + 64, (size_t)pend, stream));      // the carry at the front stays
-        BAMDEV_HIP(hipMemcpyAsync(d_raw.p, raw, o, hipMemcpyHostToDevice, stream));
-        BAMDEV_HIP(hipMemcpyAsync(d_mem.p, mem.data(), mem.size() * sizeof(Member), hipMemcpyHostToDevice, stream));
-        BAMDEV_HIP(hipMemsetAsync(d_status.p, 0, 2 * sizeof(int), stream));
         unsigned char *data = (unsigned char *)d_data[cur_buf].p;
-        hipLaunchKernelGGL(bamdev_inflate, dim3((M + 63) / 64), dim3(64), 0, stream, (const unsigned char *)d_raw.p, (const Member *)d_mem.p, M, data,
-                           (int *)d_status.p);
+        const size_t SUBWIN = (size_t)512 << 20;
+        const int max_launches = (int)(o / SUBWIN) + 2;
+        BAMDEV_HIP(d_queue.reserve((size_t)max_launches * sizeof(int)));
+        BAMDEV_HIP(hipMemcpyAsync(d_mem.p, mem.data(), mem.size() * sizeof(Member), hipMemcpyHostToDevice, stream));
+        BAMDEV_HIP(hipMemsetAsync(d_status.p, 0, 4 * sizeof(int), stream));
+        BAMDEV_HIP(hipMemsetAsync(d_queue.p, 0, (size_t)max_launches * sizeof(int), stream));
+        {
+            int which = 0, launched = 0, n_launch = 0;
+            size_t since = 0;
+            for (size_t at = 0; at < o; which ^= 1) {
+                const size_t len = std::min(STAGE, o - at);
+                BAMDEV_HIP(hipEventSynchronize(staged[which]));         // the copy that used this buffer last has finished
+                size_t got = 0;
+                while (got < len) {
+                    const ssize_t r = pread(fd, stage[which] + got, len - got, (off_t)(win_start + at + got));
+                    if (r <= 0) return fail("read error");
+                    got += (size_t)r;
+                }
+                BAMDEV_HIP(hipMemcpyAsync((unsigned char *)d_raw.p + at, stage[which], len, hipMemcpyHostToDevice, stream));
+                BAMDEV_HIP(hipEventRecord(staged[which], stream));
+                at += len;
+                since += len;
+                if (since >= SUBWIN || at == o) {
+                    int upto = launched;                                // members that lie completely inside the uploaded bytes
+                    while (upto < M && mem[(size_t)upto].coff + mem[(size_t)upto].csize + 8 <= at) ++upto;
+                    if (at == o) upto = M;
+                    if (upto > launched) {
+                        hipStream_t side = aux[n_launch % 3];
+                        BAMDEV_HIP(hipStreamWaitEvent(side, staged[which], 0));
+                        const int cnt = upto - launched;
+                        hipLaunchKernelGGL(bamdev_inflate, dim3((unsigned)std::min<long long>((cnt + 63) / 64, 3ll * n_cu)), dim3(64), 0, side,
+                                           (const unsigned char *)d_raw.p, (const Member *)d_mem.p, launched, upto, data, (int *)d_status.p,
+                                           (int *)d_queue.p + n_launch);
+                        launched = upto;
+                        ++n_launch;
+                        since = 0;
+                    }
+                }
+            }
+        }
+        lap(t_read);
+        for (int i = 0; i < 3; ++i) BAMDEV_HIP(hipStreamSynchronize(aux[i]));
         int st[2] = {0, 0};
         BAMDEV_HIP(hipMemcpyAsync(st, d_status.p, sizeof st, hipMemcpyDeviceToHost, stream));
         BAMDEV_HIP(hipStreamSynchronize(stream));
         if (st[0] != 0) return fail("inflate failed (corrupt BGZF block)");
-        std::memmove(raw, raw + o, raw_len - o);
-        raw_len -= o;
+        const bool eof = win_end == fsize;
+        const size_t raw_len = 0;          // (no compressed leftover: windows end on member boundaries)
+        win_start = win_end;
+        m0 = m1;
         lap(t_inflate);
         // ---- header (first window): parsed on the host from the front of the inflated bytes
         unsigned long long q0 = 0;
@@ -580,11 +698,11 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
         if (eof && raw_len == 0) break;
     }
     if (timing)
-        std::fprintf(stderr, "[natac_bam_dev] read %.3f s, member scan %.3f, upload + inflate %.3f, walk %.3f, chain %.3f, kept reads + carry %.3f\n", t_read,
+        std::fprintf(stderr, "[natac_bam_dev] read + upload %.3f s, waiting for the member chain %.3f, inflate %.3f, walk %.3f, chain %.3f, kept reads + carry %.3f\n", t_read,
                      t_scan, t_inflate, t_walk, t_chain, t_out);
 #undef BAMDEV_HIP
     cleanup();
-    if (!header_done) { err = any_block ? "truncated BAM header" : "not a BGZF file (bad block header)"; delete bam; return nullptr; }
+    if (!header_done) { err = "truncated BAM header"; delete bam; return nullptr; }
     if (pend != 0) { err = "truncated alignment record"; delete bam; return nullptr; }
     return bam;
 }

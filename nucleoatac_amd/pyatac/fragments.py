@@ -45,7 +45,7 @@ class FragmentStore(object):
         if isinstance(src, FragmentStore) or src in _CACHE or src in _PENDING:
             return
         import threading
-        if os.environ.get("NATAC_DEVICE_BAM", "0") == "1" and str(src).endswith(".bam"):
+        if os.environ.get("NATAC_DEVICE_BAM", "1") != "0" and str(src).endswith(".bam"):
             from .. import get_context
             from ..device import Context
             if Context.device_count() > 0:
@@ -107,18 +107,19 @@ class FragmentStore(object):
 
     @staticmethod
     def from_bam(path, n_threads=0, device=None):
-        """native decoder in libnatac_hip.so: natac_bam_open (parallel BGZF inflate + record walk on the host cores), or -- with
-        device=True / NATAC_DEVICE_BAM=1 -- natac_bam_open_device (csrc/natac_bam_dev.hpp: members inflated and records walked
-        on the GPU).  Both give the same arrays.  Measured on the MI355X box (tools/bench_bam.py, 60 M records, 4.6 GB): host
-        1.70 s with its 64 threads, 6.1 s with 4; device 1.63 s -- the device wins where host threads are scarce, so the
-        default stays the host decoder."""
+        """native decoder in libnatac_hip.so.  On a GPU box: natac_bam_open_device (csrc/natac_bam_dev.hpp) -- the file goes to the
+        device through two pinned staging buffers, every lane of the chip inflates BGZF members from a queue while the rest of
+        the file is still being read, the records are walked on the device and the chain of record starts is confirmed link by
+        link.  Without a GPU, or with device=False / NATAC_DEVICE_BAM=0: natac_bam_open, parallel inflate + record walk on the
+        host cores.  Both give the same arrays.  Measured on the MI355X box (tools/bench_bam.py, 60 M records, 4.6 GB): device
+        0.72 s; host 1.64 s with its 64 threads, 6.1 s with 4."""
         import ctypes as C
         from .. import _lib as L
         lib = L.load()
         h = C.c_void_p()
         if device is None:
             from ..device import Context
-            device = os.environ.get("NATAC_DEVICE_BAM", "0") == "1" and Context.device_count() > 0
+            device = os.environ.get("NATAC_DEVICE_BAM", "1") != "0" and Context.device_count() > 0
         if device:
             from .. import get_context
             on_dev = C.c_int(0)
