@@ -66,3 +66,11 @@ def test_writer_fuzz_slice():
     import fuzz_writer
     done, lines = fuzz_writer.run(12, 21)
     assert done == 12 and lines > 100000
+
+
+def test_bam_fuzz_slice():
+    """a short run of tests/fuzz/fuzz_bam.py: the device BAM decoder against the host decoder on random files"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
+    import fuzz_bam
+    done, on_device = fuzz_bam.run(15, 8)
+    assert done == 15 and on_device == 15
