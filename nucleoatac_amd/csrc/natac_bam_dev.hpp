@@ -508,13 +508,13 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
     size_t m0 = 0;                     // its first member in the chain
     for (;;) {
         // ---- the members of this window: as many as fit window_bytes (at least one), once the chain walk has got that far
+        // (every member the walker has published carries its ISIZE)
         size_t m1 = m0;
         {
             std::unique_lock<std::mutex> lk(chain.mu);
             chain.cv.wait(lk, [&]() { return chain.done || (!chain.ends.empty() && chain.ends.back() >= win_start + window_bytes); });
             if (!chain.error.empty()) { const std::string e = chain.error; lk.unlock(); return fail(e); }
             while (m1 < chain.ends.size() && (m1 == m0 || chain.ends[m1] <= win_start + window_bytes)) ++m1;
-            if (!chain.done && m1 == chain.ends.size()) --m1;          // the last one seen so far still lacks its ISIZE
             mem.assign(chain.members.begin() + (long)m0, chain.members.begin() + (long)m1);
         }
         if (mem.empty()) break;                                         // the whole chain is done
