@@ -30,19 +30,25 @@ def _nfrHelper(arg):
     return out
 
 
-def _batch_insertions(chunks, bam):
-    """InsertionTrack.calculateInsertions (lower 0, upper 2000, tracks.py:164-168) of every chunk in one GPU batch"""
+def _batch_insertions(chunks, bam, as_members=False):
+    """InsertionTrack.calculateInsertions (lower 0, upper 2000, tracks.py:164-168) of every chunk in one GPU batch; with
+    `as_members` also the track as finished BGZF members + its tabix records (Track.write_track + bgzip on the device)"""
     from .. import _lib as L
     from .. import get_context
     from ..pipeline import pack
     pk = pack(chunks, bam)
     b = get_context().upload(pk)
+    z = info = None
     try:
         b.run_ins(0, 2000)
         flat = b.track(L.T_INS).astype(np.float64)
+        if as_members:
+            z, info = b.format_track(L.T_INS, [c.chrom for c in chunks], [c.start for c in chunks], compress=True)
+            if info["hard"]:
+                z = info = None
     finally:
         b.free()
-    return pk.out_off, flat
+    return pk.out_off, flat, z, info
 
 
 def run_nfr(args):
@@ -86,17 +92,27 @@ def run_nfr(args):
     nb = max(1, (len(chunks) + BATCH_CHUNKS - 1) // BATCH_CHUNKS)
     nfr_path = args.out + ".nfrpos.bed" + suffix
     open(nfr_path, "w").close()
+    # one rank: the insertion track leaves the GPU as BGZF members with its tabix records (no formatting on the host, the file is
+    # not read back for the index); several ranks write part files through the host writer, rank 0 indexes the concatenation
+    from ..writer import BGZF_EOF, TbiBuilder
+    from .run_occ import DEVICE_WRITER
+    on_device = make_ins and world == 1 and DEVICE_WRITER
+    tbi = TbiBuilder() if on_device else None
+    ins_bytes = 0
     ph.mark("read_inputs")
     for bi in range(nb):
         part = chunks[bi * BATCH_CHUNKS:(bi + 1) * BATCH_CHUNKS]
         if not part:
+            if tbi is not None:
+                tbi.close()
+                tbi = None
             if make_ins:
                 write_bedgraph(ins_path, [], [], [0], np.zeros(0), append=bi > 0, compress=COMPRESS_LEVEL,
                                finish=(rank == world - 1))
             break
-        off = flat = None
+        off = flat = z = zinfo = None
         if make_ins:
-            off, flat = _batch_insertions(part, args.bam)
+            off, flat, z, zinfo = _batch_insertions(part, args.bam, as_members=on_device)
             ph.mark("insertions_gpu")
         try:
             kc, left, right, vals = nfr_batch(part, params, off, flat)
@@ -108,7 +124,17 @@ def run_nfr(args):
             names = sorted(set(c.chrom for c in part))
             idx = {c: i for i, c in enumerate(names)}
             write_bed_rows(nfr_path, names, np.array([idx[c.chrom] for c in part], dtype=np.int32)[kc], left, right, vals)
-        if make_ins:      # Track.write_track of every chunk's insertion track (run_nfr.py:55-67) through the native writer
+        if make_ins and z is not None and tbi is not None:      # members from the device: append, log the tabix records
+            with open(ins_path, "ab" if bi > 0 else "wb") as fh:
+                fh.write(memoryview(z))
+                if bi == nb - 1:
+                    fh.write(BGZF_EOF)
+            tbi.push(zinfo["index"], ins_bytes)
+            ins_bytes += len(z)
+        elif make_ins:    # Track.write_track of every chunk's insertion track (run_nfr.py:55-67) through the native writer
+            if tbi is not None:           # a sub-batch the device could not format: this file gets its index from the file
+                tbi.close()
+                tbi = None
             write_bedgraph(ins_path, [c.chrom for c in part], [c.start for c in part], off, flat, append=bi > 0,
                            compress=COMPRESS_LEVEL, finish=(bi == nb - 1 and rank == world - 1))
         ph.mark("write_rows_and_ins_track")
@@ -125,6 +151,9 @@ def run_nfr(args):
         ins_path = args.out + ".ins.bedgraph.gz"
     bgzip_file(args.out + ".nfrpos.bed", level=COMPRESS_LEVEL)       # pysam.tabix_compress + tabix_index (run_nfr.py:121-128)
     tabix_index(args.out + ".nfrpos.bed.gz")
-    if make_ins:
+    if make_ins and tbi is not None:
+        tbi.write(ins_path + ".tbi")
+        tbi.close()
+    elif make_ins:
         tabix_index(ins_path)
     ph.mark("bgzip_tabix")

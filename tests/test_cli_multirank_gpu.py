@@ -110,6 +110,15 @@ def test_run_n_ranks_equal_one_rank(tmp_path, ranks):
         assert open(outs[1] + "." + n).read() == open(outs[ranks] + "." + n).read(), n
     assert len(gzip.open(outs[1] + ".nucpos.bed.gz", "rt").read()) > 0
     assert not [f for f in os.listdir(str(tmp_path)) if ".rank" in f]
+    if ranks == 2:
+        # one rank writes nfr's insertion track on the device and builds its .tbi from the device's records: the same index
+        # natac_tabix_index builds by reading the finished file
+        import shutil
+        from nucleoatac_amd.writer import tabix_index
+        copy = str(tmp_path / "ins_copy.bedgraph.gz")
+        shutil.copy(outs[1] + ".ins.bedgraph.gz", copy)
+        tabix_index(copy)
+        assert open(copy + ".tbi", "rb").read() == open(outs[1] + ".ins.bedgraph.gz.tbi", "rb").read()
 
 
 def test_rank0_failure_ends_every_rank(tmp_path):
