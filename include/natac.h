@@ -283,6 +283,12 @@ int natac_bgzf_lines_host(const char *text, int64_t n, const int64_t *line_off, 
 int natac_write_bed_rows(const char *path, int append, int64_t n_rows, const int32_t *chrom_id, const char *const *names,
                          int32_t n_names, const int64_t *start, const int64_t *end, const double *vals, int32_t n_cols);
 
+/* the same with one more text column at the end of every row, labels[label_id[r]] -- the rows of nucmap_combined.bed
+ * (MergedNuc.asBed, nucleoatac/merge.py:23-30: chrom start end occ occ_lower occ_upper reads source) */
+int natac_write_bed_rows_labeled(const char *path, int append, int64_t n_rows, const int32_t *chrom_id, const char *const *names,
+                                 int32_t n_names, const int64_t *start, const int64_t *end, const double *vals, int32_t n_cols,
+                                 const int32_t *label_id, const char *const *labels, int32_t n_labels);
+
 /* bgzip: compress a text file into BGZF members of <= 0xff00 input bytes + the EOF marker (the reference's
  * pysam.tabix_compress, pyatac/utils.py:135-141 / run_nuc.py:204-214). */
 int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads);
@@ -301,7 +307,7 @@ int natac_tbx_read_values(natac_tbx *t, const char *chrom, int64_t start, int64_
                           int64_t *n_records);
 /* the same for n regions in one call (the three occupancy tracks of every chunk of a batch: NucChunk.getOcc,
  * nucleoatac/NucleosomeCalling.py:284-293, NFRChunk.getOcc, NFRCalling.py:63-68): region i = names[chrom_id[i]]:[start[i], end[i]),
- * written to out[out_off[i] ...].  n_threads cursors of the handle take contiguous runs of the list (0 = up to 16); a cursor keeps
+ * written to out[out_off[i] ...].  n_threads cursors of the handle take contiguous runs of the list (0 = up to 64); a cursor keeps
  * the members it inflated last, so position-sorted lists inflate and parse every member once. */
 int natac_tbx_read_regions(natac_tbx *t, int64_t n, const int32_t *chrom_id, const char *const *names, int32_t n_names,
                            const int64_t *start, const int64_t *end, int value_col, double empty, double *out, const int64_t *out_off,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "natac_format_doubles": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp, C.POINTER(_i32)]),
     "natac_bgzf_lines_host": (C.c_int, [C.c_char_p, _i64, _vp, _i64, _vp, _sz, C.POINTER(_i64)]),
     "natac_write_bed_rows": (C.c_int, [C.c_char_p, C.c_int, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]),
+    "natac_write_bed_rows_labeled": (C.c_int, [C.c_char_p, C.c_int, _i64, _vp, _vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_int32]),
     "natac_bgzip_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "natac_tabix_index": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_i64)]),
     "natac_tbx_open": (C.c_int, [C.c_char_p, _pp]),

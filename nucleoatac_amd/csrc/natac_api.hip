@@ -2248,6 +2248,21 @@ int natac_write_bed_rows(const char *path, int append, int64_t n_rows, const int
     return NATAC_OK;
 }
 
+int natac_write_bed_rows_labeled(const char *path, int append, int64_t n_rows, const int32_t *chrom_id, const char *const *names, int32_t n_names,
+                                 const int64_t *start, const int64_t *end, const double *vals, int32_t n_cols, const int32_t *label_id,
+                                 const char *const *labels, int32_t n_labels) {
+    if (!path || n_rows < 0 || n_cols < 0 || n_cols > 32) return fail(NATAC_E_ARG, "bad argument");
+    if (n_rows > 0 && (!chrom_id || !names || !start || !end || (n_cols > 0 && !vals) || !label_id || !labels)) return fail(NATAC_E_ARG, "null argument");
+    for (int64_t r = 0; r < n_rows; ++r) {
+        if (chrom_id[r] < 0 || chrom_id[r] >= n_names) return fail(NATAC_E_ARG, "row %lld: chromosome id %d out of range", (long long)r, chrom_id[r]);
+        if (label_id[r] < 0 || label_id[r] >= n_labels) return fail(NATAC_E_ARG, "row %lld: label id %d out of range", (long long)r, label_id[r]);
+    }
+    const int rc = natac_writer::write_bed_rows(path, append != 0, n_rows, chrom_id, names, start, end, vals, n_cols, label_id, labels);
+    if (rc == 1) return fail(NATAC_E_ARG, "cannot open %s", path);
+    if (rc) return fail(NATAC_E_ARG, "write error on %s", path);
+    return NATAC_OK;
+}
+
 int natac_bgzip_file(const char *src, const char *dst, int level, int n_threads) {
     if (!src || !dst) return fail(NATAC_E_ARG, "null argument");
     if (level < 1 || level > 9) return fail(NATAC_E_ARG, "level must be 1..9");

@@ -295,8 +295,10 @@ inline int write_bedgraph(const char *path, bool append, int compress, bool fini
 // BED-like rows with python-2 float columns: chrom \t start \t end (\t value)* \n -- what OccPeak.asBed / Nucleosome.asBed
 // produce (nucleoatac/Occupancy.py:166-171, NucleosomeCalling.py:195-199), formatted natively for millions of rows.
 // returns 0 ok, 1 cannot open, 2 write error
+// label_id / labels (may be null): one more text column at the end of every row (the 'occ' / 'nuc' source of the combined map)
 inline int write_bed_rows(const char *path, bool append, int64_t n_rows, const int32_t *chrom_id, const char *const *names,
-                          const int64_t *start, const int64_t *end, const double *vals, int n_cols) {
+                          const int64_t *start, const int64_t *end, const double *vals, int n_cols, const int32_t *label_id = nullptr,
+                          const char *const *labels = nullptr) {
     std::string out;
     out.reserve((size_t)n_rows * (32 + (size_t)n_cols * 16) + 64);
     char line[64 + 40 * 32];
@@ -316,6 +318,12 @@ inline int write_bed_rows(const char *path, bool append, int64_t n_rows, const i
             const double v = vals[(size_t)r * n_cols + c];
             if (v != v) { *p++ = 'n'; *p++ = 'a'; *p++ = 'n'; }
             else p = fmt_py2_float(p, v);
+        }
+        if (label_id) {
+            *p++ = '\t';
+            out.append(line, (size_t)(p - line));
+            out.append(labels[label_id[r]]);
+            p = line;
         }
         *p++ = '\n';
         out.append(line, (size_t)(p - line));

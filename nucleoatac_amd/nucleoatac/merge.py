@@ -46,16 +46,23 @@ class NucList(ChunkList):
             raise Exception("source must be 'occ' or 'nuc'")
         opener = gzip.open if bedfile[-3:] == ".gz" else open
         out = NucList()
+        add = list.append                # (ChunkList.append validates every element: 10^5-10^6 rows per genome)
         with opener(bedfile, "rt") as infile:
-            for line in infile:
-                f = line.rstrip("\n").split("\t")
-                start, end = int(f[1]), int(f[2])
-                if source == "occ":
-                    occ, lo, up, reads = float(f[3]), float(f[4]), float(f[5]), float(f[6])
-                else:
-                    occ, lo, up, reads = float(f[4]), float(f[5]), float(f[6]), float(f[10]) + float(f[11])
-                if lo >= min_occ:
-                    out.append(MergedNuc(f[0], start, end, occ, lo, up, reads, source))
+            lines = infile.read().split("\n")
+        if source == "occ":
+            for line in lines:
+                if line:
+                    f = line.split("\t")
+                    lo = float(f[4])
+                    if lo >= min_occ:
+                        add(out, MergedNuc(f[0], int(f[1]), int(f[2]), float(f[3]), lo, float(f[5]), float(f[6]), source))
+        else:
+            for line in lines:
+                if line:
+                    f = line.split("\t")
+                    lo = float(f[5])
+                    if lo >= min_occ:
+                        add(out, MergedNuc(f[0], int(f[1]), int(f[2]), float(f[4]), lo, float(f[6]), float(f[10]) + float(f[11]), source))
         return out
 
 
@@ -65,6 +72,7 @@ def merge(occ_peaks, nuc_calls, sep=120):
     comes first in (chromosome string, position) order is emitted).  A peak within `sep` of the pending call is dropped
     without consuming the call."""
     keep = NucList()
+    add = list.append
     calls = iter(nuc_calls)
     call = next(calls, None)
     for peak in occ_peaks:
@@ -79,14 +87,33 @@ def merge(occ_peaks, nuc_calls, sep=120):
                 ahead = gap > sep
             if not ahead:
                 break
-            keep.append(call)
+            add(keep, call)
             call = next(calls, None)
         if peak is not None:
-            keep.append(peak)
+            add(keep, peak)
     while call is not None:
-        keep.append(call)
+        add(keep, call)
         call = next(calls, None)
     return keep
+
+
+def write_rows(path, rows):
+    """MergedNuc.asBed of every row (merge.py:23-30), formatted natively (natac_write_bed_rows_labeled: python-2 float text) when
+    all four value columns are floats -- what NucList.read produces --, else row by row"""
+    import numpy as np
+    from ..writer import write_bed_rows
+    if not len(rows) or not all(type(v) is float for r in rows for v in (r.occ, r.occ_lower, r.occ_upper, r.reads)):
+        with open(path, "w") as out:
+            out.write(rows.asBed() if isinstance(rows, ChunkList) else "".join(r.asBed() + "\n" for r in rows))
+        return
+    names = sorted(set(r.chrom for r in rows))
+    idx = {c: i for i, c in enumerate(names)}
+    labels = sorted(set(str(r.source) for r in rows))
+    lidx = {c: i for i, c in enumerate(labels)}
+    write_bed_rows(path, names, np.array([idx[r.chrom] for r in rows], dtype=np.int32), np.array([r.start for r in rows], dtype=np.int64),
+                   np.array([r.end for r in rows], dtype=np.int64),
+                   np.array([(r.occ, r.occ_lower, r.occ_upper, r.reads) for r in rows], dtype=np.float64).reshape(-1, 4), append=False,
+                   labels=labels, label_id=np.array([lidx[str(r.source)] for r in rows], dtype=np.int32))
 
 
 def run_merge(args):
@@ -96,8 +123,7 @@ def run_merge(args):
     nuc = NucList.read(args.nucpos, "nuc", float(args.min_occ))
     new = merge(occ, nuc, int(args.sep))
     path = args.out + ".nucmap_combined.bed"
-    with open(path, "w") as out:
-        out.write(new.asBed())
+    write_rows(path, new)
     bgzip_file(path)                       # pysam.tabix_compress + rm + tabix_index (merge.py:107-109)
     tabix_index(path + ".gz")
     return new

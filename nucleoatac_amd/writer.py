@@ -26,9 +26,10 @@ def write_bedgraph(path, chroms, chunk_start, out_off, vals, append=False, compr
     return nb.value
 
 
-def write_bed_rows(path, names, chrom_id, start, end, vals, append=True):
+def write_bed_rows(path, names, chrom_id, start, end, vals, append=True, labels=None, label_id=None):
     """rows `chrom start end v0 v1 ...` with python-2 float text (natac_write_bed_rows): OccPeak.asBed / Nucleosome.asBed lines
-    for whole batches at once.  names: list of chromosome names, chrom_id: index into it per row, vals: (n_rows, n_cols)."""
+    for whole batches at once.  names: list of chromosome names, chrom_id: index into it per row, vals: (n_rows, n_cols);
+    labels / label_id: one more text column at the end (MergedNuc.asBed's source)."""
     lib = L.load()
     chrom_id = np.ascontiguousarray(chrom_id, dtype=np.int32)
     start = np.ascontiguousarray(start, dtype=np.int64)
@@ -38,6 +39,12 @@ def write_bed_rows(path, names, chrom_id, start, end, vals, append=True):
         raise ValueError("inconsistent row arrays")
     arr = (C.c_char_p * max(1, len(names)))(*[str(c).encode("ascii") for c in names])
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    if labels is not None:
+        label_id = np.ascontiguousarray(label_id, dtype=np.int32)
+        larr = (C.c_char_p * max(1, len(labels)))(*[str(c).encode("ascii") for c in labels])
+        L.check(lib.natac_write_bed_rows_labeled(str(path).encode(), 1 if append else 0, len(chrom_id), vp(chrom_id), arr, len(names),
+                                                 vp(start), vp(end), vp(vals), vals.shape[1], vp(label_id), larr, len(labels)))
+        return
     L.check(lib.natac_write_bed_rows(str(path).encode(), 1 if append else 0, len(chrom_id), vp(chrom_id), arr, len(names),
                                      vp(start), vp(end), vp(vals), vals.shape[1]))
 
