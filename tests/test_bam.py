@@ -154,3 +154,19 @@ def test_device_inflate_algorithm_on_the_host():
         g = bytearray(comp)
         g[k] ^= 0xff
         inflate(bytes(g), len(data))
+
+
+def test_prefetch_hands_the_store_or_the_error_to_open(tmp_path):
+    """FragmentStore.prefetch decodes on a thread; FragmentStore.open waits for it and raises what the decode raised"""
+    from helpers import write_bam
+    from nucleoatac_amd.pyatac.fragments import FragmentStore
+    good = str(tmp_path / "g.bam")
+    write_bam(good, [("chrI", 10000)], [(0, 100, 99, 150), (0, 220, 147, -150), (0, 300, 163, 90)])
+    FragmentStore.prefetch(good)
+    st = FragmentStore.open(good)
+    assert st.references == ["chrI"] and list(st.pos["chrI"]) == [100, 300]
+    assert FragmentStore.open(good) is st                    # cached
+    bad = str(tmp_path / "missing.bam")
+    FragmentStore.prefetch(bad)
+    with pytest.raises(Exception, match="cannot open"):
+        FragmentStore.open(bad)
