@@ -342,6 +342,13 @@ int natac_bam_open_device(natac_ctx *ctx, const char *path, natac_bam **out, int
 /* test entry: the device's raw-deflate decoder run on the host (one BGZF member payload -> isize bytes); returns its error code */
 int natac_inflate_raw_host(const void *src, size_t csize, void *out, size_t isize);
 
+/* ---- objective + finite-difference gradient of K Nucleosome.getFuzz fits (host side; reference NucleosomeCalling.py:92-97, 176-184 as
+ * scipy's L-BFGS-B sees them through its numerical differentiation).  nucleoatac/fuzzfit.py advances many fits in lockstep and
+ * calls this once per round.  X0, lb, ub: [K][n] (n = 3, 6 or 9); sig, xs: [K][M] padded; lens[K]; exp_loop / exp_data: numpy's own
+ * inner loop of float64 exp (the values must be numpy's to the last bit: csrc/natac_fuzzfit.hpp); work: (2 n + n / 3 + 1) K M doubles. */
+int natac_fuzz_evaluate(int32_t K, int32_t n, int32_t M, const double *X0, const double *lb, const double *ub, const double *sig,
+                        const double *xs, const int64_t *lens, void *exp_loop, void *exp_data, double *work, double *f, double *g);
+
 /* ---- native FASTA loader (host side): the genome as one upper-case byte array per record, what pyatac/seq.py:11-22 /
  * pyatac/bias.py:85-92 fetch region by region through pysam.FastaFile.  Plain-text FASTA; record names end at the first blank. */
 typedef struct natac_fasta natac_fasta;

@@ -92,6 +92,7 @@ SIGNATURES = {
     "natac_bam_ref_reads": (C.c_int, [_vp, _i32, _vp, _vp, _i64]),
     "natac_bam_open_device": (C.c_int, [_vp, C.c_char_p, _pp, C.POINTER(C.c_int)]),
     "natac_inflate_raw_host": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t]),
+    "natac_fuzz_evaluate": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "natac_fasta_open": (C.c_int, [C.c_char_p, C.c_int, _pp]),
     "natac_fasta_close": (None, [_vp]),
     "natac_fasta_count": (C.c_int, [_vp, C.POINTER(C.c_int32)]),

@@ -14,6 +14,7 @@
 #include "natac_bam.hpp"
 #include "natac_bam_dev.hpp"
 #include "natac_fasta.hpp"
+#include "natac_fuzzfit.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -2388,6 +2389,17 @@ int natac_tbx_read_regions(natac_tbx *t, int64_t n, const int32_t *chrom_id, con
     const int64_t u = natac_tabix::read_regions(t->impl, n, chrom_id, names, n_names, start, end, value_col, empty, out, out_off, n_threads);
     if (u < 0) return fail(NATAC_E_ARG, "read error in the indexed file");
     if (n_records) *n_records = u;
+    return NATAC_OK;
+}
+
+int natac_fuzz_evaluate(int32_t K, int32_t n, int32_t M, const double *X0, const double *lb, const double *ub, const double *sig,
+                        const double *xs, const int64_t *lens, void *exp_loop, void *exp_data, double *work, double *f, double *g) {
+    if (K < 0 || M < 0 || (n != 3 && n != 6 && n != 9)) return fail(NATAC_E_ARG, "n must be 3, 6 or 9");
+    if (K == 0) return NATAC_OK;
+    if (!X0 || !lb || !ub || !sig || !xs || !lens || !exp_loop || !work || !f || !g) return fail(NATAC_E_ARG, "null argument");
+    for (int k = 0; k < K; ++k)
+        if (lens[k] < 0 || lens[k] > M) return fail(NATAC_E_ARG, "fit %d: window length out of range", k);
+    natac_fuzzfit::evaluate(K, n, M, X0, lb, ub, sig, xs, lens, (natac_fuzzfit::ufunc_loop)exp_loop, exp_data, work, f, g);
     return NATAC_OK;
 }
 

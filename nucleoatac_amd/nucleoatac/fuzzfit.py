@@ -152,6 +152,79 @@ def _evaluate(X0, lb, ub, sig, xs, lens, work):
     return f0, ((s[:n] - f0) / dx.T).T
 
 
+NATIVE_EVAL = True      # one native call per round (natac_fuzz_evaluate) instead of ~40 numpy calls, when it gives numpy's bits
+_NATIVE = None          # (lib, exp loop pointer, exp loop data) once checked, False when unavailable
+
+
+def _numpy_exp_loop():
+    """numpy's inner loop for float64 exp: the function pointer and its data stored in the np.exp ufunc object (PyUFuncObject,
+    numpy/ufuncobject.h: PyObject_HEAD, four ints, functions, data, ntypes, reserved1, name, types).  The native evaluator calls
+    it on its own buffer, so the exponentials are numpy's to the last bit."""
+    import ctypes as C
+
+    class UFunc(C.Structure):
+        _fields_ = [("ob_refcnt", C.c_ssize_t), ("ob_type", C.c_void_p), ("nin", C.c_int), ("nout", C.c_int), ("nargs", C.c_int),
+                    ("identity", C.c_int), ("functions", C.POINTER(C.c_void_p)), ("data", C.POINTER(C.c_void_p)), ("ntypes", C.c_int),
+                    ("reserved1", C.c_int), ("name", C.c_char_p), ("types", C.POINTER(C.c_char))]
+    u = UFunc.from_address(id(np.exp))
+    if (u.nin, u.nout, u.nargs, u.name) != (1, 1, 2, b"exp") or not 0 < u.ntypes < 64:
+        raise RuntimeError("np.exp does not look like the ufunc object this was written for")
+    NPY_DOUBLE = 12
+    for i in range(u.ntypes):
+        if ord(u.types[2 * i]) == NPY_DOUBLE and ord(u.types[2 * i + 1]) == NPY_DOUBLE:
+            return u.functions[i], u.data[i]
+    raise RuntimeError("np.exp has no float64 loop")
+
+
+def _native():
+    """(lib, loop, data) of the native evaluator after it reproduced the numpy evaluation bit for bit on random fits, else False"""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            from .. import _lib as L
+            lib = L.load()
+            loop, data = _numpy_exp_loop()
+            cand = (lib, loop, data)
+            rng = np.random.default_rng(0)
+            ok = True
+            for n in (3, 6, 9):
+                K, M = 7, 150
+                lens = np.sort(rng.integers(M - 60, M + 1, K)).astype(np.int64)
+                lens[-1] = M
+                lb = np.tile([4.0, 0.001, 30.0] * (n // 3), (K, 1))
+                ub = np.tile([2500.0, 3.0, 50.0] * (n // 3), (K, 1))
+                X0 = np.clip(np.tile([100.0, 1.5, 40.0] * (n // 3), (K, 1)) * rng.uniform(0.3, 1.2, (K, n)), lb, ub)
+                X0[0, 0], X0[1, 1] = ub[0, 0], lb[1, 1]               # on a bound: the step flips
+                cols = np.arange(M, dtype=np.float64)
+                xs = np.where(cols[None, :] < lens[:, None], cols[None, :], PAD_X)
+                sig = rng.uniform(0, 2, (K, M)) * (cols[None, :] < lens[:, None])
+                work = (np.empty((n + n // 3) * K * M), np.empty((n + 1) * K * M))
+                f0, g0 = _evaluate(X0, lb, ub, sig, xs, lens, work)
+                f1, g1 = _evaluate_native(cand, X0, lb, ub, sig, xs, lens)
+                ok = ok and np.array_equal(f0, f1) and np.array_equal(g0, g1)
+            _NATIVE = cand if ok else False
+        except Exception:      # noqa: BLE001 -- no library, another numpy: the numpy evaluation stays
+            _NATIVE = False
+    return _NATIVE
+
+
+def _evaluate_native(nat, X0, lb, ub, sig, xs, lens):
+    """_evaluate through natac_fuzz_evaluate (csrc/natac_fuzzfit.hpp): the same doubles, one call"""
+    import ctypes as C
+    from .. import _lib as L
+    lib, loop, data = nat
+    K, n = X0.shape
+    M = xs.shape[1]
+    X0, lb, ub, sig, xs = (np.ascontiguousarray(a, dtype=np.float64) for a in (X0, lb, ub, sig, xs))
+    lens = np.ascontiguousarray(lens, dtype=np.int64)
+    work = np.empty((2 * n + n // 3 + 1) * K * M)
+    f, g = np.empty(K), np.empty((K, n))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.check(lib.natac_fuzz_evaluate(K, n, M, vp(X0), vp(lb), vp(ub), vp(sig), vp(xs), vp(lens), C.c_void_p(loop), C.c_void_p(data), vp(work),
+                                    vp(f), vp(g)))
+    return f, g
+
+
 def _run_group(probs, setulb):
     """K fits with the same parameter count to the end; returns x (K, n)"""
     K = len(probs)
@@ -167,12 +240,16 @@ def _run_group(probs, setulb):
     ub = np.array([p[2] for p in probs])
     states = [_State(p[3], p[1], p[2]) for p in probs]
     n = lb.shape[1]
-    work = (np.empty((n + n // 3) * K * M), np.empty((n + 1) * K * M))
+    nat = _native() if NATIVE_EVAL else False
+    work = None if nat else (np.empty((n + n // 3) * K * M), np.empty((n + 1) * K * M))
     active = [k for k in range(K) if _advance(states[k], setulb, factr)]
     while active:
         a = np.array(active)
         X0 = np.array([states[k].x for k in active])
-        f, g = _evaluate(X0, lb[a], ub[a], sig[a], xs[a], lens[a], work)
+        if nat:
+            f, g = _evaluate_native(nat, X0, lb[a], ub[a], sig[a], xs[a], lens[a])
+        else:
+            f, g = _evaluate(X0, lb[a], ub[a], sig[a], xs[a], lens[a], work)
         nxt = []
         for i, k in enumerate(active):
             st = states[k]
