@@ -248,30 +248,6 @@ def fit_fuzz_chunk(task):
     return fit_fuzz_chunks([task])[0]
 
 
-_SHARED_SEQ = [0]
-_SHARED_MAPS = {}
-
-
-def shared_track(values):
-    """write a float64 track to a file in shared memory (/dev/shm, else the temp directory) and return its path: the fit workers map
-    it (fit_fuzz_chunks) instead of receiving a pickled array per task; the caller removes the file when the results are in"""
-    import tempfile
-    root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    _SHARED_SEQ[0] += 1
-    path = os.path.join(root, "natac_smooth_%d_%d.npy" % (os.getpid(), _SHARED_SEQ[0]))
-    np.save(path, np.ascontiguousarray(values, dtype=np.float64))
-    return path
-
-
-def _shared_slice(path, a, e):
-    """values [a, e) of a shared_track file (a worker keeps the mapping of the file it saw last)"""
-    m = _SHARED_MAPS.get(path)
-    if m is None:
-        _SHARED_MAPS.clear()
-        m = _SHARED_MAPS[path] = np.load(path, mmap_mode="r")
-    return np.array(m[a:e], dtype=np.float64)
-
-
 def fit_fuzz_chunks(tasks):
     """the calls of several chunks (the unit of work of the --cores pool): one list of (fuzz, weight, fit_pos) per task.
     The fits of all tasks advance in lockstep (fuzzfit.fit_many: bit-identical to the one-at-a-time path, ~4x faster)."""
@@ -279,7 +255,7 @@ def fit_fuzz_chunks(tasks):
     lock = LOCKSTEP and FAST_FD and fuzzfit.available()
     out, probs = [], []
     for vals, keys, nonredundant_sep, smooth_sd in tasks:
-        vals = _shared_slice(*vals[1:]) if isinstance(vals, tuple) else np.array(vals, dtype=np.float64)
+        vals = np.array(vals, dtype=np.float64)
         keys = [int(k) for k in keys]
         if lock:
             probs += [fuzzfit.problem(vals, keys, k, nonredundant_sep, smooth_sd) for k in keys]

@@ -20,7 +20,7 @@ from ..pyatac.utils import read_chrom_sizes_from_bam, read_chrom_sizes_from_fast
 from ..pyatac.VMat import VMat
 from ..shard import balanced_ranges, barrier, broadcast_object, ensure_distributed, env_rank_world, shared_fragment_store
 from ..writer import bgzip_file, tabix_index, write_bed_rows, write_bedgraph
-from .NucleosomeCalling import NucParameters, fit_fuzz_tasks, nuc_batch, read_occ_tracks_many, shared_track
+from .NucleosomeCalling import NucParameters, fit_fuzz_tasks, nuc_batch, read_occ_tracks_many
 from .run_occ import DEVICE_WRITER, _Phases, _Writer, finish_indexes
 
 LAST_TIMINGS = {}
@@ -75,22 +75,9 @@ def batch_calls(r, params, pool=None, pool_workers=1):
     called = [k for k in range(len(part)) if bounds[k + 1] > bounds[k]]
     # fuzziness fits: one task per chunk with calls (the smoothed values are copied out of the pinned slot), started on the pool
     sm = tr[L.T_SMOOTH]
-    shared = None
-    if pool is not None and len(called) > 1:
-        # the workers map the sub-batch's smoothed track from one file in shared memory: pickling a 2,120-value array per task
-        # through the pool's pipes (70 MB per sub-batch) cost as much as a quarter of the fits
-        shared = shared_track(sm)
-        tasks = [(("shared", shared, int(pk.out_off[k]), int(pk.out_off[k + 1])), kp[int(bounds[k]):int(bounds[k + 1])].astype(np.int64),
-                  params.nonredundant_sep, params.smooth_sd) for k in called]
-    else:
-        tasks = [(sm[int(pk.out_off[k]):int(pk.out_off[k + 1])].copy(), kp[int(bounds[k]):int(bounds[k + 1])].astype(np.int64),
-                  params.nonredundant_sep, params.smooth_sd) for k in called]
-    try:
-        fits = fit_fuzz_tasks(tasks, pool, pool_workers, start_only=True)
-    except BaseException:
-        if shared:
-            os.remove(shared)
-        raise
+    tasks = [(sm[int(pk.out_off[k]):int(pk.out_off[k + 1])].copy(), kp[int(bounds[k]):int(bounds[k + 1])].astype(np.int64),
+              params.nonredundant_sep, params.smooth_sd) for k in called]
+    fits = fit_fuzz_tasks(tasks, pool, pool_workers, start_only=True)
     if params.occ_track is not None and called:
         # meanwhile the three occupancy tracks of every chunk with calls (NucChunk.getOcc, NucleosomeCalling.py:284-293): one native
         # call per file
@@ -99,11 +86,7 @@ def batch_calls(r, params, pool=None, pool_workers=1):
                 a, e = int(bounds[k]), int(bounds[k + 1])
                 for j in range(3):
                     vals[a:e, 1 + j] = res[j][kp[a:e]]
-    try:
-        fits = fits()
-    finally:
-        if shared:
-            os.remove(shared)
+    fits = fits()
     nonred = np.zeros(len(kc), dtype=bool)
     for k, f in zip(called, fits):
         a, e = int(bounds[k]), int(bounds[k + 1])

@@ -234,15 +234,6 @@ def test_lockstep_fits_take_the_optimisers_own_steps():
                 N.fit_fuzz_chunk(flat)
         finally:
             N.LOCKSTEP = True
-    # tasks that name a slice of a track file in shared memory (what run_nuc hands its pool) give the same fits
-    flat = np.concatenate([tk[0] for tk in tasks[:5]])
-    offs = np.r_[0, np.cumsum([len(tk[0]) for tk in tasks[:5]])]
-    path = N.shared_track(flat)
-    try:
-        via_file = N.fit_fuzz_chunks([(("shared", path, int(offs[i]), int(offs[i + 1])),) + tasks[i][1:] for i in range(5)])
-    finally:
-        os.remove(path)
-    assert np.array_equal(np.array([r for c in one[:5] for r in c], dtype=np.float64), np.array([r for c in via_file for r in c], dtype=np.float64))
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(2) as pool:                # the slicing over a --cores pool keeps the task order
         sliced = N.fit_fuzz_tasks(tasks, pool, 2)
