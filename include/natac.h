@@ -349,6 +349,16 @@ int natac_inflate_raw_host(const void *src, size_t csize, void *out, size_t isiz
 int natac_fuzz_evaluate(int32_t K, int32_t n, int32_t M, const double *X0, const double *lb, const double *ub, const double *sig,
                         const double *xs, const int64_t *lens, void *exp_loop, void *exp_data, double *work, double *f, double *g);
 
+/* ---- a (gzipped) BED-like table read into columns (host side): what `nucleoatac merge` parses row by row (nucleoatac/merge.py:36-64).
+ * cols: 0-based indices of the columns parsed as float64 (correctly rounded, like python's float()); column 0 = chromosome (names in
+ * order of first appearance), 1 / 2 = start / end.  BGZF, plain gzip and plain text alike; empty lines are skipped. */
+typedef struct natac_bedtab natac_bedtab;
+int natac_bedtab_open(const char *path, const int32_t *cols, int32_t n_cols, natac_bedtab **out);
+void natac_bedtab_close(natac_bedtab *t);
+int natac_bedtab_dims(natac_bedtab *t, int64_t *n_rows, int32_t *n_names);
+int natac_bedtab_name(natac_bedtab *t, int32_t i, char *name, size_t name_len);
+int natac_bedtab_fetch(natac_bedtab *t, int32_t *chrom_id, int64_t *start, int64_t *end, double *vals);   /* vals: [n_rows][n_cols] */
+
 /* ---- native FASTA loader (host side): the genome as one upper-case byte array per record, what pyatac/seq.py:11-22 /
  * pyatac/bias.py:85-92 fetch region by region through pysam.FastaFile.  Plain-text FASTA; record names end at the first blank. */
 typedef struct natac_fasta natac_fasta;

@@ -93,6 +93,11 @@ SIGNATURES = {
     "natac_bam_open_device": (C.c_int, [_vp, C.c_char_p, _pp, C.POINTER(C.c_int)]),
     "natac_inflate_raw_host": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t]),
     "natac_fuzz_evaluate": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "natac_bedtab_open": (C.c_int, [C.c_char_p, _vp, C.c_int32, _pp]),
+    "natac_bedtab_close": (None, [_vp]),
+    "natac_bedtab_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_int32)]),
+    "natac_bedtab_name": (C.c_int, [_vp, _i32, C.c_char_p, C.c_size_t]),
+    "natac_bedtab_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "natac_fasta_open": (C.c_int, [C.c_char_p, C.c_int, _pp]),
     "natac_fasta_close": (None, [_vp]),
     "natac_fasta_count": (C.c_int, [_vp, C.POINTER(C.c_int32)]),

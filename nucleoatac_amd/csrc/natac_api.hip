@@ -15,6 +15,7 @@
 #include "natac_bam_dev.hpp"
 #include "natac_fasta.hpp"
 #include "natac_fuzzfit.hpp"
+#include "natac_bedtab.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -2400,6 +2401,54 @@ int natac_fuzz_evaluate(int32_t K, int32_t n, int32_t M, const double *X0, const
     for (int k = 0; k < K; ++k)
         if (lens[k] < 0 || lens[k] > M) return fail(NATAC_E_ARG, "fit %d: window length out of range", k);
     natac_fuzzfit::evaluate(K, n, M, X0, lb, ub, sig, xs, lens, (natac_fuzzfit::ufunc_loop)exp_loop, exp_data, work, f, g);
+    return NATAC_OK;
+}
+
+/* ---------------- BED-like table reader ---------------- */
+
+struct natac_bedtab { natac_bedtabio::Table impl; };
+
+int natac_bedtab_open(const char *path, const int32_t *cols, int32_t n_cols, natac_bedtab **out) {
+    if (!path || !out || n_cols < 0 || n_cols > 32 || (n_cols > 0 && !cols)) return fail(NATAC_E_ARG, "bad argument");
+    *out = nullptr;
+    for (int c = 0; c < n_cols; ++c)
+        if (cols[c] < 0 || cols[c] > 4095) return fail(NATAC_E_ARG, "column index out of range");
+    natac_bedtab *t = new natac_bedtab();
+    std::string err;
+    const int rc = natac_bedtabio::load(path, cols, n_cols, &t->impl, err);
+    if (rc) { delete t; return fail(NATAC_E_ARG, "%s: %s", path, err.c_str()); }
+    *out = t;
+    return NATAC_OK;
+}
+
+void natac_bedtab_close(natac_bedtab *t) { delete t; }
+
+int natac_bedtab_dims(natac_bedtab *t, int64_t *n_rows, int32_t *n_names) {
+    if (!t) return fail(NATAC_E_ARG, "table is NULL");
+    if (n_rows) *n_rows = (int64_t)t->impl.chrom_id.size();
+    if (n_names) *n_names = (int32_t)t->impl.names.size();
+    return NATAC_OK;
+}
+
+int natac_bedtab_name(natac_bedtab *t, int32_t i, char *name, size_t name_len) {
+    if (!t || !name) return fail(NATAC_E_ARG, "null argument");
+    if (i < 0 || (size_t)i >= t->impl.names.size()) return fail(NATAC_E_ARG, "name index out of range");
+    const std::string &s = t->impl.names[(size_t)i];
+    if (s.size() + 1 > name_len) return fail(NATAC_E_ARG, "name longer than the buffer");
+    std::memcpy(name, s.c_str(), s.size() + 1);
+    return NATAC_OK;
+}
+
+int natac_bedtab_fetch(natac_bedtab *t, int32_t *chrom_id, int64_t *start, int64_t *end, double *vals) {
+    if (!t) return fail(NATAC_E_ARG, "table is NULL");
+    const size_t n = t->impl.chrom_id.size();
+    if (n && (!chrom_id || !start || !end || (t->impl.n_cols && !vals))) return fail(NATAC_E_ARG, "null argument");
+    if (n) {
+        std::memcpy(chrom_id, t->impl.chrom_id.data(), n * sizeof(int32_t));
+        std::memcpy(start, t->impl.start.data(), n * sizeof(int64_t));
+        std::memcpy(end, t->impl.end.data(), n * sizeof(int64_t));
+        if (t->impl.n_cols) std::memcpy(vals, t->impl.vals.data(), n * (size_t)t->impl.n_cols * sizeof(double));
+    }
     return NATAC_OK;
 }
 

@@ -3,6 +3,8 @@
 import gzip
 import os
 
+import numpy as np
+
 from ..pyatac.chunk import Chunk, ChunkList
 from ..pyatac.tracks import _py2_float_str
 from ..writer import bgzip_file, tabix_index
@@ -44,9 +46,23 @@ class NucList(ChunkList):
         (merge.py:36-64; NaN lower bounds fail the comparison and are dropped like in the reference)"""
         if source not in ("occ", "nuc"):
             raise Exception("source must be 'occ' or 'nuc'")
-        opener = gzip.open if bedfile[-3:] == ".gz" else open
         out = NucList()
         add = list.append                # (ChunkList.append validates every element: 10^5-10^6 rows per genome)
+        try:                             # parsed natively: columns instead of 10^5-10^6 split() / float() rounds
+            from ..writer import read_bed_table
+            names, cid, start, end, v = read_bed_table(bedfile, (3, 4, 5, 6) if source == "occ" else (4, 5, 6, 10, 11))
+        except ImportError:
+            names = None
+        if names is not None:
+            if source == "nuc":
+                v = np.column_stack([v[:, 0], v[:, 1], v[:, 2], v[:, 3] + v[:, 4]])
+            with np.errstate(invalid="ignore"):
+                keep = v[:, 1] >= min_occ                       # NaN lower bounds fail the comparison
+            chrom = [names[i] for i in cid[keep].tolist()]
+            for c, s, e, (o, lo, up, rd) in zip(chrom, start[keep].tolist(), end[keep].tolist(), v[keep].tolist()):
+                add(out, MergedNuc(c, s, e, o, lo, up, rd, source))
+            return out
+        opener = gzip.open if bedfile[-3:] == ".gz" else open
         with opener(bedfile, "rt") as infile:
             lines = infile.read().split("\n")
         if source == "occ":

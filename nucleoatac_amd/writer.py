@@ -49,6 +49,30 @@ def write_bed_rows(path, names, chrom_id, start, end, vals, append=True, labels=
                                      vp(start), vp(end), vp(vals), vals.shape[1]))
 
 
+def read_bed_table(path, cols):
+    """(names, chrom_id, start, end, vals[n_rows, len(cols)]) of a (gzipped) BED-like file, parsed natively (natac_bedtab_*): column 0
+    = chromosome, 1 / 2 = start / end, `cols` = 0-based columns read as float64 with python's float() rounding"""
+    lib = L.load()
+    c = np.ascontiguousarray(cols, dtype=np.int32)
+    h = C.c_void_p()
+    L.check(lib.natac_bedtab_open(str(path).encode(), c.ctypes.data_as(C.c_void_p), len(c), C.byref(h)))
+    try:
+        n, nn = C.c_int64(0), C.c_int32(0)
+        L.check(lib.natac_bedtab_dims(h, C.byref(n), C.byref(nn)))
+        names = []
+        for i in range(nn.value):
+            buf = C.create_string_buffer(4096)
+            L.check(lib.natac_bedtab_name(h, i, buf, 4096))
+            names.append(buf.value.decode())
+        cid, start, end = np.empty(n.value, np.int32), np.empty(n.value, np.int64), np.empty(n.value, np.int64)
+        vals = np.empty((n.value, len(c)), np.float64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.check(lib.natac_bedtab_fetch(h, vp(cid), vp(start), vp(end), vp(vals)))
+    finally:
+        lib.natac_bedtab_close(h)
+    return names, cid, start, end, vals
+
+
 def bgzip_file(src, dst=None, level=4, n_threads=0, remove=True):
     """BGZF-compress a text file (pysam.tabix_compress of the reference); returns the path of the .gz"""
     import os
