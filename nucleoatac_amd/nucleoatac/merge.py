@@ -132,9 +132,76 @@ def write_rows(path, rows):
                    labels=labels, label_id=np.array([lidx[str(r.source)] for r in rows], dtype=np.int32))
 
 
+def _table(bedfile, source, min_occ):
+    """(chromosome per row, start, end, [occ, occ_lower, occ_upper, reads]) of the rows NucList.read keeps, as columns"""
+    from ..writer import read_bed_table
+    names, cid, start, end, v = read_bed_table(bedfile, (3, 4, 5, 6) if source == "occ" else (4, 5, 6, 10, 11))
+    if source == "nuc":
+        v = np.column_stack([v[:, 0], v[:, 1], v[:, 2], v[:, 3] + v[:, 4]])
+    with np.errstate(invalid="ignore"):
+        keep = v[:, 1] >= min_occ
+    return [names[i] for i in cid[keep].tolist()], start[keep], end[keep], v[keep]
+
+
+def merge_columns(occ, nuc, sep=120):
+    """`merge` on columns: (source, row) of every surviving row in output order, from the chromosome and start columns alone --
+    the same walk as merge() without an object per row"""
+    pc, ps = occ[0], occ[1].tolist()
+    cc, cs = nuc[0], nuc[1].tolist()
+    out_src, out_row = [], []
+    j, nj = 0, len(cs)
+    for i in range(len(ps)):
+        chrom, x = pc[i], ps[i]
+        shadowed = False
+        while j < nj:
+            if chrom != cc[j]:
+                ahead = cc[j] < chrom
+            else:
+                gap = x - cs[j]
+                if -sep <= gap <= sep:
+                    shadowed = True
+                    break
+                ahead = gap > sep
+            if not ahead:
+                break
+            out_src.append(1)
+            out_row.append(j)
+            j += 1
+        if not shadowed:
+            out_src.append(0)
+            out_row.append(i)
+    out_src += [1] * (nj - j)
+    out_row += list(range(j, nj))
+    return np.array(out_src, dtype=np.int32), np.array(out_row, dtype=np.int64)
+
+
 def run_merge(args):
     if not args.out:
         args.out = ".".join(os.path.basename(args.nucpos).split(".")[0:-3])
+    path = args.out + ".nucmap_combined.bed"
+    try:
+        occ_t = _table(args.occpeaks, "occ", float(args.min_occ))
+        nuc_t = _table(args.nucpos, "nuc", float(args.min_occ))
+    except ImportError:
+        occ_t = None
+    if occ_t is not None:
+        # columns in, columns out: no object per row (10^5-10^6 rows per genome); the rows are MergedNuc.asBed's
+        from ..writer import write_bed_rows
+        src, row = merge_columns(occ_t, nuc_t, int(args.sep))
+        is_occ = src == 0
+        chrom = np.empty(len(src), dtype=object)
+        chrom[is_occ] = np.array(occ_t[0], dtype=object)[row[is_occ]] if is_occ.any() else []
+        chrom[~is_occ] = np.array(nuc_t[0], dtype=object)[row[~is_occ]] if (~is_occ).any() else []
+        names = sorted(set(chrom.tolist()))
+        idx = {c: i for i, c in enumerate(names)}
+        start, end, vals = np.empty(len(src), np.int64), np.empty(len(src), np.int64), np.empty((len(src), 4))
+        for m, t in ((is_occ, occ_t), (~is_occ, nuc_t)):
+            start[m], end[m], vals[m] = t[1][row[m]], t[2][row[m]], t[3][row[m]]
+        write_bed_rows(path, names, np.array([idx[c] for c in chrom.tolist()], dtype=np.int32), start, end, vals, append=False,
+                       labels=["occ", "nuc"], label_id=src)
+        bgzip_file(path)
+        tabix_index(path + ".gz")
+        return None
     occ = NucList.read(args.occpeaks, "occ", float(args.min_occ))
     nuc = NucList.read(args.nucpos, "nuc", float(args.min_occ))
     new = merge(occ, nuc, int(args.sep))
