@@ -26,7 +26,8 @@ MAXFUN = 15000
 MAXITER = 15000
 MAXLS = 20
 FD_STEP = 1e-8                   # absolute 2-point step of approx_derivative as L-BFGS-B calls it
-GROUP = 192                      # fits advanced together (the (GROUP, n + 1, M) temporaries stay cache-sized)
+import os
+GROUP = int(os.environ.get("NATAC_FIT_GROUP", "192"))   # fits advanced together (the (GROUP, n + 1, M) temporaries stay cache-sized)
 PAD_X = 1e9                      # abscissa of the padding columns: exp(-(1e9 - mean)^2 / 2v) == 0 < every row maximum
 
 
