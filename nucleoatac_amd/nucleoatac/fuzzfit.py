@@ -60,33 +60,29 @@ def problem(vals, allnucs, index, nonredundant_sep, smooth_sd):
 
 class _State(object):
     """workspace of one L-BFGS-B run (the arrays _minimize_lbfgsb allocates)"""
-    __slots__ = ("x", "f", "g", "lb", "ub", "nbd", "wa", "iwa", "task", "ln_task", "lsave", "isave", "dsave", "nit", "nreq", "redo")
+    __slots__ = ("x", "task", "args", "nit", "nreq", "redo")
 
     def __init__(self, guess, lb, ub):
         n, m = len(guess), M_CORR
-        self.lb, self.ub = lb, ub
         self.x = np.array(np.clip(guess, lb, ub), dtype=np.float64)
-        self.f = 0.0
-        self.g = np.zeros(n, dtype=np.float64)
-        self.nbd = np.full(n, 2, dtype=np.int32)         # both bounds finite
-        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, dtype=np.float64)
-        self.iwa = np.zeros(3 * n, dtype=np.int32)
         self.task = np.zeros(2, dtype=np.int32)
-        self.ln_task = np.zeros(2, dtype=np.int32)
-        self.lsave = np.zeros(4, dtype=np.int32)
-        self.isave = np.zeros(44, dtype=np.int32)
-        self.dsave = np.zeros(29, dtype=np.float64)
+        # setulb's argument list, built once: (m, x, l, u, nbd [both bounds finite], f, g, factr, pgtol, wa, iwa, task, lsave, isave,
+        # dsave, maxls, ln_task); slots 5 and 6 take the objective and gradient of every round
+        self.args = [m, self.x, lb, ub, np.full(n, 2, dtype=np.int32), 0.0, np.zeros(n, dtype=np.float64), FTOL / np.finfo(float).eps, GTOL,
+                     np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, dtype=np.float64), np.zeros(3 * n, dtype=np.int32), self.task,
+                     np.zeros(4, dtype=np.int32), np.zeros(44, dtype=np.int32), np.zeros(29, dtype=np.float64), MAXLS,
+                     np.zeros(2, dtype=np.int32)]
         self.nit = 0
         self.nreq = 0            # f, g requests so far: an upper bound of scipy's nfev (ScalarFunction does not count a repeated point)
         self.redo = False        # the evaluation / iteration limits came into reach: this fit is repeated through scipy.optimize.minimize
 
 
-def _advance(st, setulb, factr):
+def _advance(st, setulb, factr=None):
     """run the optimiser until it asks for f, g (True) or stops (False) -- the `while True` of _minimize_lbfgsb"""
+    args, task = st.args, st.task
     while True:
-        setulb(M_CORR, st.x, st.lb, st.ub, st.nbd, st.f, st.g, factr, GTOL, st.wa, st.iwa, st.task, st.lsave, st.isave,
-               st.dsave, MAXLS, st.ln_task)
-        t = st.task[0]
+        setulb(*args)
+        t = task[0]
         if t == 3:
             st.nreq += 1
             return True
@@ -254,9 +250,9 @@ def _run_group(probs, setulb):
         nxt = []
         for i, k in enumerate(active):
             st = states[k]
-            st.f = f[i]
-            st.g = np.ascontiguousarray(g[i])
-            if _advance(st, setulb, factr):
+            st.args[5] = f[i]
+            st.args[6] = np.ascontiguousarray(g[i])
+            if _advance(st, setulb):
                 nxt.append(k)
         active = nxt
     x = np.array([st.x for st in states])
