@@ -160,3 +160,77 @@ def write_cli_dataset(out_dir, n_chunks, chunk_len=2120, frags_per_chunk=500, se
         farr["seq_" + c] = acgt[rng.integers(0, 4, size=chrom_len)]
     np.savez(fa, **farr)
     return bed, bam, fa
+
+
+def cli_dataset_as_real_files(bam_npz, fa_npz, out_dir, level=1):
+    """The stand-in inputs of write_cli_dataset as REAL files: `reads.bam` (coordinate-sorted; every fragment as a forward first
+    read, FLAG 99, and its reverse mate, FLAG 147, 50-base reads with names / sequence / qualities of realistic size; BGZF members of
+    0xff00 bytes) and `genome.fa` (60 columns per line).  Returns (bam, fasta)."""
+    import os
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    d = np.load(bam_npz, allow_pickle=False)
+    names = [str(c) for c in d["chrom_names"]]
+    lens = [int(x) for x in d["chrom_lengths"]]
+    text = b"@HD\tVN:1.0\tSO:coordinate\n"
+    head = [b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(names))]
+    for c, n in zip(names, lens):
+        nm = c.encode() + b"\0"
+        head.append(struct.pack("<i", len(nm)) + nm + struct.pack("<i", n))
+    seq_len, name_len = 50, 20
+    rec = np.dtype([("bs", "<i4"), ("ref", "<i4"), ("pos", "<i4"), ("lname", "u1"), ("mapq", "u1"), ("bin", "<u2"), ("ncig", "<u2"),
+                    ("flag", "<u2"), ("lseq", "<i4"), ("nref", "<i4"), ("npos", "<i4"), ("tlen", "<i4"), ("name", "S%d" % name_len),
+                    ("cigar", "<u4"), ("seq", "u1", (seq_len + 1) // 2), ("qual", "u1", seq_len)])
+    rng = np.random.default_rng(1)
+    bam = os.path.join(out_dir, "reads.bam")
+    pool = ThreadPoolExecutor(min(64, os.cpu_count() or 4))
+
+    def member(chunk):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        return (bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", 18 + len(comp) + 8 - 1) + comp +
+                struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+
+    with open(bam, "wb") as fh:
+        carry = b"".join(head)
+        serial = 0
+        for ri, c in enumerate(names):
+            p, t = d["pos_" + c].astype(np.int64), d["tlen_" + c].astype(np.int64)
+            n = len(p)
+            a = np.zeros(2 * n, dtype=rec)
+            a["bs"] = rec.itemsize - 4
+            a["ref"] = a["nref"] = ri
+            a["lname"], a["mapq"], a["ncig"], a["lseq"], a["cigar"] = name_len, 30, 1, seq_len, seq_len << 4
+            mate = np.maximum(p + t - seq_len, 0)
+            a["pos"][:n], a["pos"][n:] = p, mate
+            a["npos"][:n], a["npos"][n:] = mate, p
+            a["flag"][:n], a["flag"][n:] = 99, 147
+            a["tlen"][:n], a["tlen"][n:] = t, -t
+            ids = np.arange(serial, serial + n)
+            serial += n
+            a["name"][:n] = a["name"][n:] = np.char.add(b"frag", ids.astype("S15"))
+            a["seq"] = rng.integers(0, 256, (2 * n, (seq_len + 1) // 2), dtype=np.uint8)
+            a["qual"] = rng.integers(20, 41, (2 * n, seq_len), dtype=np.uint8)
+            a = a[np.argsort(a["pos"], kind="stable")]
+            data = carry + a.tobytes()
+            cut = len(data) - len(data) % 0xff00 if ri + 1 < len(names) else len(data)
+            for m in pool.map(member, [data[o:o + 0xff00] for o in range(0, cut, 0xff00)]):
+                fh.write(m)
+            carry = data[cut:]
+        fh.write(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+    pool.shutdown()
+    g = np.load(fa_npz, allow_pickle=False)
+    fa = os.path.join(out_dir, "genome.fa")
+    with open(fa, "wb") as fh:
+        for c in g["chrom_names"]:
+            sq = g["seq_" + str(c)]
+            fh.write(b">" + str(c).encode() + b"\n")
+            full = len(sq) // 60 * 60
+            lines = np.empty((full // 60, 61), dtype=np.uint8)
+            lines[:, :60] = sq[:full].reshape(-1, 60)
+            lines[:, 60] = 10
+            fh.write(lines.tobytes())
+            if full < len(sq):
+                fh.write(sq[full:].tobytes() + b"\n")
+    return bam, fa

@@ -1,5 +1,6 @@
 """`nucleoatac occ` end to end on N chunks of the configs[2] workload written as input files (bench.py's cli_end_to_end runs the
-10,000-chunk slice; this runs any size, occ only):  python tools/e2e_occ.py 100000 [/dev/shm]"""
+10,000-chunk slice; this runs any size, occ only):  python tools/e2e_occ.py 100000 [/dev/shm] [real]
+`real`: the inputs are a real coordinate-sorted .bam (two 50-base reads per fragment) and a text .fa instead of the .npz stand-ins."""
 import contextlib
 import json
 import os
@@ -22,6 +23,10 @@ def main():
     try:
         t0 = time.perf_counter()
         bed, bam, fa = write_cli_dataset(d, n, 2120, 500, seed=0)
+        real = len(sys.argv) > 3 and sys.argv[3] == "real"
+        if real:
+            from nucleoatac_amd.synth import cli_dataset_as_real_files
+            bam, fa = cli_dataset_as_real_files(bam, fa, d)
         t_gen = time.perf_counter() - t0
         out = os.path.join(d, "e2e")
         with contextlib.redirect_stdout(sys.stderr):
@@ -31,7 +36,7 @@ def main():
         size = sum(os.path.getsize(out + "." + x + ".bedgraph.gz") for x in ("occ", "occ.lower_bound", "occ.upper_bound"))
         print(json.dumps(dict(chunks=n, bp=n * 2120, occ_seconds=round(dt, 2), occ_mbp_s=round(n * 2120 / dt / 1e6, 2), phases_s=dict(ro.LAST_TIMINGS),
                               track_bytes=size, write_gb_s=round(size / dt / 1e9, 2), out_dir=d, generate_inputs_s=round(t_gen, 1),
-                              device_writer=ro.DEVICE_WRITER)))
+                              device_writer=ro.DEVICE_WRITER, inputs="real .bam (%.2f GB) + .fa" % (os.path.getsize(bam) / 1e9) if real else ".npz stand-ins")))
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
