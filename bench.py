@@ -425,12 +425,21 @@ def cli_end_to_end(n_chunks, cores, seed=0):
             t_nfr = time.perf_counter() - t0
             from nucleoatac_amd.nucleoatac import run_nfr as _rf
             nfr_phases = dict(_rf.LAST_TIMINGS)
+            # `occ` once more from REAL input files: a coordinate-sorted .bam (both mates of every fragment) and a text .fa
+            from nucleoatac_amd.synth import cli_dataset_as_real_files
+            rbam, rfa = cli_dataset_as_real_files(bam, fa, d)
+            t0 = time.perf_counter()
+            cli_main(["occ", "--bed", bed, "--bam", rbam, "--fasta", rfa, "--out", out + "_real", "--cores", str(cores)])
+            t_occ_real = time.perf_counter() - t0
+            real = dict(occ_seconds=round(t_occ_real, 2), occ_mbp_s=round(bp / t_occ_real / 1e6, 2), bam_gb=round(os.path.getsize(rbam) / 1e9, 3),
+                        read_bam_s=_ro.LAST_TIMINGS.get("read_bam"), note="the same windows from a real .bam (BGZF members inflated and records "
+                        "walked on the GPU) and a text .fa (native loader) instead of the .npz stand-ins")
         size = lambda suffix: os.path.getsize(out + suffix)
         n_calls = sum(1 for _ in __import__("gzip").open(out + ".nucpos.bed.gz", "rt"))
         return dict(occ_mbp_s=round(bp / t_occ / 1e6, 2), nuc_mbp_s=round(bp / t_nuc / 1e6, 3), cores=cores, chunks=n_chunks, bp=bp,
                     occ_seconds=round(t_occ, 2), nuc_seconds=round(t_nuc, 2), merge_seconds=round(t_merge, 2), nfr_seconds=round(t_nfr, 2),
                     run_mbp_s=round(bp / (t_occ + t_nuc + t_merge + t_nfr) / 1e6, 3), nucleosome_calls=n_calls,
-                    occ_phases_s=occ_phases, nuc_phases_s=nuc_phases, nfr_phases_s=nfr_phases,
+                    occ_phases_s=occ_phases, nuc_phases_s=nuc_phases, nfr_phases_s=nfr_phases, real_inputs=real,
                     occ_track_bytes=sum(size("." + n + ".bedgraph.gz") for n in ("occ", "occ.lower_bound", "occ.upper_bound")),
                     nuc_track_bytes=sum(size("." + n + ".bedgraph.gz") for n in ("nucleoatac_signal", "nucleoatac_signal.smooth")),
                     out_dir=os.path.dirname(d) or "/tmp",

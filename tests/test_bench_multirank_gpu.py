@@ -43,6 +43,7 @@ def test_single_rank_default_contract():
     assert "PipelinedExecutor" in h["executor"]                 # the product's executor, not a bench-only harness
     e = d["cli_end_to_end"]          # `nucleoatac occ` / `nuc` from input files to .bedgraph.gz + .tbi
     assert e["chunks"] == 400 and e["occ_mbp_s"] > 0 and e["nuc_mbp_s"] > 0 and e["nucleosome_calls"] > 0 and e["cores"] >= 1
+    assert e["real_inputs"]["occ_mbp_s"] > 0 and e["real_inputs"]["bam_gb"] > 0      # the same windows from a real .bam + .fa
     ts = d["roofline"]["traffic_source"]
     assert ts is None or set(("file", "collected_at_source_sha16", "current_source_sha16", "stale")) <= set(ts)
 
