@@ -64,6 +64,24 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert not left, left
 
 
+def test_two_ranks_from_a_real_bam_equal_one_rank_from_the_stand_in(tmp_path):
+    """`occ` + `nuc` under two ranks from a REAL .bam: rank 0 decodes it on the GPU (natac_bam_open_device) and shares the arrays
+    through /dev/shm, both ranks take their part of the chunk list -- the tracks equal the one-rank run from the .npz stand-in"""
+    from nucleoatac_amd.synth import cli_dataset_as_real_files
+    bed, bam, fa, sizes, vm = _inputs(tmp_path)
+    fa_npz = str(tmp_path / "fa.npz")
+    seq = open(fa).read().split("\n")[1]
+    np.savez(fa_npz, chrom_names=np.array(["chrS"]), **{"seq_chrS": np.frombuffer(seq.encode(), dtype=np.uint8)})
+    real_bam, _ = cli_dataset_as_real_files(bam, fa_npz, str(tmp_path))
+    _run(1, str(tmp_path / "one"), bed, bam, fa, sizes, vm)
+    _run(2, str(tmp_path / "two"), bed, real_bam, fa, sizes, vm)
+    for n in ("occ.bedgraph.gz", "occ.upper_bound.bedgraph.gz", "nucleoatac_signal.bedgraph.gz", "nucpos.bed.gz"):
+        a = gzip.open(str(tmp_path / "one") + "." + n, "rt").read()
+        b = gzip.open(str(tmp_path / "two") + "." + n, "rt").read()
+        assert a == b and len(a) > 0, n
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("natac_frags_")]
+
+
 def test_nuc_cores_pool_equals_serial(tmp_path):
     """--cores N farms the per-nucleosome L-BFGS fits out to spawned host processes: outputs identical to --cores 1"""
     bed, bam, fa, sizes, vm = _inputs(tmp_path)
