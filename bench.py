@@ -71,7 +71,9 @@ def parse():
     ap.add_argument("--h2h-threads", type=int, default=6, help="contexts (host threads) of the host-to-host pipeline")
     ap.add_argument("--cli-chunks", type=int, default=10000, help="chunks of the CLI end-to-end measurement (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
+                    help="barrier backend.  The path has no collective (chunks are independent), so the default control plane is gloo + a "
+                         "device synchronise per rank; nccl additionally forms an RCCL group (probed, used only if every rank has it)")
     ap.add_argument("--share-device", action="store_true",
                     help="functional test of the N>1 path on a 1-GPU box: every rank uses GPU 0 (use with --dist-backend gloo)")
     return ap.parse_args()
@@ -228,6 +230,39 @@ def pmc_traffic_bytes(kernel_substr):
     return (f + w) * 1024.0
 
 
+def pmc_step_traffic():
+    """HBM bytes of ONE STEP over ALL kernels of the newest committed PMC summary: sum of FETCH_SIZE and WRITE_SIZE (KiB) of the last
+    dispatch of every kernel -- raw, and with the guide's x2 on FETCH_SIZE (MI355X_MICROARCH.md: gfx950 under-counts wide streaming
+    reads 2x; an upper bound for kernels that read 8 bytes per lane)"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.csv")))
+    if not files:
+        return None
+    f = w = 0.0
+    with open(files[-1]) as fh:
+        for row in csv.reader(l for l in fh if not l.startswith("#")):
+            if len(row) == 4 and row[1] in ("FETCH_SIZE", "WRITE_SIZE") and row[0].lstrip('"').startswith(("natac::", "void natac::")):
+                v = float(row[2]) / float(row[3]) * 1024.0
+                if row[1] == "FETCH_SIZE":
+                    f += v
+                else:
+                    w += v
+    return dict(fetch_bytes=f, write_bytes=w) if (f or w) else None
+
+
+def reference_calibration():
+    """reference vs port seconds per chunk on identical inputs (tests/golden/calibrate_cpu_baseline.py, build container)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "cpu_baseline_calibration.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    d["file"] = os.path.relpath(files[-1], ROOT)
+    return d
+
+
 def pmc_valu_issue():
     """{kernel: share of the SIMDs' issue cycles spent on VALU instructions} for the heavy kernels, from the newest committed PMC
     summary: SQ_INSTS_VALU (wave-instructions) x 4 cycles (a wave64 fp64 / fp32 instruction occupies its SIMD for 4 cycles) over
@@ -266,7 +301,10 @@ def make_workload(a, rank, world):
             desc = ("configs[4]: one independent synthetic sample per rank (own seed), %d windows x 2 kb (L=%d), %d fragments, default VMat; "
                     "fp64 multinomial_cov tolerance sweep at the candidates of 200 chunks after the timed steps")
         elif a.workload == "cfg3":
-            pk = make_synthetic_chunks(nc, L, F, seed=a.seed + 1000 * rank)
+            if world == 1:
+                pk = make_synthetic_chunks(nc, L, F, seed=a.seed)
+            else:       # N ranks share one host's cores: counter-seeded blocks on a few threads each (numpy releases the GIL)
+                pk = _blocks_threaded(nc, L, F, [a.seed, 1000 + rank], max(1, min(4, _effective_cores() // world)))
             desc = "configs[2]: synthetic %d windows x 2 kb (L=%d after slop), %d fragments, default VMat 146x121, 1 GPU-shard per rank"
         else:
             counts = fragment_counts(nc, F, seed=a.seed + 1000 * rank, hot_frac=0.01, hot_mult=10)
@@ -300,6 +338,18 @@ def make_workload(a, rank, world):
     desc = ("configs[3]: %d tiles x 10 kb (L=%d), %d fragments (Poisson(%d) per tile), chunk list sharded across %d rank(s) by "
             "sum(L) + 4 sum(F), sub-batches of <= %d chunks" % (nc, L, int(counts.sum()), F, world, a.sub_chunks))
     return subs, desc, dict(scaling="strong", imbalance=imb, total_chunks=nc)
+
+
+def _blocks_threaded(nc, L, F, seed, n_threads, block=5000):
+    """a configs[2]-shaped shard from counter-seeded blocks of `block` chunks, generated on n_threads threads"""
+    from concurrent.futures import ThreadPoolExecutor
+    from nucleoatac_amd.synth import make_synthetic_chunks
+    starts = list(range(0, nc, block))
+    gen = lambda b0: make_synthetic_chunks(min(block, nc - b0), L, F, seed=list(seed) + [b0 // block], first_chunk=b0)
+    if n_threads <= 1:
+        return _concat([gen(b0) for b0 in starts])
+    with ThreadPoolExecutor(n_threads) as ex:
+        return _concat(list(ex.map(gen, starts)))
 
 
 def _concat(parts):
@@ -483,6 +533,14 @@ def main():
         cpu = cpu_baseline(subs[0], par, sizes, nucp, nfrp, a.cpu_chunks, a.cpu_literal_chunks)
 
     ctx = setup_ctx(local_rank, par, sizes, nucp, nfrp)
+    hip_dev, pci = ctx.device_ids()
+    if dist is not None:
+        # every rank must own a GPU of its own unless --share-device says otherwise: checked before any timing
+        ids = [None] * world
+        dist.all_gather_object(ids, (rank, local_rank, hip_dev, pci, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
+        if not a.share_device and len({i[3] for i in ids}) < world:
+            raise SystemExit("bench.py: ranks share a GPU (rank, local_rank, hip device, pci bus id, HIP_VISIBLE_DEVICES, "
+                             "ROCR_VISIBLE_DEVICES): %s -- launch one rank per GPU or pass --share-device" % (ids,))
     from nucleoatac_amd.executor import ResidentShard
     t_up = time.time()
     # outputs of every sub-batch stay resident if they fit (~175 B per base incl. internal arrays); else they are recycled
@@ -526,11 +584,24 @@ def main():
         rows = [None] * world
         dist.all_gather_object(rows, dict(rank=rank, generate_s=round(t_gen, 2), upload_s=round(t_up, 2),
                                           ms_per_step=round(my_dt / a.steps * 1e3, 3), bp=my_bp, fragments=my_frags,
-                                          device=local_rank))
+                                          device=local_rank, hip_device=hip_dev, pci_bus_id=pci))
         per_rank = rows
     prof = ctx.profile()
     ms_per_step = dt / a.steps * 1e3
     value = total_bp * a.steps / dt / 1e6
+    # one more (untimed) step under the shader-clock sampler: the clock every kernel class really ran at (fp64-dense kernels pull
+    # the chip below its 2.4 GHz; peaks quoted at 2.4 GHz are not reachable by them)
+    clocks = None
+    if rank == 0 and not recycle:
+        try:
+            ctx.clock_trace_start(max_samples=20000, interval_us=50)
+            step()
+            ctx.sync()
+            tr = ctx.clock_trace_stop()
+            clocks = {k: round(v, 3) for k, v in tr["per_kernel"].items()}
+            clocks["light_load_max"] = round(float(np.nanmax(tr["ghz"])), 3) if len(tr["ghz"]) else None
+        except Exception as e:      # noqa: BLE001 -- a measurement aid must not cost the line
+            clocks = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # PCIe-inclusive figure of a resident batch (never `value`): one upload + one download of the per-base tracks that the
     # writers consume, pageable memory, no overlap -- the pipelined host-to-host rate follows below
@@ -601,17 +672,41 @@ def main():
         if valu:
             hit = [v["valu_issue_frac"] for k, v in valu.items() if KERNEL_SYMBOL[dom] in k]
             dom_issue = max(hit) if hit else None
+        st = pmc_step_traffic() if a.workload == "cfg3" else None
+        step_alg = ALG_BYTES_PER_BP[a.workload] * my_bp
+        step_traffic = None
+        if st:
+            raw, x2 = st["fetch_bytes"] + st["write_bytes"], 2 * st["fetch_bytes"] + st["write_bytes"]
+            step_traffic = {"fetch_plus_write_bytes": raw, "with_fetch_x2_bytes": x2, "algorithmic_bytes": step_alg,
+                            "ratio_raw": round(raw / step_alg, 3), "ratio_fetch_x2": round(x2 / step_alg, 3),
+                            "note": "sum over ALL kernels of one step (committed rocprofv3 --pmc passes, see traffic_source); "
+                                    "algorithmic = %.1f B/bp x the step's bases" % ALG_BYTES_PER_BP[a.workload]}
+        fp64_bound = dom == "background"
         out = {
             "metric": "Mbp/s through occ+nuc signal pipeline", "value": round(value, 3), "unit": "Mbp/s",
+            "value_boundary": "hbm_resident: packed inputs and every output track stay in HBM inside the timed region; SURVEY.md 8(d)'s "
+                              "boundary (packed inputs in host memory -> output tracks back in host memory, PCIe-bound) is value_host_to_host",
+            "value_host_to_host": None if h2h is None else h2h["host_to_host_mbp_s"],
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": info["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "chunks_total": info["total_chunks"], "chunks_this_rank": int(sum(s.n_chunks for s in subs)),
                        "bp_total": total_bp, "fragments_total": total_frags, "candidates_per_step": total_cand,
                        "sub_batches_this_rank": len(subs), "outputs_recycled": bool(recycle),
                        "sharding": "chunk list split across ranks, no collective", "shard_imbalance": info["imbalance"]},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_LABEL[dom],
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            # the dominant kernel is bound by fp64 vector issue (+ LDS transposes), not by HBM (~5e4 flop per base against
+            # ~80 bytes): achieved / peak are its executed fp64 rate against the fp64 vector peak; the HBM view the metric's name asks
+            # for is kept under "hbm" (same launch time, algorithmic bytes of the whole pipeline per launch)
+            "roofline": {"bound": "fp64_valu" if fp64_bound else "hbm", "kernel": KERNEL_LABEL[dom],
+                         "achieved": round(fft_tflops, 2) if fp64_bound else round(achieved, 2),
+                         "peak": FP64_PEAK_TFLOPS if fp64_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if fp64_bound else "GB/s",
+                         "frac": round(fft_tflops / FP64_PEAK_TFLOPS, 5) if fp64_bound else round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic,
+                         "traffic_note": "HBM bytes of THIS kernel per launch (FETCH_SIZE + WRITE_SIZE, committed PMC pass); the whole "
+                                         "step's bytes against the algorithmic bytes are under step_traffic",
+                         "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": alg_bytes},
+                         "step_traffic": step_traffic,
+                         "clock_ghz": clocks,
                          "traffic_source": pmc_source() if a.workload == "cfg3" else None,
                          # the meaningful fraction for this kernel: share of the SIMDs' issue cycles its fp64 VALU stream uses
                          "fp64_issue_frac": dom_issue,
@@ -640,6 +735,7 @@ def main():
         if cov_sweep is not None:
             out["multinomial_cov_sweep"] = cov_sweep
         if cpu is not None:
+            cpu["reference_calibration"] = reference_calibration()
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if ctx is not None:

@@ -93,6 +93,9 @@ void natac_ctx_destroy(natac_ctx *ctx);
 int natac_ctx_sync(natac_ctx *ctx);
 /* device name, CU count, global memory bytes of the context's device */
 int natac_ctx_device_info(natac_ctx *ctx, char *name, size_t name_len, int *n_cu, size_t *mem_bytes);
+/* which physical GPU the context computes on: the HIP device ordinal and its PCI bus id ("0000:05:00.0"); the multi-rank drivers
+ * print both per rank and check that ranks meant to own a GPU each really do */
+int natac_ctx_device_ids(natac_ctx *ctx, int *hip_device, char *pci_bus_id, size_t pci_len);
 
 /* ---- run-level constants --------------------------------------------------------------- */
 /* VMat template (pyatac/VMat.py:24-37): mat[(upper-lower) x (2w+1)] row-major, insert sizes [lower,upper). */
@@ -133,6 +136,13 @@ int natac_run_nuc(natac_batch *b, double smooth_sd);
 int natac_run_occ(natac_batch *b);
 /* InsertionTrack.calculateInsertions (pyatac/tracks.py:164-168) for every chunk: fills INS. */
 int natac_run_ins(natac_batch *b, int lower, int upper);
+/* natac_run_nuc + natac_run_occ (+ natac_run_ins when with_ins != 0) of one batch, CO-SCHEDULED: the reference runs
+ * OccChunk.process and NucChunk.process of a chunk in different commands (run_occ.py:23-39, run_nuc.py:22-39); the two are
+ * independent given the packed inputs, so the occupancy stage's kernels are enqueued on the context's second stream next to a
+ * persistent, half-occupancy launch of the background kernel and the rest of the background follows at full occupancy.
+ * Same outputs, bit for bit, as the three calls one after the other (which is what happens for small batches, V-plots the
+ * FFT background does not cover, or NATAC_CORUN=0).  Asynchronous. */
+int natac_run_nuc_occ(natac_batch *b, double smooth_sd, int with_ins, int ins_lower, int ins_upper);
 /* Per-candidate statistics (needs natac_run_nuc first).  cand_chunk[k] = chunk index, cand_pos[k] = position
  * relative to the chunk start.  Outputs (host, length n_cand):
  *   lr   Nucleosome.getLR       NucleosomeCalling.py:110-122
@@ -382,6 +392,15 @@ int natac_profile_enable(natac_ctx *ctx, int on);
 /* total milliseconds and launch count of kernel class `k` since the last reset */
 int natac_profile_get(natac_ctx *ctx, int k, double *ms_total, int64_t *launches);
 int natac_profile_reset(natac_ctx *ctx);
+/* Shader-clock trace (measurement aid, SURVEY.md section 8d asks for achieved rates against peaks that assume a clock): a one-wave
+ * sampler kernel on its own stream notes (wall time, shader cycle counter) every interval_us while other launches run; between
+ * two samples cycles / time = the clock the chip ran at.  _stop ends it and returns the number of samples and of profiled launches
+ * (natac_profile_enable) that fell into the trace; _fetch returns the samples (ms since the trace start, cycle counter) and for every
+ * such launch its NATAC_K_* class and its start / end on the same time axis. */
+int natac_clock_trace_start(natac_ctx *ctx, int max_samples, int interval_us);
+int natac_clock_trace_stop(natac_ctx *ctx, int64_t *n_samples, int64_t *n_intervals);
+int natac_clock_trace_fetch(natac_ctx *ctx, int64_t n_samples, double *t_ms, double *cycles, int64_t n_intervals, int32_t *iv_kernel,
+                            double *iv_t0_ms, double *iv_t1_ms);
 /* stream-ordered timer: natac_timer_start records an event, natac_timer_stop records + syncs + returns ms */
 int natac_timer_start(natac_ctx *ctx);
 int natac_timer_stop(natac_ctx *ctx, double *ms);

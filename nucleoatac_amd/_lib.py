@@ -29,6 +29,7 @@ SIGNATURES = {
     "natac_ctx_destroy": (None, [_vp]),
     "natac_ctx_sync": (C.c_int, [_vp]),
     "natac_ctx_device_info": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(C.c_int), C.POINTER(_sz)]),
+    "natac_ctx_device_ids": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_char_p, _sz]),
     "natac_set_vmat": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int]),
     "natac_set_sizes": (C.c_int, [_vp, _vp, C.c_int]),
     "natac_set_occ_model": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int, _f64, C.c_int, C.c_int]),
@@ -40,6 +41,10 @@ SIGNATURES = {
     "natac_run_nuc": (C.c_int, [_vp, _f64]),
     "natac_run_occ": (C.c_int, [_vp]),
     "natac_run_ins": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "natac_run_nuc_occ": (C.c_int, [_vp, _f64, C.c_int, C.c_int, C.c_int]),
+    "natac_clock_trace_start": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "natac_clock_trace_stop": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "natac_clock_trace_fetch": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "natac_run_candidates": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "natac_run_candidates_cov": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, _vp]),
     "natac_run_peaks": (C.c_int, [_vp, _f64, C.c_int, C.c_int, C.c_int, _vp, _i64, C.POINTER(_i64)]),

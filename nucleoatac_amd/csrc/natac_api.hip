@@ -52,6 +52,12 @@ struct natac_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // nuc stage, candidates, uploads, drop-ins
     hipStream_t stream2 = nullptr;   // occ stage + insertions: independent of the nuc stage, overlaps with it
+    // co-scheduling of the two stages (natac_run_nuc_occ): a real second stream, the events that order the streams, the
+    // {next tile, stop flag} words of the persistent background launch
+    bool corun = false;
+    int corun_prio = 0, corun_min_tiles = 4096;
+    hipEvent_t ev_pre = nullptr, ev_join = nullptr;
+    unsigned *d_corun = nullptr;
     hipDeviceProp_t prop;
     // constants
     double *d_vmat = nullptr, *d_vmat_pad = nullptr, *d_srow = nullptr, *d_sizes = nullptr;   // d_vmat_pad: VMatDev::matp
@@ -87,6 +93,14 @@ struct natac_ctx {
     double prof_ms[NATAC_K_COUNT] = {0};
     int64_t prof_n[NATAC_K_COUNT] = {0};
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    // shader-clock trace (natac_clock_trace_*): a one-wave sampler kernel on its own stream + where the profiled launches fall on its time axis
+    hipStream_t ck_stream = nullptr;
+    hipEvent_t ck_start = nullptr;
+    long long *d_ck = nullptr;       // [0] = samples written, [1] = stop flag, then (wall ticks, shader cycles) pairs
+    int ck_cap = 0;
+    bool ck_active = false;
+    struct Iv { int k; float t0, t1; };
+    std::vector<Iv> ck_iv;
     // device-side track writer (natac_textz.hpp): power-of-ten table of the '%.12g' formatter, CRC-32 tables
     natac_text::P10 *d_p10 = nullptr;
     natac_deflate::CrcTables *d_crc = nullptr;
@@ -156,6 +170,13 @@ static hipError_t sync_all(natac_ctx *c) {
     return e != hipSuccess ? e : e2;
 }
 
+// Two streams: work that `to` is about to receive must see everything `from` has been given so far.
+static hipError_t stream_after(natac_ctx *c, hipStream_t to, hipStream_t from) {
+    if (to == from) return hipSuccess;
+    hipError_t e = hipEventRecord(c->ev_join, from);
+    return e != hipSuccess ? e : hipStreamWaitEvent(to, c->ev_join, 0);
+}
+
 static int track_ready(natac_batch *b, int t);
 
 static void prof_begin(natac_ctx *c, int k, natac_ctx::Ev &ev, hipStream_t st = nullptr) {
@@ -179,6 +200,10 @@ static void prof_collect(natac_ctx *c) {
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
             c->prof_ms[e.k] += ms;
             c->prof_n[e.k] += 1;
+            float t0 = 0, t1 = 0;
+            if (c->ck_active && hipEventElapsedTime(&t0, c->ck_start, e.a) == hipSuccess &&
+                hipEventElapsedTime(&t1, c->ck_start, e.b) == hipSuccess)
+                c->ck_iv.push_back({e.k, t0, t1});
         }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -567,7 +592,22 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // measured on MI355X: a second stream for the occ stage does not overlap with the nuc stage (the background
     // kernel's workgroups keep every CU's LDS full), so both stages share one stream -- keeps per-kernel timing exact
+    // -- on its own.  natac_run_nuc_occ co-schedules them on purpose (NATAC_CORUN=0 switches that off): the background
+    // kernel runs as ONE workgroup per CU (one wave per SIMD, half the registers and LDS left free) while the occupancy
+    // stage's kernels run on stream2, and as the regular two-waves-per-SIMD launch for the tiles left after that.
     c->stream2 = c->stream;
+    {
+        const char *e = getenv("NATAC_CORUN");
+        c->corun = e && e[0] == '1';
+        if ((e = getenv("NATAC_CORUN_PRIO"))) c->corun_prio = atoi(e);
+        if ((e = getenv("NATAC_CORUN_MIN_TILES"))) c->corun_min_tiles = atoi(e);
+    }
+    if (c->corun) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        HIPCHK(hipMalloc((void **)&c->d_corun, 2 * sizeof(unsigned)));
+    }
     HIPCHK(hipEventCreate(&c->t0));
     HIPCHK(hipEventCreate(&c->t1));
     {   // NATAC_BG_DIRECT=1 selects the direct-summation background kernel (validation / A-B timing of the FFT path)
@@ -593,6 +633,13 @@ void natac_ctx_destroy(natac_ctx *c) {
     dev_free(c->d_p10); dev_free(c->d_crc);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->stream2 && c->stream2 != c->stream) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->d_corun) (void)hipFree(c->d_corun);
+    if (c->ck_stream) (void)hipStreamDestroy(c->ck_stream);
+    if (c->ck_start) (void)hipEventDestroy(c->ck_start);
+    if (c->d_ck) (void)hipFree(c->d_ck);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -612,6 +659,16 @@ int natac_ctx_device_info(natac_ctx *c, char *name, size_t name_len, int *n_cu, 
     }
     if (n_cu) *n_cu = c->prop.multiProcessorCount;
     if (mem_bytes) *mem_bytes = c->prop.totalGlobalMem;
+    return NATAC_OK;
+}
+
+int natac_ctx_device_ids(natac_ctx *c, int *hip_device, char *pci_bus_id, size_t pci_len) {
+    if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
+    if (hip_device) *hip_device = c->device;
+    if (pci_bus_id && pci_len) {
+        pci_bus_id[0] = 0;
+        HIPCHK(hipDeviceGetPCIBusId(pci_bus_id, (int)pci_len, c->device));
+    }
     return NATAC_OK;
 }
 
@@ -1015,7 +1072,12 @@ static int ensure_track(natac_batch *b, int t) {
     return dev_alloc(&b->d_track[t], (size_t)b->total_bp);  // INS uses the first half of a double slot (int32)
 }
 
-int natac_run_nuc(natac_batch *b, double smooth_sd) {
+struct CoRun { bool occ, ins; int ins_lower, ins_upper; bool used; };
+static int occ_prepare(natac_batch *b);
+static int occ_launch(natac_batch *b);
+static int ins_launch(natac_batch *b, int lower, int upper);
+
+static int run_nuc_impl(natac_batch *b, double smooth_sd, CoRun *co) {
     if (!b) return fail(NATAC_E_ARG, "batch is NULL");
     natac_ctx *c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -1055,6 +1117,14 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     const VMatDev vm = make_vmat(c);
     natac_ctx::Ev ev;
     if (!b->d_ranges256 && (rc = dev_alloc(&b->d_ranges256, (size_t)b->n_tiles256))) return rc;
+    if ((M - 1) / 2 == 30 && !b->d_tiles1k && (rc = build_tiles(b, 1024, &b->d_tiles1k, &b->n_tiles1k))) return rc;
+    // co-scheduled occupancy stage: everything of it that allocates, uploads or synchronises happens before the first launch
+    const bool co_ok = co && use_fft && c->corun && c->stream2 != c->stream && b->n_tiles_bg >= c->corun_min_tiles && c->have_occ;
+    if (co_ok) {
+        if (co->occ && (rc = occ_prepare(b))) return rc;
+        if (co->ins && (rc = ensure_track(b, NATAC_T_INS))) return rc;
+    }
+    HIPCHK(stream_after(c, c->stream, c->stream2));     // this stage rewrites arrays the other stream's last kernels may still read
     prof_begin(c, NATAC_K_FRAG_GATHER, ev);
     if (b->ranges256_w != c->vw) {
         hipLaunchKernelGGL(natac_tile_ranges256, dim3((b->n_tiles256 + 255) / 256), dim3(256), 0, c->stream, ct, b->d_tiles256,
@@ -1075,9 +1145,32 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     if (use_fft) {
         const int EW = FFT_N + ((vm.upper - 2) >> 1) + ((vm.upper - 1) >> 1);
         const size_t lds = ((size_t)((EW + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
+        const unsigned *first = nullptr;
+        if (co_ok) {
+            // natac_background_fft_persist: one workgroup (four waves, one tile each at a time) per CU.  More than half of the
+            // CU's LDS per workgroup keeps a second one out; the other half and half of every SIMD's registers stay free for
+            // the occupancy stage on stream2, which starts behind ev_pre (gather + exp(bias) done) and raises the stop flag
+            // behind its last kernel; the tiles left then take the regular launch.
+            const int wave_doubles = (int)(lds / sizeof(double));
+            const size_t lds_p = std::max((size_t)4 * lds, (size_t)80 * 1024 + 512);      // gfx950: 160 KB of LDS per CU
+            HIPCHK(hipMemsetAsync(c->d_corun, 0, 2 * sizeof(unsigned), c->stream));
+            HIPCHK(hipEventRecord(c->ev_pre, c->stream));
+            auto kp = c->corun_prio ? natac_background_fft_persist<3> : natac_background_fft_persist<0>;
+            HIPCHK(hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+            hipLaunchKernelGGL(kp, dim3(c->prop.multiProcessorCount), dim3(256), lds_p, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
+                               c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
+                               b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, c->d_corun, (unsigned)b->n_tiles_bg, wave_doubles);
+            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_pre, 0));
+            co->used = true;
+            b->nuc_done = true; b->nuc_w = c->vw; b->nuc_upper = c->vupper;      // the gather's coverage tracks are ordered by ev_pre
+            if (co->occ && (rc = occ_launch(b))) return rc;
+            if (co->ins && (rc = ins_launch(b, co->ins_lower, co->ins_upper))) return rc;
+            HIPCHK(hipMemsetAsync(c->d_corun + 1, 0xff, sizeof(unsigned), c->stream2));
+            first = c->d_corun;
+        }
         hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
                            c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov);
+                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, first, (unsigned)b->n_tiles_bg);
     } else if (fast) {
         switch (b->bgG) {
             case 7: launch_bg<7>(b, ct, vm); break;
@@ -1095,7 +1188,6 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     {
         const int h = (M - 1) / 2;
         if (h == 30) {      // the cli's smooth_sd = 10: four bases per lane
-            if (!b->d_tiles1k && (rc = build_tiles(b, 1024, &b->d_tiles1k, &b->n_tiles1k))) return rc;
             hipLaunchKernelGGL((natac_smooth_same4<true, 30>), dim3(b->n_tiles1k), dim3(256), (size_t)8 * SM4_S(30) * sizeof(double),
                                c->stream, ct, b->d_tiles1k, c->d_win_nuc, c->win_nuc_sum, b->d_track[NATAC_T_NORM],
                                b->d_track[NATAC_T_SMOOTH]);
@@ -1112,6 +1204,19 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     b->nuc_w = c->vw;
     b->nuc_upper = c->vupper;
     return NATAC_OK;
+}
+
+int natac_run_nuc(natac_batch *b, double smooth_sd) { return run_nuc_impl(b, smooth_sd, nullptr); }
+
+int natac_run_nuc_occ(natac_batch *b, double smooth_sd, int with_ins, int ins_lower, int ins_upper) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    if (!b->ctx->have_occ) return fail(NATAC_E_STATE, "natac_set_occ_model has not been called");
+    CoRun co{true, with_ins != 0, ins_lower, ins_upper, false};
+    int rc = run_nuc_impl(b, smooth_sd, &co);
+    if (rc || co.used) return rc;
+    // not co-scheduled (small batch, another background kernel, NATAC_CORUN=0): the stages one after the other
+    if ((rc = natac_run_occ(b))) return rc;
+    return with_ins ? natac_run_ins(b, ins_lower, ins_upper) : NATAC_OK;
 }
 
 // natac_occ_smooth (one base per lane, any step / window): smoothed occupancy -> dst_occ (un-filled), bounds -> dst_lo / dst_hi (or null)
@@ -1170,7 +1275,9 @@ static int materialise_prefill(natac_batch *b) {
     return NATAC_OK;
 }
 
-int natac_run_occ(natac_batch *b) {
+// natac_run_occ, part 1: every allocation, table upload and host synchronisation of the stage (nothing is launched that
+// depends on another stream), so that part 2 can be enqueued behind a running kernel without stalling the host
+static int occ_prepare(natac_batch *b) {
     if (!b) return fail(NATAC_E_ARG, "batch is NULL");
     natac_ctx *c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -1215,9 +1322,6 @@ int natac_run_occ(natac_batch *b) {
         if ((rc = ensure_track(b, t))) return rc;
     b->prefill_valid = false;
     if (!b->d_ebias && b->d_bias && (rc = dev_alloc(&b->d_ebias, (size_t)b->nb))) return rc;
-    const ChunkTable ct = make_table(b);
-    const OccModelDev om = make_occ(c);
-    natac_ctx::Ev ev;
     const bool fast = c->occ_fast_ok && !c->occ_force_general;
     if (fast) {   // per-block sum buffers + tile table of natac_occ_gsum (geometry: step / flank of the model)
         const int Q = 2 * c->flank / c->step;
@@ -1242,7 +1346,7 @@ int natac_run_occ(natac_batch *b) {
         }
         if (!b->d_gsum && (rc = dev_alloc(&b->d_gsum, (size_t)4 * b->total_blocks))) return rc;
     }
-    prof_begin(c, NATAC_K_OCC_MLE, ev, c->stream2);
+    // geometry checks + tables of the smoothing pass
     {
         const int U = c->occ_upper, UP = (U + 1) & ~1;
         const int span = (OCC_T * OCC_NP - 1) * c->step + M + c->step;
@@ -1252,6 +1356,49 @@ int natac_run_occ(natac_batch *b) {
                            (size_t)2 * OCC_FMAX * sizeof(int);
         if (lds > 64 * 1024)
             return fail(NATAC_E_ARG, "occupancy window / step too large for the device tile (step=%d flank=%d upper=%d)", c->step, c->flank, U);
+        if (fast) {
+            const int R = c->occ_nm - 1, Q = b->gs_Q;
+            const size_t lds_gs = ((size_t)((GS_BLOCKS * 5 + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
+            const int NGP = (64 + Q + 1) & ~1;
+            const size_t lds_od = (size_t)4 * ((OD_FM + 4) + 4 * NGP + OD_FM / 2) * sizeof(double);
+            if (lds_gs > 64 * 1024 || lds_od > 64 * 1024)
+                return fail(NATAC_E_ARG, "occupancy window too large for the device tile (flank=%d upper=%d)", c->flank, U);
+        }
+    }
+    const bool blk = (c->step == 5) && (((M - 1) / 2) % c->step == 0);     // natac_occ_smooth_blk<5>
+    if (blk) {
+        const int h = (M - 1) / 2, NB = 2 * (h / c->step) + 2;
+        if ((rc = ensure_block_weights(c, M, sd, NB))) return rc;
+        if (b->os_width != 256 * c->step) {
+            if ((rc = build_tiles(b, 256 * c->step, &b->d_tiles_os, &b->n_tiles_os))) return rc;
+            b->os_width = 256 * c->step;
+        }
+        if (!b->d_occ_minkey && (rc = dev_alloc(&b->d_occ_minkey, (size_t)b->nc))) return rc;
+        if (!b->d_occ_nan && (rc = dev_alloc(&b->d_occ_nan, (size_t)b->nc))) return rc;
+    } else {
+        if ((rc = ensure_track(b, NATAC_T_OCC_PREFILL))) return rc;
+    }
+    return NATAC_OK;
+}
+
+// natac_run_occ, part 2: the launches, all on stream2
+static int occ_launch(natac_batch *b) {
+    natac_ctx *c = b->ctx;
+    const int M = 2 * c->flank + 1;
+    int rc;
+    b->prefill_valid = false;
+    const ChunkTable ct = make_table(b);
+    const OccModelDev om = make_occ(c);
+    natac_ctx::Ev ev;
+    const bool fast = c->occ_fast_ok && !c->occ_force_general;
+    prof_begin(c, NATAC_K_OCC_MLE, ev, c->stream2);
+    {
+        const int U = c->occ_upper, UP = (U + 1) & ~1;
+        const int span = (OCC_T * OCC_NP - 1) * c->step + M + c->step;
+        const int EW = span + ((U - 2) >> 1) + ((U - 1) >> 1) + 2;
+        const int n_ones = ((OCC_T - 1) * c->step + M + c->step + 3) & ~1;
+        const size_t lds = ((size_t)((EW + 1) & ~1) + (size_t)OCC_T * UP + 2 * (size_t)UP + OCC_ACL + n_ones) * sizeof(double) +
+                           (size_t)2 * OCC_FMAX * sizeof(int);
         if (b->ranges_occ_key[0] != c->step || b->ranges_occ_key[1] != c->halfstep || b->ranges_occ_key[2] != c->flank) {
             // an index over the (immutable) fragment list, like the 256-base tiles' ranges: formed once per batch and geometry
             hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
@@ -1269,8 +1416,6 @@ int natac_run_occ(natac_batch *b) {
             const size_t lds_gs = ((size_t)((GS_BLOCKS * 5 + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
             const int NGP = (64 + of.Q + 1) & ~1;
             const size_t lds_od = (size_t)4 * ((OD_FM + 4) + 4 * NGP + OD_FM / 2) * sizeof(double);
-            if (lds_gs > 64 * 1024 || lds_od > 64 * 1024)
-                return fail(NATAC_E_ARG, "occupancy window too large for the device tile (flank=%d upper=%d)", c->flank, U);
             HIPCHK(hipMemsetAsync(b->d_defer, 0, sizeof(int), c->stream2));
             if ((rc = run_exp_bias(b, c->stream2, true))) return rc;
             hipLaunchKernelGGL((natac_occ_gsum<5>), dim3(b->n_tiles_gs), dim3(256), lds_gs, c->stream2, ct, b->d_tiles_gs, of, b->d_blk_off,
@@ -1302,13 +1447,6 @@ int natac_run_occ(natac_batch *b) {
     const bool blk = (c->step == 5) && (((M - 1) / 2) % c->step == 0);     // natac_occ_smooth_blk<5>
     if (blk) {
         const int h = (M - 1) / 2, NB = 2 * (h / c->step) + 2;
-        if ((rc = ensure_block_weights(c, M, sd, NB))) return rc;
-        if (b->os_width != 256 * c->step) {
-            if ((rc = build_tiles(b, 256 * c->step, &b->d_tiles_os, &b->n_tiles_os))) return rc;
-            b->os_width = 256 * c->step;
-        }
-        if (!b->d_occ_minkey && (rc = dev_alloc(&b->d_occ_minkey, (size_t)b->nc))) return rc;
-        if (!b->d_occ_nan && (rc = dev_alloc(&b->d_occ_nan, (size_t)b->nc))) return rc;
         HIPCHK(hipMemsetAsync(b->d_occ_minkey, 0xff, (size_t)b->nc * sizeof(unsigned long long), c->stream2));
         HIPCHK(hipMemsetAsync(b->d_occ_nan, 0, (size_t)b->nc * sizeof(int), c->stream2));
         hipLaunchKernelGGL((natac_occ_smooth_blk<5>), dim3(b->n_tiles_os), dim3(256), ((size_t)3 * (256 + NB) + 256 * 5) * sizeof(double), c->stream2, ct,
@@ -1316,7 +1454,6 @@ int natac_run_occ(natac_batch *b) {
                            b->d_track[NATAC_T_OCC], b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER], b->d_occ_minkey,
                            b->d_occ_nan);
     } else {
-        if ((rc = ensure_track(b, NATAC_T_OCC_PREFILL))) return rc;
         launch_occ_smooth_generic(b, ct, om, M, b->d_track[NATAC_T_OCC_PREFILL], b->d_track[NATAC_T_OCC_LOWER],
                                   b->d_track[NATAC_T_OCC_UPPER]);
         b->prefill_valid = true;
@@ -1345,12 +1482,25 @@ int natac_run_occ(natac_batch *b) {
     return NATAC_OK;
 }
 
+int natac_run_occ(natac_batch *b) {
+    int rc = occ_prepare(b);
+    if (rc) return rc;
+    natac_ctx *c = b->ctx;
+    HIPCHK(stream_after(c, c->stream2, c->stream));     // exp(bias) / coverage of a preceding natac_run_nuc
+    return occ_launch(b);
+}
+
 int natac_run_ins(natac_batch *b, int lower, int upper) {
     if (!b) return fail(NATAC_E_ARG, "batch is NULL");
     natac_ctx *c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     int rc = ensure_track(b, NATAC_T_INS);
     if (rc) return rc;
+    return ins_launch(b, lower, upper);
+}
+
+static int ins_launch(natac_batch *b, int lower, int upper) {
+    natac_ctx *c = b->ctx;
     const ChunkTable ct = make_table(b);
     natac_ctx::Ev ev;
     prof_begin(c, NATAC_K_INS, ev, c->stream2);
@@ -1721,6 +1871,7 @@ int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes)
     if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, track needs %zu", dst_bytes, need);
     HIPCHK(hipSetDevice(b->ctx->device));
     if (track == NATAC_T_OCC_PREFILL && (rc = materialise_prefill(b))) return rc;
+    HIPCHK(stream_after(b->ctx, b->ctx->stream, b->ctx->stream2));
     HIPCHK(hipMemcpyAsync(dst, b->d_track[track], need, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(sync_all(b->ctx));
     prof_collect(b->ctx);
@@ -1734,6 +1885,7 @@ int natac_batch_download_grid(natac_batch *b, int which, double *dst, size_t dst
     const size_t need = (size_t)b->total_grid * sizeof(double);
     if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, grid needs %zu", dst_bytes, need);
     HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(stream_after(b->ctx, b->ctx->stream, b->ctx->stream2));
     HIPCHK(hipMemcpyAsync(dst, b->d_grid[which], need, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(sync_all(b->ctx));
     return NATAC_OK;
@@ -1759,6 +1911,7 @@ int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes) {
     if (!b || !dst) return fail(NATAC_E_ARG, "null argument");
     if (dst_bytes != (size_t)b->nc * sizeof(int)) return fail(NATAC_E_ARG, "status buffer must hold n_chunks int32");
     HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(stream_after(b->ctx, b->ctx->stream, b->ctx->stream2));
     HIPCHK(hipMemcpyAsync(dst, b->d_status, dst_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(sync_all(b->ctx));
     return NATAC_OK;
@@ -2648,6 +2801,97 @@ int natac_timer_stop(natac_ctx *c, double *ms) {
     HIPCHK(hipEventElapsedTime(&f, c->t0, c->t1));
     *ms = f;
     prof_collect(c);
+    return NATAC_OK;
+}
+
+/* ---------------- shader-clock trace ---------------- */
+}  // extern "C"
+
+// one wave; lane 0 notes (constant-rate wall ticks since its start, shader cycle counter) every `interval` wall ticks and sleeps in
+// between: the slope between two samples is the clock the CU ran at -- under whatever else the chip is executing meanwhile
+__global__ void __launch_bounds__(64) natac_clock_sampler(long long *__restrict__ buf, int cap, long long interval) {
+    if (threadIdx.x) return;
+    const long long w0 = wall_clock64();
+    long long next = w0;
+    int i = 0;
+    for (; i < cap; ++i) {
+        long long w;
+        do {
+            __builtin_amdgcn_s_sleep(64);
+            w = wall_clock64();
+        } while (w < next);
+        buf[2 + 2 * i] = w - w0;
+        buf[3 + 2 * i] = clock64();
+        next = w + interval;
+        if (__hip_atomic_load(buf + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { ++i; break; }
+    }
+    buf[0] = i;
+}
+
+extern "C" {
+
+int natac_clock_trace_start(natac_ctx *c, int max_samples, int interval_us) {
+    if (!c || max_samples < 2 || interval_us < 1) return fail(NATAC_E_ARG, "bad argument");
+    if (c->ck_active) return fail(NATAC_E_STATE, "a clock trace is already running");
+    HIPCHK(hipSetDevice(c->device));
+    int khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    if (khz <= 0) return fail(NATAC_E_HIP, "the device reports no wall clock rate");
+    if (!c->ck_stream) HIPCHK(hipStreamCreateWithFlags(&c->ck_stream, hipStreamNonBlocking));
+    if (!c->ck_start) HIPCHK(hipEventCreate(&c->ck_start));
+    if (c->ck_cap < max_samples) {
+        if (c->d_ck) (void)hipFree(c->d_ck);
+        c->d_ck = nullptr;
+        HIPCHK(hipMalloc((void **)&c->d_ck, (2 + 2 * (size_t)max_samples) * sizeof(long long)));
+        c->ck_cap = max_samples;
+    }
+    HIPCHK(hipMemsetAsync(c->d_ck, 0, 2 * sizeof(long long), c->ck_stream));
+    HIPCHK(hipEventRecord(c->ck_start, c->ck_stream));
+    hipLaunchKernelGGL(natac_clock_sampler, dim3(1), dim3(64), 0, c->ck_stream, c->d_ck, max_samples,
+                       (long long)khz * interval_us / 1000);
+    HIPCHK(hipGetLastError());
+    c->ck_iv.clear();
+    c->ck_active = true;
+    return NATAC_OK;
+}
+
+int natac_clock_trace_stop(natac_ctx *c, int64_t *n_samples, int64_t *n_intervals) {
+    if (!c) return fail(NATAC_E_ARG, "ctx is NULL");
+    if (!c->ck_active) return fail(NATAC_E_STATE, "no clock trace is running");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(sync_all(c));
+    prof_collect(c);                     // intervals of the launches profiled since the start
+    const long long one = 1;
+    HIPCHK(hipMemcpy(c->d_ck + 1, &one, sizeof one, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(c->ck_stream));
+    long long n = 0;
+    HIPCHK(hipMemcpy(&n, c->d_ck, sizeof n, hipMemcpyDeviceToHost));
+    c->ck_active = false;
+    if (n_samples) *n_samples = n;
+    if (n_intervals) *n_intervals = (int64_t)c->ck_iv.size();
+    return NATAC_OK;
+}
+
+int natac_clock_trace_fetch(natac_ctx *c, int64_t n_samples, double *t_ms, double *cycles, int64_t n_intervals, int32_t *iv_kernel,
+                            double *iv_t0_ms, double *iv_t1_ms) {
+    if (!c || (n_samples > 0 && (!t_ms || !cycles)) || (n_intervals > 0 && (!iv_kernel || !iv_t0_ms || !iv_t1_ms)))
+        return fail(NATAC_E_ARG, "null argument");
+    if (c->ck_active) return fail(NATAC_E_STATE, "stop the clock trace first");
+    if (n_samples > c->ck_cap || n_intervals > (int64_t)c->ck_iv.size()) return fail(NATAC_E_ARG, "more than was recorded");
+    HIPCHK(hipSetDevice(c->device));
+    int khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    std::vector<long long> h(2 * (size_t)n_samples);
+    if (n_samples) HIPCHK(hipMemcpy(h.data(), c->d_ck + 2, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n_samples; ++i) {
+        t_ms[i] = (double)h[2 * i] / (double)khz;
+        cycles[i] = (double)h[2 * i + 1];
+    }
+    for (int64_t i = 0; i < n_intervals; ++i) {
+        iv_kernel[i] = c->ck_iv[(size_t)i].k;
+        iv_t0_ms[i] = c->ck_iv[(size_t)i].t0;
+        iv_t1_ms[i] = c->ck_iv[(size_t)i].t1;
+    }
     return NATAC_OK;
 }
 

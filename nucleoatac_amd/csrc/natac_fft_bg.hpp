@@ -215,22 +215,21 @@ __global__ void __launch_bounds__(64) natac_fft_template(const double *__restric
 // confined to the bases whose window touches it) are evaluated by direct summation in the same order as natac_background.
 constexpr double FFT_MAX_RANGE = 3e4;   // real Tn5 PWM log-bias spans <= 8.7 log units genome-wide (e^8.7 = 6e3)
 
-// two waves per SIMD on purpose: a third one (reachable with the stage-2 twiddles in LDS, 145 VGPRs) only adds LDS contention
-// (measured 11.4 vs 8.7 ms per 20 k chunks)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) natac_background_fft(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
-                                                             const double *__restrict__ tw, const double *__restrict__ ktab,
-                                                             const double *__restrict__ nuc_cov, const double *__restrict__ raw,
-                                                             double *__restrict__ bg, double *__restrict__ norm,
-                                                             double *__restrict__ bnum, double *__restrict__ bcov) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x;
+// one tile of the background through FFTs; `smem` = this wave's LDS (EWP + 2 FFT_LA doubles), `t` = (chunk, x0).
+// TW_LOADED: the caller holds the per-lane twiddles in `tww` (persistent kernel); otherwise they are loaded here, after the
+// conditioning test, exactly where the one-tile-per-workgroup kernel always loaded them.
+template <bool TW_LOADED>
+__device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, const VMatDev &vm, const double *__restrict__ tw,
+                                            const double *__restrict__ ktab, const double *__restrict__ nuc_cov,
+                                            const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
+                                            double *__restrict__ bnum, double *__restrict__ bcov, double *smem, FftTwiddles &tww,
+                                            const int lane) {
     const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
     const int EW = FFT_N + A + Bh, EWP = (EW + 1) & ~1;
     double *Et = smem;
     double2 *ca = (double2 *)(Et + EWP), *cb = ca;     // complex scratch of the transposes; layouts A and B are never live together
     double *sar = (double *)ca, *sai = sar + FFT_LA;   // the same memory as two real arrays (epilogue)
-    const int2 t = tiles[blockIdx.x];
     const int chunk = t.x, x0 = t.y;
     const int L = ct.chunk_len[chunk];
     bool use_fft;
@@ -286,8 +285,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         return;
     }
-    FftTwiddles tww;
-    fft_load_twiddles(tww, tw, lane);
+    if (!TW_LOADED) fft_load_twiddles(tww, tw, lane);
     double accr[8], acci[8], q[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) { accr[m] = 0.0; acci[m] = 0.0; q[m] = 0.0; }
@@ -453,6 +451,58 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             bnum[o] = num;           // sum B V and sum B of the window at this base: reused by the candidate statistics
             bcov[o] = cv;
         }
+    }
+}
+
+// background + normalised signal for tiles of TV = 512 - W + 1 bases; one tile per wave, one wave per workgroup.
+// two waves per SIMD on purpose: a third one (reachable with the stage-2 twiddles in LDS, 145 VGPRs) only adds LDS contention
+// (measured 11.4 vs 8.7 ms per 20 k chunks).
+// `first` (or null): the launch covers tiles[min(*first, n_tiles) + blockIdx.x ...] -- the tiles a preceding persistent launch
+// (below) did not claim; workgroups past the end leave at once.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) natac_background_fft(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
+                                                             const double *__restrict__ tw, const double *__restrict__ ktab,
+                                                             const double *__restrict__ nuc_cov, const double *__restrict__ raw,
+                                                             double *__restrict__ bg, double *__restrict__ norm,
+                                                             double *__restrict__ bnum, double *__restrict__ bcov,
+                                                             const unsigned *__restrict__ first, unsigned n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    unsigned ti = blockIdx.x;
+    if (first) {
+        ti += min(*first, n_tiles);
+        if (ti >= n_tiles) return;
+    }
+    FftTwiddles tww;
+    bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x);
+}
+
+// The same tiles as a PERSISTENT launch that leaves room on every SIMD: one workgroup of four independent waves per CU (the
+// launch asks for more than half of a CU's LDS, so a second workgroup never fits), one wave per SIMD at <= 256 VGPRs -- half of
+// the register file and half of the LDS stay free for the kernels of the occupancy stage on the context's second stream, whose
+// dense fp64 streams issue while this kernel's waves sit in their LDS transposes.  Each wave claims tiles from `state[0]` until
+// they run out or `state[1]` becomes non-zero (set on the second stream behind the last co-running kernel); the tiles not
+// claimed by then are left to a regular two-waves-per-SIMD launch of natac_background_fft(first = state).
+template <int PRIO>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) natac_background_fft_persist(
+    ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm, const double *__restrict__ tw, const double *__restrict__ ktab,
+    const double *__restrict__ nuc_cov, const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
+    double *__restrict__ bnum, double *__restrict__ bcov, unsigned *__restrict__ state, unsigned n_tiles, int wave_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *mine = smem + (size_t)wave * wave_doubles;
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+    for (;;) {
+        unsigned ti = 0xffffffffu;
+        if (lane == 0) {
+            if (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                ti = __hip_atomic_fetch_add(state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ti = __builtin_amdgcn_readfirstlane(ti);
+        if (ti >= n_tiles) break;
+        FftTwiddles tww;      // re-loaded per tile (L1-resident table): keeping them across the staging and the epilogue spills
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));   // opaque per trip, or ~40 lane-based LDS addresses are hoisted out of the tile loop and spill
+        bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, mine, tww, lane_t);
+        __builtin_amdgcn_wave_barrier();     // the next tile's staging overwrites this tile's epilogue scratch
     }
 }
 

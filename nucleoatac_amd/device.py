@@ -106,6 +106,13 @@ class Context(object):
         L.check(self._lib.natac_ctx_device_info(self._h, name, 256, C.byref(ncu), C.byref(mem)))
         return dict(name=name.value.decode(), n_cu=ncu.value, mem_bytes=mem.value)
 
+    def device_ids(self):
+        """(HIP device ordinal, PCI bus id) of the GPU this context computes on"""
+        dev = C.c_int(-1)
+        buf = C.create_string_buffer(64)
+        L.check(self._lib.natac_ctx_device_ids(self._h, C.byref(dev), buf, 64))
+        return dev.value, buf.value.decode()
+
     def sync(self):
         L.check(self._lib.natac_ctx_sync(self._h))
 
@@ -289,6 +296,32 @@ class Context(object):
             out[name] = (ms.value, n.value)
         return out
 
+    def clock_trace_start(self, max_samples=20000, interval_us=100):
+        """start the one-wave shader-clock sampler (natac_clock_trace_start); profile_enable(True) makes the launches that follow
+        appear as intervals on its time axis"""
+        L.check(self._lib.natac_clock_trace_start(self._h, int(max_samples), int(interval_us)))
+
+    def clock_trace_stop(self):
+        """-> dict(t_ms, ghz: clock between consecutive samples; per_kernel: {kernel name: mean GHz over its launches' intervals,
+        weighted by time}; intervals: [(kernel name, t0_ms, t1_ms)])"""
+        ns, ni = C.c_int64(0), C.c_int64(0)
+        L.check(self._lib.natac_clock_trace_stop(self._h, C.byref(ns), C.byref(ni)))
+        t, cyc = np.empty(ns.value, np.float64), np.empty(ns.value, np.float64)
+        ik, i0, i1 = np.empty(ni.value, np.int32), np.empty(ni.value, np.float64), np.empty(ni.value, np.float64)
+        L.check(self._lib.natac_clock_trace_fetch(self._h, ns.value, _ptr(t), _ptr(cyc), ni.value, _ptr(ik), _ptr(i0), _ptr(i1)))
+        dt = np.diff(t)
+        ghz = np.where(dt > 0, np.diff(cyc) / np.maximum(dt, 1e-12) / 1e6, np.nan)     # cycles per ms / 1e6 = GHz
+        mid = 0.5 * (t[1:] + t[:-1])
+        per, w = {}, {}
+        for k, a, b in zip(ik, i0, i1):
+            m = (mid >= a) & (mid <= b) & np.isfinite(ghz)
+            if m.any():
+                name = L.KERNEL_NAMES[int(k)]
+                per[name] = per.get(name, 0.0) + float(np.sum(ghz[m] * dt[m]))
+                w[name] = w.get(name, 0.0) + float(np.sum(dt[m]))
+        return dict(t_ms=t, ghz=ghz, per_kernel={k: per[k] / w[k] for k in per},
+                    intervals=[(L.KERNEL_NAMES[int(k)], float(a), float(b)) for k, a, b in zip(ik, i0, i1)])
+
     def timer_start(self):
         L.check(self._lib.natac_timer_start(self._h))
 
@@ -349,6 +382,11 @@ class DeviceBatch(object):
 
     def run_ins(self, lower=0, upper=2000):
         L.check(self._lib.natac_run_ins(self._h, int(lower), int(upper)))
+
+    def run_nuc_occ(self, smooth_sd=10, ins=None):
+        """run_nuc + run_occ (+ run_ins(*ins)) co-scheduled on the context's two streams (natac_run_nuc_occ); same results"""
+        lo, hi = ins if ins is not None else (0, 0)
+        L.check(self._lib.natac_run_nuc_occ(self._h, float(smooth_sd), 0 if ins is None else 1, int(lo), int(hi)))
 
     def run_candidates(self, cand_chunk, cand_pos):
         cc = np.ascontiguousarray(cand_chunk, dtype=np.int32)

@@ -58,9 +58,9 @@ def run_nfr(args):
         raise Exception("Must supply either bam file or insertion track")
     if not args.out:
         args.out = ".".join(os.path.basename(args.calls).split(".")[0:-3])
-    if env_rank_world()[0] == 0 and isinstance(args.bam, str):
+    if env_rank_world()[2] == 0 and isinstance(args.bam, str):      # the node's publishing rank
         from ..pyatac.fragments import FragmentStore
-        FragmentStore.prefetch(args.bam)       # rank 0 decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
+        FragmentStore.prefetch(args.bam)       # it decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
     if getattr(args, "fasta", None):
         from ..pyatac.seq import FastaStore
         FastaStore.prefetch(args.fasta)        # the genome loads on its own thread; the BED file only needs the record lengths

@@ -114,9 +114,9 @@ def batch_calls(r, params, pool=None, pool_workers=1):
 
 def run_nuc(args):
     ph = _Phases(LAST_TIMINGS)
-    if env_rank_world()[0] == 0 and isinstance(args.bam, str):
+    if env_rank_world()[2] == 0 and isinstance(args.bam, str):      # the node's publishing rank
         from ..pyatac.fragments import FragmentStore
-        FragmentStore.prefetch(args.bam)       # rank 0 decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
+        FragmentStore.prefetch(args.bam)       # it decodes (shard.shared_fragment_store): start now, next to the FASTA index / BED reads
     if getattr(args, "fasta", None):
         from ..pyatac.seq import FastaStore
         FastaStore.prefetch(args.fasta)        # the genome loads on its own thread; the BED file only needs the record lengths

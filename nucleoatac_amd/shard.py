@@ -44,8 +44,8 @@ def ensure_distributed(prefer=None, device=None):
     would merge part files that other ranks are still writing.
 
     The control plane -- barriers, gathers of small per-chunk objects, the ok / failed flag of single-rank steps -- is a gloo
-    group (CPU, always available) with a long timeout; there is no data-path collective.  When `prefer` (default: the
-    NATAC_DIST_BACKEND environment variable, else "nccl") is "nccl", an RCCL subgroup is created on top of it and probed; whether
+    group (CPU, always available) with a long timeout; there is no data-path collective, so RCCL is OPT-IN: when `prefer`
+    (default: the NATAC_DIST_BACKEND environment variable, else "gloo") is "nccl", an RCCL subgroup is created on top of it and probed; whether
     it is used is decided COLLECTIVELY (a MIN all-reduce of the per-rank probe results over gloo), so one rank with a broken
     RCCL cannot leave the others waiting in an RCCL collective for long (its own timeout is 10 minutes).  The drivers' barriers
     always use gloo; `barrier(sync_cuda=True)` -- the benchmark's timing barrier -- synchronises over RCCL when all ranks have
@@ -61,7 +61,7 @@ def ensure_distributed(prefer=None, device=None):
     import datetime
     import sys
     import torch
-    prefer = prefer or os.environ.get("NATAC_DIST_BACKEND", "nccl")
+    prefer = prefer or os.environ.get("NATAC_DIST_BACKEND", "gloo")
     dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=GROUP_TIMEOUT_S))
     _STATE["backend"] = "gloo"
     if prefer == "nccl":
@@ -165,40 +165,60 @@ def broadcast_object(obj, src=0):
 
 
 def shared_fragment_store(bam):
-    """FragmentStore of `bam`, decoded ONCE per node: rank 0 decodes the BAM (native streaming decoder) and publishes the
-    per-chromosome arrays as .npy files in shared memory (/dev/shm); the other ranks map them read-only instead of decoding
-    the whole file again (global pre-steps once, before sharding).  One rank: plain FragmentStore.open."""
+    """FragmentStore of `bam`, decoded ONCE PER NODE: on every host the rank with the lowest LOCAL_RANK decodes the BAM (native
+    streaming / device decoder) and publishes the per-chromosome arrays as .npy files in a private (0700, mkdtemp) directory of
+    that host's shared memory (/dev/shm); the other ranks of the host map them read-only instead of decoding the whole file
+    again (global pre-steps once, before sharding).  A publisher that fails tells everybody -- every
+    rank raises instead of waiting for metadata that never comes -- and a rank that cannot map the files decodes the BAM
+    itself.  One rank: plain FragmentStore.open."""
     from .pyatac.fragments import FragmentStore
-    rank, world, _ = env_rank_world()
+    rank, world, local = env_rank_world()
     if world <= 1 or isinstance(bam, FragmentStore):
         return FragmentStore.open(bam)
-    import hashlib
+    import shutil
+    import socket
     import tempfile
     dist, _ = ensure_distributed()
+    host = socket.gethostname()
+    who = [None] * world
+    dist.all_gather_object(who, (host, local, rank))
+    publisher = min((l, r) for h, l, r in who if h == host)[1]          # this host's publishing rank
     root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    tag = hashlib.sha1(("%s|%s|%s" % (os.path.abspath(bam), os.environ.get("MASTER_PORT", ""), os.environ.get("TORCHELASTIC_RUN_ID", ""))).encode()).hexdigest()[:16]
-    base = os.path.join(root, "natac_frags_%s" % tag)
-    meta = None
-    if rank == 0:
-        st = FragmentStore.open(bam)
-        for i, c in enumerate(st.references):
-            np.save("%s.%d.pos.npy" % (base, i), st.pos[c])
-            np.save("%s.%d.tlen.npy" % (base, i), st.tlen[c])
-        meta = (st.references, st.lengths)
-    meta = broadcast_object(meta)
-    if rank != 0:
-        refs, lens = meta
-        st = FragmentStore(refs, lens, {c: np.load("%s.%d.pos.npy" % (base, i), mmap_mode="r") for i, c in enumerate(refs)},
-                           {c: np.load("%s.%d.tlen.npy" % (base, i), mmap_mode="r") for i, c in enumerate(refs)}, trusted=True)
-        FragmentStore.register(bam, st)
-    dist.barrier()                       # every rank has mapped the files: rank 0 unlinks them (the mappings stay valid)
-    if rank == 0:
-        for i in range(len(meta[0])):
-            for kind in ("pos", "tlen"):
-                try:
-                    os.remove("%s.%d.%s.npy" % (base, i, kind))
-                except OSError:
-                    pass
+    mine, st, err, d = None, None, None, None
+    if rank == publisher:
+        try:
+            st = FragmentStore.open(bam)
+            d = tempfile.mkdtemp(prefix="natac_frags_", dir=root)           # 0700, unpredictable name
+            for i, c in enumerate(st.references):
+                np.save(os.path.join(d, "%d.pos.npy" % i), st.pos[c])
+                np.save(os.path.join(d, "%d.tlen.npy" % i), st.tlen[c])
+            mine = (host, "ok", d, st.references, st.lengths)
+        except BaseException as e:      # noqa: BLE001 -- re-raised below, after the other ranks were told
+            err = e
+            mine = (host, "failed", "%s: %s" % (type(e).__name__, str(e)[:300]), None, None)
+            if d is not None:
+                shutil.rmtree(d, ignore_errors=True)
+    try:
+        notes = [None] * world
+        dist.all_gather_object(notes, mine)
+        if err is not None:
+            raise err
+        failed = [n for n in notes if n is not None and n[1] == "failed"]
+        if failed:
+            raise RuntimeError("reading %s failed on host %s (%s)" % (bam, failed[0][0], failed[0][2]))
+        if rank != publisher:
+            _, _, pdir, refs, lens = next(n for n in notes if n is not None and n[0] == host)
+            try:
+                st = FragmentStore(refs, lens, {c: np.load(os.path.join(pdir, "%d.pos.npy" % i), mmap_mode="r") for i, c in enumerate(refs)},
+                                   {c: np.load(os.path.join(pdir, "%d.tlen.npy" % i), mmap_mode="r") for i, c in enumerate(refs)},
+                                   trusted=True)
+                FragmentStore.register(bam, st)
+            except (OSError, ValueError):                                   # not visible from here after all: decode it ourselves
+                st = FragmentStore.open(bam)
+        dist.barrier()                   # every rank has mapped the files: the publisher unlinks them (the mappings stay valid)
+    finally:
+        if rank == publisher and d is not None:
+            shutil.rmtree(d, ignore_errors=True)
     return st
 
 

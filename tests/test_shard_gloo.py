@@ -115,3 +115,61 @@ def test_bench_cfg4_shards_partition_the_workload():
             assert np.array_equal(x, y), (world, sub)
         imb = parts[0][1]["imbalance"]
         assert len(imb["bp_per_rank"]) == world and imb["bp_max_over_mean"] < 1.02 and parts[0][1]["scaling"] == "strong"
+
+
+def _control_plane_worker(rank, world, port, q, bam_ok, bam_bad):
+    """ensure_distributed(prefer="nccl") without GPUs, then shared_fragment_store: publish / map, and a failing publisher"""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from nucleoatac_amd import shard
+    t0 = time.time()
+    dist, created = shard.ensure_distributed(prefer="nccl")
+    t_init = time.time() - t0
+    backend = shard.control_backend()
+    shard.barrier(sync_cuda=True)                       # the bench's barrier form must work on the fallback too
+    st = shard.shared_fragment_store(bam_ok)
+    reads = {c: (np.array(st.pos[c]), np.array(st.tlen[c])) for c in st.references}
+    mapped = any(isinstance(st.pos[c], np.memmap) for c in st.references)
+    t0 = time.time()
+    try:
+        shard.shared_fragment_store(bam_bad)
+        failed = None
+    except Exception as e:      # noqa: BLE001
+        failed = "%s: %s" % (type(e).__name__, e)
+    t_fail = time.time() - t0
+    left = [f for f in os.listdir("/dev/shm") if f.startswith("natac_frags_")] if os.path.isdir("/dev/shm") else []
+    shard.barrier()
+    q.put((rank, created, backend, t_init, reads, mapped, failed, t_fail, left))
+    dist.destroy_process_group()
+
+
+def test_control_plane_without_gpus_and_fragments_published_per_node(tmp_path):
+    """two gloo ranks, no GPU: asking for RCCL lands on gloo within seconds on both ranks (decided collectively); the reads of a
+    BAM stand-in are decoded by the node's first rank and mapped by the other; a publisher that fails raises on BOTH ranks at
+    once (nobody waits for metadata), and nothing is left in /dev/shm"""
+    import torch.multiprocessing as mp
+    from nucleoatac_amd.pyatac.fragments import FragmentStore
+    rng = np.random.default_rng(3)
+    pos = {"chrA": np.sort(rng.integers(0, 100000, 5000)), "chrB": np.sort(rng.integers(0, 50000, 1200))}
+    tl = {c: rng.integers(30, 400, len(p)) for c, p in pos.items()}
+    bam_ok = str(tmp_path / "reads.bam.npz")
+    FragmentStore(["chrA", "chrB"], [100000, 50000], pos, tl).save_npz(bam_ok)
+    bam_bad = str(tmp_path / "missing.bam.npz")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_control_plane_worker, args=(r, 2, port, q, bam_ok, bam_bad)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rows = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    ref = FragmentStore.open(bam_ok)
+    for rank, created, backend, t_init, reads, mapped, failed, t_fail, left in rows:
+        assert created and backend == "gloo" and t_init < 60
+        assert mapped == (rank == 1)                     # rank 0 published, rank 1 mapped the shared arrays
+        for c in ref.references:
+            assert np.array_equal(reads[c][0], ref.pos[c]) and np.array_equal(reads[c][1], ref.tlen[c])
+        assert failed is not None and t_fail < 60, (failed, t_fail)
+        assert not left
