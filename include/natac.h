@@ -392,6 +392,26 @@ int natac_profile_enable(natac_ctx *ctx, int on);
 /* total milliseconds and launch count of kernel class `k` since the last reset */
 int natac_profile_get(natac_ctx *ctx, int k, double *ms_total, int64_t *launches);
 int natac_profile_reset(natac_ctx *ctx);
+/* Resident tracks between the stages of ONE process (`nucleoatac run` = occ -> vprocess -> nuc -> merge -> nfr, cli.py:34-64 of the
+ * reference).  The reference hands the occupancy tracks from `occ` to `nuc` / `nfr` through files: Track.write_track + bgzip, then
+ * tabix reads per chunk (NucChunk.getOcc, NucleosomeCalling.py:284-293; NFRChunk.getOcc, NFRCalling.py:64-67).  Inside one process the
+ * values can stay in HBM instead -- exactly the values a reader of the file would get:
+ *   natac_store_adopt   a COPY of the batch's tracks as the file shows them: every run rounded to its twelve printed digits
+ *                       (float('%.12g' % v)), NaN where Track.write_track writes no line (write_zero as in natac_batch_format_track);
+ *                       returns the segment id, or -1 with *n_hard > 0 when a value cannot be rounded exactly on the device
+ *                       (|v| < 1e-11, >= 1e34): nothing is kept and the caller reads the file for these regions;
+ *   natac_store_read    ranges [offset, offset + length) of slot `slot` (the i-th adopted track) of the named segments, concatenated
+ *                       into `out` (host): whole chunks for nfr's gap statistics, single positions for nuc's calls.
+ * Offsets are positions in the batch's flat per-base layout (chunk k starts at out_off[k]).  Thread-safe. */
+typedef struct natac_store natac_store;
+int natac_store_create(natac_store **out);
+void natac_store_free(natac_store *s);
+int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const int32_t *tracks, int write_zero, int64_t *segment,
+                      int32_t *n_hard);
+int natac_store_read(natac_store *s, natac_ctx *ctx, int64_t n, const int64_t *segment, const int64_t *offset, const int64_t *length,
+                     int32_t slot, double *out, size_t out_values);
+int natac_store_info(natac_store *s, int64_t *n_segments, int64_t *bytes);
+
 /* Shader-clock trace (measurement aid, SURVEY.md section 8d asks for achieved rates against peaks that assume a clock): a one-wave
  * sampler kernel on its own stream notes (wall time, shader cycle counter) every interval_us while other launches run; between
  * two samples cycles / time = the clock the chip ran at.  _stop ends it and returns the number of samples and of profiled launches

@@ -2804,6 +2804,137 @@ int natac_timer_stop(natac_ctx *c, double *ms) {
     return NATAC_OK;
 }
 
+/* ---------------- resident tracks between the stages of one process ---------------- */
+
+struct natac_store {
+    struct Seg { double *p[4]; int n_tracks; long long n; int device; };
+    std::mutex mu;
+    std::vector<Seg> segs;
+};
+
+int natac_store_create(natac_store **out) {
+    if (!out) return fail(NATAC_E_ARG, "out is NULL");
+    *out = new natac_store();
+    return NATAC_OK;
+}
+
+void natac_store_free(natac_store *s) {
+    if (!s) return;
+    for (auto &g : s->segs)
+        for (int i = 0; i < g.n_tracks; ++i) dev_free(g.p[i]);
+    delete s;
+}
+
+int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const int32_t *tracks, int write_zero, int64_t *segment,
+                      int32_t *n_hard) {
+    using namespace natac_textz;
+    if (!s || !b || !tracks || !segment || n_tracks < 1 || n_tracks > 4) return fail(NATAC_E_ARG, "bad argument");
+    *segment = -1;
+    if (n_hard) *n_hard = 0;
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    for (int i = 0; i < n_tracks; ++i) {
+        if (tracks[i] == NATAC_T_INS) return fail(NATAC_E_ARG, "float64 tracks only");
+        if ((rc = track_ready(b, tracks[i]))) return rc;
+    }
+    if (b->total_bp >= 0xffffffffLL) return fail(NATAC_E_ARG, "batch too long (%lld bases)", b->total_bp);
+    if ((rc = ensure_text_tables(c))) return rc;
+    HIPCHK(sync_all(c));
+    TmpFree tmp;
+    int *d_tc = nullptr, *d_C = nullptr, *d_hard = nullptr;
+    unsigned long long *d_tb = nullptr;
+    unsigned int *d_R = nullptr;
+    const int nt = b->n_tiles256;
+#define TRYS(x) do { if ((rc = (x)) != NATAC_OK) { for (int q_ = 0; q_ < 4; ++q_) dev_free(seg.p[q_]); return rc; } } while (0)
+    natac_store::Seg seg{{nullptr, nullptr, nullptr, nullptr}, n_tracks, b->total_bp, c->device};
+    TRYS(dev_alloc(&d_hard, 1)); tmp.keep(d_hard);
+    TRYS(dev_alloc(&d_tc, (size_t)nt)); tmp.keep(d_tc);
+    TRYS(dev_alloc(&d_tb, (size_t)nt + 1)); tmp.keep(d_tb);
+    hipError_t e = hipMemsetAsync(d_hard, 0, sizeof(int), c->stream);
+    int hard = 0;
+    for (int i = 0; i < n_tracks && e == hipSuccess; ++i) {
+        TextJob job;
+        job.vals = b->d_track[tracks[i]]; job.out_off = b->d_out_off; job.chunk_len = b->d_len; job.tiles = b->d_tiles256; job.ntiles = nt;
+        job.chrom_id = nullptr; job.chunk_start = nullptr; job.names = nullptr; job.name_off = nullptr; job.p10 = c->d_p10;
+        job.write_zero = write_zero & 1; job.keep_before_nan = (write_zero >> 1) & 1;
+        hipLaunchKernelGGL(tz_flags_count, dim3(nt), dim3(256), 0, c->stream, job, d_tc);
+        TRYS(dev_scan(c, d_tc, (long long)nt, d_tb));
+        unsigned long long nruns = 0;
+        if ((e = hipMemcpyAsync(&nruns, d_tb + nt, sizeof nruns, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
+        dev_free(d_R); dev_free(d_C);
+        d_R = nullptr; d_C = nullptr;
+        if ((rc = dev_alloc(&d_R, (size_t)nruns)) || (rc = dev_alloc(&d_C, (size_t)nruns))) { dev_free(d_R); dev_free(d_C); TRYS(rc); }
+        hipLaunchKernelGGL(tz_scatter_runs, dim3(nt), dim3(256), 0, c->stream, job, d_tb, d_R, d_C);
+        if ((rc = dev_alloc(&seg.p[i], (size_t)b->total_bp))) { dev_free(d_R); dev_free(d_C); TRYS(rc); }
+        hipLaunchKernelGGL(tz_as_written, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C,
+                           seg.p[i], d_hard);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&hard, d_hard, sizeof hard, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_R); dev_free(d_C);
+    if (e != hipSuccess) { for (int q = 0; q < 4; ++q) dev_free(seg.p[q]); return fail(NATAC_E_HIP, "store_adopt: %s", hipGetErrorString(e)); }
+#undef TRYS
+    if (n_hard) *n_hard = hard;
+    if (hard) {      // a value the device cannot round like the text round trip would: nothing is adopted, the caller reads the file
+        for (int q = 0; q < 4; ++q) dev_free(seg.p[q]);
+        return NATAC_OK;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->segs.push_back(seg);
+    *segment = (int64_t)s->segs.size() - 1;
+    return NATAC_OK;
+}
+
+int natac_store_read(natac_store *s, natac_ctx *c, int64_t n, const int64_t *segment, const int64_t *offset, const int64_t *length,
+                     int32_t slot, double *out, size_t out_values) {
+    using namespace natac_textz;
+    if (!s || !c || n < 0 || (n > 0 && (!segment || !offset || !length || !out))) return fail(NATAC_E_ARG, "null argument");
+    if (n == 0) return NATAC_OK;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<StoreRegion> reg((size_t)n);
+    long long total = 0;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        for (int64_t j = 0; j < n; ++j) {
+            if (segment[j] < 0 || segment[j] >= (int64_t)s->segs.size()) return fail(NATAC_E_ARG, "region %lld: no segment %lld", (long long)j, (long long)segment[j]);
+            const natac_store::Seg &g = s->segs[(size_t)segment[j]];
+            if (slot < 0 || slot >= g.n_tracks) return fail(NATAC_E_ARG, "segment %lld holds %d tracks", (long long)segment[j], g.n_tracks);
+            if (g.device != c->device) return fail(NATAC_E_ARG, "segment %lld lives on device %d", (long long)segment[j], g.device);
+            if (offset[j] < 0 || length[j] < 0 || offset[j] + length[j] > g.n)
+                return fail(NATAC_E_ARG, "region %lld: [%lld, +%lld) outside its segment (%lld values)", (long long)j, (long long)offset[j], (long long)length[j], g.n);
+            reg[(size_t)j] = {g.p[slot] + offset[j], total, (long long)length[j]};
+            total += length[j];
+        }
+    }
+    if ((size_t)total != out_values) return fail(NATAC_E_ARG, "destination holds %zu values, the regions %lld", out_values, total);
+    if (total == 0) return NATAC_OK;
+    StoreRegion *d_reg = nullptr;
+    double *d_out = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &d_reg, reg.data(), reg.size()))) return rc;
+    if ((rc = dev_alloc(&d_out, (size_t)total))) { dev_free(d_reg); return rc; }
+    hipLaunchKernelGGL(tz_store_gather, dim3((unsigned)n), dim3(256), 0, c->stream, d_reg, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_reg); dev_free(d_out);
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "store_read: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
+int natac_store_info(natac_store *s, int64_t *n_segments, int64_t *bytes) {
+    if (!s) return fail(NATAC_E_ARG, "store is NULL");
+    std::lock_guard<std::mutex> lk(s->mu);
+    long long by = 0;
+    for (auto &g : s->segs) by += (long long)g.n_tracks * g.n * (long long)sizeof(double);
+    if (n_segments) *n_segments = (int64_t)s->segs.size();
+    if (bytes) *bytes = by;
+    return NATAC_OK;
+}
+
 /* ---------------- shader-clock trace ---------------- */
 }  // extern "C"
 

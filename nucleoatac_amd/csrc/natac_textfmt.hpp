@@ -156,4 +156,61 @@ NATAC_HD inline char *fmt_py2_float(char *p, double v, const P10 *tab, int *hard
 
 constexpr int MAX_VALUE_CHARS = 24;     // "-1.23456789012e-308" is 19
 
+// The double a reader gets back from fmt_py2_float's text: float('%.12g' % v) -- v rounded (half-even, exactly, as above) to twelve
+// significant digits D x 10^(e10 - 11), then that decimal rounded to the nearest double.  For 0 <= |e10 - 11| <= 22 both D (< 10^12)
+// and the power of ten are exact doubles, so ONE IEEE division / multiplication is the correctly rounded result (what strtod and
+// the native tabix reader's fast path return).  Outside that range (|v| < 1e-11 or >= 1e34), or when the twelfth digit could not be
+// decided, *hard is incremented and the value is returned unrounded: the caller must not use the array as "what the file holds".
+NATAC_HD inline double round12(double v, const P10 *tab, int *hard) {
+    union { double d; uint64_t u; } cv;
+    cv.d = v;
+    const uint64_t bits = cv.u;
+    const int ef = (int)((bits >> 52) & 0x7ff);
+    const uint64_t frac = bits & 0xfffffffffffffull;
+    if (ef == 0x7ff || (ef == 0 && frac == 0)) return v;             // nan, inf, +-0
+    uint64_t m = ef ? (frac | (1ull << 52)) : frac;
+    int e2 = ef ? ef - 1075 : -1074;
+    const int lz = clz64(m);
+    m <<= lz;
+    e2 -= lz;
+    int e10 = ((e2 + 63) * 78913) >> 18;
+    uint64_t D = 0;
+    int h = 0;
+    for (int it = 0; it < 3; ++it) {                                  // the digit loop of fmt_py2_float
+        const int s = 11 - e10;
+        if (s < NATAC_P10_SMIN || s > NATAC_P10_SMAX) { ++*hard; return v; }
+        const P10 T = tab[s - NATAC_P10_SMIN];
+        uint64_t l1, h1;
+        const uint64_t l0 = mul64(m, T.lo, &l1);
+        const uint64_t h0 = mul64(m, T.hi, &h1);
+        const uint64_t p0 = l0;
+        const uint64_t p1 = l1 + h0;
+        const uint64_t p2 = h1 + (p1 < l1 ? 1 : 0);
+        const int sh = -(e2 + T.e) - 128;
+        const uint64_t D0 = p2 >> sh;
+        if (D0 >= 1000000000000ull) { ++e10; continue; }
+        const uint64_t hb = (p2 >> (sh - 1)) & 1;
+        const uint64_t mask = (1ull << (sh - 1)) - 1;
+        const uint64_t rest = p2 & mask;
+        bool up;
+        h = 0;
+        if (T.exact) up = hb && ((rest | p1 | p0) != 0 || (D0 & 1));
+        else {
+            up = hb != 0;
+            if (!hb && rest == mask && p1 == ~0ull) h = 1;
+        }
+        D = D0 + (up ? 1 : 0);
+        if (D < 100000000000ull) { --e10; continue; }
+        if (D >= 1000000000000ull) { D = 100000000000ull; ++e10; }
+        break;
+    }
+    const int s = 11 - e10;                                           // value = D / 10^s
+    if (h || s > 22 || s < -22) { ++*hard; return v; }
+    const double P[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19,
+                          1e20, 1e21, 1e22};
+    const double d = (double)D;
+    const double r = s >= 0 ? d / P[s] : d * P[-s];
+    return (bits >> 63) ? -r : r;
+}
+
 }  // namespace natac_text

@@ -169,6 +169,29 @@ __device__ __forceinline__ RunInfo run_info(const TextJob &job, long long k, lon
     r.emitted = !(r.v != r.v) && (r.v != 0.0 || job.write_zero) && (job.keep_before_nan || !nan_follows);
     return r;
 }
+// What a reader of the finished file sees at every base: the run's value rounded to its twelve printed digits (natac_text::round12)
+// where a line is written, NaN where none is (NaN runs, runs lost before a NaN, zero runs without write_zero) -- the in-process
+// stand-in for "write the track, tabix-read it back" (NucChunk.getOcc, NucleosomeCalling.py:284-293).  One thread per run; `out` is
+// a second array (a neighbour's look at vals[b] must see the unwritten value).
+__global__ void __launch_bounds__(256) tz_as_written(TextJob job, long long nruns, const unsigned int *__restrict__ R, const int *__restrict__ C,
+                                                      double *__restrict__ out, int *__restrict__ hard_total) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nruns) return;
+    const RunInfo r = run_info(job, k, nruns, R, C);
+    int hard = 0;
+    const double w = r.emitted ? natac_text::round12(r.v, job.p10, &hard) : __builtin_nan("");
+    const long long cb = job.out_off[r.chunk];
+    for (long long i = cb + r.a_rel; i < cb + r.b_rel; ++i) out[i] = w;
+    if (hard) atomicAdd(hard_total, hard);
+}
+
+// ranges of resident arrays -> one flat array (natac_store_read): region j = src[j][0 .. len[j]) -> dst[dst_off[j] ...]
+struct StoreRegion { const double *src; long long dst_off, len; };
+__global__ void __launch_bounds__(256) tz_store_gather(const StoreRegion *__restrict__ reg, double *__restrict__ dst) {
+    const StoreRegion r = reg[blockIdx.x];
+    for (long long i = threadIdx.x; i < r.len; i += 256) dst[r.dst_off + i] = r.src[i];
+}
+
 constexpr int MAX_LINE = 160;      // name (<= 64) + 2 coordinates (<= 20 each) + value (<= 24) + 4 separators
 constexpr int VTXT = 24;           // bytes kept per run for the text of its value ("-1.23456789012e-308" is 19)
 

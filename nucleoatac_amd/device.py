@@ -60,6 +60,46 @@ def pool_trim():
     L.check(L.load().natac_pool_trim())
 
 
+class TrackStore(object):
+    """device-resident copies of batch tracks as their .bedgraph file shows them (natac_store_*; see occstore.py)"""
+
+    def __init__(self):
+        self._lib = L.load()
+        self._h = C.c_void_p()
+        L.check(self._lib.natac_store_create(C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.natac_store_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
+
+    def adopt(self, batch, tracks, write_zero=True, keep_runs_before_nan=False):
+        """copy `tracks` of `batch` into the store; returns the segment id, or None when a value cannot be rounded exactly on the
+        device (nothing is kept then)"""
+        t = np.ascontiguousarray(tracks, dtype=np.int32)
+        seg, hard = C.c_int64(-1), C.c_int32(0)
+        L.check(self._lib.natac_store_adopt(self._h, batch._h, len(t), _ptr(t), (1 if write_zero else 0) | (2 if keep_runs_before_nan else 0),
+                                            C.byref(seg), C.byref(hard)))
+        return None if seg.value < 0 else int(seg.value)
+
+    def read(self, ctx, segment, offset, length, slot):
+        sg, of, ln = (np.ascontiguousarray(a, dtype=np.int64) for a in (segment, offset, length))
+        out = np.empty(int(ln.sum()), dtype=np.float64)
+        L.check(self._lib.natac_store_read(self._h, ctx._h, len(sg), _ptr(sg), _ptr(of), _ptr(ln), int(slot), _ptr(out), out.size))
+        return out
+
+    def info(self):
+        n, by = C.c_int64(0), C.c_int64(0)
+        L.check(self._lib.natac_store_info(self._h, C.byref(n), C.byref(by)))
+        return dict(segments=n.value, bytes=by.value)
+
+
 class Context(object):
     """one HIP device + stream (natac_ctx)"""
 

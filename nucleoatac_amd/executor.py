@@ -36,12 +36,14 @@ class Stages(object):
     peaks       kwargs of DeviceBatch.run_peaks (candidate search + LR / var / z), or None
     occ_peaks   kwargs of DeviceBatch.run_occ_peaks (OccChunk.callPeaks + getNucDist), or None
     tracks      per-base tracks to download as arrays (NATAC_T_* ids)
+    keep        (TrackStore, tracks): a copy of these tracks, as their .bedgraph file shows them, stays in HBM (occstore.py)
     text_tracks per-base tracks to bring back as finished bedGraph.gz bytes instead: Track.write_track + bgzip run on the device
                 (natac_batch_format_track); the sub-batch needs `chroms` and `chunk_start` (pipeline.pack sets them)
     """
 
-    def __init__(self, nuc_sd=10, occ=True, ins=(0, 2000), peaks=None, occ_peaks=None, tracks=(), text_tracks=()):
+    def __init__(self, nuc_sd=10, occ=True, ins=(0, 2000), peaks=None, occ_peaks=None, tracks=(), text_tracks=(), keep=None):
         self.nuc_sd, self.occ, self.ins, self.peaks, self.occ_peaks = nuc_sd, occ, ins, peaks, occ_peaks
+        self.keep = keep      # (device.TrackStore, track ids): adopt these tracks into the store (Result.store_seg)
         self.tracks = tuple(int(t) for t in tracks)
         self.text_tracks = tuple(int(t) for t in text_tracks)
 
@@ -102,7 +104,7 @@ class ResidentShard(object):
 
 class Result(object):
     """outputs of one sub-batch in page-locked host memory; `release()` hands the buffers back to the executor"""
-    __slots__ = ("seq", "packed", "tag", "tracks", "text", "text_index", "peaks", "occ_peaks", "status", "_slot", "_ex")
+    __slots__ = ("seq", "packed", "tag", "tracks", "text", "text_index", "peaks", "occ_peaks", "status", "store_seg", "_slot", "_ex")
 
     def release(self):
         if self._slot is not None:
@@ -197,6 +199,7 @@ class PipelinedExecutor(object):
             r.peaks = b.download_peaks(n) if st.peaks is not None else None
             r.occ_peaks = b.run_occ_peaks(**st.occ_peaks) if st.occ_peaks is not None else None
             r.status = b.status()
+            r.store_seg = st.keep[0].adopt(b, st.keep[1]) if st.keep is not None else None
             down = sum(a.nbytes for a in r.tracks.values()) + (n * 32 if st.peaks is not None else 0) + \
                 sum(a.nbytes for a in r.text.values() if a is not None)
             up = packed.frag_lpos.nbytes + packed.frag_ilen.nbytes + (packed.bias_log.nbytes if packed.bias_log is not None else 0)

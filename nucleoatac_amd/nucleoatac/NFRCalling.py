@@ -150,6 +150,14 @@ def nfr_batch(chunks, params, ins_off=None, ins_flat=None):
         return t.vals
 
     def column(path, value_col=4):   # (flat values, offsets) of one file: one native call for the batch, else chunk by chunk
+        if value_col == 4:           # an occupancy track this process wrote: its values are still in HBM, as the file shows them
+            from .. import get_context, occstore
+            slot, occ_path = occstore.slot_of(path)
+            res = occstore.lookup(occ_path)
+            if res is not None:
+                got = res.read_regions(get_context(), [c.chrom for c in chunks], starts, ends, slot)
+                if got is not None:
+                    return got
         got = read_regions_of(path, chunks, value_col)
         if got is not None:
             return got

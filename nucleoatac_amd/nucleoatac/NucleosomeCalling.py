@@ -144,20 +144,26 @@ def read_regions_of(path, chunks, value_col=4):
 
 
 def read_occ_tracks_many(occ_track, chunks):
-    """read_occ_tracks for a list of chunks: per chunk [occ, lower, upper], or None where the read failed (Nucleosome.getOcc
-    turns any failure into NaN, NucleosomeCalling.py:128-135)"""
+    """read_occ_tracks for a list of chunks: per chunk [occ, lower, upper].  A missing / damaged track file or index RAISES, as
+    NucChunk.getOcc does in the reference (NucleosomeCalling.py:284-293: Track.read_track outside any try -- the run aborts);
+    only the per-position lookup of Nucleosome.getOcc (:128-135) turns a failure into NaN, and that stays with the callers."""
+    from .. import occstore
+    res = occstore.lookup(occ_track)
+    if res is not None and chunks:          # written by this process: the values are still in HBM, as the files show them
+        from .. import get_context
+        ctx, chroms = get_context(), [c.chrom for c in chunks]
+        starts, ends = [c.start for c in chunks], [c.end for c in chunks]
+        three = [res.read_regions(ctx, chroms, starts, ends, slot) for slot in range(3)]
+        if all(t is not None for t in three):
+            return [[flat[int(off[k]):int(off[k + 1])] for flat, off in three] for k in range(len(chunks))]
     base = occ_track[:-11]
-    try:
-        three = [read_regions_of(f, chunks) for f in (occ_track, base + "lower_bound.bedgraph.gz", base + "upper_bound.bedgraph.gz")]
-    except Exception:      # noqa: BLE001 -- e.g. one damaged member: find out chunk by chunk which reads still work
-        three = [None]
-    if any(t is None for t in three):
-        def one(ch):
-            try:
-                return read_occ_tracks(occ_track, ch.chrom, ch.start, ch.end)
-            except Exception:      # noqa: BLE001
-                return None
-        return map_in_slices(one, chunks)
+    files = (occ_track, base + "lower_bound.bedgraph.gz", base + "upper_bound.bedgraph.gz")
+    for f in files:
+        if not os.path.exists(f):
+            raise IOError("occupancy track %s not found (expected next to --occ_track %s)" % (f, occ_track))
+    three = [read_regions_of(f, chunks) for f in files]
+    if any(t is None for t in three):      # no index / no native reader: chunk by chunk through Track.read_track
+        return map_in_slices(lambda ch: read_occ_tracks(occ_track, ch.chrom, ch.start, ch.end), chunks)
     return [[flat[int(off[k]):int(off[k + 1])] for flat, off in three] for k in range(len(chunks))]
 
 

@@ -154,6 +154,7 @@ def nucleoatac_main(args):
         from .run_vprocess import run_vprocess
         from ..shard import barrier
         print("---------Step1: Computing Occupancy and Nucleosomal Insert Distribution---------")
+        occ_args.keep_resident = True      # the occupancy tracks also stay in HBM for steps 3 and 5 of this process (occstore.py)
         run_occ(occ_args)
         barrier()
         print("---------Step2: Processing Vplot------------------------------------------------")
@@ -166,6 +167,8 @@ def nucleoatac_main(args):
         print("---------Step5: Calling NFR positions-------------------------------------------")
         run_nfr(nfr_args)
         barrier()
+        from .. import occstore
+        occstore.release(args.out + ".occ.bedgraph.gz")
     else:
         raise SystemExit("usage: nucleoatac {run,occ,vprocess,nuc,merge,nfr} ...")
 

@@ -250,10 +250,18 @@ def run_occ(args):
         pos = np.array([c.start for c in part], dtype=np.int64)[cc] + cp
         write_bed_rows(peaks_path, names, cid, pos, pos + 1, np.stack([p_occ, p_lo, p_up, p_rd], axis=1))
 
+    # inside `nucleoatac run` the three tracks also stay in HBM, as the files show them, for the nuc and nfr steps of this process
+    resident = None
+    if getattr(args, "keep_resident", False) and parts:
+        from .. import occstore
+        if occstore.ENABLED:
+            resident = occstore.OccTrackStore()
+            occstore.register(args.out + ".occ.bedgraph.gz", resident)
     if parts:
         stages = Stages(nuc_sd=None, occ=True, ins=None, occ_peaks=dict(min_occ=params.min_occ, sep=params.sep),
                         tracks=() if DEVICE_WRITER else tuple(track_of.values()),
-                        text_tracks=tuple(track_of.values()) if DEVICE_WRITER else ())
+                        text_tracks=tuple(track_of.values()) if DEVICE_WRITER else (),
+                        keep=(resident.dev, occstore.TRACKS) if resident is not None else None)
         writer = _Writer(paths, track_of, peaks_and_dists, len(parts), rank == world - 1)
         writer.start()
 
@@ -284,6 +292,8 @@ def run_occ(args):
                         print("Caught exception when processing:\n" + r.tag[k].asBed() + "\n")
                         r.release()
                         raise ValueError("min() arg is an empty sequence (occupancy likelihood undefined in %s)" % r.tag[k].asBed())
+                    if resident is not None:
+                        resident.add(r.tag, r.packed.out_off, r.store_seg)
                     writer.put(r)
         finally:
             writer.finish()
