@@ -8,20 +8,32 @@ Sub-packages mirror the reference's module names for the hot path:
 All numerics run in libnatac_hip.so (include/natac.h); there is no CPU fallback.
 """
 import os
+import threading
 
 __version__ = "0.1.0"
 
 _default_ctx = None
+# The process-wide context is ONE stream with per-context model state (V-plot, sizes, occupancy model): work on it from more than
+# one thread (a driver's writer thread re-doing an overflow chunk while the main thread packs, a reader pulling resident tracks)
+# takes this lock for the whole install-constants + run + download sequence.  The executor's worker contexts are private to their
+# threads and need none.
+context_lock = threading.RLock()
 
 
 def get_context():
     """process-wide natac context on GPU `LOCAL_RANK` (0 when unset); created on first use"""
     global _default_ctx
-    if _default_ctx is None:
+    with context_lock:
+        if _default_ctx is None:
+            _default_ctx = _make_default()
+    return _default_ctx
+
+
+def _make_default():
+    if True:
         from .device import Context
         # one context per process: GPU = LOCAL_RANK (torchrun); NATAC_DEVICE overrides it (e.g. several ranks on one GPU in tests)
-        _default_ctx = Context(int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
-    return _default_ctx
+        return Context(int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
 
 
 def set_context(ctx):

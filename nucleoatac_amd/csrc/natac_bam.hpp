@@ -46,7 +46,7 @@ inline Bam *decode(const char *path, int n_threads, std::string &err, size_t bat
     if (!f) { err = std::string("cannot open ") + path; return nullptr; }
     if (n_threads <= 0) n_threads = natac_cores::default_threads(64);
     batch_bytes = std::max<size_t>(batch_bytes, (size_t)4096);           // + 64 KiB below: always room for one maximal BGZF block
-    struct Blk { size_t off, csize; uint32_t isize; size_t uoff; };
+    struct Blk { size_t off, csize; uint32_t isize; size_t uoff; uint32_t crc; };
     std::vector<unsigned char> raw, data;
     std::vector<Blk> blks;
     size_t raw_len = 0;            // valid bytes in raw (starts with the leftover of the previous window)
@@ -55,6 +55,7 @@ inline Bam *decode(const char *path, int n_threads, std::string &err, size_t bat
     int32_t n_ref = 0;
     Bam *bam = new Bam();
     auto fail = [&](const char *msg) -> Bam * { err = msg; delete bam; std::fclose(f); return nullptr; };
+    unsigned long long window_file_off = 0;      // file offset of raw[0]
     raw.resize(batch_bytes + ((size_t)1 << 16));
     while (!eof || raw_len > 0) {
         // ---- refill the compressed window
@@ -84,7 +85,7 @@ inline Bam *decode(const char *path, int n_threads, std::string &err, size_t bat
             // a BGZF member inflates to at most 64 KiB (SAM spec 4.1): a larger ISIZE is a corrupt or hostile file and would
             // otherwise size the window buffer (the bounded-memory guarantee of this decoder rests on this check)
             if (isize > 65536) return fail("corrupt BGZF block (ISIZE > 65536)");
-            blks.push_back({o + 12 + xlen, bsize - 12 - xlen - 8, isize, utotal});
+            blks.push_back({o + 12 + xlen, bsize - 12 - xlen - 8, isize, utotal, rd32(h + bsize - 8)});
             utotal += isize;
             o += bsize;
             any_block = true;
@@ -102,13 +103,17 @@ inline Bam *decode(const char *path, int n_threads, std::string &err, size_t bat
             const int nt = std::max(1, std::min<int>(n_threads, (int)blks.size()));
             std::atomic<size_t> next(0);
             std::atomic<int> bad(0);
+            std::atomic<long long> bad_crc(-1);
             auto work = [&]() {
                 z_stream zs;
                 for (;;) {
                     const size_t i = next.fetch_add(1);
                     if (i >= blks.size()) break;
                     const Blk &bk = blks[i];
-                    if (bk.isize == 0) continue;
+                    if (bk.isize == 0) {
+                        if (bk.crc != 0) { long long none = -1; bad_crc.compare_exchange_strong(none, (long long)i); }
+                        continue;
+                    }
                     std::memset(&zs, 0, sizeof zs);
                     if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
                     zs.next_in = raw.data() + bk.off;
@@ -118,6 +123,12 @@ inline Bam *decode(const char *path, int n_threads, std::string &err, size_t bat
                     const int rc = inflate(&zs, Z_FINISH);
                     inflateEnd(&zs);
                     if (rc != Z_STREAM_END || zs.total_out != bk.isize) { bad = 1; return; }
+                    // the member's CRC-32 (RFC 1952; htslib checks it behind every pysam read of the reference, pyatac/fragments.pyx:21):
+                    // a damaged payload can still inflate to ISIZE bytes
+                    if ((uint32_t)crc32(0L, data.data() + bk.uoff, bk.isize) != bk.crc) {
+                        long long none = -1;
+                        bad_crc.compare_exchange_strong(none, (long long)i);
+                    }
                 }
             };
             std::vector<std::thread> th;
@@ -125,9 +136,20 @@ inline Bam *decode(const char *path, int n_threads, std::string &err, size_t bat
             work();
             for (auto &x : th) x.join();
             if (bad) return fail("inflate failed (corrupt BGZF block)");
+            if (bad_crc >= 0) {
+                // the member starts 12 + XLEN bytes before its payload; XLEN is 6 for every BGZF writer, read it back to be exact
+                const size_t pay = blks[(size_t)bad_crc.load()].off;
+                size_t hdr = pay >= 18 ? pay - 18 : 0;
+                for (size_t b = pay >= 18 ? pay - 18 : 0; b + 12 <= pay; ++b)      // (only XLEN = pay - b - 12 is consistent)
+                    if (raw[b] == 0x1f && raw[b + 1] == 0x8b && (size_t)rd16(raw.data() + b + 10) == pay - b - 12) { hdr = b; break; }
+                static thread_local char msg[128];
+                std::snprintf(msg, sizeof msg, "CRC-32 mismatch in the BGZF member at file offset %llu (corrupt file)", window_file_off + hdr);
+                return fail(msg);
+            }
         }
         std::memmove(raw.data(), raw.data() + o, raw_len - o);      // leftover compressed bytes (a partial block)
         raw_len -= o;
+        window_file_off += o;
         // ---- walk the uncompressed bytes [0, utotal)
         const unsigned char *p = data.data();
         const size_t n = utotal;

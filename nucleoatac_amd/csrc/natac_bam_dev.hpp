@@ -232,8 +232,34 @@ constexpr int INFLATE_LDS_U16 = (288 + 32 + 4 * 16) * 64;
 // A launch covers the members [m_begin, n_members) whose bytes have arrived; it fills the chip at most once (3 workgroups per CU: the
 // LDS tables) and every lane takes members from the launch's queue until it is empty: a serial decoder needs ~85 ms per 64-KiB member, so with one member per lane a launch of 55 k members took two rounds
 // of 49 k lanes, the second nearly empty.
+// CRC-32 (IEEE, reflected) of p[0, n) with the slicing-by-8 tables t8[8][256] (t8[0] = the byte table): eight independent lookups
+// per 8 bytes, so the dependent chain is one load per 8 bytes -- ~0.5 ms for a 64-KiB member next to the ~85 ms its inflate takes
+__device__ __forceinline__ unsigned int crc32_slice8(const unsigned int *__restrict__ t8, const unsigned char *p, unsigned int n) {
+    unsigned int c = 0xffffffffu;
+    while (n && ((uintptr_t)p & 7)) { c = t8[(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
+    for (; n >= 8; n -= 8, p += 8) {
+        const unsigned long long w = *(const unsigned long long *)p;
+        const unsigned int lo = (unsigned int)w ^ c, hi = (unsigned int)(w >> 32);
+        c = t8[7 * 256 + (lo & 0xff)] ^ t8[6 * 256 + ((lo >> 8) & 0xff)] ^ t8[5 * 256 + ((lo >> 16) & 0xff)] ^ t8[4 * 256 + (lo >> 24)] ^
+            t8[3 * 256 + (hi & 0xff)] ^ t8[2 * 256 + ((hi >> 8) & 0xff)] ^ t8[1 * 256 + ((hi >> 16) & 0xff)] ^ t8[hi >> 24];
+    }
+    while (n) { c = t8[(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
+    return c ^ 0xffffffffu;
+}
+inline void crc32_slice8_tables(unsigned int *t8) {       // host: the tables above
+    for (unsigned int i = 0; i < 256; ++i) {
+        unsigned int c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0xedb88320u : c >> 1;
+        t8[i] = c;
+    }
+    for (int s = 1; s < 8; ++s)
+        for (unsigned int i = 0; i < 256; ++i) t8[s * 256 + i] = t8[(s - 1) * 256 + i] >> 8 ^ t8[t8[(s - 1) * 256 + i] & 0xff];
+}
+
+// error code 7: the member inflated to ISIZE bytes but its CRC-32 (the four bytes behind the payload, RFC 1952) does not match
 __global__ void __launch_bounds__(64) bamdev_inflate(const unsigned char *__restrict__ raw, const Member *__restrict__ mem, int m_begin, int n_members,
-                                                     unsigned char *__restrict__ data, int *__restrict__ status, int *__restrict__ queue) {
+                                                     unsigned char *__restrict__ data, int *__restrict__ status, int *__restrict__ queue,
+                                                     const unsigned int *__restrict__ crc_t8) {
     __shared__ unsigned short tab[INFLATE_LDS_U16];
     unsigned char lengths[320];
     typedef Strided<unsigned char, 1> L8;
@@ -243,9 +269,15 @@ __global__ void __launch_bounds__(64) bamdev_inflate(const unsigned char *__rest
         const int m = m_begin + atomicAdd(queue, 1);
         if (m >= n_members) break;
         const Member mb = mem[m];
-        if (mb.isize == 0) continue;
-        const int rc = inflate_member(raw + mb.coff, mb.csize, data + mb.uoff, mb.isize, L8{lengths}, T16{t}, T16{t + 288 * 64}, T16{t + 304 * 64},
-                                      T16{t + 320 * 64}, T16{t + 352 * 64}, T16{t + 368 * 64});
+        const unsigned char *tr = raw + mb.coff + mb.csize;              // trailer: CRC-32, ISIZE
+        const unsigned int want = (unsigned int)tr[0] | ((unsigned int)tr[1] << 8) | ((unsigned int)tr[2] << 16) | ((unsigned int)tr[3] << 24);
+        int rc = 0;
+        if (mb.isize == 0) rc = want == 0 ? 0 : 7;
+        else {
+            rc = inflate_member(raw + mb.coff, mb.csize, data + mb.uoff, mb.isize, L8{lengths}, T16{t}, T16{t + 288 * 64}, T16{t + 304 * 64},
+                                T16{t + 320 * 64}, T16{t + 352 * 64}, T16{t + 368 * 64});
+            if (rc == 0 && crc32_slice8(crc_t8, data + mb.uoff, mb.isize) != want) rc = 7;
+        }
         if (rc != 0 && atomicCAS(&status[0], 0, rc) == 0) status[1] = m;
     }
 }
@@ -464,7 +496,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
     unsigned char *stage[2] = {nullptr, nullptr};
     hipEvent_t staged[2] = {nullptr, nullptr};
     natac_bamio::Bam *bam = new natac_bamio::Bam();
-    DevBuf d_raw, d_mem, d_data[2], d_wo, d_base, d_ref, d_pos, d_tlen, d_status, d_queue;
+    DevBuf d_raw, d_mem, d_data[2], d_wo, d_base, d_ref, d_pos, d_tlen, d_status, d_queue, d_crc;
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     std::vector<Member> mem;
     std::vector<WalkOut> wo;
@@ -490,6 +522,13 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
     }
     for (int i = 0; i < 3; ++i) BAMDEV_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
     BAMDEV_HIP(d_status.reserve(4 * sizeof(int)));
+    {
+        std::vector<unsigned int> t8(8 * 256);
+        crc32_slice8_tables(t8.data());
+        BAMDEV_HIP(d_crc.reserve(t8.size() * sizeof(unsigned int)));
+        BAMDEV_HIP(hipMemcpyAsync(d_crc.p, t8.data(), t8.size() * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
+        BAMDEV_HIP(hipStreamSynchronize(stream));      // t8 is a local
+    }
     int n_cu = 256;
     {
         int dev = 0;
@@ -576,7 +615,7 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
                         const int cnt = upto - launched;
                         hipLaunchKernelGGL(bamdev_inflate, dim3((unsigned)std::min<long long>((cnt + 63) / 64, 3ll * n_cu)), dim3(64), 0, side,
                                            (const unsigned char *)d_raw.p, (const Member *)d_mem.p, launched, upto, data, (int *)d_status.p,
-                                           (int *)d_queue.p + n_launch);
+                                           (int *)d_queue.p + n_launch, (const unsigned int *)d_crc.p);
                         launched = upto;
                         ++n_launch;
                         since = 0;
@@ -589,6 +628,11 @@ inline natac_bamio::Bam *decode_device(const char *path, hipStream_t stream, std
         int st[2] = {0, 0};
         BAMDEV_HIP(hipMemcpyAsync(st, d_status.p, sizeof st, hipMemcpyDeviceToHost, stream));
         BAMDEV_HIP(hipStreamSynchronize(stream));
+        if (st[0] == 7) {      // the member's file offset: where the previous member of the chain ends
+            unsigned long long at = 0;
+            { std::lock_guard<std::mutex> lk(chain.mu); if (m0 + (size_t)st[1] > 0) at = chain.ends[m0 + (size_t)st[1] - 1]; }
+            return fail("CRC-32 mismatch in the BGZF member at file offset " + std::to_string(at) + " (corrupt file)");
+        }
         if (st[0] != 0) return fail("inflate failed (corrupt BGZF block)");
         const bool eof = win_end == fsize;
         const size_t raw_len = 0;          // (no compressed leftover: windows end on member boundaries)

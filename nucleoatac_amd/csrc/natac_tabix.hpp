@@ -188,6 +188,9 @@ inline int index_bed(const char *path, const char *tbi_path, int n_threads, int6
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
             if (rc != Z_STREAM_END || zs.avail_out != 0) { err[t] = 3; return; }
+            const unsigned char *tr = d + k.coff + k.csize - 8;          // CRC-32 of the member (RFC 1952)
+            const uint32_t want = tr[0] | (tr[1] << 8) | (tr[2] << 16) | ((uint32_t)tr[3] << 24);
+            if ((uint32_t)crc32(0L, (const Bytef *)&text[k.uoff], k.usize) != want) { err[t] = 3; return; }
         }
     };
     {
@@ -303,7 +306,11 @@ inline int inflate_all(const char *path, std::string &out) {
             zs.avail_out = isize;
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
-            if (rc != Z_STREAM_END) return 3;
+            if (rc != Z_STREAM_END || zs.total_out != isize) return 3;
+        }
+        {   // CRC-32 of the member (RFC 1952)
+            const uint32_t want = d[p + bsize - 8] | (d[p + bsize - 7] << 8) | (d[p + bsize - 6] << 16) | ((uint32_t)d[p + bsize - 5] << 24);
+            if ((uint32_t)crc32(0L, isize ? (const Bytef *)&out[o] : (const Bytef *)"", isize) != want) return 3;
         }
         p += bsize;
     }
@@ -485,7 +492,11 @@ inline Reader::Block *get_block(Reader *r, uint64_t coff) {
         zs.avail_out = isize;
         const int rc = inflate(&zs, Z_FINISH);
         inflateEnd(&zs);
-        if (rc != Z_STREAM_END) return nullptr;
+        if (rc != Z_STREAM_END || zs.total_out != isize) return nullptr;
+    }
+    {   // CRC-32 of the member (RFC 1952): a damaged payload that still inflates must not be parsed
+        const uint32_t want = b[clen - 8] | (b[clen - 7] << 8) | (b[clen - 6] << 16) | ((uint32_t)b[clen - 5] << 24);
+        if ((uint32_t)crc32(0L, isize ? (const Bytef *)slot->text.data() : (const Bytef *)"", isize) != want) return nullptr;
     }
     // line table: [0, head_end) belongs to the line the previous member ended in (or is a whole line when that member ended on
     // a newline: the reader decides from its carry), complete lines follow, [tail_off, size) continues in the next member

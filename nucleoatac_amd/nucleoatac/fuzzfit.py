@@ -158,6 +158,15 @@ def _numpy_exp_loop():
     numpy/ufuncobject.h: PyObject_HEAD, four ints, functions, data, ntypes, reserved1, name, types).  The native evaluator calls
     it on its own buffer, so the exponentials are numpy's to the last bit."""
     import ctypes as C
+    import sys
+    import sysconfig
+    # the struct below is the layout of a regular CPython build with numpy 1.x / 2.x; anywhere else (PyPy, a free-threaded or
+    # debug interpreter with a larger object header, a numpy whose major version this was not checked against) reading it would
+    # dereference garbage -- which no try / except catches -- so those keep the numpy evaluation
+    if (sys.implementation.name != "cpython" or sysconfig.get_config_var("Py_GIL_DISABLED") or hasattr(sys, "gettotalrefcount")
+            or int(np.__version__.split(".")[0]) not in (1, 2) or C.sizeof(C.c_void_p) != 8 or type(np.exp) is not np.ufunc
+            or object.__basicsize__ != 16):
+        raise RuntimeError("interpreter / numpy layout not known to this reader")
 
     class UFunc(C.Structure):
         _fields_ = [("ob_refcnt", C.c_ssize_t), ("ob_type", C.c_void_p), ("nin", C.c_int), ("nout", C.c_int), ("nargs", C.c_int),

@@ -209,4 +209,4 @@ def run_merge(args):
     write_rows(path, new)
     bgzip_file(path)                       # pysam.tabix_compress + rm + tabix_index (merge.py:107-109)
     tabix_index(path + ".gz")
-    return new
+    return None                            # like the column path above and the reference's run_merge (merge.py:94-109): files only

@@ -96,8 +96,10 @@ def batch_calls(r, params, pool=None, pool_workers=1):
         nonred[a:e] = np.isin(keys, nr)
     out = {"nucpos": (kc[nonred], kp[nonred], vals[nonred]), "nucpos.redundant": (kc[~nonred], kp[~nonred], vals[~nonred])}
     if over:     # chunks with more local maxima than the device peak finder holds per chunk: the per-chunk API path, merged in order
+        from .. import context_lock
         for k in sorted(over):
-            nc = nuc_batch([part[k]], params)[0]
+            with context_lock:           # this runs on the writer thread, on the process-wide context (see nucleoatac_amd/__init__.py)
+                nc = nuc_batch([part[k]], params)[0]
             for name, ids in (("nucpos", nc.nonredundant), ("nucpos.redundant", nc.redundant)):
                 rows = [nc.nuc_collection[int(i)] for i in sorted(ids)]
                 if not rows:
@@ -192,7 +194,8 @@ def run_nuc(args):
                 pos = start_of[kc] + kp
                 write_bed_rows(call_paths[name], names, cid_of[kc], pos, pos + 1, vals)
 
-    if parts:
+    try:
+      if parts:
         # the calls need coverage, raw and smoothed values at the candidates: downloaded with the tracks that are written
         need = [L.T_NORM, L.T_SMOOTH, L.T_RAW, L.T_NUC_COV, L.T_NFR_COV]
         if not DEVICE_WRITER:
@@ -222,8 +225,9 @@ def run_nuc(args):
         ph.mark("pipeline_wall")
         LAST_TIMINGS["writer_inside_pipeline"] = round(writer.seconds, 3)
         LAST_TIMINGS["calls_and_fits_inside_writer"] = round(calls_s[0], 3)
-    if pool is not None:
-        pool.shutdown()
+    finally:
+        if pool is not None:             # also on a failure: the spawn workers of the fit pool must not outlive the run
+            pool.shutdown()
     to_index = finish_indexes(writer if parts else None, list(track_of), lambda n: args.out + "." + n + ".bedgraph.gz")
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
     if rank == 0:

@@ -225,7 +225,9 @@ def run_occ(args):
         over = np.nonzero(r.status & 2)[0]
         if len(over):
             # chunks with more local maxima than the device peak finder holds per chunk: the per-chunk API path (host call_peaks)
-            redo = {int(k): occ_batch([part[int(k)]], params)[0] for k in over}
+            from .. import context_lock
+            with context_lock:           # writer thread, process-wide context (nucleoatac_amd/__init__.py)
+                redo = {int(k): occ_batch([part[int(k)]], params)[0] for k in over}
             fine = ~np.isin(cc, over)
             for k in range(len(part)):           # rows must stay in chunk order: write around the re-done chunks
                 if k in redo:

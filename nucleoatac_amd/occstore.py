@@ -73,7 +73,9 @@ class OccTrackStore(object):
         if loc is None:
             return None
         lens = np.asarray(ends, dtype=np.int64) - np.asarray(starts, dtype=np.int64)
-        flat = self.dev.read(ctx, loc[0], loc[1], lens, slot)
+        from . import context_lock
+        with context_lock:
+            flat = self.dev.read(ctx, loc[0], loc[1], lens, slot)
         self.reads += len(lens)
         return flat, np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
 
@@ -83,7 +85,9 @@ class OccTrackStore(object):
         if loc is None:
             return None
         self.reads += len(positions)
-        return self.dev.read(ctx, loc[0], loc[1], np.ones(len(positions), dtype=np.int64), slot)
+        from . import context_lock
+        with context_lock:
+            return self.dev.read(ctx, loc[0], loc[1], np.ones(len(positions), dtype=np.int64), slot)
 
     def close(self):
         self.dev.close()

@@ -170,3 +170,62 @@ def test_prefetch_hands_the_store_or_the_error_to_open(tmp_path):
     FragmentStore.prefetch(bad)
     with pytest.raises(Exception, match="cannot open"):
         FragmentStore.open(bad)
+
+
+def test_crc_of_every_member_is_verified(tmp_path):
+    """a flipped bit inside a STORED deflate block inflates to the right length: only the member's CRC-32 tells (RFC 1952; htslib
+    checks it behind pyatac/fragments.pyx:21).  The host BAM decoder names the member's file offset; the tabix reader refuses the
+    damaged member of a track file."""
+    import struct
+    import zlib
+    from nucleoatac_amd._lib import NatacError
+
+    def bgzf0(data, blk):
+        out = bytearray()
+        for o in range(0, len(data), blk):
+            chunk = data[o:o + blk]
+            co = zlib.compressobj(0, zlib.DEFLATED, -15)
+            comp = co.compress(chunk) + co.flush()
+            out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0]) + struct.pack("<H", 18 + len(comp) + 8 - 1)
+            out += comp + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+        out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+        return bytes(out)
+
+    p = str(tmp_path / "x.bam")
+    _write_bam(p, [("c", 100000)], [(0, 5 + 7 * i, 0x63, 100 + i % 50) for i in range(2000)])
+    import gzip
+    raw = gzip.open(p, "rb").read()
+    blk = 4000
+    good = bgzf0(raw, blk)
+    open(p, "wb").write(good)
+    ok = FragmentStore.from_bam(p, device=False)
+    assert len(ok.pos["c"]) == 2000
+    per = 18 + 5 + blk + 8
+    for k in (0, 2, len(raw) // blk - 1):
+        g = bytearray(good)
+        g[k * per + 18 + 5 + 77] ^= 0x01
+        bad = str(tmp_path / ("bad%d.bam" % k))
+        open(bad, "wb").write(bytes(g))
+        with pytest.raises(NatacError, match=r"CRC-32 mismatch in the BGZF member at file offset %d " % (k * per)):
+            FragmentStore.from_bam(bad, device=False)
+    # a track file: the tabix reader must not hand out values of a member that fails its CRC
+    from nucleoatac_amd.pyatac.tracks import Track
+    from nucleoatac_amd.writer import tabix_index
+    text = "".join("chr1\t%d\t%d\t%s\n" % (i, i + 1, repr(0.25 + i * 1e-3)) for i in range(3000)).encode()
+    t = str(tmp_path / "t.bedgraph.gz")
+    z = bgzf0(text, 3000)
+    open(t, "wb").write(z)
+    tabix_index(t)
+    tr = Track("chr1", 100, 200)
+    tr.read_track(t)
+    assert abs(tr.vals[0] - 0.35) < 1e-12
+    g = bytearray(z)
+    g[18 + 5 + 1500] ^= 0x01                     # inside a digit of the first member: still text, still inflates
+    t2 = str(tmp_path / "t2.bedgraph.gz")         # a new path (readers cache inflated members per file): damaged data, intact index
+    open(t2, "wb").write(bytes(g))
+    open(t2 + ".tbi", "wb").write(open(t + ".tbi", "rb").read())
+    with pytest.raises(Exception):
+        tr2 = Track("chr1", 100, 200)
+        tr2.read_track(t2)
+    with pytest.raises(Exception):               # and the indexer, which inflates every member, refuses the file too
+        tabix_index(t2)
