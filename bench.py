@@ -439,7 +439,7 @@ def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_thread
 
 # ------------------------------------------------------------------------------------------------ CLI end to end
 def cli_end_to_end(n_chunks, cores, seed=0):
-    """`nucleoatac occ` and `nucleoatac nuc` as a user runs them, on a slice of the configs[2] workload written as input files
+    """`nucleoatac run` (occ -> vprocess -> nuc -> merge -> nfr) as a user runs it, on a slice of the configs[2] workload written as input files
     (BED + reads .npz + genome .npz): files in -> .bedgraph.gz + .tbi + calls out, everything included (reading the inputs,
     PWM bias of the genome on the GPU, packing, the pipelined executor, the native writers, bgzip + tabix).  `nuc` runs with
     --cores for its per-nucleosome L-BFGS fits (host)."""
@@ -454,27 +454,22 @@ def cli_end_to_end(n_chunks, cores, seed=0):
         out = os.path.join(d, "e2e")
         bp = n_chunks * 2120
         with contextlib.redirect_stdout(sys.stderr):
-            t0 = time.perf_counter()
-            cli_main(["occ", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores)])
-            t_occ = time.perf_counter() - t0
-            from nucleoatac_amd.nucleoatac import run_nuc as _rn, run_occ as _ro
-            occ_phases = dict(_ro.LAST_TIMINGS)
-            cli_main(["vprocess", "--sizes", out + ".nuc_dist.txt", "--out", out])
-            t0 = time.perf_counter()
-            cli_main(["nuc", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores), "--occ_track",
-                      out + ".occ.bedgraph.gz", "--vmat", out + ".VMat", "--sizes", out + ".fragmentsizes.txt"])
-            t_nuc = time.perf_counter() - t0
-            nuc_phases = dict(_rn.LAST_TIMINGS)
-            # the two remaining steps of `nucleoatac run` (cli.py:34-64 of the reference): merge and nfr
-            t0 = time.perf_counter()
-            cli_main(["merge", "--occpeaks", out + ".occpeaks.bed.gz", "--nucpos", out + ".nucpos.bed.gz", "--out", out])
-            t_merge = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            cli_main(["nfr", "--bed", bed, "--occ_track", out + ".occ.bedgraph.gz", "--calls", out + ".nucmap_combined.bed.gz", "--out", out,
-                      "--fasta", fa, "--bam", bam])
-            t_nfr = time.perf_counter() - t0
-            from nucleoatac_amd.nucleoatac import run_nfr as _rf
-            nfr_phases = dict(_rf.LAST_TIMINGS)
+            # `nucleoatac run` as a user runs it (one process: the occupancy tracks of step 1 stay resident in HBM for steps 3 and 5),
+            # timed per step
+            from nucleoatac_amd.nucleoatac import run_nfr as _rf, run_nuc as _rn, run_occ as _ro
+            from nucleoatac_amd.nucleoatac.cli import nucleoatac_parser, run_chain
+            secs, phases = {}, {}
+
+            def on_step(name, seconds):
+                secs[name] = seconds
+                src = {"occ": _ro, "nuc": _rn, "nfr": _rf}.get(name)
+                if src is not None:
+                    phases[name] = dict(src.LAST_TIMINGS)
+
+            run_chain(nucleoatac_parser().parse_args(["run", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores)]),
+                      on_step)
+            t_occ, t_nuc, t_merge, t_nfr = secs["occ"], secs["nuc"], secs["merge"], secs["nfr"]
+            occ_phases, nuc_phases, nfr_phases = phases["occ"], phases["nuc"], phases["nfr"]
             # `occ` once more from REAL input files: a coordinate-sorted .bam (both mates of every fragment) and a text .fa
             from nucleoatac_amd.synth import cli_dataset_as_real_files
             rbam, rfa = cli_dataset_as_real_files(bam, fa, d)
@@ -488,7 +483,9 @@ def cli_end_to_end(n_chunks, cores, seed=0):
         n_calls = sum(1 for _ in __import__("gzip").open(out + ".nucpos.bed.gz", "rt"))
         return dict(occ_mbp_s=round(bp / t_occ / 1e6, 2), nuc_mbp_s=round(bp / t_nuc / 1e6, 3), cores=cores, chunks=n_chunks, bp=bp,
                     occ_seconds=round(t_occ, 2), nuc_seconds=round(t_nuc, 2), merge_seconds=round(t_merge, 2), nfr_seconds=round(t_nfr, 2),
-                    run_mbp_s=round(bp / (t_occ + t_nuc + t_merge + t_nfr) / 1e6, 3), nucleosome_calls=n_calls,
+                    run_mbp_s=round(bp / sum(secs.values()) / 1e6, 3), run_seconds=round(sum(secs.values()), 2), nucleosome_calls=n_calls,
+                    resident_occ_tracks="steps 3 and 5 read the occupancy tracks of step 1 from HBM, as the files show them (occstore.py); "
+                                        "the files are written all the same",
                     occ_phases_s=occ_phases, nuc_phases_s=nuc_phases, nfr_phases_s=nfr_phases, real_inputs=real,
                     occ_track_bytes=sum(size("." + n + ".bedgraph.gz") for n in ("occ", "occ.lower_bound", "occ.upper_bound")),
                     nuc_track_bytes=sum(size("." + n + ".bedgraph.gz") for n in ("nucleoatac_signal", "nucleoatac_signal.smooth")),

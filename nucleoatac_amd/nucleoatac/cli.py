@@ -131,46 +131,53 @@ def nucleoatac_main(args):
         print("---------Calling NFR positions----------------------------------------")
         run_nfr(args)
     elif args.call == "run":
-        # the five steps chained through their output files exactly as the reference does (cli.py:34-64)
-        parser = nucleoatac_parser()
-        occ_args = parser.parse_args(["occ", "--bed", args.bed, "--bam", args.bam, "--fasta", args.fasta, "--pwm", args.pwm,
-                                      "--out", args.out, "--cores", str(args.cores)])
-        vprocess_args = parser.parse_args(["vprocess", "--sizes", args.out + ".nuc_dist.txt", "--out", args.out])
-        nuc_list = ["nuc", "--bed", args.bed, "--bam", args.bam, "--out", args.out, "--cores", str(args.cores), "--occ_track",
-                    args.out + ".occ.bedgraph.gz", "--vmat", args.out + ".VMat", "--fasta", args.fasta, "--pwm", args.pwm,
-                    "--sizes", args.out + ".fragmentsizes.txt"]
-        if args.write_all:
-            nuc_list.append("--write_all")
-        nuc_args = parser.parse_args(nuc_list)
-        merge_args = parser.parse_args(["merge", "--occpeaks", args.out + ".occpeaks.bed.gz", "--nucpos", args.out + ".nucpos.bed.gz",
-                                        "--out", args.out])
-        nfr_args = parser.parse_args(["nfr", "--bed", args.bed, "--occ_track", args.out + ".occ.bedgraph.gz", "--calls",
-                                      args.out + ".nucmap_combined.bed.gz", "--out", args.out, "--fasta", args.fasta, "--pwm",
-                                      args.pwm, "--bam", args.bam])
-        from .merge import run_merge
-        from .run_nfr import run_nfr
-        from .run_nuc import run_nuc
-        from .run_occ import run_occ
-        from .run_vprocess import run_vprocess
-        from ..shard import barrier
-        print("---------Step1: Computing Occupancy and Nucleosomal Insert Distribution---------")
-        occ_args.keep_resident = True      # the occupancy tracks also stay in HBM for steps 3 and 5 of this process (occstore.py)
-        run_occ(occ_args)
-        barrier()
-        print("---------Step2: Processing Vplot------------------------------------------------")
-        _rank0_only(run_vprocess, vprocess_args)
-        print("---------Step3: Obtaining nucleosome signal and calling positions---------------")
-        run_nuc(nuc_args)
-        barrier()
-        print("---------Step4: Making combined nucleosome position map ------------------------")
-        _rank0_only(run_merge, merge_args)
-        print("---------Step5: Calling NFR positions-------------------------------------------")
-        run_nfr(nfr_args)
-        barrier()
-        from .. import occstore
-        occstore.release(args.out + ".occ.bedgraph.gz")
+        run_chain(args)
     else:
         raise SystemExit("usage: nucleoatac {run,occ,vprocess,nuc,merge,nfr} ...")
+
+
+def run_chain(args, on_step=None):
+    """`nucleoatac run`: the five steps chained through their output files exactly as the reference does (cli.py:34-64); the three
+    occupancy tracks of step 1 additionally stay in HBM for steps 3 and 5 of this process (occstore.py).  on_step(name, seconds), if
+    given, is called after every step (bench.py / tools/e2e_run.py read the drivers' phase clocks there)."""
+    import time
+    parser = nucleoatac_parser()
+    occ_args = parser.parse_args(["occ", "--bed", args.bed, "--bam", args.bam, "--fasta", args.fasta, "--pwm", args.pwm,
+                                  "--out", args.out, "--cores", str(args.cores)])
+    vprocess_args = parser.parse_args(["vprocess", "--sizes", args.out + ".nuc_dist.txt", "--out", args.out])
+    nuc_list = ["nuc", "--bed", args.bed, "--bam", args.bam, "--out", args.out, "--cores", str(args.cores), "--occ_track",
+                args.out + ".occ.bedgraph.gz", "--vmat", args.out + ".VMat", "--fasta", args.fasta, "--pwm", args.pwm,
+                "--sizes", args.out + ".fragmentsizes.txt"]
+    if args.write_all:
+        nuc_list.append("--write_all")
+    nuc_args = parser.parse_args(nuc_list)
+    merge_args = parser.parse_args(["merge", "--occpeaks", args.out + ".occpeaks.bed.gz", "--nucpos", args.out + ".nucpos.bed.gz",
+                                    "--out", args.out])
+    nfr_args = parser.parse_args(["nfr", "--bed", args.bed, "--occ_track", args.out + ".occ.bedgraph.gz", "--calls",
+                                  args.out + ".nucmap_combined.bed.gz", "--out", args.out, "--fasta", args.fasta, "--pwm",
+                                  args.pwm, "--bam", args.bam])
+    from .merge import run_merge
+    from .run_nfr import run_nfr
+    from .run_nuc import run_nuc
+    from .run_occ import run_occ
+    from .run_vprocess import run_vprocess
+    from .. import occstore
+    from ..shard import barrier
+    occ_args.keep_resident = True      # the occupancy tracks also stay in HBM for steps 3 and 5 of this process (occstore.py)
+    steps = (("occ", "Step1: Computing Occupancy and Nucleosomal Insert Distribution---------", lambda: (run_occ(occ_args), barrier())),
+             ("vprocess", "Step2: Processing Vplot------------------------------------------------", lambda: _rank0_only(run_vprocess, vprocess_args)),
+             ("nuc", "Step3: Obtaining nucleosome signal and calling positions---------------", lambda: (run_nuc(nuc_args), barrier())),
+             ("merge", "Step4: Making combined nucleosome position map ------------------------", lambda: _rank0_only(run_merge, merge_args)),
+             ("nfr", "Step5: Calling NFR positions-------------------------------------------", lambda: (run_nfr(nfr_args), barrier())))
+    try:
+        for name, banner, fn in steps:
+            print("---------" + banner)
+            t0 = time.perf_counter()
+            fn()
+            if on_step is not None:
+                on_step(name, time.perf_counter() - t0)
+    finally:
+        occstore.release(args.out + ".occ.bedgraph.gz")
 
 
 def _init_distributed():

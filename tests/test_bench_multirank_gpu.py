@@ -24,6 +24,8 @@ def test_two_ranks_share_device():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "Mbp/s"
     assert d["value"] > 0 and abs(d["value"] - 2 * 4000 * 2120 * 2 / (d["ms_per_step"] * 2 / 1e3) / 1e6) < 1e-3 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["launches"] == 2
+    assert d["control_plane"] == "gloo" and [r["rank"] for r in d["per_rank"]] == [0, 1]
+    assert all(r["pci_bus_id"] and r["hip_device"] == 0 for r in d["per_rank"])
 
 
 def test_single_rank_default_contract():
@@ -36,6 +38,13 @@ def test_single_rank_default_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["higher_is_better"] is True
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    r = d["roofline"]               # round 4: fp64 view first, the HBM view beside it, step traffic, live clocks
+    assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1
+    assert r["hbm"]["unit"] == "GB/s" and r["hbm"]["peak"] == 8000.0 and 0 < r["hbm"]["frac"] < 1
+    assert r["clock_ghz"] and 1.0 < r["clock_ghz"]["background"] < 3.0
+    assert d["value_boundary"].startswith("hbm_resident") and d["value_host_to_host"] == d["host_to_host"]["host_to_host_mbp_s"]
+    cal = d["cpu_baseline"]["reference_calibration"]
+    assert cal is None or cal["reference_s_per_chunk"] > cal["port_literal_s_per_chunk"] > cal["port_optimised_s_per_chunk"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
     assert d["cpu_baseline"]["literal"]["chunks"] == 16 and d["cpu_baseline"]["optimised"]["chunks"] == 32
     h = d["host_to_host"]            # pipelined host -> host rate: pinned buffers, 3 contexts, sub-batches of 1000 chunks
@@ -43,6 +52,7 @@ def test_single_rank_default_contract():
     assert "PipelinedExecutor" in h["executor"]                 # the product's executor, not a bench-only harness
     e = d["cli_end_to_end"]          # `nucleoatac occ` / `nuc` from input files to .bedgraph.gz + .tbi
     assert e["chunks"] == 400 and e["occ_mbp_s"] > 0 and e["nuc_mbp_s"] > 0 and e["nucleosome_calls"] > 0 and e["cores"] >= 1
+    assert e["run_seconds"] > 0 and e["run_mbp_s"] > 0 and "HBM" in e["resident_occ_tracks"]
     assert e["real_inputs"]["occ_mbp_s"] > 0 and e["real_inputs"]["bam_gb"] > 0      # the same windows from a real .bam + .fa
     ts = d["roofline"]["traffic_source"]
     assert ts is None or set(("file", "collected_at_source_sha16", "current_source_sha16", "stale")) <= set(ts)
@@ -71,17 +81,30 @@ def test_cfg4_strong_scaling_two_ranks_share_device():
 
 
 def test_rccl_failure_falls_back_to_gloo():
-    """default backend (RCCL) with two ranks on ONE GPU: RCCL refuses the duplicate device; the bench's collectives (barrier,
-    max / sum of three scalars) are not data, so it goes on over gloo and still prints its line"""
+    """RCCL asked for (--dist-backend nccl; the default is gloo since round 4) with two ranks on ONE GPU: RCCL cannot form a
+    communicator on a duplicate device and the ranks agree on that; the bench's collectives (barrier, max / sum of three scalars) are
+    not data, so it goes on over gloo and still prints its line"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29536", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--chunks", "2000", "--share-device", "--no-cpu-baseline"]
+           "--chunks", "2000", "--share-device", "--no-cpu-baseline", "--dist-backend", "nccl"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "RCCL group not used" in out.stderr
     d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["control_plane"] == "gloo"
+
+
+def test_ranks_that_share_a_gpu_are_refused_without_the_switch():
+    """one rank per GPU is checked before any timing: two ranks that land on the same PCI device without --share-device end with a
+    message that lists (rank, local_rank, hip device, pci bus id, visible-device variables) of every rank"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--chunks", "1000", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NATAC_DEVICE="0", HIP_VISIBLE_DEVICES="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert "ranks share a GPU" in out.stderr and "--share-device" in out.stderr
 
 
 def test_eight_ranks_share_device_cfg4():

@@ -41,37 +41,24 @@ def main():
         bp = n * L
         sec, phases = {}, {}
 
-        def timed(name, argv, timings=None):
-            t = time.perf_counter()
-            cli_main(argv)
-            sec[name] = round(time.perf_counter() - t, 2)
-            if timings is not None:
-                phases[name] = dict(timings)
+        from nucleoatac_amd.nucleoatac.cli import nucleoatac_parser, run_chain
+        resident = {}
+
+        def on_step(name, seconds):
+            sec[name] = round(seconds, 2)
+            src = {"occ": ro, "nuc": rn, "nfr": rf}.get(name)
+            if src is not None:
+                phases[name] = dict(src.LAST_TIMINGS)
+            st = occstore.lookup(out + ".occ.bedgraph.gz")
+            if st is not None:
+                resident.update(st.dev.info(), regions_served=st.reads)
 
         with contextlib.redirect_stdout(sys.stderr):
             t_all = time.perf_counter()
-            # `nucleoatac run` = these five calls in one process (cli.py); issued one by one here for the per-step clocks, with the
-            # occupancy tracks kept resident for steps 3 and 5 exactly as `run` does
-            class A(object):
-                pass
-            from nucleoatac_amd.nucleoatac.cli import nucleoatac_parser
-            p = nucleoatac_parser()
-            occ_args = p.parse_args(["occ", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores)])
-            occ_args.keep_resident = True
-            t = time.perf_counter()
-            ro.run_occ(occ_args)
-            sec["occ"] = round(time.perf_counter() - t, 2)
-            phases["occ"] = dict(ro.LAST_TIMINGS)
-            timed("vprocess", ["vprocess", "--sizes", out + ".nuc_dist.txt", "--out", out])
-            timed("nuc", ["nuc", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores), "--occ_track",
-                          out + ".occ.bedgraph.gz", "--vmat", out + ".VMat", "--sizes", out + ".fragmentsizes.txt"], rn.LAST_TIMINGS)
-            timed("merge", ["merge", "--occpeaks", out + ".occpeaks.bed.gz", "--nucpos", out + ".nucpos.bed.gz", "--out", out])
-            timed("nfr", ["nfr", "--bed", bed, "--occ_track", out + ".occ.bedgraph.gz", "--calls", out + ".nucmap_combined.bed.gz",
-                          "--out", out, "--fasta", fa, "--bam", bam], rf.LAST_TIMINGS)
+            run_chain(nucleoatac_parser().parse_args(["run", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", str(cores)]),
+                      on_step)
             total = time.perf_counter() - t_all
-            st = occstore.lookup(out + ".occ.bedgraph.gz")
-            resident = dict(st.dev.info(), regions_served=st.reads) if st is not None else None
-            occstore.release()
+        resident = resident or None
         size = lambda s: os.path.getsize(out + s) if os.path.exists(out + s) else None
         import gzip
         n_calls = sum(1 for _ in gzip.open(out + ".nucpos.bed.gz", "rt"))
