@@ -351,6 +351,8 @@ class Context(object):
         L.check(self._lib.natac_clock_trace_fetch(self._h, ns.value, _ptr(t), _ptr(cyc), ni.value, _ptr(ik), _ptr(i0), _ptr(i1)))
         dt = np.diff(t)
         ghz = np.where(dt > 0, np.diff(cyc) / np.maximum(dt, 1e-12) / 1e6, np.nan)     # cycles per ms / 1e6 = GHz
+        if len(dt):      # the two counters are read a few cycles apart: a slope over a very short interval (or a wrapped counter) is noise
+            ghz[(dt < 0.25 * np.median(dt)) | ~(ghz > 0) | (ghz > 10.0)] = np.nan
         mid = 0.5 * (t[1:] + t[:-1])
         per, w = {}, {}
         for k, a, b in zip(ik, i0, i1):

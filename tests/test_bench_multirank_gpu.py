@@ -101,7 +101,7 @@ def test_ranks_that_share_a_gpu_are_refused_without_the_switch():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--chunks", "1000", "--no-cpu-baseline"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NATAC_DEVICE="0", HIP_VISIBLE_DEVICES="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NATAC_DEVICE="0")      # both ranks on GPU 0, without --share-device
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode != 0
     assert "ranks share a GPU" in out.stderr and "--share-device" in out.stderr
