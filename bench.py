@@ -531,6 +531,12 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and subs:
         cpu = cpu_baseline(subs[0], par, sizes, nucp, nfrp, a.cpu_chunks, a.cpu_literal_chunks)
 
+    from nucleoatac_amd.device import Context as _Ctx
+    n_vis = _Ctx.device_count()
+    if n_vis > 0 and local_rank >= n_vis:
+        # a launcher that narrows every rank's view to its own GPU (ROCR_ / HIP_VISIBLE_DEVICES per rank) leaves ordinal 0 only: wrap, the
+        # PCI bus ids gathered below still tell whether the ranks really sit on different GPUs
+        local_rank %= n_vis
     ctx = setup_ctx(local_rank, par, sizes, nucp, nfrp)
     hip_dev, pci = ctx.device_ids()
     if dist is not None:

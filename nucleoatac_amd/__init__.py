@@ -30,10 +30,19 @@ def get_context():
 
 
 def _make_default():
-    if True:
-        from .device import Context
-        # one context per process: GPU = LOCAL_RANK (torchrun); NATAC_DEVICE overrides it (e.g. several ranks on one GPU in tests)
-        return Context(int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    from .device import Context
+    # one context per process: GPU = LOCAL_RANK (torchrun); NATAC_DEVICE overrides it (e.g. several ranks on one GPU in tests)
+    return Context(default_device())
+
+
+def default_device():
+    """ordinal of the GPU this process computes on: NATAC_DEVICE, else LOCAL_RANK (torchrun) wrapped into the visible devices -- a
+    launcher that shows every rank only its own GPU leaves ordinal 0"""
+    if "NATAC_DEVICE" in os.environ:
+        return int(os.environ["NATAC_DEVICE"])
+    from .device import Context
+    dev, n = int(os.environ.get("LOCAL_RANK", "0")), Context.device_count()
+    return dev % n if n > 0 else dev
 
 
 def set_context(ctx):

@@ -212,7 +212,8 @@ def run_nuc(args):
             return prefetch_map(lambda part: (pack(part, st, params.fasta, fa_chrs, params.pwm, atac=params.atac, window=params.window,
                                                    upper=params.upper, bias_on_device=True), part), parts, depth=3)
 
-        device = int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        from .. import default_device
+        device = default_device()
         try:
             with PipelinedExecutor(device, params.install, stages, n_contexts=min(N_CONTEXTS, len(parts))) as ex:
                 for r in ex.map(items()):

@@ -281,7 +281,8 @@ def run_occ(args):
         def items():       # sub-batches packed up to three ahead of the GPU, on their own threads
             return prefetch_map(pack_part, parts, depth=3)
 
-        device = int(os.environ.get("NATAC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        from .. import default_device
+        device = default_device()
         try:
             with PipelinedExecutor(device, lambda ctx: params.occ_calc_params.install(ctx, step=params.step, flank=params.flank),
                                    stages, n_contexts=min(N_CONTEXTS, len(parts))) as ex:
