@@ -84,8 +84,13 @@ class TrackStore(object):
         device (nothing is kept then)"""
         t = np.ascontiguousarray(tracks, dtype=np.int32)
         seg, hard = C.c_int64(-1), C.c_int32(0)
-        L.check(self._lib.natac_store_adopt(self._h, batch._h, len(t), _ptr(t), (1 if write_zero else 0) | (2 if keep_runs_before_nan else 0),
-                                            C.byref(seg), C.byref(hard)))
+        try:
+            L.check(self._lib.natac_store_adopt(self._h, batch._h, len(t), _ptr(t), (1 if write_zero else 0) | (2 if keep_runs_before_nan else 0),
+                                                C.byref(seg), C.byref(hard)))
+        except L.NatacError as e:
+            if e.code == -4:        # NATAC_E_NOMEM: HBM is full (24 bytes per base add up on a large genome) -- the files are there
+                return None
+            raise
         return None if seg.value < 0 else int(seg.value)
 
     def read(self, ctx, segment, offset, length, slot):

@@ -74,3 +74,13 @@ def test_bam_fuzz_slice():
     import fuzz_bam
     done, on_device = fuzz_bam.run(15, 8)
     assert done == 15 and on_device == 15
+
+
+def test_round4_paths_fuzz_slice():
+    """a short run of tests/fuzz/fuzz_round4.py: co-scheduled stages == serial stages, resident store == the parse of the device's own
+    text, on random ragged batches (incl. non-finite bias stretches)"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_round4.py"), "12", "7"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "fuzz_round4 ok: 12 rounds" in out.stdout
