@@ -592,9 +592,10 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // measured on MI355X: a second stream for the occ stage does not overlap with the nuc stage (the background
     // kernel's workgroups keep every CU's LDS full), so both stages share one stream -- keeps per-kernel timing exact
-    // -- on its own.  natac_run_nuc_occ co-schedules them on purpose (NATAC_CORUN=0 switches that off): the background
-    // kernel runs as ONE workgroup per CU (one wave per SIMD, half the registers and LDS left free) while the occupancy
-    // stage's kernels run on stream2, and as the regular two-waves-per-SIMD launch for the tiles left after that.
+    // -- on its own.  With NATAC_CORUN=1 natac_run_nuc_occ co-schedules them on purpose: the background kernel runs as ONE
+    // workgroup per CU (one wave per SIMD, half the registers and LDS left free) while the occupancy stage's kernels run on
+    // stream2, and as the regular two-waves-per-SIMD launch for the tiles left after that.  Exact, overlapping as designed,
+    // and not faster on MI355X (clock-limited fp64 kernels): off by default.
     c->stream2 = c->stream;
     {
         const char *e = getenv("NATAC_CORUN");
