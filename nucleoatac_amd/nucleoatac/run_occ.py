@@ -17,7 +17,7 @@ import numpy as np
 
 from .. import _lib as L
 from ..executor import PipelinedExecutor, Stages
-from ..pipeline import chunk_fragment_counts, pack, prefetch_map
+from ..pipeline import SUB_BATCH_BP, chunk_fragment_counts, pack, prefetch_map, sub_batches
 from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
@@ -211,7 +211,8 @@ def run_occ(args):
     paths = {n: args.out + "." + n + ".bedgraph.gz" + suffix for n in track_of}
     peaks_path = args.out + ".occpeaks.bed" + suffix
     open(peaks_path, "w").close()
-    parts = [mine[i:i + BATCH_CHUNKS] for i in range(0, len(mine), BATCH_CHUNKS)]
+    # sub-batches of <= BATCH_CHUNKS chunks and ~9 Mbp (pipeline.sub_batches); an explicit NATAC_BATCH_CHUNKS fixes the chunk count alone
+    parts = sub_batches(mine, BATCH_CHUNKS, SUB_BATCH_BP if "NATAC_BATCH_CHUNKS" not in os.environ else 1 << 62)
     dists = []
     if not parts:
         for n in track_of:

@@ -214,3 +214,25 @@ class BatchRunner(object):
 
     def candidates(self, cand_chunk, cand_pos):
         return self.batch.run_candidates(cand_chunk, cand_pos)
+
+
+# bases per sub-batch of the pipelined drivers: ~9 Mbp keeps a sub-batch's device arrays, its pinned output slots (30 bytes of
+# compressed track per base and track) and its latency small enough that the first result arrives after a fraction of a second and
+# the writer thread is fed evenly -- what 4,096 chunks are for 2-kb windows.  Measured on one GPU's share of BASELINE configs[3]
+# (60 k x 10 kb tiles): `occ` 4.3-4.8 s with 4,096 chunks (41 Mbp) per sub-batch, 2.9-3.0 s with 512-1,024 (5-10 Mbp).
+SUB_BATCH_BP = 9000000
+
+
+def sub_batches(chunks, max_chunks=4096, target_bp=SUB_BATCH_BP):
+    """consecutive slices of `chunks` (a list / ChunkList), each at most `max_chunks` chunks and -- unless a single chunk is longer --
+    at most `target_bp` bases: the reference maps `cores * 5` chunks per round whatever their length (run_occ.py:101-123)"""
+    out, a, bp = [], 0, 0
+    for i, c in enumerate(chunks):
+        n = c.end - c.start
+        if i > a and (i - a >= max_chunks or bp + n > target_bp):
+            out.append(chunks[a:i])
+            a, bp = i, 0
+        bp += n
+    if len(chunks) > a:
+        out.append(chunks[a:len(chunks)])
+    return out
