@@ -211,7 +211,7 @@ def run_occ(args):
     paths = {n: args.out + "." + n + ".bedgraph.gz" + suffix for n in track_of}
     peaks_path = args.out + ".occpeaks.bed" + suffix
     open(peaks_path, "w").close()
-    # sub-batches of <= BATCH_CHUNKS chunks and ~9 Mbp (pipeline.sub_batches); an explicit NATAC_BATCH_CHUNKS fixes the chunk count alone
+    # sub-batches of <= BATCH_CHUNKS chunks and ~4.5 Mbp (pipeline.sub_batches); an explicit NATAC_BATCH_CHUNKS fixes the chunk count alone
     parts = sub_batches(mine, BATCH_CHUNKS, SUB_BATCH_BP if "NATAC_BATCH_CHUNKS" not in os.environ else 1 << 62)
     dists = []
     if not parts:

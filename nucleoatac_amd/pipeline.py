@@ -216,11 +216,13 @@ class BatchRunner(object):
         return self.batch.run_candidates(cand_chunk, cand_pos)
 
 
-# bases per sub-batch of the pipelined drivers: ~9 Mbp keeps a sub-batch's device arrays, its pinned output slots (30 bytes of
-# compressed track per base and track) and its latency small enough that the first result arrives after a fraction of a second and
-# the writer thread is fed evenly -- what 4,096 chunks are for 2-kb windows.  Measured on one GPU's share of BASELINE configs[3]
-# (60 k x 10 kb tiles): `occ` 4.3-4.8 s with 4,096 chunks (41 Mbp) per sub-batch, 2.9-3.0 s with 512-1,024 (5-10 Mbp).
-SUB_BATCH_BP = 9000000
+# bases per sub-batch of `occ`'s pipeline: small enough that the device arrays and the pinned output slots of a sub-batch (30 bytes of
+# compressed track per base and track) are allocated in a blink, the first result arrives after < 0.1 s and the writer thread is fed
+# evenly; large enough that the per-launch and per-call overheads stay small.  tools/occ_batch_sweep.py, three contexts, seconds of
+# `nucleoatac occ` (pipeline wall):   60 k x 10 kb tiles:  41 Mbp (4,096 chunks, the old rule) 4.3-4.8 (3.0) | 18 Mbp 3.33 (2.24) |
+# 9 Mbp 2.97 (2.06) | 4.5 Mbp 2.49 (1.63) | 3 Mbp 2.50 (1.64) | 2.2 Mbp 2.71 (1.82) | 1.1 Mbp 2.78 (1.92);
+# 100 k x 2 kb windows:  18 Mbp 1.83 (1.06) | 9 Mbp (4,096 chunks, the old rule) 1.83 (1.09) | 4.5 Mbp 1.54 (0.83) | 2.2 Mbp 1.57 (0.91).
+SUB_BATCH_BP = 4500000
 
 
 def sub_batches(chunks, max_chunks=4096, target_bp=SUB_BATCH_BP):
