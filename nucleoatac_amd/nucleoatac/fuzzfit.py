@@ -13,7 +13,8 @@ depend on the position in an array, the row maximum is exact, and the row sums a
 values and take the same steps: tests/test_host_logic.py compares the two paths on every fit of a few hundred chunks.
 
 The driver loop below is `scipy.optimize._lbfgsb_py._minimize_lbfgsb` (scipy 1.15) with the bookkeeping this fit does not use
-removed.  `available()` runs one small fit through both paths at import time of the caller; a scipy whose private routine has
+removed.  Attribution for that restated loop: SciPy, Copyright (c) 2001-2002 Enthought, Inc. 2003-, SciPy Developers, BSD 3-Clause
+License (the L-BFGS-B Fortran code behind `setulb` -- C. Zhu, R. Byrd, P. Lu, J. Nocedal, J. L. Morales -- is called, not copied).  `available()` runs one small fit through both paths at import time of the caller; a scipy whose private routine has
 another signature, or answers differently, makes the callers fall back to `fit_fuzz_one`."""
 from bisect import bisect_left
 
