@@ -89,7 +89,7 @@ class _Writer(threading.Thread):
         self.index_log = {n: [] for n in paths}      # (tabix records of a result, offset it was written at)
         self.index_ok = {n: True for n in paths}
         from concurrent.futures import ThreadPoolExecutor
-        self.pool = ThreadPoolExecutor(max(1, len(paths)), thread_name_prefix="natac-track-file")
+        self.pool = ThreadPoolExecutor(max(1, len(paths)) + 1, thread_name_prefix="natac-track-file")
 
     def run(self):
         import time
@@ -119,10 +119,18 @@ class _Writer(threading.Thread):
                                            compress=COMPRESS_LEVEL, finish=last)
                             self.index_ok[name] = False
 
-                    # one file per track: the appends run side by side (write() releases the GIL), every file still in order
-                    list(self.pool.map(write_one, list(self.paths)))
-                    self.seconds_files += time.perf_counter() - t0
-                    self.extra(r)
+                    # one file per track: the appends run side by side (write() releases the GIL), every file still in order; the
+                    # per-result extra work (peak rows / calls of THIS result, in result order) runs next to them
+                    jobs = [self.pool.submit(write_one, n) for n in self.paths]
+                    more = self.pool.submit(self.extra, r)
+                    try:
+                        for j in jobs:
+                            j.result()
+                        self.seconds_files += time.perf_counter() - t0
+                    finally:                 # the result's buffers are released below: nothing may still be reading them
+                        from concurrent.futures import wait
+                        wait(jobs + [more])
+                    more.result()
                     self.seconds += time.perf_counter() - t0
             except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
                 self.err = e

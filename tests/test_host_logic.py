@@ -289,3 +289,24 @@ def test_fasta_sizes_without_loading_and_prefetch(tmp_path):
     open(fa2, "w").write(">a x\nACGTAC\nGT\n>b\nAC\n")
     open(fa2 + ".fai", "w").write("a\t8\t5\t6\t7\nb\t2\t18\t2\t3\n")
     assert S.FastaStore.sizes(fa2) == {"a": 8, "b": 2} and fa2 not in S._CACHE
+
+
+def test_sub_batches_cut_by_bases_and_by_count():
+    """pipeline.sub_batches: consecutive slices that cover the list in order, each <= max_chunks chunks and -- unless a single chunk
+    is longer -- <= target_bp bases (the rule `occ` cuts its pipeline's sub-batches by)"""
+    from nucleoatac_amd.pipeline import SUB_BATCH_BP, sub_batches
+    from nucleoatac_amd.pyatac.chunk import Chunk, ChunkList
+    rng = np.random.default_rng(4)
+    for lens, max_chunks, target in (([2120] * 10000, 4096, SUB_BATCH_BP), ([10120] * 3000, 4096, SUB_BATCH_BP),
+                                     (list(rng.integers(121, 60000, 500)), 64, 200000), ([50_000_000, 100, 100], 4096, SUB_BATCH_BP), ([], 10, 10)):
+        cl = ChunkList(*[Chunk("c", 100000 * i, 100000 * i + int(n)) for i, n in enumerate(lens)])
+        parts = sub_batches(cl, max_chunks, target)
+        flat = [c for p in parts for c in p]
+        assert [c.start for c in flat] == [c.start for c in cl] and all(len(p) > 0 for p in parts)
+        for p in parts:
+            bp = sum(c.end - c.start for c in p)
+            assert len(p) <= max_chunks and (bp <= target or len(p) == 1)
+        # greedy: a slice could not have taken the next chunk as well
+        for p, q in zip(parts[:-1], parts[1:]):
+            assert len(p) == max_chunks or sum(c.end - c.start for c in p) + (q[0].end - q[0].start) > target
+    assert len(sub_batches(ChunkList(*[Chunk("c", 0, 2120)] * 5000), 4096, SUB_BATCH_BP)) == 3       # 2,122 chunks of 2 kb per ~4.5 Mbp
