@@ -795,10 +795,8 @@ template <int STEP, int FLANK, int ABL = 0, int ROWS = 0>   // ABL != 0: ablatio
                                                           // ROWS: row-parallel phase 2 (n_alpha <= 16 * OCC_RA)
 // tile_list != nullptr: the workgroups walk the first *tile_count entries of tile_list (tiles deferred by the fast path,
 // natac_occ_fast.hpp) instead of taking tile blockIdx.x.
-#ifndef NATAC_OCC_MLE_WAVES
-#define NATAC_OCC_MLE_WAVES 3
-#endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NATAC_OCC_MLE_WAVES, NATAC_OCC_MLE_WAVES))) natac_occ_mle(ChunkTable ct, const int2 *__restrict__ tiles,
+// three waves per SIMD with 96-204 B of scratch beat two waves without spills (general path on the configs[2] step: 54.2 vs 64.8 ms)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) natac_occ_mle(ChunkTable ct, const int2 *__restrict__ tiles,
                                                        const int2 *__restrict__ ranges, OccModelDev om,
                                                        double *__restrict__ g_occ, double *__restrict__ g_lo,
                                                        double *__restrict__ g_hi, int *__restrict__ status,
