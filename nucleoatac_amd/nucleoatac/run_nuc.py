@@ -12,7 +12,7 @@ import numpy as np
 
 from .. import _lib as L
 from ..executor import PipelinedExecutor, Stages
-from ..pipeline import pack, prefetch_map
+from ..pipeline import pack, prefetch_map, sub_batches
 from ..pyatac.bias import PWM
 from ..pyatac.chunk import ChunkList
 from ..pyatac.fragmentsizes import FragmentSizes
@@ -26,6 +26,11 @@ from .run_occ import DEVICE_WRITER, _Phases, _Writer, finish_indexes
 LAST_TIMINGS = {}
 
 BATCH_CHUNKS = int(os.environ.get("NATAC_BATCH_CHUNKS", "4096"))
+# bases per sub-batch of the nuc pipeline.  The writer finishes sub-batch k (waits for its fits) only after it has started sub-batch
+# k + 1 (batch_calls_start / _finish), so the fit pool does not idle at sub-batch borders and small sub-batches cost nothing there
+# while the first result arrives sooner.  `nucleoatac run` on 60 k x 10 kb tiles, seconds of `nuc`: 4,096 chunks = 41 Mbp without the
+# look-ahead 21.5, with it 17.1; 18 Mbp 14.7; 9 Mbp 14.4; 4.5 Mbp 15.6 (2-kb windows: 4,096 chunks are 8.7 Mbp either way).
+NUC_SUB_BP = int(os.environ.get("NATAC_NUC_SUB_BP", "9000000"))
 N_CONTEXTS = int(os.environ.get("NATAC_CONTEXTS", "3"))
 COMPRESS_LEVEL = 4
 
@@ -51,10 +56,11 @@ def _nucHelperBatch(chunks, params):
     return out
 
 
-def batch_calls(r, params, pool=None, pool_workers=1):
-    """NucChunk.findAllNucs + fit for every chunk of a finished sub-batch (NucleosomeCalling.py:294-324) from the device's
-    candidate arrays: returns {"nucpos": rows, "nucpos.redundant": rows} with rows = (chunk index, position, 10 value columns:
-    z, occ, occ_lower, occ_upper, lr, norm_signal, nuc_signal, nuc_cov, nfr_cov, fuzz) in chunk / position order."""
+def batch_calls_start(r, params, pool=None, pool_workers=1):
+    """first half of batch_calls: everything that needs the sub-batch's downloaded arrays -- thresholds, values at the calls, the
+    fuzziness-fit tasks (SUBMITTED to the pool here), the occupancy values -- so that the result's page-locked buffers can go back to
+    the executor; batch_calls_finish(state) waits for the fits and forms the rows.  The writer finishes sub-batch k only after it has
+    started sub-batch k + 1: the fit pool always holds the next sub-batch's tasks when it runs out of this one's."""
     part, pk = r.tag, r.packed
     cc, cp, lr, _var, z = r.peaks
     tr = r.tracks
@@ -80,13 +86,19 @@ def batch_calls(r, params, pool=None, pool_workers=1):
     fits = fit_fuzz_tasks(tasks, pool, pool_workers, start_only=True)
     if params.occ_track is not None and called:
         # meanwhile the three occupancy tracks of every chunk with calls (NucChunk.getOcc, NucleosomeCalling.py:284-293): one native
-        # call per file
+        # call per file, or out of HBM when this process wrote them (occstore.py)
         for k, res in zip(called, read_occ_tracks_many(params.occ_track, [part[k] for k in called])):
             if res is not None:
                 a, e = int(bounds[k]), int(bounds[k + 1])
                 for j in range(3):
                     vals[a:e, 1 + j] = res[j][kp[a:e]]
-    fits = fits()
+    return dict(part=part, kc=kc, kp=kp, vals=vals, bounds=bounds, called=called, fits=fits, over=over, params=params)
+
+
+def batch_calls_finish(st):
+    """second half of batch_calls: wait for the fits of the sub-batch, reduce to the non-redundant set, merge the overflow chunks"""
+    part, kc, kp, vals, bounds, called, over, params = (st[k] for k in ("part", "kc", "kp", "vals", "bounds", "called", "over", "params"))
+    fits = st["fits"]()
     nonred = np.zeros(len(kc), dtype=bool)
     for k, f in zip(called, fits):
         a, e = int(bounds[k]), int(bounds[k + 1])
@@ -112,6 +124,13 @@ def batch_calls(r, params, pool=None, pool_workers=1):
                 out[name] = (np.insert(c0, where, k), np.insert(p0, where, [n.start - part[k].start for n in rows]),
                              np.insert(v0, where, add, axis=0))
     return out
+
+
+def batch_calls(r, params, pool=None, pool_workers=1):
+    """NucChunk.findAllNucs + fit for every chunk of a finished sub-batch (NucleosomeCalling.py:294-324) from the device's
+    candidate arrays: returns {"nucpos": rows, "nucpos.redundant": rows} with rows = (chunk index, position, 10 value columns:
+    z, occ, occ_lower, occ_upper, lr, norm_signal, nuc_signal, nuc_cov, nfr_cov, fuzz) in chunk / position order."""
+    return batch_calls_finish(batch_calls_start(r, params, pool, pool_workers))
 
 
 def run_nuc(args):
@@ -168,33 +187,39 @@ def run_nuc(args):
     call_paths = {n: args.out + "." + n + ".bed" + suffix for n in outputs if n.startswith("nucpos")}
     for p in call_paths.values():
         open(p, "w").close()
-    # sub-batches by chunk count: `nuc` is bound by the per-call fits on the host pool, which larger sub-batches keep busier (measured on
-    # 60 k x 10 kb tiles: 17.3 s of fits with 4,096-chunk sub-batches, 20.4 s with ~9-Mbp ones); `occ` cuts by bases (pipeline.sub_batches)
-    parts = [mine[i:i + BATCH_CHUNKS] for i in range(0, len(mine), BATCH_CHUNKS)]
+    # sub-batches: <= BATCH_CHUNKS chunks and NUC_SUB_BP bases (pipeline.sub_batches)
+    parts = sub_batches(mine, BATCH_CHUNKS, NUC_SUB_BP if "NATAC_BATCH_CHUNKS" not in os.environ else 1 << 62)
     if not parts:
         for n in track_of:
             write_bedgraph(paths[n], [], [], [0], np.zeros(0), append=False, compress=COMPRESS_LEVEL, finish=(rank == world - 1))
 
     calls_s = [0.0]
 
-    def calls(r):
-        import time
-        t0 = time.perf_counter()
-        try:
-            _calls(r)
-        finally:
-            calls_s[0] += time.perf_counter() - t0
+    def timed(fn):
+        def run(x):
+            import time
+            t0 = time.perf_counter()
+            try:
+                return fn(x)
+            finally:
+                calls_s[0] += time.perf_counter() - t0
+        return run
 
-    def _calls(r):
-        part = r.tag
+    def calls_start(r):          # thresholds, values at the calls, fits submitted, occupancy values: needs the result's buffers
+        return batch_calls_start(r, params, pool, getattr(args, "cores", 1) or 1)
+
+    def calls_finish(st):        # waits for the fits; rows in chunk / position order
+        part = st["part"]
         names = sorted(set(c.chrom for c in part))
         idx = {c: i for i, c in enumerate(names)}
         cid_of = np.array([idx[c.chrom] for c in part], dtype=np.int32)
         start_of = np.array([c.start for c in part], dtype=np.int64)
-        for name, (kc, kp, vals) in batch_calls(r, params, pool, getattr(args, "cores", 1) or 1).items():
+        for name, (kc, kp, vals) in batch_calls_finish(st).items():
             if len(kc):
                 pos = start_of[kc] + kp
                 write_bed_rows(call_paths[name], names, cid_of[kc], pos, pos + 1, vals)
+
+    calls = (timed(calls_start), timed(calls_finish))
 
     try:
       if parts:

@@ -79,8 +79,13 @@ class _Writer(threading.Thread):
     .tbi can be built without reading the file again (finish_indexes)."""
 
     def __init__(self, paths, track_of, extra, n_batches, last_rank):
+        """extra: a function of the result, or a pair (start, finish): start(result) -> state runs next to the result's file appends
+        and before its buffers are released, finish(state) for sub-batch k only after start of sub-batch k + 1 (still in result
+        order) -- whatever start handed to a worker pool has company before the writer waits for it"""
         threading.Thread.__init__(self, daemon=True)
         self.paths, self.track_of, self.extra, self.nb, self.last_rank = paths, track_of, extra, n_batches, last_rank
+        self.two_phase = isinstance(extra, tuple)
+        self._pending = None
         self.q = queue.Queue(maxsize=2)
         self.err = None
         self.seconds = 0.0
@@ -122,7 +127,7 @@ class _Writer(threading.Thread):
                     # one file per track: the appends run side by side (write() releases the GIL), every file still in order; the
                     # per-result extra work (peak rows / calls of THIS result, in result order) runs next to them
                     jobs = [self.pool.submit(write_one, n) for n in self.paths]
-                    more = self.pool.submit(self.extra, r)
+                    more = self.pool.submit(self.extra[0] if self.two_phase else self.extra, r)
                     try:
                         for j in jobs:
                             j.result()
@@ -130,7 +135,12 @@ class _Writer(threading.Thread):
                     finally:                 # the result's buffers are released below: nothing may still be reading them
                         from concurrent.futures import wait
                         wait(jobs + [more])
-                    more.result()
+                    state = more.result()
+                    if self.two_phase:
+                        r.release()          # start() has copied what finish() needs: the slot goes back before the wait
+                        prev, self._pending = self._pending, state
+                        if prev is not None:
+                            self.extra[1](prev)
                     self.seconds += time.perf_counter() - t0
             except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
                 self.err = e
@@ -146,6 +156,12 @@ class _Writer(threading.Thread):
         self.q.put(None)
         self.join()
         self.pool.shutdown()
+        if self.err is None and self._pending is not None:      # the last sub-batch's second half
+            import time
+            t0 = time.perf_counter()
+            prev, self._pending = self._pending, None
+            self.extra[1](prev)
+            self.seconds += time.perf_counter() - t0
         if self.err is not None:
             raise self.err
 
