@@ -310,3 +310,49 @@ def test_sub_batches_cut_by_bases_and_by_count():
         for p, q in zip(parts[:-1], parts[1:]):
             assert len(p) == max_chunks or sum(c.end - c.start for c in p) + (q[0].end - q[0].start) > target
     assert len(sub_batches(ChunkList(*[Chunk("c", 0, 2120)] * 5000), 4096, SUB_BATCH_BP)) == 3       # 2,122 chunks of 2 kb per ~4.5 Mbp
+
+
+def test_writer_two_phase_lookahead_order():
+    """run_occ._Writer with a (start, finish) pair: start(k) runs before the result's buffers are released, finish(k) only after
+    start(k + 1), every finish in result order, the last one at finish(); a failing start surfaces on the caller's thread"""
+    from nucleoatac_amd.nucleoatac.run_occ import _Writer
+    log = []
+
+    class R(object):
+        def __init__(self, seq):
+            self.seq, self.tag, self.text, self.tracks, self.released = seq, [], {}, {}, False
+
+        def release(self):
+            if not self.released:
+                log.append(("release", self.seq))
+            self.released = True
+
+    def start(r):
+        assert not r.released
+        log.append(("start", r.seq))
+        return r.seq
+
+    def finish(k):
+        log.append(("finish", k))
+
+    w = _Writer({}, {}, (start, finish), 4, True)
+    w.start()
+    for k in range(4):
+        w.put(R(k))
+    w.finish()
+    pos = {e: i for i, e in enumerate(log)}
+    for k in range(4):
+        assert pos[("start", k)] < pos[("release", k)] < pos[("finish", k)]
+        if k < 3:
+            assert pos[("start", k + 1)] < pos[("finish", k)] < pos[("finish", k + 1)]
+    assert log[-1] == ("finish", 3)
+
+    def bad(r):
+        raise ValueError("boom %d" % r.seq)
+
+    w = _Writer({}, {}, (bad, finish), 2, True)
+    w.start()
+    w.put(R(0))
+    with pytest.raises(ValueError, match="boom 0"):
+        w.put(R(1))
+        w.finish()
