@@ -333,6 +333,16 @@ def run_occ(args):
         LAST_TIMINGS["writer_inside_pipeline"] = round(writer.seconds, 3)
         LAST_TIMINGS["file_appends_inside_writer"] = round(writer.seconds_files, 3)
     dists = gather_in_chunk_order(dists, dst=0)
+    peaks_job, peaks_err = None, []
+    if world == 1:      # one rank: occpeaks.bed is complete -- its bgzip + tabix (run_occ.py:130-136) run next to the track indexes
+        def _peaks():
+            try:
+                bgzip_file(args.out + ".occpeaks.bed", level=COMPRESS_LEVEL)
+                tabix_index(args.out + ".occpeaks.bed.gz")
+            except BaseException as e:      # noqa: BLE001 -- re-raised below, on the main thread
+                peaks_err.append(e)
+        peaks_job = threading.Thread(target=_peaks, name="natac-occpeaks", daemon=True)
+        peaks_job.start()
     to_index = finish_indexes(writer if parts else None, list(track_of), lambda n: args.out + "." + n + ".bedgraph.gz")
     ph.mark("gather_and_track_indexes")
     barrier()      # every rank has closed its part files (raises if WORLD_SIZE > 1 without a process group)
@@ -347,8 +357,13 @@ def run_occ(args):
                         os.remove(base + ".rank%d" % r)
         # bgzip + tabix of every output like the reference (run_occ.py:130-136)
         ph.mark("merge_part_files")
-        bgzip_file(args.out + ".occpeaks.bed", level=COMPRESS_LEVEL)
-        tabix_index(args.out + ".occpeaks.bed.gz")
+        if peaks_job is not None:
+            peaks_job.join()
+            if peaks_err:
+                raise peaks_err[0]
+        else:
+            bgzip_file(args.out + ".occpeaks.bed", level=COMPRESS_LEVEL)
+            tabix_index(args.out + ".occpeaks.bed.gz")
         ph.mark("occpeaks_bgzip_tabix")
         for path in to_index:
             tabix_index(path)
