@@ -356,3 +356,31 @@ def test_writer_two_phase_lookahead_order():
     with pytest.raises(ValueError, match="boom 0"):
         w.put(R(1))
         w.finish()
+
+
+def test_occstore_interval_index():
+    """occstore.OccTrackStore.locate: a region is served only when it lies inside ONE stored chunk; offsets follow the batch layout"""
+    from nucleoatac_amd import occstore
+    from nucleoatac_amd.pyatac.chunk import Chunk
+    st = occstore.OccTrackStore()
+    try:
+        part0 = [Chunk("chr1", 1000, 3120), Chunk("chr1", 5000, 7120), Chunk("chr2", 100, 900)]
+        part1 = [Chunk("chr1", 9000, 9500)]
+        st.add(part0, np.array([0, 2120, 4240, 5040]), 0)
+        st.add(part1, np.array([0, 500]), 1)
+        st.add([Chunk("chr3", 0, 10)], np.array([0, 10]), None)          # a sub-batch the device could not adopt: not indexed
+        seg, off = st.locate(["chr1", "chr2", "chr1", "chr1"], [1000, 150, 5100, 9000], [3120, 160, 7120, 9500])
+        assert list(seg) == [0, 0, 0, 1] and list(off) == [0, 4240 + 50, 2120 + 100, 0]
+        assert st.locate(["chr1"], [3000], [3200]) is None               # runs past the end of its chunk
+        assert st.locate(["chr1"], [4000], [4100]) is None               # between two chunks
+        assert st.locate(["chr1"], [900], [1100]) is None                # starts before the first chunk
+        assert st.locate(["chr3"], [0], [5]) is None and st.locate(["chrX"], [0], [5]) is None
+        assert st.locate(["chr1", "chr1"], [1000, 4000], [1010, 4010]) is None      # one uncovered region spoils the request
+        assert occstore.slot_of("/x/s.occ.lower_bound.bedgraph.gz") == (1, "/x/s.occ.bedgraph.gz")
+        assert occstore.slot_of("/x/s.occ.upper_bound.bedgraph.gz") == (2, "/x/s.occ.bedgraph.gz")
+        assert occstore.slot_of("/x/s.occ.bedgraph.gz") == (0, "/x/s.occ.bedgraph.gz")
+        occstore.register("/tmp/natac_test.occ.bedgraph.gz", st)
+        assert occstore.lookup("/tmp/natac_test.occ.bedgraph.gz") is st and occstore.lookup("/tmp/other.occ.bedgraph.gz") is None
+    finally:
+        occstore.release("/tmp/natac_test.occ.bedgraph.gz")
+    assert occstore.lookup("/tmp/natac_test.occ.bedgraph.gz") is None
