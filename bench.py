@@ -23,8 +23,11 @@ Also reported (rank 0, N = 1): the host-to-host rate -- packed inputs in (pinned
 (pinned) host memory, sub-batches pipelined over six contexts so that uploads, kernels and downloads overlap -- and the CPU
 baseline (the oracle in the reference's Pool.map shape on the box's host cores).
 
-Launch: python bench.py --gpus 1            (default)
-        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+Launch: python bench.py --gpus N            (N = 1 by default)
+`--gpus N` MEANS N ranks, one per GPU, whoever launches it: started plainly with N > 1 (no WORLD_SIZE in the environment) the script
+starts its own N ranks through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 and a free port and
+hands their single JSON line through (like the reference's `--cores N`, which forks its own pool: nucleoatac/run_occ.py:101-102);
+started by a launcher that already set WORLD_SIZE, it insists on WORLD_SIZE == --gpus and exits with status 2 otherwise.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -53,7 +56,9 @@ H2H_TRACKS = ("T_NORM", "T_SMOOTH", "T_OCC", "T_OCC_LOWER", "T_OCC_UPPER")   # w
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="number of ranks = GPUs (default: WORLD_SIZE if a launcher set it, else 1); N > 1 without a launcher: the script "
+                         "starts its own N ranks")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["cfg3", "cfg3-heavy", "cfg4", "cfg5"], default="cfg3")
@@ -77,6 +82,40 @@ def parse():
     ap.add_argument("--share-device", action="store_true",
                     help="functional test of the N>1 path on a 1-GPU box: every rank uses GPU 0 (use with --dist-backend gloo)")
     return ap.parse_args()
+
+
+def resolve_ranks(gpus, environ):
+    """what `--gpus` and the launcher's environment say together: ("run", world) = this process is one of `world` ranks (or the only one);
+    ("spawn", n) = started plainly with --gpus n > 1, the script has to start its own n ranks; ("error", message) = a launcher's
+    WORLD_SIZE contradicts --gpus (a line that says n_gpus = X must have been measured on X ranks)."""
+    ws = environ.get("WORLD_SIZE")
+    if ws is None:
+        if gpus is None or gpus == 1:
+            return "run", 1
+        if gpus < 1:
+            return "error", "bench.py: --gpus %d" % gpus
+        return "spawn", gpus
+    world = int(ws)
+    if gpus is not None and gpus != world:
+        return "error", ("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; start `python bench.py --gpus %d` plainly (it launches "
+                         "its own ranks) or give the launcher --nproc-per-node %d" % (gpus, world, gpus, gpus))
+    return "run", world
+
+
+def spawn_ranks(n):
+    """re-exec this command line under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free port); the
+    children inherit stdout / stderr, so rank 0's JSON line is this process's line"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -499,9 +538,15 @@ def cli_end_to_end(n_chunks, cores, seed=0):
 # ------------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
+    what, world = resolve_ranks(a.gpus, os.environ)
+    if what == "error":
+        sys.stderr.write(world + "\n")
+        sys.exit(2)
+    if what == "spawn":
+        sys.exit(spawn_ranks(world))
+    a.gpus = world
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if "NATAC_DEVICE" in os.environ:          # the CLI's device override (nucleoatac_amd.get_context) holds for the bench too
         local_rank = int(os.environ["NATAC_DEVICE"])
@@ -692,7 +737,7 @@ def main():
             "value_boundary": "hbm_resident: packed inputs and every output track stay in HBM inside the timed region; SURVEY.md 8(d)'s "
                               "boundary (packed inputs in host memory -> output tracks back in host memory, PCIe-bound) is value_host_to_host",
             "value_host_to_host": None if h2h is None else h2h["host_to_host_mbp_s"],
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": info["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "chunks_total": info["total_chunks"], "chunks_this_rank": int(sum(s.n_chunks for s in subs)),
                        "bp_total": total_bp, "fragments_total": total_frags, "candidates_per_step": total_cand,
@@ -742,7 +787,9 @@ def main():
         if cpu is not None:
             cpu["reference_calibration"] = reference_calibration()
             out["cpu_baseline"] = cpu
+        assert out["n_gpus"] == world == a.gpus and (per_rank is None or sorted(r["rank"] for r in per_rank) == list(range(world)))
         print(json.dumps(out))
+        sys.stdout.flush()
     if ctx is not None:
         ctx.close()
     if dist is not None:

@@ -28,6 +28,20 @@ def test_two_ranks_share_device():
     assert all(r["pci_bus_id"] and r["hip_device"] == 0 for r in d["per_rank"])
 
 
+def test_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` started PLAINLY (no torchrun, no WORLD_SIZE): the script launches its own two ranks and the line says
+    n_gpus = 2 with two per-rank rows (VERDICT r4 #1; the reference's --cores N forks its own pool, nucleoatac/run_occ.py:101-102)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--chunks", "4000",
+                          "--no-cpu-baseline", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and [r["rank"] for r in d["per_rank"]] == [0, 1] and d["control_plane"] == "gloo"
+    assert d["config"]["chunks_total"] == 8000 and d["config"]["chunks_this_rank"] == 4000 and d["value"] > 0
+
+
 def test_single_rank_default_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chunks", "3000", "--cpu-chunks", "32",
                           "--cpu-literal-chunks", "16", "--h2h-sub", "1000", "--cli-chunks", "400"], capture_output=True, text=True, timeout=900, cwd=ROOT)
