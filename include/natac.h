@@ -136,14 +136,6 @@ int natac_run_nuc(natac_batch *b, double smooth_sd);
 int natac_run_occ(natac_batch *b);
 /* InsertionTrack.calculateInsertions (pyatac/tracks.py:164-168) for every chunk: fills INS. */
 int natac_run_ins(natac_batch *b, int lower, int upper);
-/* natac_run_nuc + natac_run_occ (+ natac_run_ins when with_ins != 0) of one batch in one call.  The reference runs
- * OccChunk.process and NucChunk.process of a chunk in different commands (run_occ.py:23-39, run_nuc.py:22-39); the two are
- * independent given the packed inputs.  With NATAC_CORUN=1 (read at natac_ctx_create) they are CO-SCHEDULED: the occupancy stage's
- * kernels are enqueued on the context's second stream next to a persistent, half-occupancy launch of the background kernel and
- * the rest of the background follows at full occupancy -- measured on MI355X: the overlap happens as designed and the step is not
- * faster (the fp64 kernels are clock-limited), so the default is the three calls one after the other.
- * The outputs are the same bits either way.  Asynchronous. */
-int natac_run_nuc_occ(natac_batch *b, double smooth_sd, int with_ins, int ins_lower, int ins_upper);
 /* Per-candidate statistics (needs natac_run_nuc first).  cand_chunk[k] = chunk index, cand_pos[k] = position
  * relative to the chunk start.  Outputs (host, length n_cand):
  *   lr   Nucleosome.getLR       NucleosomeCalling.py:110-122

@@ -41,7 +41,6 @@ SIGNATURES = {
     "natac_run_nuc": (C.c_int, [_vp, _f64]),
     "natac_run_occ": (C.c_int, [_vp]),
     "natac_run_ins": (C.c_int, [_vp, C.c_int, C.c_int]),
-    "natac_run_nuc_occ": (C.c_int, [_vp, _f64, C.c_int, C.c_int, C.c_int]),
     "natac_store_create": (C.c_int, [_pp]),
     "natac_store_free": (None, [_vp]),
     "natac_store_adopt": (C.c_int, [_vp, _vp, _i32, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i32)]),

@@ -50,14 +50,7 @@ static int fail(int code, const char *fmt, ...) {
 
 struct natac_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;    // nuc stage, candidates, uploads, drop-ins
-    hipStream_t stream2 = nullptr;   // occ stage + insertions: independent of the nuc stage, overlaps with it
-    // co-scheduling of the two stages (natac_run_nuc_occ): a real second stream, the events that order the streams, the
-    // {next tile, stop flag} words of the persistent background launch
-    bool corun = false;
-    int corun_prio = 0, corun_min_tiles = 4096;
-    hipEvent_t ev_pre = nullptr, ev_join = nullptr;
-    unsigned *d_corun = nullptr;
+    hipStream_t stream = nullptr;    // every stage, uploads, drop-ins: one stream
     hipDeviceProp_t prop;
     // constants
     double *d_vmat = nullptr, *d_vmat_pad = nullptr, *d_srow = nullptr, *d_sizes = nullptr;   // d_vmat_pad: VMatDev::matp
@@ -164,18 +157,7 @@ struct natac_batch {
     long long nuc_gen = -1;                        // model generation natac_run_nuc ran with
 };
 
-static hipError_t sync_all(natac_ctx *c) {
-    hipError_t e = hipStreamSynchronize(c->stream);
-    hipError_t e2 = (c->stream2 != c->stream) ? hipStreamSynchronize(c->stream2) : hipSuccess;
-    return e != hipSuccess ? e : e2;
-}
-
-// Two streams: work that `to` is about to receive must see everything `from` has been given so far.
-static hipError_t stream_after(natac_ctx *c, hipStream_t to, hipStream_t from) {
-    if (to == from) return hipSuccess;
-    hipError_t e = hipEventRecord(c->ev_join, from);
-    return e != hipSuccess ? e : hipStreamWaitEvent(to, c->ev_join, 0);
-}
+static hipError_t sync_all(natac_ctx *c) { return hipStreamSynchronize(c->stream); }
 
 static int track_ready(natac_batch *b, int t);
 
@@ -590,25 +572,10 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
     c->device = device_id;
     HIPCHK(hipGetDeviceProperties(&c->prop, device_id));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    // measured on MI355X: a second stream for the occ stage does not overlap with the nuc stage (the background
-    // kernel's workgroups keep every CU's LDS full), so both stages share one stream -- keeps per-kernel timing exact
-    // -- on its own.  With NATAC_CORUN=1 natac_run_nuc_occ co-schedules them on purpose: the background kernel runs as ONE
-    // workgroup per CU (one wave per SIMD, half the registers and LDS left free) while the occupancy stage's kernels run on
-    // stream2, and as the regular two-waves-per-SIMD launch for the tiles left after that.  Exact, overlapping as designed,
-    // and not faster on MI355X (clock-limited fp64 kernels): off by default.
-    c->stream2 = c->stream;
-    {
-        const char *e = getenv("NATAC_CORUN");
-        c->corun = e && e[0] == '1';
-        if ((e = getenv("NATAC_CORUN_PRIO"))) c->corun_prio = atoi(e);
-        if ((e = getenv("NATAC_CORUN_MIN_TILES"))) c->corun_min_tiles = atoi(e);
-    }
-    if (c->corun) {
-        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        HIPCHK(hipMalloc((void **)&c->d_corun, 2 * sizeof(unsigned)));
-    }
+    // one stream for both stages.  Measured on MI355X: a second stream for the occ stage does not overlap with the nuc stage on its
+    // own (the background kernel's workgroups keep every CU's LDS full); co-scheduling them on purpose (a persistent half-occupancy
+    // background launch next to the occupancy kernels, round 4) overlapped exactly as designed and was not faster -- the fp64
+    // kernels are clock-limited.  The experiment lives in DESIGN.md section 3.3c and profiles/r4/, not in the library.
     HIPCHK(hipEventCreate(&c->t0));
     HIPCHK(hipEventCreate(&c->t1));
     {   // NATAC_BG_DIRECT=1 selects the direct-summation background kernel (validation / A-B timing of the FFT path)
@@ -634,10 +601,6 @@ void natac_ctx_destroy(natac_ctx *c) {
     dev_free(c->d_p10); dev_free(c->d_crc);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
-    if (c->stream2 && c->stream2 != c->stream) (void)hipStreamDestroy(c->stream2);
-    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->d_corun) (void)hipFree(c->d_corun);
     if (c->ck_stream) (void)hipStreamDestroy(c->ck_stream);
     if (c->ck_start) (void)hipEventDestroy(c->ck_start);
     if (c->d_ck) (void)hipFree(c->d_ck);
@@ -1073,12 +1036,7 @@ static int ensure_track(natac_batch *b, int t) {
     return dev_alloc(&b->d_track[t], (size_t)b->total_bp);  // INS uses the first half of a double slot (int32)
 }
 
-struct CoRun { bool occ, ins; int ins_lower, ins_upper; bool used; };
-static int occ_prepare(natac_batch *b);
-static int occ_launch(natac_batch *b);
-static int ins_launch(natac_batch *b, int lower, int upper);
-
-static int run_nuc_impl(natac_batch *b, double smooth_sd, CoRun *co) {
+int natac_run_nuc(natac_batch *b, double smooth_sd) {
     if (!b) return fail(NATAC_E_ARG, "batch is NULL");
     natac_ctx *c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -1119,13 +1077,6 @@ static int run_nuc_impl(natac_batch *b, double smooth_sd, CoRun *co) {
     natac_ctx::Ev ev;
     if (!b->d_ranges256 && (rc = dev_alloc(&b->d_ranges256, (size_t)b->n_tiles256))) return rc;
     if ((M - 1) / 2 == 30 && !b->d_tiles1k && (rc = build_tiles(b, 1024, &b->d_tiles1k, &b->n_tiles1k))) return rc;
-    // co-scheduled occupancy stage: everything of it that allocates, uploads or synchronises happens before the first launch
-    const bool co_ok = co && use_fft && c->corun && c->stream2 != c->stream && b->n_tiles_bg >= c->corun_min_tiles && c->have_occ;
-    if (co_ok) {
-        if (co->occ && (rc = occ_prepare(b))) return rc;
-        if (co->ins && (rc = ensure_track(b, NATAC_T_INS))) return rc;
-    }
-    HIPCHK(stream_after(c, c->stream, c->stream2));     // this stage rewrites arrays the other stream's last kernels may still read
     prof_begin(c, NATAC_K_FRAG_GATHER, ev);
     if (b->ranges256_w != c->vw) {
         hipLaunchKernelGGL(natac_tile_ranges256, dim3((b->n_tiles256 + 255) / 256), dim3(256), 0, c->stream, ct, b->d_tiles256,
@@ -1146,32 +1097,9 @@ static int run_nuc_impl(natac_batch *b, double smooth_sd, CoRun *co) {
     if (use_fft) {
         const int EW = FFT_N + ((vm.upper - 2) >> 1) + ((vm.upper - 1) >> 1);
         const size_t lds = ((size_t)((EW + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
-        const unsigned *first = nullptr;
-        if (co_ok) {
-            // natac_background_fft_persist: one workgroup (four waves, one tile each at a time) per CU.  More than half of the
-            // CU's LDS per workgroup keeps a second one out; the other half and half of every SIMD's registers stay free for
-            // the occupancy stage on stream2, which starts behind ev_pre (gather + exp(bias) done) and raises the stop flag
-            // behind its last kernel; the tiles left then take the regular launch.
-            const int wave_doubles = (int)(lds / sizeof(double));
-            const size_t lds_p = std::max((size_t)4 * lds, (size_t)80 * 1024 + 512);      // gfx950: 160 KB of LDS per CU
-            HIPCHK(hipMemsetAsync(c->d_corun, 0, 2 * sizeof(unsigned), c->stream));
-            HIPCHK(hipEventRecord(c->ev_pre, c->stream));
-            auto kp = c->corun_prio ? natac_background_fft_persist<3> : natac_background_fft_persist<0>;
-            HIPCHK(hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-            hipLaunchKernelGGL(kp, dim3(c->prop.multiProcessorCount), dim3(256), lds_p, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
-                               c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                               b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, c->d_corun, (unsigned)b->n_tiles_bg, wave_doubles);
-            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_pre, 0));
-            co->used = true;
-            b->nuc_done = true; b->nuc_w = c->vw; b->nuc_upper = c->vupper;      // the gather's coverage tracks are ordered by ev_pre
-            if (co->occ && (rc = occ_launch(b))) return rc;
-            if (co->ins && (rc = ins_launch(b, co->ins_lower, co->ins_upper))) return rc;
-            HIPCHK(hipMemsetAsync(c->d_corun + 1, 0xff, sizeof(unsigned), c->stream2));
-            first = c->d_corun;
-        }
         hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
                            c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, first, (unsigned)b->n_tiles_bg);
+                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg);
     } else if (fast) {
         switch (b->bgG) {
             case 7: launch_bg<7>(b, ct, vm); break;
@@ -1207,19 +1135,6 @@ static int run_nuc_impl(natac_batch *b, double smooth_sd, CoRun *co) {
     return NATAC_OK;
 }
 
-int natac_run_nuc(natac_batch *b, double smooth_sd) { return run_nuc_impl(b, smooth_sd, nullptr); }
-
-int natac_run_nuc_occ(natac_batch *b, double smooth_sd, int with_ins, int ins_lower, int ins_upper) {
-    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
-    if (!b->ctx->have_occ) return fail(NATAC_E_STATE, "natac_set_occ_model has not been called");
-    CoRun co{true, with_ins != 0, ins_lower, ins_upper, false};
-    int rc = run_nuc_impl(b, smooth_sd, &co);
-    if (rc || co.used) return rc;
-    // not co-scheduled (small batch, another background kernel, NATAC_CORUN=0): the stages one after the other
-    if ((rc = natac_run_occ(b))) return rc;
-    return with_ins ? natac_run_ins(b, ins_lower, ins_upper) : NATAC_OK;
-}
-
 // natac_occ_smooth (one base per lane, any step / window): smoothed occupancy -> dst_occ (un-filled), bounds -> dst_lo / dst_hi (or null)
 static void launch_occ_smooth_generic(natac_batch *b, const ChunkTable &ct, const OccModelDev &om, int M, double *dst_occ, double *dst_lo,
                                       double *dst_hi) {
@@ -1227,7 +1142,7 @@ static void launch_occ_smooth_generic(natac_batch *b, const ChunkTable &ct, cons
     const int h = (M - 1) / 2;
     const int NB = 2 * ((h + c->step - 1) / c->step) + 2, NG = (255 + 2 * h) / c->step + 3;
     const size_t lds = ((size_t)((M + 1) & ~1) + (size_t)c->step * NB + 3 * (size_t)NG) * sizeof(double);
-    hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream2, ct, b->d_tiles256, om, c->d_win_occ, M,
+    hipLaunchKernelGGL(natac_occ_smooth, dim3(b->n_tiles256), dim3(256), lds, c->stream, ct, b->d_tiles256, om, c->d_win_occ, M,
                        b->d_grid[0], b->d_grid[1], b->d_grid[2], dst_occ, dst_lo, dst_hi);
 }
 
@@ -1382,7 +1297,7 @@ static int occ_prepare(natac_batch *b) {
     return NATAC_OK;
 }
 
-// natac_run_occ, part 2: the launches, all on stream2
+// natac_run_occ, part 2: the launches
 static int occ_launch(natac_batch *b) {
     natac_ctx *c = b->ctx;
     const int M = 2 * c->flank + 1;
@@ -1392,7 +1307,7 @@ static int occ_launch(natac_batch *b) {
     const OccModelDev om = make_occ(c);
     natac_ctx::Ev ev;
     const bool fast = c->occ_fast_ok && !c->occ_force_general;
-    prof_begin(c, NATAC_K_OCC_MLE, ev, c->stream2);
+    prof_begin(c, NATAC_K_OCC_MLE, ev, c->stream);
     {
         const int U = c->occ_upper, UP = (U + 1) & ~1;
         const int span = (OCC_T * OCC_NP - 1) * c->step + M + c->step;
@@ -1402,7 +1317,7 @@ static int occ_launch(natac_batch *b) {
                            (size_t)2 * OCC_FMAX * sizeof(int);
         if (b->ranges_occ_key[0] != c->step || b->ranges_occ_key[1] != c->halfstep || b->ranges_occ_key[2] != c->flank) {
             // an index over the (immutable) fragment list, like the 256-base tiles' ranges: formed once per batch and geometry
-            hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream2, ct, b->d_tiles_occ,
+            hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream, ct, b->d_tiles_occ,
                                b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
             b->ranges_occ_key[0] = c->step; b->ranges_occ_key[1] = c->halfstep; b->ranges_occ_key[2] = c->flank;
         }
@@ -1417,16 +1332,16 @@ static int occ_launch(natac_batch *b) {
             const size_t lds_gs = ((size_t)((GS_BLOCKS * 5 + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
             const int NGP = (64 + of.Q + 1) & ~1;
             const size_t lds_od = (size_t)4 * ((OD_FM + 4) + 4 * NGP + OD_FM / 2) * sizeof(double);
-            HIPCHK(hipMemsetAsync(b->d_defer, 0, sizeof(int), c->stream2));
-            if ((rc = run_exp_bias(b, c->stream2, true))) return rc;
-            hipLaunchKernelGGL((natac_occ_gsum<5>), dim3(b->n_tiles_gs), dim3(256), lds_gs, c->stream2, ct, b->d_tiles_gs, of, b->d_blk_off,
+            HIPCHK(hipMemsetAsync(b->d_defer, 0, sizeof(int), c->stream));
+            if ((rc = run_exp_bias(b, c->stream, true))) return rc;
+            hipLaunchKernelGGL((natac_occ_gsum<5>), dim3(b->n_tiles_gs), dim3(256), lds_gs, c->stream, ct, b->d_tiles_gs, of, b->d_blk_off,
                                b->total_blocks, b->d_gsum);
             if (c->occ_rn16)
-                hipLaunchKernelGGL((natac_occ_decide<5, 16>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream2, ct,
+                hipLaunchKernelGGL((natac_occ_decide<5, 16>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream, ct,
                                    b->d_tiles_occ, b->n_tiles_occ, b->d_ranges_occ, of, b->d_blk_off, b->total_blocks, b->d_gsum,
                                    b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_defer, b->d_defer + 1);
             else
-                hipLaunchKernelGGL((natac_occ_decide<5, 4>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream2, ct,
+                hipLaunchKernelGGL((natac_occ_decide<5, 4>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream, ct,
                                    b->d_tiles_occ, b->n_tiles_occ, b->d_ranges_occ, of, b->d_blk_off, b->total_blocks, b->d_gsum,
                                    b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_defer, b->d_defer + 1);
             d_count = b->d_defer;
@@ -1434,23 +1349,23 @@ static int occ_launch(natac_batch *b) {
             grid_general = (unsigned)std::min(b->n_tiles_occ, 2048);   // walks the deferred list (normally empty)
         }
         if (c->step == 5 && c->flank == 60 && c->n_alpha <= 16 * OCC_RA)
-            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0, 1>), dim3(grid_general), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
+            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0, 1>), dim3(grid_general), dim3(256), lds, c->stream, ct, b->d_tiles_occ,
                                b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status, d_list, d_count);
         else if (c->step == 5 && c->flank == 60)
-            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0>), dim3(grid_general), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
+            hipLaunchKernelGGL((natac_occ_mle<5, 60, 0>), dim3(grid_general), dim3(256), lds, c->stream, ct, b->d_tiles_occ,
                                b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status, d_list, d_count);
         else
-            hipLaunchKernelGGL((natac_occ_mle<0, 0, 0>), dim3(grid_general), dim3(256), lds, c->stream2, ct, b->d_tiles_occ,
+            hipLaunchKernelGGL((natac_occ_mle<0, 0, 0>), dim3(grid_general), dim3(256), lds, c->stream, ct, b->d_tiles_occ,
                                b->d_ranges_occ, om, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_status, d_list, d_count);
     }
     prof_end(c, ev);
-    prof_begin(c, NATAC_K_OCC_SMOOTH, ev, c->stream2);
+    prof_begin(c, NATAC_K_OCC_SMOOTH, ev, c->stream);
     const bool blk = (c->step == 5) && (((M - 1) / 2) % c->step == 0);     // natac_occ_smooth_blk<5>
     if (blk) {
         const int h = (M - 1) / 2, NB = 2 * (h / c->step) + 2;
-        HIPCHK(hipMemsetAsync(b->d_occ_minkey, 0xff, (size_t)b->nc * sizeof(unsigned long long), c->stream2));
-        HIPCHK(hipMemsetAsync(b->d_occ_nan, 0, (size_t)b->nc * sizeof(int), c->stream2));
-        hipLaunchKernelGGL((natac_occ_smooth_blk<5>), dim3(b->n_tiles_os), dim3(256), ((size_t)3 * (256 + NB) + 256 * 5) * sizeof(double), c->stream2, ct,
+        HIPCHK(hipMemsetAsync(b->d_occ_minkey, 0xff, (size_t)b->nc * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMemsetAsync(b->d_occ_nan, 0, (size_t)b->nc * sizeof(int), c->stream));
+        hipLaunchKernelGGL((natac_occ_smooth_blk<5>), dim3(b->n_tiles_os), dim3(256), ((size_t)3 * (256 + NB) + 256 * 5) * sizeof(double), c->stream, ct,
                            b->d_tiles_os, om, c->d_win_occ, M, c->d_wb_occ, NB, b->d_grid[0], b->d_grid[1], b->d_grid[2],
                            b->d_track[NATAC_T_OCC], b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER], b->d_occ_minkey,
                            b->d_occ_nan);
@@ -1463,19 +1378,19 @@ static int occ_launch(natac_batch *b) {
         if (b->nuc_done && b->cov_from_nuc && c->flank == b->nuc_w && c->occ_upper == b->nuc_upper) {
             // natac_frag_gather of natac_run_nuc already wrote OCC_COV = nuc_cov + nfr_cov for this geometry
         } else if (b->nuc_done && c->flank == b->nuc_w && c->occ_upper == b->nuc_upper)
-            hipLaunchKernelGGL(natac_add_tracks, dim3(4096), dim3(256), 0, c->stream2, b->d_track[NATAC_T_NUC_COV],
+            hipLaunchKernelGGL(natac_add_tracks, dim3(4096), dim3(256), 0, c->stream, b->d_track[NATAC_T_NUC_COV],
                                b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_OCC_COV], b->total_bp);
         else
-            hipLaunchKernelGGL(natac_occ_cov, dim3(b->n_tiles256), dim3(256), 0, c->stream2, ct, b->d_tiles256, c->occ_upper, c->flank,
+            hipLaunchKernelGGL(natac_occ_cov, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, c->occ_upper, c->flank,
                                b->d_track[NATAC_T_OCC_COV]);
     }
     prof_end(c, ev);
-    prof_begin(c, NATAC_K_OCC_FILL, ev, c->stream2);
+    prof_begin(c, NATAC_K_OCC_FILL, ev, c->stream);
     if (blk)     // in place, and only the chunks that hold a NaN
-        hipLaunchKernelGGL(natac_fill_nan_chunks, dim3(b->nc), dim3(256), 0, c->stream2, ct, b->d_occ_minkey, b->d_occ_nan,
+        hipLaunchKernelGGL(natac_fill_nan_chunks, dim3(b->nc), dim3(256), 0, c->stream, ct, b->d_occ_minkey, b->d_occ_nan,
                            b->d_track[NATAC_T_OCC]);
     else
-        hipLaunchKernelGGL(natac_fill_nan_min, dim3(b->nc), dim3(256), 0, c->stream2, ct, b->d_track[NATAC_T_OCC_PREFILL],
+        hipLaunchKernelGGL(natac_fill_nan_min, dim3(b->nc), dim3(256), 0, c->stream, ct, b->d_track[NATAC_T_OCC_PREFILL],
                            b->d_track[NATAC_T_OCC]);
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
@@ -1486,10 +1401,10 @@ static int occ_launch(natac_batch *b) {
 int natac_run_occ(natac_batch *b) {
     int rc = occ_prepare(b);
     if (rc) return rc;
-    natac_ctx *c = b->ctx;
-    HIPCHK(stream_after(c, c->stream2, c->stream));     // exp(bias) / coverage of a preceding natac_run_nuc
     return occ_launch(b);
 }
+
+static int ins_launch(natac_batch *b, int lower, int upper);
 
 int natac_run_ins(natac_batch *b, int lower, int upper) {
     if (!b) return fail(NATAC_E_ARG, "batch is NULL");
@@ -1504,15 +1419,15 @@ static int ins_launch(natac_batch *b, int lower, int upper) {
     natac_ctx *c = b->ctx;
     const ChunkTable ct = make_table(b);
     natac_ctx::Ev ev;
-    prof_begin(c, NATAC_K_INS, ev, c->stream2);
+    prof_begin(c, NATAC_K_INS, ev, c->stream);
     int maxL = 0;
     for (int i = 0; i < b->nc; ++i) maxL = std::max(maxL, b->h_len[i]);
     if ((size_t)maxL * sizeof(int) <= 60 * 1024) {
-        hipLaunchKernelGGL(natac_insertions_lds, dim3(b->nc), dim3(256), (size_t)maxL * sizeof(int), c->stream2, ct, lower, upper,
+        hipLaunchKernelGGL(natac_insertions_lds, dim3(b->nc), dim3(256), (size_t)maxL * sizeof(int), c->stream, ct, lower, upper,
                            (int *)b->d_track[NATAC_T_INS]);
     } else {
-        HIPCHK(hipMemsetAsync(b->d_track[NATAC_T_INS], 0, (size_t)b->total_bp * sizeof(int), c->stream2));
-        hipLaunchKernelGGL(natac_insertions, dim3(b->nc), dim3(256), 0, c->stream2, ct, lower, upper, (int *)b->d_track[NATAC_T_INS]);
+        HIPCHK(hipMemsetAsync(b->d_track[NATAC_T_INS], 0, (size_t)b->total_bp * sizeof(int), c->stream));
+        hipLaunchKernelGGL(natac_insertions, dim3(b->nc), dim3(256), 0, c->stream, ct, lower, upper, (int *)b->d_track[NATAC_T_INS]);
     }
     prof_end(c, ev);
     HIPCHK(hipGetLastError());
@@ -1872,7 +1787,6 @@ int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes)
     if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, track needs %zu", dst_bytes, need);
     HIPCHK(hipSetDevice(b->ctx->device));
     if (track == NATAC_T_OCC_PREFILL && (rc = materialise_prefill(b))) return rc;
-    HIPCHK(stream_after(b->ctx, b->ctx->stream, b->ctx->stream2));
     HIPCHK(hipMemcpyAsync(dst, b->d_track[track], need, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(sync_all(b->ctx));
     prof_collect(b->ctx);
@@ -1886,7 +1800,6 @@ int natac_batch_download_grid(natac_batch *b, int which, double *dst, size_t dst
     const size_t need = (size_t)b->total_grid * sizeof(double);
     if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, grid needs %zu", dst_bytes, need);
     HIPCHK(hipSetDevice(b->ctx->device));
-    HIPCHK(stream_after(b->ctx, b->ctx->stream, b->ctx->stream2));
     HIPCHK(hipMemcpyAsync(dst, b->d_grid[which], need, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(sync_all(b->ctx));
     return NATAC_OK;
@@ -1912,7 +1825,6 @@ int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes) {
     if (!b || !dst) return fail(NATAC_E_ARG, "null argument");
     if (dst_bytes != (size_t)b->nc * sizeof(int)) return fail(NATAC_E_ARG, "status buffer must hold n_chunks int32");
     HIPCHK(hipSetDevice(b->ctx->device));
-    HIPCHK(stream_after(b->ctx, b->ctx->stream, b->ctx->stream2));
     HIPCHK(hipMemcpyAsync(dst, b->d_status, dst_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(sync_all(b->ctx));
     return NATAC_OK;

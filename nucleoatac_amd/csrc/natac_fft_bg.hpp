@@ -457,53 +457,16 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
 // background + normalised signal for tiles of TV = 512 - W + 1 bases; one tile per wave, one wave per workgroup.
 // two waves per SIMD on purpose: a third one (reachable with the stage-2 twiddles in LDS, 145 VGPRs) only adds LDS contention
 // (measured 11.4 vs 8.7 ms per 20 k chunks).
-// `first` (or null): the launch covers tiles[min(*first, n_tiles) + blockIdx.x ...] -- the tiles a preceding persistent launch
-// (below) did not claim; workgroups past the end leave at once.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) natac_background_fft(ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm,
                                                              const double *__restrict__ tw, const double *__restrict__ ktab,
                                                              const double *__restrict__ nuc_cov, const double *__restrict__ raw,
                                                              double *__restrict__ bg, double *__restrict__ norm,
                                                              double *__restrict__ bnum, double *__restrict__ bcov,
-                                                             const unsigned *__restrict__ first, unsigned n_tiles) {
+                                                             unsigned n_tiles) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    unsigned ti = blockIdx.x;
-    if (first) {
-        ti += min(*first, n_tiles);
-        if (ti >= n_tiles) return;
-    }
+    const unsigned ti = blockIdx.x;
     FftTwiddles tww;
     bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x);
-}
-
-// The same tiles as a PERSISTENT launch that leaves room on every SIMD: one workgroup of four independent waves per CU (the
-// launch asks for more than half of a CU's LDS, so a second workgroup never fits), one wave per SIMD at <= 256 VGPRs -- half of
-// the register file and half of the LDS stay free for the kernels of the occupancy stage on the context's second stream, whose
-// dense fp64 streams issue while this kernel's waves sit in their LDS transposes.  Each wave claims tiles from `state[0]` until
-// they run out or `state[1]` becomes non-zero (set on the second stream behind the last co-running kernel); the tiles not
-// claimed by then are left to a regular two-waves-per-SIMD launch of natac_background_fft(first = state).
-template <int PRIO>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) natac_background_fft_persist(
-    ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm, const double *__restrict__ tw, const double *__restrict__ ktab,
-    const double *__restrict__ nuc_cov, const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
-    double *__restrict__ bnum, double *__restrict__ bcov, unsigned *__restrict__ state, unsigned n_tiles, int wave_doubles) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *mine = smem + (size_t)wave * wave_doubles;
-    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
-    for (;;) {
-        unsigned ti = 0xffffffffu;
-        if (lane == 0) {
-            if (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
-                ti = __hip_atomic_fetch_add(state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        ti = __builtin_amdgcn_readfirstlane(ti);
-        if (ti >= n_tiles) break;
-        FftTwiddles tww;      // re-loaded per tile (L1-resident table): keeping them across the staging and the epilogue spills
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));   // opaque per trip, or ~40 lane-based LDS addresses are hoisted out of the tile loop and spill
-        bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, mine, tww, lane_t);
-        __builtin_amdgcn_wave_barrier();     // the next tile's staging overwrites this tile's epilogue scratch
-    }
 }
 
 }  // namespace natac

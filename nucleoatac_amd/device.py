@@ -430,11 +430,6 @@ class DeviceBatch(object):
     def run_ins(self, lower=0, upper=2000):
         L.check(self._lib.natac_run_ins(self._h, int(lower), int(upper)))
 
-    def run_nuc_occ(self, smooth_sd=10, ins=None):
-        """run_nuc + run_occ (+ run_ins(*ins)) in one call (natac_run_nuc_occ; co-scheduled on two streams when NATAC_CORUN=1); same results"""
-        lo, hi = ins if ins is not None else (0, 0)
-        L.check(self._lib.natac_run_nuc_occ(self._h, float(smooth_sd), 0 if ins is None else 1, int(lo), int(hi)))
-
     def run_candidates(self, cand_chunk, cand_pos):
         cc = np.ascontiguousarray(cand_chunk, dtype=np.int32)
         cp = np.ascontiguousarray(cand_pos, dtype=np.int32)

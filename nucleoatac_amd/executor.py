@@ -50,15 +50,12 @@ class Stages(object):
     def run(self, batch):
         """launch every stage on `batch` (asynchronous except the candidate counts); returns the number of nuc candidates
         (0 without a peaks stage).  Candidate arrays stay in HBM (download_peaks)."""
-        if self.nuc_sd is not None and self.occ:      # both stages in one call (co-scheduled on two streams when NATAC_CORUN=1)
-            batch.run_nuc_occ(self.nuc_sd, self.ins)
-        else:
-            if self.nuc_sd is not None:
-                batch.run_nuc(self.nuc_sd)
-            if self.occ:
-                batch.run_occ()
-            if self.ins is not None:
-                batch.run_ins(*self.ins)
+        if self.nuc_sd is not None:
+            batch.run_nuc(self.nuc_sd)
+        if self.occ:
+            batch.run_occ()
+        if self.ins is not None:
+            batch.run_ins(*self.ins)
         n = 0
         if self.peaks is not None:
             n = batch.run_peaks(download=False, **self.peaks)

@@ -1,5 +1,6 @@
 """Randomised sweep over round 4's device paths (development / release check), on the ragged chunk sets of fuzz_parity.py:
-  * natac_run_nuc_occ co-scheduled on two streams (NATAC_CORUN=1, threshold 1 tile) == the stages one after the other, bit for bit;
+  * the stages of a batch in another order on a second context (ins, occ, nuc) == (nuc, occ, ins), bit for bit (round 4 ran the
+    co-scheduled launch of DESIGN.md section 3.3c here; that path left the library in round 5);
   * natac_store_adopt / natac_store_read == the parse of the device's own text of the same tracks (what a reader of the file gets).
 usage: python tests/fuzz/fuzz_round4.py [n_rounds] [seed]"""
 import os
@@ -57,7 +58,9 @@ def random_batch(rng):
 
 def everything(b, co, kw):
     if co:
-        b.run_nuc_occ(10, (0, 2000))
+        b.run_ins(0, 2000)
+        b.run_occ()
+        b.run_nuc(10)
     else:
         b.run_nuc(10)
         b.run_occ()
@@ -105,8 +108,8 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    plain = make_ctx({"NATAC_CORUN": "0"})
-    co = make_ctx({"NATAC_CORUN": "1", "NATAC_CORUN_MIN_TILES": "1", "NATAC_CORUN_PRIO": str(seed & 1)})
+    plain = make_ctx({})
+    co = make_ctx({})
     store = TrackStore()
     t0 = time.time()
     bp = n_hard = 0
@@ -116,7 +119,7 @@ def main():
         b0, b1 = plain.upload(pk), co.upload(pk)
         ref, got = everything(b0, False, kw), everything(b1, True, kw)
         for i, (x, y) in enumerate(zip(ref, got)):
-            assert x.shape == y.shape and np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), ("co-scheduled != serial", r, i)
+            assert x.shape == y.shape and np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), ("stage order changed a result", r, i)
         # the store: what a reader of the written track gets
         chroms = ["chr%d" % (1 + k % 3) for k in range(pk.n_chunks)]
         tracks = (L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER, L.T_OCC_COV)
