@@ -392,9 +392,15 @@ int natac_profile_reset(natac_ctx *ctx);
  *   natac_store_adopt   a COPY of the batch's tracks as the file shows them: every run rounded to its twelve printed digits
  *                       (float('%.12g' % v)), NaN where Track.write_track writes no line (write_zero as in natac_batch_format_track);
  *                       returns the segment id, or -1 with *n_hard > 0 when a value cannot be rounded exactly on the device
- *                       (|v| < 1e-11, >= 1e34): nothing is kept and the caller reads the file for these regions;
+ *                       (|v| < 1e-11, >= 1e34): nothing is kept and the caller reads the file for these regions; -1 with
+                       *n_hard == -1 when the store's HBM budget declines the segment (below) -- same consequence;
+ *   natac_store_set_budget  the store never fills the device: a segment is adopted only while the store stays below max_bytes
+ *                       (< 0: no cap; env NATAC_STORE_MAX_BYTES) AND the device keeps min_free_bytes for the pipeline's batches
+ *                       (< 0: a quarter of the device's memory; env NATAC_STORE_MIN_FREE_BYTES), counting the blocks the library
+ *                       caches as free.  The first refusal closes the store: later sub-batches go through the files unasked;
  *   natac_store_read    ranges [offset, offset + length) of slot `slot` (the i-th adopted track) of the named segments, concatenated
  *                       into `out` (host): whole chunks for nfr's gap statistics, single positions for nuc's calls.
+ *   natac_store_declined  how many segments the budget declined.
  * Offsets are positions in the batch's flat per-base layout (chunk k starts at out_off[k]).  Thread-safe. */
 typedef struct natac_store natac_store;
 int natac_store_create(natac_store **out);
@@ -404,6 +410,8 @@ int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const in
 int natac_store_read(natac_store *s, natac_ctx *ctx, int64_t n, const int64_t *segment, const int64_t *offset, const int64_t *length,
                      int32_t slot, double *out, size_t out_values);
 int natac_store_info(natac_store *s, int64_t *n_segments, int64_t *bytes);
+int natac_store_set_budget(natac_store *s, int64_t max_bytes, int64_t min_free_bytes);
+int natac_store_declined(natac_store *s, int64_t *n_declined);
 
 /* Shader-clock trace (measurement aid, SURVEY.md section 8d asks for achieved rates against peaks that assume a clock): a one-wave
  * sampler kernel on its own stream notes (wall time, shader cycle counter) every interval_us while other launches run; between

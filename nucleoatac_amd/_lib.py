@@ -46,6 +46,8 @@ SIGNATURES = {
     "natac_store_adopt": (C.c_int, [_vp, _vp, _i32, _vp, C.c_int, C.POINTER(_i64), C.POINTER(_i32)]),
     "natac_store_read": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _sz]),
     "natac_store_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "natac_store_set_budget": (C.c_int, [_vp, _i64, _i64]),
+    "natac_store_declined": (C.c_int, [_vp, C.POINTER(_i64)]),
     "natac_clock_trace_start": (C.c_int, [_vp, C.c_int, C.c_int]),
     "natac_clock_trace_stop": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "natac_clock_trace_fetch": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),

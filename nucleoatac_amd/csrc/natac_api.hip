@@ -238,7 +238,20 @@ static hipError_t pool_alloc(void **p, size_t bytes) {
         e = hipMalloc(p, bytes);
     }
     if (e == hipSuccess) g_pool.live[*p] = {dev, bytes};
+    else (void)hipGetLastError();      // reported through the return value; a later hipGetLastError() on this thread must not see it again
     return e;
+}
+
+// bytes the device could still hand out: what the driver reports as free + the blocks this process caches for reuse
+static hipError_t pool_mem_info(int dev, size_t *avail, size_t *total) {
+    size_t fr = 0, tot = 0;
+    hipError_t e = hipMemGetInfo(&fr, &tot);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto &kv : g_pool.free_blocks[dev & 15]) fr += kv.first;
+    *avail = fr;
+    *total = tot;
+    return hipSuccess;
 }
 
 static void dev_free(void *p) {
@@ -2723,11 +2736,30 @@ struct natac_store {
     struct Seg { double *p[4]; int n_tracks; long long n; int device; };
     std::mutex mu;
     std::vector<Seg> segs;
+    // HBM budget: the store is a convenience next to the files, it must never be what fills the device.  A segment is adopted only
+    // while the store stays below max_bytes AND the device keeps min_free bytes (default: a quarter of its memory) for the batches
+    // of the pipeline; the first refusal closes the store (later sub-batches go through the files without asking again).
+    long long bytes = 0, max_bytes = -1, min_free = -1, declined = 0;
+    bool closed = false;
 };
 
 int natac_store_create(natac_store **out) {
     if (!out) return fail(NATAC_E_ARG, "out is NULL");
-    *out = new natac_store();
+    natac_store *s = new natac_store();
+    const char *e = getenv("NATAC_STORE_MAX_BYTES");
+    if (e && *e) s->max_bytes = atoll(e);
+    e = getenv("NATAC_STORE_MIN_FREE_BYTES");
+    if (e && *e) s->min_free = atoll(e);
+    *out = s;
+    return NATAC_OK;
+}
+
+int natac_store_set_budget(natac_store *s, int64_t max_bytes, int64_t min_free_bytes) {
+    if (!s) return fail(NATAC_E_ARG, "store is NULL");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->max_bytes = max_bytes;
+    s->min_free = min_free_bytes;
+    s->closed = false;
     return NATAC_OK;
 }
 
@@ -2752,6 +2784,21 @@ int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const in
         if ((rc = track_ready(b, tracks[i]))) return rc;
     }
     if (b->total_bp >= 0xffffffffLL) return fail(NATAC_E_ARG, "batch too long (%lld bases)", b->total_bp);
+    {   // budget first: nothing is launched or allocated for a segment the store will not keep
+        const long long need = (long long)n_tracks * b->total_bp * (long long)sizeof(double);
+        size_t avail = 0, total = 0;
+        HIPCHK(pool_mem_info(c->device, &avail, &total));
+        std::lock_guard<std::mutex> lk(s->mu);
+        const long long min_free = s->min_free >= 0 ? s->min_free : (long long)(total / 4);
+        // run tables + one pass of scratch ride on top of the segment itself while it is formed
+        const long long scratch = 2 * b->total_bp * (long long)sizeof(int) + (1 << 20);
+        if (s->closed || (s->max_bytes >= 0 && s->bytes + need > s->max_bytes) || (long long)avail - need - scratch < min_free) {
+            s->closed = true;
+            ++s->declined;
+            if (n_hard) *n_hard = -1;      // declined: budget (the caller reads the files, as for n_hard > 0)
+            return NATAC_OK;
+        }
+    }
     if ((rc = ensure_text_tables(c))) return rc;
     HIPCHK(sync_all(c));
     TmpFree tmp;
@@ -2759,7 +2806,7 @@ int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const in
     unsigned long long *d_tb = nullptr;
     unsigned int *d_R = nullptr;
     const int nt = b->n_tiles256;
-#define TRYS(x) do { if ((rc = (x)) != NATAC_OK) { for (int q_ = 0; q_ < 4; ++q_) dev_free(seg.p[q_]); return rc; } } while (0)
+#define TRYS(x) do { if ((rc = (x)) != NATAC_OK) { for (int q_ = 0; q_ < 4; ++q_) dev_free(seg.p[q_]); dev_free(d_R); dev_free(d_C); return rc; } } while (0)
     natac_store::Seg seg{{nullptr, nullptr, nullptr, nullptr}, n_tracks, b->total_bp, c->device};
     TRYS(dev_alloc(&d_hard, 1)); tmp.keep(d_hard);
     TRYS(dev_alloc(&d_tc, (size_t)nt)); tmp.keep(d_tc);
@@ -2778,9 +2825,10 @@ int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const in
         if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
         dev_free(d_R); dev_free(d_C);
         d_R = nullptr; d_C = nullptr;
-        if ((rc = dev_alloc(&d_R, (size_t)nruns)) || (rc = dev_alloc(&d_C, (size_t)nruns))) { dev_free(d_R); dev_free(d_C); TRYS(rc); }
+        TRYS(dev_alloc(&d_R, (size_t)nruns));
+        TRYS(dev_alloc(&d_C, (size_t)nruns));
         hipLaunchKernelGGL(tz_scatter_runs, dim3(nt), dim3(256), 0, c->stream, job, d_tb, d_R, d_C);
-        if ((rc = dev_alloc(&seg.p[i], (size_t)b->total_bp))) { dev_free(d_R); dev_free(d_C); TRYS(rc); }
+        TRYS(dev_alloc(&seg.p[i], (size_t)b->total_bp));
         hipLaunchKernelGGL(tz_as_written, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C,
                            seg.p[i], d_hard);
         e = hipGetLastError();
@@ -2797,6 +2845,7 @@ int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const in
     }
     std::lock_guard<std::mutex> lk(s->mu);
     s->segs.push_back(seg);
+    s->bytes += (long long)n_tracks * b->total_bp * (long long)sizeof(double);
     *segment = (int64_t)s->segs.size() - 1;
     return NATAC_OK;
 }
@@ -2845,6 +2894,13 @@ int natac_store_info(natac_store *s, int64_t *n_segments, int64_t *bytes) {
     for (auto &g : s->segs) by += (long long)g.n_tracks * g.n * (long long)sizeof(double);
     if (n_segments) *n_segments = (int64_t)s->segs.size();
     if (bytes) *bytes = by;
+    return NATAC_OK;
+}
+
+int natac_store_declined(natac_store *s, int64_t *n_declined) {
+    if (!s || !n_declined) return fail(NATAC_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    *n_declined = s->declined;
     return NATAC_OK;
 }
 

@@ -17,6 +17,9 @@
 
 namespace natac {
 
+#ifndef NATAC_FFT_HFOLD
+#define NATAC_FFT_HFOLD 1      // dft8: 1/sqrt2 folded into the output butterflies of the odd half (tools/fft_ab.sh "0 1" NATAC_FFT_HFOLD)
+#endif
 constexpr int FFT_N = 512;
 constexpr int FFT_LA = 576;   // layout A: p + 8 * (p >> 6)
 constexpr int FFT_LB = 520;   // layout B: (p & 7) * 65 + (p >> 3)
@@ -43,22 +46,37 @@ __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
     // odd outputs: DFT4 of a4, a5 W, a6 W^2, a7 W^3  with W = exp(-+ i pi/4)
     {
         const double c0r = ar[4], c0i = ai[4];
-        double c1r, c1i, c2r, c2i, c3r, c3i;
+        double c2r, c2i;
+        if (!INV) { c2r = ai[6]; c2i = -ar[6]; }                              // -i
+        else      { c2r = -ai[6]; c2i = ar[6]; }                              // +i
+        const double d0r = c0r + c2r, d0i = c0i + c2i, d2r = c0r - c2r, d2i = c0i - c2i;
+#if NATAC_FFT_HFOLD
+        // c1 = h p1, c3 = h p3 with p1 = a5 (1 -+ i), p3 = a7 (-1 -+ i): the factor h = 1/sqrt2 is not applied to p1, p3 but folded
+        // into the four output butterflies as FMAs (out = d +- h (p1 +- p3)): 4 + 4 additions and 8 FMAs instead of 4 + 4 + 8
+        // additions and 4 multiplications
+        double p1r, p1i, p3r, p3i;
+        if (!INV) { p1r = ar[5] + ai[5]; p1i = ai[5] - ar[5]; p3r = ai[7] - ar[7]; p3i = -(ai[7] + ar[7]); }
+        else      { p1r = ar[5] - ai[5]; p1i = ai[5] + ar[5]; p3r = -(ar[7] + ai[7]); p3i = ar[7] - ai[7]; }
+        const double e1r = p1r + p3r, e1i = p1i + p3i;       // d1 / h
+        const double ur = p1r - p3r, ui = p1i - p3i;         // t / h;  d3 = -+ i t
+        re[1] = fma(h, e1r, d0r); im[1] = fma(h, e1i, d0i); re[5] = fma(-h, e1r, d0r); im[5] = fma(-h, e1i, d0i);
+        if (!INV) { re[3] = fma(h, ui, d2r); im[3] = fma(-h, ur, d2i); re[7] = fma(-h, ui, d2r); im[7] = fma(h, ur, d2i); }
+        else      { re[3] = fma(-h, ui, d2r); im[3] = fma(h, ur, d2i); re[7] = fma(h, ui, d2r); im[7] = fma(-h, ur, d2i); }
+#else
+        double c1r, c1i, c3r, c3i;
         if (!INV) {
             c1r = (ar[5] + ai[5]) * h; c1i = (ai[5] - ar[5]) * h;            // (1 - i)/sqrt2
-            c2r = ai[6]; c2i = -ar[6];                                        // -i
             c3r = (ai[7] - ar[7]) * h; c3i = -(ai[7] + ar[7]) * h;           // (-1 - i)/sqrt2
         } else {
             c1r = (ar[5] - ai[5]) * h; c1i = (ai[5] + ar[5]) * h;            // (1 + i)/sqrt2
-            c2r = -ai[6]; c2i = ar[6];                                        // +i
             c3r = -(ar[7] + ai[7]) * h; c3i = (ar[7] - ai[7]) * h;           // (-1 + i)/sqrt2
         }
-        const double d0r = c0r + c2r, d0i = c0i + c2i, d2r = c0r - c2r, d2i = c0i - c2i;
         const double d1r = c1r + c3r, d1i = c1i + c3i;
         const double tr = c1r - c3r, ti = c1i - c3i;
         const double d3r = INV ? -ti : ti, d3i = INV ? tr : -tr;
         re[1] = d0r + d1r; im[1] = d0i + d1i; re[5] = d0r - d1r; im[5] = d0i - d1i;
         re[3] = d2r + d3r; im[3] = d2i + d3i; re[7] = d2r - d3r; im[7] = d2i - d3i;
+#endif
     }
 }
 
@@ -218,7 +236,7 @@ constexpr double FFT_MAX_RANGE = 3e4;   // real Tn5 PWM log-bias spans <= 8.7 lo
 // one tile of the background through FFTs; `smem` = this wave's LDS (EWP + 2 FFT_LA doubles), `t` = (chunk, x0).
 // TW_LOADED: the caller holds the per-lane twiddles in `tww` (persistent kernel); otherwise they are loaded here, after the
 // conditioning test, exactly where the one-tile-per-workgroup kernel always loaded them.
-template <bool TW_LOADED>
+template <bool TW_LOADED, bool SYNC = false>
 __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, const VMatDev &vm, const double *__restrict__ tw,
                                             const double *__restrict__ ktab, const double *__restrict__ nuc_cov,
                                             const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
@@ -325,6 +343,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
             const double sa = vm.srow[2 * pair], sb = vm.srow[2 * pair + 1];
             const double *k = ktab + (size_t)pair * 2 * FFT_N;
             double kr[8], ki[8], re[8], im[8];
+            if (SYNC) __builtin_amdgcn_s_barrier();      // the waves of a workgroup walk the row pairs in step: one L2 fetch of a pair's spectrum per CU
 #pragma unroll
             for (int m = 0; m < 8; ++m) { kr[m] = k[m * 64 + lane]; ki[m] = k[FFT_N + m * 64 + lane]; }
             __builtin_amdgcn_sched_barrier(0);
@@ -467,6 +486,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned ti = blockIdx.x;
     FftTwiddles tww;
     bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x);
+}
+
+// experiment (tools/test_fft_bg.hip): NW waves per workgroup, one tile each, optionally stepping through the row pairs together
+template <int NW, bool SYNC>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) natac_background_fft_wg(
+    ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm, const double *__restrict__ tw, const double *__restrict__ ktab,
+    const double *__restrict__ nuc_cov, const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
+    double *__restrict__ bnum, double *__restrict__ bcov, unsigned n_tiles, int wave_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned ti = blockIdx.x * NW + wave;
+    if (ti >= n_tiles) return;
+    FftTwiddles tww;
+    bg_fft_tile<false, SYNC>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem + (size_t)wave * wave_doubles, tww, lane);
 }
 
 }  // namespace natac

@@ -79,9 +79,14 @@ class TrackStore(object):
         except Exception:       # noqa: BLE001
             pass
 
+    def set_budget(self, max_bytes=-1, min_free_bytes=-1):
+        """HBM budget (natac_store_set_budget): the store stays below max_bytes and leaves min_free_bytes of the device to the
+        pipeline's batches (defaults: no cap / a quarter of the device); the first refusal closes the store"""
+        L.check(self._lib.natac_store_set_budget(self._h, int(max_bytes), int(min_free_bytes)))
+
     def adopt(self, batch, tracks, write_zero=True, keep_runs_before_nan=False):
         """copy `tracks` of `batch` into the store; returns the segment id, or None when a value cannot be rounded exactly on the
-        device (nothing is kept then)"""
+        device or the store's HBM budget declines the segment (nothing is kept then; the caller reads the files)"""
         t = np.ascontiguousarray(tracks, dtype=np.int32)
         seg, hard = C.c_int64(-1), C.c_int32(0)
         try:
@@ -102,7 +107,9 @@ class TrackStore(object):
     def info(self):
         n, by = C.c_int64(0), C.c_int64(0)
         L.check(self._lib.natac_store_info(self._h, C.byref(n), C.byref(by)))
-        return dict(segments=n.value, bytes=by.value)
+        d = C.c_int64(0)
+        L.check(self._lib.natac_store_declined(self._h, C.byref(d)))
+        return dict(segments=n.value, bytes=by.value, declined=d.value)
 
 
 class Context(object):

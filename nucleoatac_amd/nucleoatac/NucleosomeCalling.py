@@ -146,7 +146,10 @@ def read_regions_of(path, chunks, value_col=4):
 def read_occ_tracks_many(occ_track, chunks):
     """read_occ_tracks for a list of chunks: per chunk [occ, lower, upper].  A missing / damaged track file or index RAISES, as
     NucChunk.getOcc does in the reference (NucleosomeCalling.py:284-293: Track.read_track outside any try -- the run aborts);
-    only the per-position lookup of Nucleosome.getOcc (:128-135) turns a failure into NaN, and that stays with the callers."""
+    only the per-position lookup of Nucleosome.getOcc (:128-135) turns a failure into NaN, and that stays with the callers.
+    Deviation, on purpose: the drivers call this for chunks WITH calls only (`batch_calls_start`), the reference reads the track of every
+    chunk -- so the three files and their indexes are checked once up front here, for any chunk list, and a damaged member under a
+    chunk without calls goes unnoticed (its values are never used)."""
     from .. import occstore
     res = occstore.lookup(occ_track)
     if res is not None and chunks:          # written by this process: the values are still in HBM, as the files show them

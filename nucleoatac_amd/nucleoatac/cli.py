@@ -181,8 +181,8 @@ def run_chain(args, on_step=None):
 
 
 def _init_distributed():
-    """under torchrun (WORLD_SIZE > 1) the chunk list is sharded over the ranks; torch.distributed (RCCL = backend "nccl",
-    or NATAC_DIST_BACKEND=gloo) only carries the barrier and the gather of small per-chunk results"""
+    """under torchrun (WORLD_SIZE > 1) the chunk list is sharded over the ranks; torch.distributed (gloo by default;
+    NATAC_DIST_BACKEND=nccl adds a probed RCCL group) only carries the barrier and the gather of small per-chunk results"""
     from ..shard import ensure_distributed
     return ensure_distributed()[0]
 

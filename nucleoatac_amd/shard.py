@@ -169,8 +169,8 @@ def shared_fragment_store(bam):
     streaming / device decoder) and publishes the per-chromosome arrays as .npy files in a private (0700, mkdtemp) directory of
     that host's shared memory (/dev/shm); the other ranks of the host map them read-only instead of decoding the whole file
     again (global pre-steps once, before sharding).  A publisher that fails tells everybody -- every
-    rank raises instead of waiting for metadata that never comes -- and a rank that cannot map the files decodes the BAM
-    itself.  One rank: plain FragmentStore.open."""
+    rank raises instead of waiting for metadata that never comes --, a rank that cannot map the files decodes the BAM itself,
+    and a rank that fails at that too tells everybody before anyone waits for it.  One rank: plain FragmentStore.open."""
     from .pyatac.fragments import FragmentStore
     rank, world, local = env_rank_world()
     if world <= 1 or isinstance(bam, FragmentStore):
@@ -206,16 +206,28 @@ def shared_fragment_store(bam):
         failed = [n for n in notes if n is not None and n[1] == "failed"]
         if failed:
             raise RuntimeError("reading %s failed on host %s (%s)" % (bam, failed[0][0], failed[0][2]))
+        map_err = None
         if rank != publisher:
             _, _, pdir, refs, lens = next(n for n in notes if n is not None and n[0] == host)
             try:
-                st = FragmentStore(refs, lens, {c: np.load(os.path.join(pdir, "%d.pos.npy" % i), mmap_mode="r") for i, c in enumerate(refs)},
-                                   {c: np.load(os.path.join(pdir, "%d.tlen.npy" % i), mmap_mode="r") for i, c in enumerate(refs)},
-                                   trusted=True)
-                FragmentStore.register(bam, st)
-            except (OSError, ValueError):                                   # not visible from here after all: decode it ourselves
-                st = FragmentStore.open(bam)
-        dist.barrier()                   # every rank has mapped the files: the publisher unlinks them (the mappings stay valid)
+                try:
+                    st = FragmentStore(refs, lens, {c: np.load(os.path.join(pdir, "%d.pos.npy" % i), mmap_mode="r") for i, c in enumerate(refs)},
+                                       {c: np.load(os.path.join(pdir, "%d.tlen.npy" % i), mmap_mode="r") for i, c in enumerate(refs)},
+                                       trusted=True)
+                    FragmentStore.register(bam, st)
+                except (OSError, ValueError):                               # not visible from here after all: decode it ourselves
+                    st = FragmentStore.open(bam)
+            except BaseException as e:      # noqa: BLE001 -- announced below: no rank may be left waiting in a barrier for this one
+                map_err = e
+        # every rank has mapped the files (or says that it could not): the publisher unlinks them (the mappings stay valid).  The
+        # gather is the barrier; a rank that failed here raises its own error and every other rank raises with it.
+        oks = [None] * world
+        dist.all_gather_object(oks, None if map_err is None else "%s: %s" % (type(map_err).__name__, str(map_err)[:300]))
+        if map_err is not None:
+            raise map_err
+        bad = [(r, o) for r, o in enumerate(oks) if o is not None]
+        if bad:
+            raise RuntimeError("rank %d could not get the fragments of %s (%s)" % (bad[0][0], bam, bad[0][1]))
     finally:
         if rank == publisher and d is not None:
             shutil.rmtree(d, ignore_errors=True)

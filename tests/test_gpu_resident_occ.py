@@ -125,3 +125,40 @@ def test_run_with_resident_tracks_is_byte_identical_to_the_file_path(tmp_path, m
         b = gzip.open(outs[False][0] + "." + suffix, "rb").read()
         assert a == b, suffix
         assert len(a) > 0 or suffix == "nfrpos.bed.gz"
+
+
+def test_store_budget_declines_and_the_run_finishes_through_the_files(tmp_path, monkeypatch):
+    """the store must never be what fills HBM.  A segment beyond the byte budget, or one that would leave the device less than
+    min_free, is declined (None, counted, the store closes itself); `nucleoatac run` with a store that keeps nothing finishes through the
+    files, byte-identical to the resident run."""
+    from nucleoatac_amd import occstore
+    from nucleoatac_amd.device import TrackStore
+    from nucleoatac_amd.nucleoatac.cli import main
+    pk = make_synthetic_chunks(20, 1500, 300, seed=4)
+    tracks = (L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER)
+    with _ctx() as ctx:
+        b = ctx.upload(pk)
+        b.run_occ()
+        store = TrackStore()
+        need = 3 * 8 * pk.total_bp
+        store.set_budget(max_bytes=2 * need - 1)
+        assert store.adopt(b, tracks) == 0 and store.info() == dict(segments=1, bytes=need, declined=0)
+        assert store.adopt(b, tracks) is None and store.info()["declined"] == 1        # the second one would pass the cap
+        store.set_budget(max_bytes=-1)                                                  # an explicit budget re-opens the store
+        assert store.adopt(b, tracks) == 1
+        store.set_budget(min_free_bytes=1 << 50)                                        # more headroom than any device has
+        assert store.adopt(b, tracks) is None and store.adopt(b, tracks) is None and store.info()["declined"] == 3
+        assert store.info()["segments"] == 2 and len(store.read(ctx, [1], [3], [4], 1)) == 4
+        store.close()
+        b.free()
+    bed = os.path.join(GOLDEN, "ref_example.bed")
+    bam, fa = synth_saccer3(str(tmp_path), read_bed3(bed), seed=3)
+    outs = {}
+    for mode in ("resident", "declined"):
+        if mode == "declined":
+            monkeypatch.setenv("NATAC_STORE_MAX_BYTES", "1000")
+        out = str(tmp_path / mode)
+        main(["run", "--bed", bed, "--bam", bam, "--fasta", fa, "--out", out, "--cores", "4"])
+        outs[mode] = out
+    for suffix in ("occ.bedgraph.gz", "nucpos.bed.gz", "nucmap_combined.bed.gz", "nfrpos.bed.gz", "nucleoatac_signal.smooth.bedgraph.gz"):
+        assert gzip.open(outs["resident"] + "." + suffix, "rb").read() == gzip.open(outs["declined"] + "." + suffix, "rb").read(), suffix

@@ -137,6 +137,19 @@ def _control_plane_worker(rank, world, port, q, bam_ok, bam_bad):
     except Exception as e:      # noqa: BLE001
         failed = "%s: %s" % (type(e).__name__, e)
     t_fail = time.time() - t0
+    # a NON-publisher that can neither map nor decode: every rank raises together (nobody waits in a barrier for it)
+    from nucleoatac_amd.pyatac.fragments import FragmentStore
+    if rank == 1:
+        def broken(*a, **k):
+            raise RuntimeError("mapping broke on this rank")
+        FragmentStore.register = staticmethod(broken)
+    t0 = time.time()
+    try:
+        shard.shared_fragment_store(bam_ok + ".copy.npz")
+        failed2 = None
+    except Exception as e:      # noqa: BLE001
+        failed2 = "%s: %s" % (type(e).__name__, e)
+    failed = (failed, failed2, time.time() - t0)
     left = [f for f in os.listdir("/dev/shm") if f.startswith("natac_frags_")] if os.path.isdir("/dev/shm") else []
     shard.barrier()
     q.put((rank, created, backend, t_init, reads, mapped, failed, t_fail, left))
@@ -154,6 +167,7 @@ def test_control_plane_without_gpus_and_fragments_published_per_node(tmp_path):
     tl = {c: rng.integers(30, 400, len(p)) for c, p in pos.items()}
     bam_ok = str(tmp_path / "reads.bam.npz")
     FragmentStore(["chrA", "chrB"], [100000, 50000], pos, tl).save_npz(bam_ok)
+    FragmentStore(["chrA", "chrB"], [100000, 50000], pos, tl).save_npz(bam_ok + ".copy.npz")
     bam_bad = str(tmp_path / "missing.bam.npz")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -171,5 +185,6 @@ def test_control_plane_without_gpus_and_fragments_published_per_node(tmp_path):
         assert mapped == (rank == 1)                     # rank 0 published, rank 1 mapped the shared arrays
         for c in ref.references:
             assert np.array_equal(reads[c][0], ref.pos[c]) and np.array_equal(reads[c][1], ref.tlen[c])
-        assert failed is not None and t_fail < 60, (failed, t_fail)
+        assert failed[0] is not None and t_fail < 60, (failed, t_fail)
+        assert failed[1] is not None and "mapping broke" in failed[1] and failed[2] < 60, failed      # on BOTH ranks, at once
         assert not left

@@ -9,27 +9,46 @@ using namespace natac;
 static double *g_x1 = nullptr, *g_x2 = nullptr;   // the kernels' bnum / bcov outputs
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
+template <int NW, bool SYNC>
+static void launch_wg(int nt, size_t lds, const ChunkTable &ct, int2 *d_t, const VMatDev &v, const double *d_tw, const double *d_k, double *d_a,
+                      double *d_b, double *d_o1, double *d_o2) {
+    auto kp = natac_background_fft_wg<NW, SYNC>;
+    CK(hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NW * lds)));
+    hipLaunchKernelGGL(kp, dim3((nt + NW - 1) / NW), dim3(64 * NW), NW * lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt,
+                       (int)(lds / 8));
+}
+
+// variant: 0 = the product kernel (one wave per workgroup); NW * 10 + SYNC = natac_background_fft_wg<NW, SYNC>
 float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const double *d_tw, const double *d_k, double *d_a, double *d_b,
-              double *d_o1, double *d_o2, int reps) {
+              double *d_o1, double *d_o2, int reps, int variant = 0) {
     const int TV = FFT_N - v.W + 1;
     std::vector<int2> tiles;
     for (int i = 0; i < nc; ++i) for (int x = 0; x < L; x += TV) tiles.push_back(make_int2(i, x));
     int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2)));
     CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
     const int EW = FFT_N + 249, EWP = (EW + 1) & ~1;
-    const size_t lds = (size_t)(EWP + 2 * FFT_LA) * 8; const int FW = 1;
+    const size_t lds = (size_t)(EWP + 2 * FFT_LA) * 8;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     const int nt = (int)tiles.size();
     for (int it = 0; it < reps + 1; ++it) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2);
+        switch (variant) {
+            case 20: launch_wg<2, false>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
+            case 21: launch_wg<2, true>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
+            case 40: launch_wg<4, false>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
+            case 41: launch_wg<4, true>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
+            case 80: launch_wg<8, false>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
+            case 81: launch_wg<8, true>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
+            default:
+                hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt);
+        }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (it > 0 && ms < best) best = ms;
     }
     CK(hipGetLastError());
-    printf("FFT FW=%d tiles=%zu lds=%zu  %.3f ms  %.1f Mbp/s\n", FW, tiles.size(), lds, best, (double)nc * L / best / 1e3);
+    printf("FFT variant=%d tiles=%zu lds=%zu  %.3f ms  %.1f Mbp/s\n", variant, tiles.size(), lds, best, (double)nc * L / best / 1e3);
     CK(hipFree(d_t));
     return best;
 }
@@ -74,7 +93,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(natac_fft_template, dim3(npair), dim3(64), 0, 0, d_vm, d_srow, R, W, d_tw, d_k);
     CK(hipDeviceSynchronize());
     // direct kernel (G=17)
-    {
+    if (!(argc > 4)) {
         constexpr int G = 17; const int TW = 64 * G;
         std::vector<int2> tiles;
         for (int i = 0; i < nc; ++i) for (int x = 0; x < L; x += TW) tiles.push_back(make_int2(i, x));
@@ -94,7 +113,8 @@ int main(int argc, char **argv) {
         CK(hipGetLastError());
         printf("direct G=17  %.3f ms  %.1f Mbp/s\n", best, (double)nc * L / best / 1e3);
     }
-    run_fft(ct, v, nc, L, d_tw, d_k, d_a, d_b, d_o1, d_o2, 2);
+    const int variant = argc > 3 ? atoi(argv[3]) : 0;
+    run_fft(ct, v, nc, L, d_tw, d_k, d_a, d_b, d_o1, d_o2, 2, variant);
     {
         std::vector<double> x(nbp), y(nbp);
         CK(hipMemcpy(x.data(), d_p1, nbp * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), d_o1, nbp * 8, hipMemcpyDeviceToHost));
