@@ -155,7 +155,9 @@ int natac_run_candidates_cov(natac_batch *b, int64_t n_cand, const int32_t *cand
  * (nucleoatac/NucleosomeCalling.py:297-301, pyatac/utils.py:56-102), followed by LR / variance / z for every candidate.
  * jitter[n_jitter] is the reference's tie-break stream np.random.RandomState(25).uniform(0, 1e-12, n) generated by the
  * host (n_jitter >= longest chunk).  *n_cand receives the number of candidates (chunk order, ascending position);
- * fetch them with natac_download_peaks.  Chunks longer than 2048*(order+1) bases set status bit 1 (list truncated). */
+ * fetch them with natac_download_peaks.  Batches whose longest chunk has at most 16,384 bases: a
+ * chunk with more than 2,048 local maxima sets status bit 1 (list truncated; the drivers redo those chunks with utils.call_peaks on the
+ * host).  Longer chunks (merged windows of tens of kb to Mb) keep their lists in device memory: no limit. */
 int natac_run_peaks(natac_batch *b, double min_signal, int sep, int boundary, int order, const double *jitter,
                     int64_t n_jitter, int64_t *n_cand);
 int natac_download_peaks(natac_batch *b, int64_t n_cand, int32_t *cand_chunk, int32_t *cand_pos, double *lr, double *var,

@@ -60,7 +60,7 @@ struct natac_ctx {
     long long model_gen = 0;         // bumped by natac_set_vmat / natac_set_sizes
     // FFT background path: twiddles (once) and template spectra (per V-plot)
     double *d_fft_tw = nullptr, *d_fft_k = nullptr;
-    bool fft_dirty = true, bg_direct = false;
+    bool fft_dirty = true, bg_direct = false, occ_ordered = true, occ_zero_nfr = false;
     std::vector<double> h_sizes;
     double *d_nucp = nullptr, *d_nfrp = nullptr, *d_alphas = nullptr;
     int occ_upper = 0, n_alpha = 0, step = 0, halfstep = 0, flank = 0;
@@ -119,6 +119,7 @@ struct natac_batch {
     int n_tiles1k = 0;
     bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
+    int *d_order_occ = nullptr;      // natac_tile_heavy: {count, claims, list[HEAVY_CAP], flag bytes[n_tiles_occ]} of the occupancy tiles
     int ranges256_w = -1;
     int ranges_occ_key[3] = {-1, -1, -1};   // (step, halfstep, flank) the occupancy tiles' fragment ranges were formed for
     int n_tiles256 = 0, n_tiles_bg = 0, n_tiles_occ = 0, bgG = 0;   // bgG: lanes' output count of the direct kernel, -1 = FFT tiles
@@ -142,6 +143,8 @@ struct natac_batch {
     double *d_jitter = nullptr, *d_pk_out = nullptr;
     long long *d_cap_off = nullptr, *d_pk_offs = nullptr;
     int *d_slot = nullptr, *d_pk_count = nullptr, *d_pk_chunk = nullptr, *d_pk_pos = nullptr;
+    double *d_pk_big = nullptr;       // natac_peaks_chunk: global (sig, pos, state) lists of chunks with more maxima than fit in LDS
+    long long pk_big_slots = 0;
     long long n_jitter = 0, pk_cap = 0, pk_n = -1, slot_total = 0;
     int pk_order = -1;
     bool pk_has_stats = false;
@@ -557,6 +560,30 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     return NATAC_OK;
 }
 
+// natac_occ_gsum<STEP, REM> + natac_occ_decide<STEP, RN> for the model's step and window remainder
+struct OccFastLaunch { natac_batch *b; const ChunkTable &ct; const OccFastDev &of; size_t lds_gs, lds_od; int rem; bool rn16; };
+template <int STEP, int REM = 0>
+static void occ_gsum_launch(const OccFastLaunch &f) {
+    if constexpr (REM < STEP) {
+        if (f.rem == REM)
+            hipLaunchKernelGGL((natac_occ_gsum<STEP, REM>), dim3(f.b->n_tiles_gs), dim3(256), f.lds_gs, f.b->ctx->stream, f.ct, f.b->d_tiles_gs, f.of,
+                               f.b->d_blk_off, f.b->total_blocks, f.b->d_gsum);
+        else
+            occ_gsum_launch<STEP, REM + 1>(f);
+    }
+}
+template <int STEP>
+static void occ_fast_launch(const OccFastLaunch &f) {
+    natac_batch *b = f.b;
+    occ_gsum_launch<STEP>(f);
+    auto kd = (f.of.flags & 2) ? (f.rn16 ? natac_occ_decide<STEP, 16, true> : natac_occ_decide<STEP, 4, true>)
+                               : (f.rn16 ? natac_occ_decide<STEP, 16, false> : natac_occ_decide<STEP, 4, false>);
+    const bool heavy_first = b->ctx->occ_ordered;
+    hipLaunchKernelGGL(kd, dim3((b->n_tiles_occ + (heavy_first ? HEAVY_CAP : 0) + 3) / 4), dim3(256), f.lds_od, b->ctx->stream, f.ct, b->d_tiles_occ,
+                       b->n_tiles_occ, b->d_ranges_occ, heavy_first ? b->d_order_occ : nullptr, f.of, b->d_blk_off, b->total_blocks, b->d_gsum, b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_defer,
+                       b->d_defer + 1);
+}
+
 extern "C" {
 
 int natac_abi_version(void) { return NATAC_ABI_VERSION; }
@@ -596,6 +623,8 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
         c->bg_direct = e && e[0] == '1';
         e = getenv("NATAC_OCC_GENERAL");   // NATAC_OCC_GENERAL=1: every tile through natac_occ_mle (validation / A-B timing)
         c->occ_force_general = e && e[0] == '1';
+        e = getenv("NATAC_OCC_ORDER");     // NATAC_OCC_ORDER=0: natac_occ_decide visits its tiles in chunk order (A-B timing of the ordering)
+        c->occ_ordered = !(e && e[0] == '0');
     }
     *out = c;
     return NATAC_OK;
@@ -731,32 +760,50 @@ int natac_set_occ_model(natac_ctx *c, const double *nuc_probs, const double *nfr
     }
     c->occ_upper = upper; c->n_alpha = n_alpha; c->cutoff = cutoff; c->step = step;
     c->halfstep = (step - 1) / 2; c->flank = flank;
-    {   // fast path (natac_occ_fast.hpp): 101 increasing alphas in [0, 1], strictly positive finite nfr probabilities, window =
-        // whole number of steps + 1, and a probability range that keeps four likelihood factors inside the fp64 range
+    {   // fast path (natac_occ_fast.hpp): up to 101 increasing alphas in [0, 1], no insert size with probability 0 under both models, an odd
+        // step up to 9 (kernel instantiations; the CLI's --step), a window of at least one step (any --flank: a whole number of
+        // step-blocks + the first (2 flank + 1) % step bases of the next one), and a probability range that keeps four likelihood
+        // factors inside the fp64 range
         dev_free(c->d_occ_q4); dev_free(c->d_occ_rho);
         c->d_occ_q4 = c->d_occ_rho = nullptr;
-        bool ok = n_alpha == OD_NA && step == 5 && (2 * flank) % step == 0 && flank >= step;
+        bool ok = n_alpha <= OD_NA && step <= 9 && 2 * flank + 1 >= step;
         for (int a = 0; ok && a < n_alpha; ++a) ok = alphas[a] >= 0.0 && alphas[a] <= 1.0 && (a == 0 || alphas[a] > alphas[a - 1]);
         double rmin = std::numeric_limits<double>::infinity(), rmax = 0.0, pmin = 1.0;
         bool anynuc = false;
         std::vector<double> rho((size_t)upper, 0.0);
+        bool zero_nfr = false;
         for (int j = 0; ok && j < upper; ++j) {
             const double a = nuc_probs[j], f = nfr_probs[j];
-            ok = f > 0.0 && std::isfinite(f) && a >= 0.0 && std::isfinite(a);
+            ok = f >= 0.0 && std::isfinite(f) && a >= 0.0 && std::isfinite(a) && (f > 0.0 || a > 0.0);   // 0 under both: natac_occ_mle
             if (!ok) break;
+            if (f == 0.0) {       // a fragment of this size can only be nucleosomal: factor alpha (occ_eval, ZF)
+                rho[j] = std::numeric_limits<double>::infinity();
+                zero_nfr = true;
+                anynuc = true;
+                pmin = std::min(pmin, a);
+                continue;
+            }
             rho[j] = a / f;
             ok = std::isfinite(rho[j]);
             if (a > 0.0) { anynuc = true; rmin = std::min(rmin, rho[j]); rmax = std::max(rmax, rho[j]); pmin = std::min(pmin, a); }
             pmin = std::min(pmin, f);
         }
+        if (rmax == 0.0) { rmin = 1.0; rmax = 1.0; }      // every nucleosomal size has nfr_prob 0: no finite ratio to bound
         ok = ok && anynuc && rmax <= rmin * std::ldexp(1.0, 200) && pmin >= std::ldexp(1.0, -200);
+        // a zero probability excludes alpha = 1 (nuc) or alpha = 0 (nfr) for every window (Occupancy.py:112-114); with an alpha strictly
+        // between them the likelihood is positive somewhere, so the all-(-inf) case (the reference raises) cannot reach these kernels
+        if ((zero_nfr || (c->occ_zero_flags & 1)) && n_alpha < 3) ok = false;
+        c->occ_zero_nfr = ok && zero_nfr;
         c->occ_fast_ok = ok;
         // a likelihood factor 1 + alpha (rho kappa - 1) lies in [1 - alpha, 1 + rmax / rmin] with 1 - alpha >= the grid's
         // smallest positive value (or exactly 0 at alpha = 1): 16 of them between two renormalisations stay far inside the
         // fp64 range when rmax / rmin < 2^50 and that smallest step is > 2^-50
         {
             double amin = 1.0;
-            for (int a = 0; ok && a < n_alpha; ++a) if (1 - alphas[a] > 0) amin = std::min(amin, 1 - alphas[a]);
+            for (int a = 0; ok && a < n_alpha; ++a) {
+                if (1 - alphas[a] > 0) amin = std::min(amin, 1 - alphas[a]);
+                if (zero_nfr && alphas[a] > 0) amin = std::min(amin, alphas[a]);       // the factor alpha of a zero-nfr size
+            }
             c->occ_rn16 = ok && rmax <= rmin * std::ldexp(1.0, 50) && amin >= std::ldexp(1.0, -50);
         }
         if (ok) {
@@ -1005,8 +1052,10 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_ebias);
     dev_free(b->d_occ_minkey); dev_free(b->d_occ_nan); dev_free(b->d_tiles_os); dev_free(b->d_tiles1k);
     dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
+    dev_free(b->d_order_occ);
     dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
+    dev_free(b->d_pk_big);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
     dev_free(b->d_bnum); dev_free(b->d_bcov); dev_free(b->d_fmt_out);
     dev_free(b->d_blk_off); dev_free(b->d_gsum); dev_free(b->d_tiles_gs); dev_free(b->d_defer);
@@ -1159,6 +1208,13 @@ static void launch_occ_smooth_generic(natac_batch *b, const ChunkTable &ct, cons
                        b->d_grid[0], b->d_grid[1], b->d_grid[2], dst_occ, dst_lo, dst_hi);
 }
 
+// blocks the STEP bases of a step-block see in natac_occ_smooth_blk: ceil(h / step) to the left + their own + (h + step - 1) / step to
+// the right; for h a multiple of the step that is 2 h / step + 1, launched with the spare (zero-weight) block round 2 measured with
+static int occ_smooth_blocks(int h, int step) {
+    if (h % step == 0) return 2 * (h / step) + 2;
+    return (h + step - 1) / step + (h + step - 1) / step + 1;
+}
+
 // block weights of natac_occ_smooth_blk: wb[bi][j] = sum of the window taps that fall on block bmin + bi for a base at offset j
 // of its block -- the table natac_occ_smooth forms per workgroup, same summation order
 static int ensure_block_weights(natac_ctx *c, int M, double sd, int NB) {
@@ -1167,14 +1223,14 @@ static int ensure_block_weights(natac_ctx *c, int M, double sd, int NB) {
     dev_free(c->d_wb_occ);
     c->d_wb_occ = nullptr;
     const int h = (M - 1) / 2, step = c->step;
-    std::vector<double> w((size_t)M), wb((size_t)step * NB);
+    std::vector<double> w((size_t)M), wb((size_t)step * NB + step);     // + the full denominators wb[NB][j] of the clean sweep
     for (int i = 0; i < M; ++i) {           // as ensure_window
         const double n = (double)i - (M - 1) / 2.0, q = n / sd;
         w[i] = std::exp(-0.5 * (q * q));
     }
     for (int j = 0; j < step; ++j)
         for (int bi = 0; bi < NB; ++bi) {
-            const int bmin = -(h / step);    // h is a multiple of step
+            const int bmin = -((h + step - 1) / step);    // leftmost block any base of a block reaches
             double sacc = 0.0;
             for (int d = 0; d < step; ++d) {
                 const int n = j + h - (bmin + bi) * step - d;
@@ -1182,6 +1238,11 @@ static int ensure_block_weights(natac_ctx *c, int M, double sd, int NB) {
             }
             wb[(size_t)bi * step + j] = sacc;
         }
+    for (int j = 0; j < step; ++j) {        // den[j] of a base with every block present: the kernel's own sequence fma(w, 1, den)
+        double den = 0.0;
+        for (int bi = 0; bi < NB; ++bi) den = std::fma(wb[(size_t)bi * step + j], 1.0, den);
+        wb[(size_t)NB * step + j] = den;
+    }
     int rc = dev_upload(c, &c->d_wb_occ, wb.data(), wb.size());
     if (rc) return rc;
     HIPCHK(sync_all(c));
@@ -1238,10 +1299,12 @@ static int occ_prepare(natac_batch *b) {
             if ((rc = dev_alloc(&b->d_grid[i], (size_t)b->total_grid))) return rc;
         }
         if ((rc = build_tiles(b, OCC_T * OCC_NP, &b->d_tiles_occ, &b->n_tiles_occ, true, c->step, c->halfstep))) return rc;
-        dev_free(b->d_ranges_occ);
-        b->d_ranges_occ = nullptr;
+        dev_free(b->d_ranges_occ); dev_free(b->d_order_occ);
+        b->d_ranges_occ = nullptr; b->d_order_occ = nullptr;
         if ((rc = dev_alloc(&b->d_ranges_occ, (size_t)b->n_tiles_occ))) return rc;
+        if ((rc = dev_alloc(&b->d_order_occ, (size_t)2 + HEAVY_CAP + ((size_t)b->n_tiles_occ + 3) / 4))) return rc;
         b->ranges_occ_key[0] = -1;       // new tile table: ranges not formed yet
+        b->gs_Q = -1;                    // ... and the block tables of natac_occ_gsum follow the grid
         b->grid_step = c->step;
         b->grid_half = c->halfstep;
     }
@@ -1253,7 +1316,7 @@ static int occ_prepare(natac_batch *b) {
     if (!b->d_ebias && b->d_bias && (rc = dev_alloc(&b->d_ebias, (size_t)b->nb))) return rc;
     const bool fast = c->occ_fast_ok && !c->occ_force_general;
     if (fast) {   // per-block sum buffers + tile table of natac_occ_gsum (geometry: step / flank of the model)
-        const int Q = 2 * c->flank / c->step;
+        const int Q = (2 * c->flank + 1) / c->step;      // whole step-blocks of a window; the rest is a prefix of the next block
         if (b->gs_Q != Q) {
             HIPCHK(sync_all(c));
             std::vector<long long> bo((size_t)b->nc + 1);
@@ -1287,16 +1350,16 @@ static int occ_prepare(natac_batch *b) {
             return fail(NATAC_E_ARG, "occupancy window / step too large for the device tile (step=%d flank=%d upper=%d)", c->step, c->flank, U);
         if (fast) {
             const int R = c->occ_nm - 1, Q = b->gs_Q;
-            const size_t lds_gs = ((size_t)((GS_BLOCKS * 5 + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
+            const size_t lds_gs = ((size_t)((GS_BLOCKS * c->step + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
             const int NGP = (64 + Q + 1) & ~1;
             const size_t lds_od = (size_t)4 * ((OD_FM + 4) + 4 * NGP + OD_FM / 2) * sizeof(double);
             if (lds_gs > 64 * 1024 || lds_od > 64 * 1024)
                 return fail(NATAC_E_ARG, "occupancy window too large for the device tile (flank=%d upper=%d)", c->flank, U);
         }
     }
-    const bool blk = (c->step == 5) && (((M - 1) / 2) % c->step == 0);     // natac_occ_smooth_blk<5>
+    const bool blk = c->step <= 9;     // natac_occ_smooth_blk<1, 3, 5, 7, 9> (the step is odd)
     if (blk) {
-        const int h = (M - 1) / 2, NB = 2 * (h / c->step) + 2;
+        const int NB = occ_smooth_blocks((M - 1) / 2, c->step);
         if ((rc = ensure_block_weights(c, M, sd, NB))) return rc;
         if (b->os_width != 256 * c->step) {
             if ((rc = build_tiles(b, 256 * c->step, &b->d_tiles_os, &b->n_tiles_os))) return rc;
@@ -1332,31 +1395,35 @@ static int occ_launch(natac_batch *b) {
             // an index over the (immutable) fragment list, like the 256-base tiles' ranges: formed once per batch and geometry
             hipLaunchKernelGGL(natac_occ_tile_ranges, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream, ct, b->d_tiles_occ,
                                b->n_tiles_occ, c->step, c->halfstep, c->flank, b->d_ranges_occ);
+            // ... and the heavy tiles natac_occ_decide visits first: more than four times the batch's mean fragment count (and > 256)
+            const double span = (double)(OCC_T * OCC_NP - 1) * c->step + 2.0 * c->flank + 1.0;
+            const int thr = (int)std::max(256.0, 4.0 * (double)b->nf * span / (double)std::max<long long>(1, b->total_bp));
+            HIPCHK(hipMemsetAsync(b->d_order_occ, 0, 2 * sizeof(int), c->stream));
+            hipLaunchKernelGGL(natac_tile_heavy, dim3((b->n_tiles_occ + 255) / 256), dim3(256), 0, c->stream, b->d_ranges_occ, b->n_tiles_occ, thr,
+                               b->d_order_occ, b->d_order_occ + 2, (unsigned char *)(b->d_order_occ + 2 + HEAVY_CAP));
             b->ranges_occ_key[0] = c->step; b->ranges_occ_key[1] = c->halfstep; b->ranges_occ_key[2] = c->flank;
         }
         const int *d_list = nullptr, *d_count = nullptr;
         unsigned grid_general = (unsigned)b->n_tiles_occ;
         if (fast) {
             OccFastDev of;
-            of.q4 = c->d_occ_q4; of.rho = c->d_occ_rho; of.alphas = c->d_alphas; of.nm = c->occ_nm; of.upper = U; of.step = c->step;
-            of.halfstep = c->halfstep; of.flank = c->flank; of.Q = b->gs_Q; of.flags = c->occ_zero_flags & 1;
+            of.q4 = c->d_occ_q4; of.rho = c->d_occ_rho; of.alphas = c->d_alphas; of.na = c->n_alpha; of.nm = c->occ_nm; of.upper = U; of.step = c->step;
+            of.halfstep = c->halfstep; of.flank = c->flank; of.Q = b->gs_Q; of.flags = (c->occ_zero_flags & 1) | (c->occ_zero_nfr ? 2 : 0);
             of.ci_factor = om.ci_factor; of.e_lo = std::ldexp(1.0, -190); of.e_hi = std::ldexp(1.0, 190);
             const int R = of.nm - 1;
-            const size_t lds_gs = ((size_t)((GS_BLOCKS * 5 + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
+            const size_t lds_gs = ((size_t)((GS_BLOCKS * c->step + 2 * R + 2 * GS_MG + 1) & ~1) + 16 * 64) * sizeof(double);
             const int NGP = (64 + of.Q + 1) & ~1;
             const size_t lds_od = (size_t)4 * ((OD_FM + 4) + 4 * NGP + OD_FM / 2) * sizeof(double);
             HIPCHK(hipMemsetAsync(b->d_defer, 0, sizeof(int), c->stream));
             if ((rc = run_exp_bias(b, c->stream, true))) return rc;
-            hipLaunchKernelGGL((natac_occ_gsum<5>), dim3(b->n_tiles_gs), dim3(256), lds_gs, c->stream, ct, b->d_tiles_gs, of, b->d_blk_off,
-                               b->total_blocks, b->d_gsum);
-            if (c->occ_rn16)
-                hipLaunchKernelGGL((natac_occ_decide<5, 16>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream, ct,
-                                   b->d_tiles_occ, b->n_tiles_occ, b->d_ranges_occ, of, b->d_blk_off, b->total_blocks, b->d_gsum,
-                                   b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_defer, b->d_defer + 1);
-            else
-                hipLaunchKernelGGL((natac_occ_decide<5, 4>), dim3((b->n_tiles_occ + 3) / 4), dim3(256), lds_od, c->stream, ct,
-                                   b->d_tiles_occ, b->n_tiles_occ, b->d_ranges_occ, of, b->d_blk_off, b->total_blocks, b->d_gsum,
-                                   b->d_grid[0], b->d_grid[1], b->d_grid[2], b->d_defer, b->d_defer + 1);
+            const OccFastLaunch fl{b, ct, of, lds_gs, lds_od, (2 * c->flank + 1) % c->step, c->occ_rn16};
+            switch (c->step) {
+                case 1: occ_fast_launch<1>(fl); break;
+                case 3: occ_fast_launch<3>(fl); break;
+                case 5: occ_fast_launch<5>(fl); break;
+                case 7: occ_fast_launch<7>(fl); break;
+                default: occ_fast_launch<9>(fl); break;
+            }
             d_count = b->d_defer;
             d_list = b->d_defer + 1;
             grid_general = (unsigned)std::min(b->n_tiles_occ, 2048);   // walks the deferred list (normally empty)
@@ -1373,12 +1440,15 @@ static int occ_launch(natac_batch *b) {
     }
     prof_end(c, ev);
     prof_begin(c, NATAC_K_OCC_SMOOTH, ev, c->stream);
-    const bool blk = (c->step == 5) && (((M - 1) / 2) % c->step == 0);     // natac_occ_smooth_blk<5>
+    const bool blk = c->step <= 9;     // natac_occ_smooth_blk<1, 3, 5, 7, 9> (the step is odd)
     if (blk) {
-        const int h = (M - 1) / 2, NB = 2 * (h / c->step) + 2;
+        const int NB = occ_smooth_blocks((M - 1) / 2, c->step);
         HIPCHK(hipMemsetAsync(b->d_occ_minkey, 0xff, (size_t)b->nc * sizeof(unsigned long long), c->stream));
         HIPCHK(hipMemsetAsync(b->d_occ_nan, 0, (size_t)b->nc * sizeof(int), c->stream));
-        hipLaunchKernelGGL((natac_occ_smooth_blk<5>), dim3(b->n_tiles_os), dim3(256), ((size_t)3 * (256 + NB) + 256 * 5) * sizeof(double), c->stream, ct,
+        const size_t lds_os = ((size_t)3 * (256 + NB) + 256 * c->step) * sizeof(double);
+        auto ks = c->step == 1 ? natac_occ_smooth_blk<1> : c->step == 3 ? natac_occ_smooth_blk<3> : c->step == 5 ? natac_occ_smooth_blk<5>
+                : c->step == 7 ? natac_occ_smooth_blk<7> : natac_occ_smooth_blk<9>;
+        hipLaunchKernelGGL(ks, dim3(b->n_tiles_os), dim3(256), lds_os, c->stream, ct,
                            b->d_tiles_os, om, c->d_win_occ, M, c->d_wb_occ, NB, b->d_grid[0], b->d_grid[1], b->d_grid[2],
                            b->d_track[NATAC_T_OCC], b->d_track[NATAC_T_OCC_LOWER], b->d_track[NATAC_T_OCC_UPPER], b->d_occ_minkey,
                            b->d_occ_nan);
@@ -1634,8 +1704,25 @@ static int run_peaks_impl(natac_batch *b, const double *sig_a, const double *sig
         } else {   // longer still: segments of 4,096 bases, signal read per segment
             const int seg = 4096;
             const size_t lds = (size_t)((seg + 2 * order + 1) & ~1) * sizeof(double) + lds_lists;
+            double *big_sig = nullptr;
+            int *big_pos = nullptr;
+            unsigned char *big_state = nullptr;
+            if (maxL / (order + 1) + 2 > pk_cap) {      // some chunk can hold more maxima than the LDS lists: global lists for those
+                if (b->pk_big_slots < b->slot_total) {
+                    dev_free(b->d_pk_big);
+                    b->d_pk_big = nullptr;
+                    b->pk_big_slots = 0;
+                    // per slot: sig (8 bytes) + pos (4) + state (1), laid out as three arrays in one block
+                    if ((rc = dev_alloc(&b->d_pk_big, (size_t)b->slot_total * 2 + 2))) return rc;
+                    b->pk_big_slots = b->slot_total;
+                }
+                big_sig = b->d_pk_big;
+                big_pos = (int *)(b->d_pk_big + b->slot_total);
+                big_state = (unsigned char *)(big_pos + b->slot_total);
+            }
             hipLaunchKernelGGL(natac_peaks_chunk, dim3(b->nc), dim3(256), lds, c->stream, ct, norm, sm, b->d_jitter, min_signal,
-                               boundary, order, sep, seg, pk_cap, b->d_cap_off, b->d_slot, b->d_pk_count, b->d_status);
+                               boundary, order, sep, seg, pk_cap, b->d_cap_off, b->d_slot, b->d_pk_count, b->d_status, big_sig, big_pos,
+                               big_state);
         }
 #undef NATAC_PEAKS_REG
     }

@@ -613,6 +613,25 @@ __global__ void __launch_bounds__(256) natac_occ_tile_ranges(ChunkTable ct, cons
     ranges[i] = make_int2(t0, t1);
 }
 
+// Tiles whose cost follows their fragment count (heavy-tailed peak sets: a few windows hold ten times the reads of the rest): the
+// HEAVY ones -- more fragments than `thr` (the host: a multiple of the batch's mean) -- are listed so that a launch can visit them
+// first; their long waves then run beside the bulk instead of after it.  Everything else keeps the chunk order (neighbouring tiles
+// share cache lines of the fragment list and of the block sums: a full sort by count measured 2 % slower on a uniform batch).
+// head[0] = number of listed tiles (<= HEAVY_CAP; more stay in chunk order), list[], flag[tile] = 1 for the listed ones.
+constexpr int HEAVY_CAP = 65536;
+__global__ void __launch_bounds__(256) natac_tile_heavy(const int2 *__restrict__ ranges, int n, int thr, int *__restrict__ head,
+                                                          int *__restrict__ list, unsigned char *__restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int2 r = ranges[i];
+    unsigned char f = 0;
+    if (r.y - r.x > thr) {
+        const int k = atomicAdd(head + 1, 1);        // head[1]: claims (may pass the cap), head[0] = min(claims, cap) below
+        if (k < HEAVY_CAP) { list[k] = i; f = 1; atomicMax(head, k + 1); }
+    }
+    flag[i] = f;
+}
+
 // ---- phase 2 of natac_occ_mle, row-parallel form: each 16-lane row of a wave owns one grid point (4 per wave, the 16 of
 // a tile in one pass) and each lane 7 of the <= 112 alphas (a = l + 16 t).  The per-grid-point overheads of the
 // wave-per-grid-point form (normaliser reductions, window search, per-fragment probabilities, the argmax / interval
@@ -1177,8 +1196,10 @@ __device__ __forceinline__ double key_double(unsigned long long k) {
     return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
 }
 
-// The same smoothing, one lane per step-block (STEP bases), for windows with h = (M - 1) / 2 a multiple of STEP: the STEP
-// bases of a block see the same 2 h / STEP + 2 blocks, so a lane reads each block's three values once for all of them (16
+// The same smoothing, one lane per step-block (STEP bases): the STEP bases of a block see the same NB blocks -- ceil(h / STEP) to the
+// left of their own, (h + STEP - 1) / STEP to the right (2 h / STEP + 2 with a zero-weight spare for h a multiple of STEP; a block
+// that only some of the bases reach has the weight 0 for the others, which adds +0 like the skipped blocks of natac_occ_smooth)
+// --, so a lane reads each block's three values once for all of them (16
 // LDS reads per base instead of 104) and the block weights wb[bi][j] -- the table natac_occ_smooth builds per workgroup,
 // here precomputed by the host in the same summation order -- are wave-uniform scalar loads.  Term order, NaN skipping and
 // the cut last block are those of natac_occ_smooth: identical bits.  Also leaves, per chunk, the minimum finite smoothed
@@ -1193,7 +1214,7 @@ __global__ void __launch_bounds__(256) natac_occ_smooth_blk(ChunkTable ct, const
                                                               double *__restrict__ s_lo, double *__restrict__ s_hi,
                                                               unsigned long long *__restrict__ cmin_key, int *__restrict__ cnan) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int h = (M - 1) / 2, nbh = h / STEP;
+    const int h = (M - 1) / 2, nbh = (h + STEP - 1) / STEP;      // blocks to the left of a base's own block that its window can reach
     const int NG = 256 + NB;
     double *gv = smem, *gl = gv + NG, *gh = gl + NG;
     const int2 t = tiles[blockIdx.x];
@@ -1215,14 +1236,23 @@ __global__ void __launch_bounds__(256) natac_occ_smooth_blk(ChunkTable ct, const
 #pragma unroll
     for (int j = 0; j < STEP; ++j) { nv[j] = 0.0; nl[j] = 0.0; nh[j] = 0.0; den[j] = 0.0; }
     // only the last block of a chunk can be cut by the chunk end, and only when L is not a whole number of blocks past the
-    // half step: the per-lane test is compiled in for those chunks only (block-uniform)
-    auto sweep = [&](auto may_cut) {
+    // half step: the per-lane test is compiled in for those chunks only (block-uniform).
+    // CLEAN (wave-uniform): no NaN block -- no fragment-free stretch, no chunk border -- and no cut block within reach of any lane of
+    // the wave, the ordinary case: every select falls away and the denominator is the table's own sum wb[NB][j], formed by the host
+    // with the same fma sequence (the same bits as adding the weights up here).
+    auto sweep = [&](auto may_cut, auto clean) {
+        constexpr bool CLEAN = decltype(clean)::value;
         for (int bi = 0; bi < NB; ++bi) {
             const int u = threadIdx.x + bi, kb = kme - nbh + bi;
             const double v = gv[u], lo = gl[u], hi = gh[u];
             double w[STEP];
 #pragma unroll
             for (int j = 0; j < STEP; ++j) w[j] = wb[bi * STEP + j];    // wave-uniform: one group of scalar loads
+            if (CLEAN) {
+#pragma unroll
+                for (int j = 0; j < STEP; ++j) { nv[j] = fma(w[j], v, nv[j]); nl[j] = fma(w[j], lo, nl[j]); nh[j] = fma(w[j], hi, nh[j]); }
+                continue;
+            }
             const bool skip = v != v;                           // NaN block (no inserts) or outside the chunk: adds w * 0 = +0 to
             const double vz = skip ? 0.0 : v, lz = skip ? 0.0 : lo, hz = skip ? 0.0 : hi;   // every sum (the table weights are finite)
             const double okf = skip ? 0.0 : 1.0;                // den + w as fma(w, 1, den): the same bits
@@ -1243,9 +1273,23 @@ __global__ void __launch_bounds__(256) natac_occ_smooth_blk(ChunkTable ct, const
                 den[j] = fma(w[j], okf, den[j]);
             }
         }
+        if (CLEAN) {
+#pragma unroll
+            for (int j = 0; j < STEP; ++j) den[j] = wb[NB * STEP + j];
+        }
     };
+    bool wave_clean;
+    {   // the wave's lanes reach blocks u = w0 .. w0 + 63 + NB - 1 of the staged strip (w0 = first lane's threadIdx)
+        const int w0 = threadIdx.x & ~63, ln = threadIdx.x & 63;
+        bool bad = gv[w0 + ln] != gv[w0 + ln];
+        if (ln < NB) bad = bad || (gv[w0 + 64 + ln] != gv[w0 + 64 + ln]);
+        // ... and the last block any lane reaches lies whole inside the chunk (a cut last block is not NaN, but its weights differ)
+        wave_clean = __ballot(bad) == 0ull && (long long)(kb0 + w0 + 63 + (NB - 1 - nbh) + 1) * STEP <= L;
+    }
     if (base0 < L) {
-        if (nk * STEP > L) sweep(std::true_type{}); else sweep(std::false_type{});
+        if (wave_clean) sweep(std::false_type{}, std::true_type{});      // a cut block's successor is outside the chunk: NaN, never clean
+        else if (nk * STEP > L) sweep(std::true_type{}, std::false_type{});
+        else sweep(std::false_type{}, std::false_type{});
     }
     // results -> the wave's LDS strip (lane-major: [lane][j], conflict-free for odd STEP) -> coalesced stores of 64 STEP bases
     double mn = __builtin_inf();
@@ -1729,7 +1773,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(USEBG 
 //   3. x[g] >= min_signal, boundary <= g < L - boundary;
 //   4. reduce_peaks: visit peaks by decreasing x, keep a peak and drop every peak closer than `sep` (utils.py:56-78).
 // ------------------------------------------------------------------------------------------------
-constexpr int PEAK_MAX = 2048;   // peaks per chunk held in LDS by natac_peaks_chunk (more: status bit 1, host fallback)
+constexpr int PEAK_MAX = 2048;   // local maxima per chunk held in LDS.  natac_peaks_chunk (chunks longer than 16,384 bases) keeps the lists of a
+                                 // chunk with more in global scratch; the register variants set status bit 1 (host fallback)
 
 // steps 4 + output of the peak search for one chunk (see natac_peaks_chunk): n maxima in (pos, sig, state = 0), ascending
 __device__ __forceinline__ void peaks_thin_and_write(int n, int pk_cap, int sep, const double *sig, const int *pos, unsigned char *state,
@@ -1796,7 +1841,9 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk(ChunkTable ct, const do
                                                            const double *__restrict__ smooth, const double *__restrict__ jitter,
                                                            double min_signal, int boundary, int order, int sep, int seg, int pk_cap,
                                                            const long long *__restrict__ cap_off, int *__restrict__ cand_slot,
-                                                           int *__restrict__ count, int *__restrict__ status) {
+                                                           int *__restrict__ count, int *__restrict__ status,
+                                                           double *__restrict__ big_sig, int *__restrict__ big_pos,
+                                                           unsigned char *__restrict__ big_state) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4];
     __shared__ int wave_cnt[16];
@@ -1807,6 +1854,12 @@ __global__ void __launch_bounds__(256) natac_peaks_chunk(ChunkTable ct, const do
     int *pos = (int *)(sig + pk_cap);
     unsigned char *state = (unsigned char *)(pos + pk_cap);   // 0 free, 1 kept, 2 excluded
     const int chunk = blockIdx.x;
+    {   // a chunk that can hold more maxima than the LDS lists (L / (order + 1) + 2 > pk_cap: tens of kb and more, what ChunkList.merge
+        // makes of adjacent windows) keeps its lists in the global scratch, region cap_off[chunk] ...: no overflow, no host fallback
+        const long long c0 = cap_off[chunk];
+        const int cap_c = (int)(cap_off[chunk + 1] - c0);
+        if (big_sig && cap_c > pk_cap) { sig = big_sig + c0; pos = big_pos + c0; state = big_state + c0; pk_cap = cap_c; }
+    }
     const int L = ct.chunk_len[chunk];
     const long long ob = ct.out_off[chunk];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -9,10 +9,10 @@
 // (2) sn is a box sum over the window's bases of  g_n(x) = sum_j nuc_probs[j] B0[j, x],  B0[j, x] = E[x-(j-1)//2] E[x+j//2]
 //     (chunkmat2d.py:140-153; j == 1: E[x]).  With j = 2m, 2m+1:
 //         g(x) = E[x] (p0 E[x+1] + p1) + sum_{m>=1} E[x+m] (p_{2m} E[x-m+1] + p_{2m+1} E[x-m]).
-//     The window of grid point k is Q = 2 flank / step aligned step-blocks plus the first base of block k + Q, so
-//     natac_occ_gsum forms per block the sums of g_n, g_f over its bases (the base loop merged into the m loop:
-//     18 fp64 ops per m and block instead of ~30 per base) and their values at the block's first base, ONCE per block;
-//     natac_occ_decide adds Q + 1 of them per grid point.
+//     The window of grid point k (2 flank + 1 bases, starting on a block border) is Q = (2 flank + 1) / step aligned step-blocks
+//     plus the first REM = (2 flank + 1) % step bases of block k + Q (the defaults: 24 blocks + 1 base), so natac_occ_gsum forms
+//     per block the sums of g_n, g_f over its bases (the base loop merged into the m loop: 18 fp64 ops per m and block instead of
+//     ~30 per base) and over its first REM bases, ONCE per block; natac_occ_decide adds Q + 1 of them per grid point.
 // (3) log L(alpha) is concave in alpha, so the first maximum over the 101-point alpha grid and the two ends of the
 //     likelihood-ratio interval are found by a fixed-schedule multi-section search (31 likelihood evaluations per grid
 //     point in five rounds instead of 101), one LANE per grid point: no cross-lane reductions at all.
@@ -20,8 +20,8 @@
 // replaces); the alpha indices are identical on every golden vector and on 848,000 grid points of the configs[2] batch
 // (tests/test_gpu_properties.py).  Tiles the fast path cannot treat exactly like the reference -- exp(bias) values that
 // are not finite or could make a probability under- / overflow -- are handed to the general kernel natac_occ_mle through a
-// device-side list; models with zero nfr probabilities, other alpha grids than 101 increasing values, or windows that are
-// not a whole number of steps use natac_occ_mle for everything.
+// device-side list; models with an insert size of probability zero under BOTH distributions, alpha grids that are not increasing or
+// longer than 101 values, or steps beyond 9 use natac_occ_mle for everything.  Any odd step up to 9 (the CLI's --step) and any flank (--flank) stay here.
 #pragma once
 #include "natac_kernels.hpp"
 
@@ -30,15 +30,17 @@ namespace natac {
 constexpr int GS_BLOCKS = 64;    // step-blocks per natac_occ_gsum workgroup (one per lane; the 4 waves split the m range)
 constexpr int GS_MG = 8;         // m values per fully unrolled register window
 constexpr int OD_FM = 512;       // valid fragments of a 64-grid-point tile staged in LDS (denser tiles read global memory)
-constexpr int OD_NA = 101;       // alpha grid of the fast path
+constexpr int OD_NA = 101;       // longest alpha grid of the fast path (the schedule's coarse points are 0, 10, ..., 100, clipped)
 
 struct OccFastDev {
     const double *q4;       // [nm][4] = {nuc_probs[2m], nuc_probs[2m+1], nfr_probs[2m], nfr_probs[2m+1]} (0 beyond upper)
     const double *rho;      // [upper] nuc_probs / nfr_probs
-    const double *alphas;   // [101]
+    const double *alphas;   // [na]
+    int na;                 // number of alphas, <= OD_NA
     int nm;                 // (upper + 1) / 2
     int upper, step, halfstep, flank, Q;
-    int flags;              // bit 0: some nuc_prob == 0 (alpha with 1 - alpha == 0 is excluded, Occupancy.py:112-114)
+    int flags;              // bit 0: some nuc_prob == 0 (alpha with 1 - alpha == 0 is excluded, Occupancy.py:112-114);
+                            // bit 1: some nfr_prob == 0 (alpha == 0 is excluded likewise; such a bin has rho = +inf, see occ_eval)
     double ci_factor;       // exp(-cutoff / 2)
     double e_lo, e_hi;      // exp(bias) values outside [e_lo, e_hi] = 2^-+190 (or NaN) send a tile to the general kernel: inside, no
                             // probability nuc_probs[j] b[j] / sn of the reference can under- or overflow (b ratio >= 2^-760 / 121,
@@ -47,8 +49,8 @@ struct OccFastDev {
 
 // ---- per-block sums of g_n, g_f --------------------------------------------------------------------------------
 // tile = (chunk, b0): blocks b0 .. b0 + 63 of the chunk; block b covers bases xs + b step .. + step - 1, xs = halfstep - flank.
-// out[0..3][blk_off[chunk] + b] = {sum g_n, sum g_f, g_n(first base), g_f(first base)}.
-template <int STEP>
+// out[0..3][blk_off[chunk] + b] = {sum g_n, sum g_f, g_n over the first REM bases, g_f over the first REM bases}.
+template <int STEP, int REM>
 __global__ void __launch_bounds__(256) natac_occ_gsum(ChunkTable ct, const int2 *__restrict__ tiles, OccFastDev om,
                                                         const long long *__restrict__ blk_off, long long total_blocks,
                                                         double *__restrict__ out) {
@@ -101,9 +103,9 @@ __global__ void __launch_bounds__(256) natac_occ_gsum(ChunkTable ct, const int2 
         for (int i = 0; i < STEP; ++i) {
             const double ex = e0[i];
             const double pa = ex * e0[i + 1];
-            if (i == 0) { gn0 = fma(p0n, pa, p1n * ex); gf0 = fma(p0f, pa, p1f * ex); }
             sa += pa;
             sb += ex;
+            if (i == REM - 1) { gn0 = fma(p0n, sa, p1n * sb); gf0 = fma(p0f, sa, p1f * sb); }     // the first REM bases
         }
         Gn = fma(p0n, sa, p1n * sb);
         Gf = fma(p0f, sa, p1f * sb);
@@ -122,18 +124,13 @@ __global__ void __launch_bounds__(256) natac_occ_gsum(ChunkTable ct, const int2 
                 const double *q = om.q4 + 4 * (m + d);        // scalar loads: the index is wave-uniform
                 const double pn0 = q[0], pn1 = q[1], pf0 = q[2], pf1 = q[3];
                 // base i: E[x+m'] = ep[d + i];  E[x-m'+1] = em[MG - 1 - d + i + 1];  E[x-m'] = em[MG - 1 - d + i]   (m' = m + d)
-                double sa, sb;
-                {
-                    const double a0 = ep[d] * em[GS_MG - d], c0 = ep[d] * em[GS_MG - 1 - d];
-                    gn0 = fma(pn0, a0, fma(pn1, c0, gn0));
-                    gf0 = fma(pf0, a0, fma(pf1, c0, gf0));
-                    sa = a0;
-                    sb = c0;
-                }
+                double sa = ep[d] * em[GS_MG - d], sb = ep[d] * em[GS_MG - 1 - d];
+                if (REM == 1) { gn0 = fma(pn0, sa, fma(pn1, sb, gn0)); gf0 = fma(pf0, sa, fma(pf1, sb, gf0)); }
 #pragma unroll
                 for (int i = 1; i < STEP; ++i) {
                     sa = fma(ep[d + i], em[GS_MG - d + i], sa);
                     sb = fma(ep[d + i], em[GS_MG - 1 - d + i], sb);
+                    if (i == REM - 1) { gn0 = fma(pn0, sa, fma(pn1, sb, gn0)); gf0 = fma(pf0, sa, fma(pf1, sb, gf0)); }   // prefix of REM bases
                 }
                 Gn = fma(pn0, sa, fma(pn1, sb, Gn));
                 Gf = fma(pf0, sa, fma(pf1, sb, Gf));
@@ -167,7 +164,10 @@ __device__ __forceinline__ bool lik_gt(double m1, int e1, double m2, int e2) {  
 // wave runs `trips` (multiple of 4) iterations, fragments past its own window contribute the factor 1.
 // GLOBAL: the tile's fragments are read from global memory (cen / iln not compacted: invalid sizes give the factor 1).
 // RN: factors between two frexp renormalisations (4 or 16; the host picks 16 when 16 factors cannot leave the fp64 range)
-template <int K, bool GLOBAL, int RN>
+// ZF: the model has insert sizes with nfr_prob == 0 < nuc_prob (rho = +inf).  A fragment of such a size has the probability
+//     alpha pn[n] -- the constant pn[n] drops out of every comparison like the prod pf of the others --, i.e. the factor alpha
+//     instead of 1 + alpha t: factor = u + alpha t with (u, t) = (0, 1).
+template <int K, bool GLOBAL, int RN, bool ZF>
 __device__ __forceinline__ void occ_eval(const double (&al)[K], double kappa, int f0, int cnt, int trips, const double *rho_s,
                                          const int *iln_g, const double *rho_g, int U, int flags, double (&m)[K], int (&e)[K]) {
 #pragma unroll
@@ -176,18 +176,23 @@ __device__ __forceinline__ void occ_eval(const double (&al)[K], double kappa, in
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const bool ok = i + v < cnt;
-            double t = 0.0;
+            double t = 0.0, u = 1.0;
             if (GLOBAL) {
                 if (ok) {
                     const int n = iln_g[f0 + i + v];
-                    if (n >= 0 && n < U) t = fma(rho_g[n], kappa, -1.0);
+                    if (n >= 0 && n < U) {
+                        const double r = rho_g[n];
+                        t = fma(r, kappa, -1.0);
+                        if (ZF && r == __builtin_inf()) { t = 1.0; u = 0.0; }
+                    }
                 }
             } else {
                 const double r = rho_s[ok ? f0 + i + v : 0];
                 t = ok ? fma(r, kappa, -1.0) : 0.0;
+                if (ZF && ok && r == __builtin_inf()) { t = 1.0; u = 0.0; }
             }
 #pragma unroll
-            for (int k = 0; k < K; ++k) m[k] *= fma(al[k], t, 1.0);
+            for (int k = 0; k < K; ++k) m[k] *= ZF ? fma(al[k], t, u) : fma(al[k], t, 1.0);
         }
         if (RN == 4 || ((i >> 2) & (RN / 4 - 1)) == RN / 4 - 1) {      // wave-uniform
 #pragma unroll
@@ -202,17 +207,20 @@ __device__ __forceinline__ void occ_eval(const double (&al)[K], double kappa, in
     for (int k = 0; k < K; ++k) {
         // alpha with 1 - alpha == 0 while some nuc_prob is 0: 0 * log(0) = NaN -> -inf in the reference (Occupancy.py:112-114)
         if ((flags & 1) && (1 - al[k]) == 0.0) m[k] = 0.0;
+        if (ZF && (flags & 2) && al[k] == 0.0) m[k] = 0.0;        // ... and alpha == 0 while some nfr_prob is 0
         if (!(m[k] > 0.0)) { m[k] = 0.0; e[k] = 0; }
     }
 }
 
 // One wave = one tile of 64 consecutive grid points of one chunk (the tile table of natac_occ_mle), one lane per grid
-// point; a workgroup holds 4 independent waves.  sums[0..3] = the natac_occ_gsum arrays.  Tiles that cannot be decided
+// point; a workgroup holds 4 independent waves.  `heavy` (or null; natac_tile_heavy): every lane of a wave runs its tile's longest
+// window, so a dense tile is a long wave -- the launch has HEAVY_CAP leading slots that visit the listed heavy tiles first, the slots
+// behind them visit all tiles in chunk order and skip the listed ones.  sums[0..3] = the natac_occ_gsum arrays.  Tiles that cannot be decided
 // here (non-finite / non-positive normalisers: poisoned blocks) are appended to `defer` for natac_occ_mle.
-template <int STEP, int RN>
+template <int STEP, int RN, bool ZF>
 __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int2 *__restrict__ tiles, int ntiles,
-                                                          const int2 *__restrict__ ranges, OccFastDev om,
-                                                          const long long *__restrict__ blk_off, long long total_blocks,
+                                                          const int2 *__restrict__ ranges, const int *__restrict__ heavy,
+                                                          OccFastDev om, const long long *__restrict__ blk_off, long long total_blocks,
                                                           const double *__restrict__ sums, double *__restrict__ g_occ,
                                                           double *__restrict__ g_lo, double *__restrict__ g_hi,
                                                           int *__restrict__ defer_count, int *__restrict__ defer_list) {
@@ -225,7 +233,17 @@ __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int
     double *rho_s = smem + wave * per_wave;
     double *gs = rho_s + OD_FM + 4;
     int *cen_s = (int *)(gs + 4 * NGP);
-    const int tile = blockIdx.x * 4 + wave;
+    int tile = blockIdx.x * 4 + wave;
+    if (heavy) {        // heavy = {count, claims, list[HEAVY_CAP], flag bytes[ntiles]}
+        const unsigned char *flag = (const unsigned char *)(heavy + 2 + HEAVY_CAP);
+        if (tile < HEAVY_CAP) {
+            if (tile >= heavy[0]) return;
+            tile = heavy[2 + tile];
+        } else {
+            tile -= HEAVY_CAP;
+            if (tile >= ntiles || flag[tile]) return;
+        }
+    }
     if (tile >= ntiles) return;
     const int2 t = tiles[tile];
     const int chunk = t.x, k0 = t.y;
@@ -298,17 +316,18 @@ __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int
                 max(__builtin_amdgcn_readlane(trips, 32), __builtin_amdgcn_readlane(trips, 48)));
     trips = (trips + 3) & ~3;
     const double *al_g = om.alphas;
+    const int NA = om.na;                                      // <= OD_NA; coarse point c is index min(10 c, NA - 1)
     auto eval11 = [&](const double (&al)[11], double (&m)[11], int (&e)[11]) {
-        if (staged) occ_eval<11, false, RN>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
-        else occ_eval<11, true, RN>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
+        if (staged) occ_eval<11, false, RN, ZF>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
+        else occ_eval<11, true, RN, ZF>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
     };
     auto eval8 = [&](const double (&al)[8], double (&m)[8], int (&e)[8]) {
-        if (staged) occ_eval<8, false, RN>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
-        else occ_eval<8, true, RN>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
+        if (staged) occ_eval<8, false, RN, ZF>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
+        else occ_eval<8, true, RN, ZF>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
     };
     auto eval2 = [&](const double (&al)[2], double (&m)[2], int (&e)[2]) {
-        if (staged) occ_eval<2, false, RN>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
-        else occ_eval<2, true, RN>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
+        if (staged) occ_eval<2, false, RN, ZF>(al, kappa, f0, cnt, trips, rho_s, nullptr, nullptr, U, om.flags, m, e);
+        else occ_eval<2, true, RN, ZF>(al, kappa, f0, cnt, trips, nullptr, iln_g, om.rho, U, om.flags, m, e);
     };
     // ---- round A: the coarse grid 0, 10, ..., 100
     double cm[11];
@@ -316,24 +335,24 @@ __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int
     {
         double al[11];
 #pragma unroll
-        for (int c = 0; c < 11; ++c) al[c] = al_g[10 * c];
+        for (int c = 0; c < 11; ++c) al[c] = al_g[min(10 * c, NA - 1)];
         eval11(al, cm, ce);
     }
     int cbest = 0;
     double bm = cm[0];
     int be = ce[0];
 #pragma unroll
-    for (int c = 1; c < 11; ++c)
+    for (int c = 1; c < 11; ++c)                                // a clipped duplicate of the last point is never strictly larger
         if (lik_gt(cm[c], ce[c], bm, be)) { bm = cm[c]; be = ce[c]; cbest = c; }
     // ---- round B: 10 cbest +- 2, 4, 6, 8 (clipped); the maximum over the alpha grid lies within 10 of the coarse one (concavity)
-    int amax = 10 * cbest;
+    int amax = min(10 * cbest, NA - 1);
     {
         double al[8], m[8];
         int e[8], idx[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int off = (j < 4) ? 2 * j - 8 : 2 * j - 6;     // -8 -6 -4 -2 +2 +4 +6 +8
-            idx[j] = min(max(10 * cbest + off, 0), OD_NA - 1);
+            idx[j] = min(max(10 * cbest + off, 0), NA - 1);
             al[j] = al_g[idx[j]];
         }
         eval8(al, m, e);
@@ -349,7 +368,7 @@ __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int
     {
         double al[2], m[2];
         int e[2];
-        const int i0 = max(amax - 1, 0), i1 = min(amax + 1, OD_NA - 1);
+        const int i0 = max(amax - 1, 0), i1 = min(amax + 1, NA - 1);
         al[0] = al_g[i0];
         al[1] = al_g[i1];
         eval2(al, m, e);
@@ -363,16 +382,18 @@ __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int
         return m > 0.0 && d > -1100 && ldexp(m, d) > thr;
     };
     // brackets from the coarse points: lower end in (pl, sl], upper end in [sh, ph)
-    int pl = -1, ph = OD_NA;
+    int pl = -1, ph = NA;
 #pragma unroll
     for (int c = 0; c < 11; ++c) {
         const bool in = inset(cm[c], ce[c]);
-        if (!in && 10 * c < amax) pl = 10 * c;                  // the largest such c (ascending loop)
+        const int ic = min(10 * c, NA - 1);
+        if (!in && ic < amax) pl = ic;                          // the largest such c (ascending loop)
     }
 #pragma unroll
     for (int c = 10; c >= 0; --c) {
         const bool in = inset(cm[c], ce[c]);
-        if (!in && 10 * c > amax) ph = 10 * c;                  // the smallest such c
+        const int ic = min(10 * c, NA - 1);
+        if (!in && ic > amax) ph = ic;                          // the smallest such c
     }
     const int sl = min(pl + 10, amax), sh = max(ph - 10, amax);
     int ilo, ihi;
@@ -382,7 +403,7 @@ __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             idx[j] = max(min(pl + 2 * (j + 1), sl), 0);
-            idx[4 + j] = min(max(ph - 2 * (j + 1), sh), OD_NA - 1);
+            idx[4 + j] = min(max(ph - 2 * (j + 1), sh), NA - 1);
             al[j] = al_g[idx[j]];
             al[4 + j] = al_g[idx[4 + j]];
         }
@@ -398,7 +419,7 @@ __global__ void __launch_bounds__(256) natac_occ_decide(ChunkTable ct, const int
     {   // round E: the one unknown neighbour on each side
         double al[2], m[2];
         int e[2];
-        const int i0 = max(ilo - 1, 0), i1 = min(ihi + 1, OD_NA - 1);
+        const int i0 = max(ilo - 1, 0), i1 = min(ihi + 1, NA - 1);
         al[0] = al_g[i0];
         al[1] = al_g[i1];
         eval2(al, m, e);

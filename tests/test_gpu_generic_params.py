@@ -87,3 +87,63 @@ def test_generic_occupancy_parameters():
         # even step is decremented like the reference (Occupancy.py:190-191)
         c.set_occ_model(nucp, nfrp, alphas=alphas, cutoff=3.84, step=4, flank=flank)
         assert c.occ_step == 3
+
+
+@pytest.mark.parametrize("step,flank,n_alpha,upper,zero", [
+    (3, 60, 101, 251, None), (5, 61, 101, 251, None), (5, 62, 101, 251, None), (7, 62, 101, 251, None), (9, 44, 65, 200, None),
+    (1, 20, 37, 251, None), (5, 60, 95, 251, None), (9, 4, 11, 251, None), (3, 73, 2, 251, None),
+    (5, 60, 101, 251, "nfr"), (3, 61, 51, 251, "nfr"), (5, 60, 101, 251, "nuc"), (7, 33, 101, 251, "both sides")])
+def test_fast_occupancy_path_for_any_odd_step_and_flank(step, flank, n_alpha, upper, zero):
+    """--step 3 or --flank 61 used to drop the whole stage to the sliding-window kernel (5x slower).  The block-sum
+    kernels now take any odd step up to 9, any flank (a window = whole step-blocks + the first (2 flank + 1) % step bases of the next
+    one) and any increasing alpha grid of up to 101 values: alpha indices bit-exact against the oracle's literal log arithmetic and
+    against the general kernel (NATAC_OCC_GENERAL=1); smoothed tracks (natac_occ_smooth_blk<STEP> for any flank) against the oracle and,
+    bit for bit, against the one-base-per-lane smoothing kernel behind OCC_PREFILL"""
+    import os
+    from nucleoatac_amd.device import Context
+    from oracle import natac_oracle as O
+    nucp, nfrp = synth_occ_distributions(251)
+    nucp, nfrp = nucp[:upper].copy(), nfrp[:upper].copy()
+    # exact zeros in the models (Occupancy.py:112-114: 0 * log 0 = NaN -> -inf shuts out alpha = 0 / alpha = 1 for EVERY window; a
+    # fragment whose size has nfr_prob 0 contributes the factor alpha): still the block-sum kernels, no size is 0 under both
+    if zero in ("nfr", "both sides"):
+        nfrp[170:] = 0.0
+    if zero in ("nuc", "both sides"):
+        nucp[:90] = 0.0
+    nucp, nfrp = nucp / nucp.sum(), nfrp / nfrp.sum()
+    alphas = np.linspace(0, 1, n_alpha)
+    Lc = 1203
+    pk = make_synthetic_chunks(24, Lc, 330, seed=step * 100 + flank)
+    out = {}
+    for mode in ("fast", "general"):
+        if mode == "general":
+            os.environ["NATAC_OCC_GENERAL"] = "1"
+        try:
+            with Context(0) as c:
+                c.set_occ_model(nucp, nfrp, alphas=alphas, step=step, flank=flank)
+                b = c.upload(pk)
+                b.run_occ()
+                assert not b.status().any()
+                out[mode] = ([b.grid(g) for g in (L.G_OCC, L.G_LOWER, L.G_UPPER)],
+                             [b.track(t) for t in (L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER, L.T_OCC_COV)], b.track(L.T_OCC_PREFILL))
+                b.free()
+        finally:
+            os.environ.pop("NATAC_OCC_GENERAL", None)
+    for a, g in zip(out["fast"][0] + out["fast"][1], out["general"][0] + out["general"][1]):
+        assert np.array_equal(a, g, equal_nan=True)
+    nk = len(range((step - 1) // 2, Lc, step))
+    pre = out["fast"][2]
+    occ, lo, hi, cov = out["fast"][1]
+    for k in (0, 7, 23):
+        l, n = pk.chunk_frags(k)
+        oc = O.occ_chunk_tracks(l.astype(np.int64), n.astype(np.int64), 0, Lc, pk.chunk_bias(k), -246, nucp, nfrp, upper=upper,
+                                flank=flank, step=step, n_alpha=n_alpha)
+        for gi, key in enumerate(("occ", "occ_lower", "occ_upper")):
+            assert_track(expand_grid(out["fast"][0][gi][k * nk:(k + 1) * nk], Lc, step), oc[key], key, exact=True)
+        sl = slice(k * Lc, (k + 1) * Lc)
+        assert_track(pre[sl], oc["smoothed_vals"], "smoothed")
+        assert_track(lo[sl], oc["smoothed_lower"], "smoothed_lower")
+        assert_track(hi[sl], oc["smoothed_upper"], "smoothed_upper")
+        assert_track(cov[sl], oc["cov"], "cov", exact=True)
+        gap = np.isnan(pre[sl])
+        assert np.array_equal(occ[sl][~gap], pre[sl][~gap])          # block-per-lane smoothing == one-base-per-lane smoothing, bit for bit
