@@ -17,11 +17,6 @@
 
 namespace natac {
 
-#ifndef NATAC_FFT_PRUNE
-#define NATAC_FFT_PRUNE 0      // 1: short last tiles (<= 320 points of 512) skip their zero blocks.  Same bits, 13 % fewer fp64 instructions in
-                               // one tile of six -- and measured SLOWER (8.31 vs 8.25 ms per 20 k chunks, 41.0 vs 40.6 ms in the step: a second
-                               // copy of the pair loop, 256 instead of 243 VGPRs); tools/fft_ab.sh "0 1" NATAC_FFT_PRUNE
-#endif
 #ifndef NATAC_FFT_HFOLD
 #define NATAC_FFT_HFOLD 1      // dft8: 1/sqrt2 folded into the output butterflies of the odd half (tools/fft_ab.sh "0 1" NATAC_FFT_HFOLD)
 #endif
@@ -30,22 +25,14 @@ constexpr int FFT_LA = 576;   // layout A: p + 8 * (p >> 6)
 constexpr int FFT_LB = 520;   // layout B: (p & 7) * 65 + (p >> 3)
 
 // 8-point DFT in registers, natural order in and out.  INV: conjugate twiddles (unnormalised inverse).
-// NZ < 8: inputs NZ .. 7 are known to be +0.0 (the zero padding of a short tile): their additions are left out -- x + 0.0 and
-// x - 0.0 are x for every x but -0.0, and the inputs here are products of exp() values and padding zeros, never -0.0: same bits.
-template <bool INV, int NZ = 8>
+template <bool INV>
 __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
-    static_assert(NZ >= 4 && NZ <= 8, "pruned first stage: inputs 0..3 are always present");
     const double h = 0.70710678118654752440;
     double ar[8], ai[8];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        if (n + 4 < NZ) {
-            ar[n] = re[n] + re[n + 4]; ai[n] = im[n] + im[n + 4];
-            ar[n + 4] = re[n] - re[n + 4]; ai[n + 4] = im[n] - im[n + 4];
-        } else {
-            ar[n] = re[n]; ai[n] = im[n];
-            ar[n + 4] = re[n]; ai[n + 4] = im[n];
-        }
+        ar[n] = re[n] + re[n + 4]; ai[n] = im[n] + im[n + 4];
+        ar[n + 4] = re[n] - re[n + 4]; ai[n + 4] = im[n] - im[n + 4];
     }
     // even outputs: DFT4 of a0..a3
     {
@@ -96,18 +83,16 @@ __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
 // eight doubles base[64 j], j = 0..7, as eight ds_read_b64 (2 LDS cycles each).  Left to the compiler these become four
 // ds_read2st64_b64, which move the same bytes at half the rate (MI355X_MICROARCH.md, LDS table: 8 cycles per 1 KiB against
 // 2 x 2) -- and the FFT kernel is bound by the LDS pipe.  The values are only valid after lds_wait16().
-// NZ < 8 (short tile): only the first NZ of them; the others keep what they hold.
-template <int NZ = 8>
 __device__ __forceinline__ void lds_read8_b64(double (&v)[8], const double *base) {
     const unsigned a = (unsigned)(uintptr_t)base;     // LDS offset = low half of the generic pointer
     asm volatile("ds_read_b64 %0, %1" : "=v"(v[0]) : "v"(a));
     asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(v[1]) : "v"(a));
     asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(v[2]) : "v"(a));
     asm volatile("ds_read_b64 %0, %1 offset:1536" : "=v"(v[3]) : "v"(a));
-    if (NZ > 4) asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(v[4]) : "v"(a));
-    if (NZ > 5) asm volatile("ds_read_b64 %0, %1 offset:2560" : "=v"(v[5]) : "v"(a));
-    if (NZ > 6) asm volatile("ds_read_b64 %0, %1 offset:3072" : "=v"(v[6]) : "v"(a));
-    if (NZ > 7) asm volatile("ds_read_b64 %0, %1 offset:3584" : "=v"(v[7]) : "v"(a));
+    asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(v[4]) : "v"(a));
+    asm volatile("ds_read_b64 %0, %1 offset:2560" : "=v"(v[5]) : "v"(a));
+    asm volatile("ds_read_b64 %0, %1 offset:3072" : "=v"(v[6]) : "v"(a));
+    asm volatile("ds_read_b64 %0, %1 offset:3584" : "=v"(v[7]) : "v"(a));
 }
 // wait for the reads above; the operands tie every later use of the 16 values to this point
 __device__ __forceinline__ void lds_wait16(double (&x)[8], double (&y)[8]) {
@@ -174,9 +159,8 @@ __device__ __forceinline__ void fft512_fwd_rest(double (&re)[8], double (&im)[8]
 // NATAC_FFT_ABL (tools/test_fft_bg.hip only): 1 = no LDS transposes (wrong results; what the round trips cost),
 // 2 = no template-spectrum loads, 3 = no exp(bias) operand reads
 
-template <int NZ = 8>
 __device__ __forceinline__ void fft512_fwd(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sa, double2 *sb, int lane) {
-    dft8<false, NZ>(re, im);
+    dft8<false>(re, im);
     if (NATAC_FFT_ABL == 1) {
 #pragma unroll
         for (int m = 1; m < 8; ++m) { const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])); im[m] = fma(re[m], t.w1i[m], im[m] * t.w1r[m]); re[m] = xr; }
@@ -340,70 +324,63 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         for (int j = 0; j < 8; ++j) carry[j] = c0[lane + 64 * j];
     }
     if (pairs_full && NATAC_FFT_ABL == 0) {
+        // Measured in round 5 and not kept (tools/test_fft_bg.hip on 20 k chunks, 8.25-8.30 ms as it stands): (1) the short last tile of a
+        // chunk (2,120 bases leave 280 points of 512 for the sixth tile) with the zero blocks' operand reads, products, column sums and
+        // first-stage additions left out -- same bits, 13 % fewer fp64 instructions in one tile of six -- 8.31 ms: a second copy of this
+        // loop, 256 VGPRs; (2) two pairs per trip with the carried factor ping-ponging between two buffers instead of the eight
+        // v_mov_b64 per trip below -- 8.86 ms: 256 VGPRs + 28 bytes of scratch; (3) even moving this loop into a generic lambda
+        // cost 0.25 ms of the 41 in the step.  The loop sits at the register limit of two waves per SIMD; leave its shape alone.
         // Software pipeline of a row pair: the template spectrum is requested at the top of the trip (the whole transform covers
         // its L2 round trip; left to the compiler the loads sit right before the last DFT) and the exp(bias) operands of the
         // NEXT pair after the last DFT, so that the accumulation covers their LDS round trip.
-        // NZ: 64-point blocks of the tile's product rows that hold data.  The last tile of a chunk is short -- 2,120 bases leave 160
-        // + 120 = 280 points for the sixth tile --: blocks NZ .. 7 are zero padding, their operand reads, products, column sums and
-        // first-stage additions are left out (same bits, see dft8).
-        // The factor two consecutive pairs share is never copied: two buffers ca_ / cb_ take turns as "carried from the last pair" and
-        // "read for this pair" (two pairs per trip), the factor both rows of a pair share goes through sh.
-        double sh[8], cb_[8];
-        double (&ca_)[8] = carry;
-        auto run_pairs = [&](auto nz_tag) {
-            constexpr int NZ = decltype(nz_tag)::value;
-            // operands of `pair`: sh <- the factor its two rows share, cnw <- the other factor of its second row
-            auto issue = [&](int pair, double (&cnw)[8]) {
-                const int ia = vm.lower + 2 * pair, ib = ia + 1;
-                if (lodd) {       // shared left factor; new: right factor of b
-                    lds_read8_b64<NZ>(sh, Et + (A - floor_half(ia - 1)) + lane);
-                    lds_read8_b64<NZ>(cnw, Et + (A + floor_half(ib)) + lane);
-                } else {          // shared right factor; new: left factor of b
-                    lds_read8_b64<NZ>(sh, Et + (A + floor_half(ia)) + lane);
-                    lds_read8_b64<NZ>(cnw, Et + (A - floor_half(ib - 1)) + lane);
-                }
-            };
-            // one pair: row a = sh * cin (the factor carried over), row b = sh * cnw; cin is free afterwards and takes the next pair's read
-            auto body = [&](int pair, double (&cin)[8], double (&cnw)[8]) {
-                const double sa = vm.srow[2 * pair], sb = vm.srow[2 * pair + 1];
-                const double *k = ktab + (size_t)pair * 2 * FFT_N;
-                double kr[8], ki[8], re[8], im[8];
-                if (SYNC) __builtin_amdgcn_s_barrier();      // the waves of a workgroup walk the row pairs in step: one L2 fetch of a pair's spectrum per CU
+        double x[8], y[8];
+        auto issue_xy = [&](int pair) {
+            const int ia = vm.lower + 2 * pair, ib = ia + 1;
+            if (lodd) {       // shared left factor x; y = right factor of b
+                lds_read8_b64(x, Et + (A - floor_half(ia - 1)) + lane);
+                lds_read8_b64(y, Et + (A + floor_half(ib)) + lane);
+            } else {          // shared right factor y; x = left factor of b
+                lds_read8_b64(x, Et + (A - floor_half(ib - 1)) + lane);
+                lds_read8_b64(y, Et + (A + floor_half(ia)) + lane);
+            }
+        };
+        issue_xy(0);
+        for (int pair = 0; pair < npair; ++pair) {
+            const double sa = vm.srow[2 * pair], sb = vm.srow[2 * pair + 1];
+            const double *k = ktab + (size_t)pair * 2 * FFT_N;
+            double kr[8], ki[8], re[8], im[8];
+            if (SYNC) __builtin_amdgcn_s_barrier();      // the waves of a workgroup walk the row pairs in step: one L2 fetch of a pair's spectrum per CU
 #pragma unroll
-                for (int m = 0; m < 8; ++m) { kr[m] = k[m * 64 + lane]; ki[m] = k[FFT_N + m * 64 + lane]; }
-                __builtin_amdgcn_sched_barrier(0);
-                lds_wait16(sh, cnw);
+            for (int m = 0; m < 8; ++m) { kr[m] = k[m * 64 + lane]; ki[m] = k[FFT_N + m * 64 + lane]; }
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait16(x, y);
+            if (lodd) {       // carry = right factor of a
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    if (j < NZ) {
-                        re[j] = sh[j] * cin[j];
-                        im[j] = sh[j] * cnw[j];
-                        q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
-                    } else { re[j] = 0.0; im[j] = 0.0; }
+                    re[j] = x[j] * carry[j];
+                    im[j] = x[j] * y[j];
+                    carry[j] = y[j];
+                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
                 }
-                fft512_fwd<NZ>(re, im, tww, ca, cb, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                issue(min(pair + 1, npair - 1), cin);
+            } else {          // carry = left factor of a
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
-                    accr[m] = fma(re[m], kr[m], fma(im[m], ki[m], accr[m]));
-                    acci[m] = fma(im[m], kr[m], fma(-re[m], ki[m], acci[m]));
+                for (int j = 0; j < 8; ++j) {
+                    re[j] = carry[j] * y[j];
+                    im[j] = x[j] * y[j];
+                    carry[j] = x[j];
+                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
                 }
-            };
-            issue(0, cb_);
-            for (int pair = 0; pair < npair; pair += 2) {
-                body(pair, ca_, cb_);
-                if (pair + 1 < npair) body(pair + 1, cb_, ca_);        // wave-uniform
             }
-            lds_wait16(sh, ca_);      // the re-read of the last trip (into whichever buffer)
-            lds_wait16(sh, cb_);
-        };
+            fft512_fwd(re, im, tww, ca, cb, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_xy(min(pair + 1, npair - 1));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sh[j] = 0.0; cb_[j] = 0.0; }
-        // points of the tile's product rows that feed bases of this chunk: outputs + W - 1
-        const int npts = min(TV, L - x0) + W - 1;
-        if (NATAC_FFT_PRUNE && npts <= 5 * 64) run_pairs(std::integral_constant<int, 5>{});      // wave-uniform
-        else run_pairs(std::integral_constant<int, 8>{});
+            for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
+                accr[m] = fma(re[m], kr[m], fma(im[m], ki[m], accr[m]));
+                acci[m] = fma(im[m], kr[m], fma(-re[m], ki[m], acci[m]));
+            }
+        }
+        lds_wait16(x, y);     // the re-read of the last trip
     } else   // odd row count (or an ablation build): the plain loop
     for (int pair = 0; pair < npair; ++pair) {
         const int ra = 2 * pair, rb = ra + 1;
