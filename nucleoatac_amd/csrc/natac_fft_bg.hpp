@@ -329,7 +329,9 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         // first-stage additions left out -- same bits, 13 % fewer fp64 instructions in one tile of six -- 8.31 ms: a second copy of this
         // loop, 256 VGPRs; (2) two pairs per trip with the carried factor ping-ponging between two buffers instead of the eight
         // v_mov_b64 per trip below -- 8.86 ms: 256 VGPRs + 28 bytes of scratch; (3) even moving this loop into a generic lambda
-        // cost 0.25 ms of the 41 in the step.  The loop sits at the register limit of two waves per SIMD; leave its shape alone.
+        // cost 0.25 ms of the 41 in the step; (4) the size weights sa / sb requested one trip ahead (their load sits in front of the 16
+        // template loads and the column sums wait for it): 8.21 against 8.15 ms, the other wave of the SIMD already covers that wait.
+        // The loop sits at the register limit of two waves per SIMD; leave its shape alone.
         // Software pipeline of a row pair: the template spectrum is requested at the top of the trip (the whole transform covers
         // its L2 round trip; left to the compiler the loads sit right before the last DFT) and the exp(bias) operands of the
         // NEXT pair after the last DFT, so that the accumulation covers their LDS round trip.

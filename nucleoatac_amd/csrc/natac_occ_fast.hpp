@@ -175,24 +175,26 @@ __device__ __forceinline__ void occ_eval(const double (&al)[K], double kappa, in
     for (int i = 0; i < trips; i += 4) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const bool ok = i + v < cnt;
-            double t = 0.0, u = 1.0;
-            if (GLOBAL) {
-                if (ok) {
+            // lanes past their own window sit this fragment out under the exec mask (their factor is exactly 1): a predicated block
+            // costs one compare, the select form (index, t) cost four VALU instructions per fragment and pass
+            if (i + v < cnt) {
+                double t, u = 1.0;
+                if (GLOBAL) {
                     const int n = iln_g[f0 + i + v];
+                    t = 0.0;
                     if (n >= 0 && n < U) {
                         const double r = rho_g[n];
                         t = fma(r, kappa, -1.0);
                         if (ZF && r == __builtin_inf()) { t = 1.0; u = 0.0; }
                     }
+                } else {
+                    const double r = rho_s[f0 + i + v];
+                    t = fma(r, kappa, -1.0);
+                    if (ZF && r == __builtin_inf()) { t = 1.0; u = 0.0; }
                 }
-            } else {
-                const double r = rho_s[ok ? f0 + i + v : 0];
-                t = ok ? fma(r, kappa, -1.0) : 0.0;
-                if (ZF && ok && r == __builtin_inf()) { t = 1.0; u = 0.0; }
-            }
 #pragma unroll
-            for (int k = 0; k < K; ++k) m[k] *= ZF ? fma(al[k], t, u) : fma(al[k], t, 1.0);
+                for (int k = 0; k < K; ++k) m[k] *= ZF ? fma(al[k], t, u) : fma(al[k], t, 1.0);
+            }
         }
         if (RN == 4 || ((i >> 2) & (RN / 4 - 1)) == RN / 4 - 1) {      // wave-uniform
 #pragma unroll
