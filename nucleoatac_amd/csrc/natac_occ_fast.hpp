@@ -156,6 +156,13 @@ struct OccLik {           // likelihood as mantissa x 2^exponent, m in [0.5, 1) 
     double m;
     int e;
 };
+// m -> mantissa in [0.5, 1), e += exponent.  The two instructions frexp() is made of, without its special cases (a likelihood
+// here is 0 or a finite positive number far inside the fp64 range: v_frexp_mant / v_frexp_exp give (0, 0) for 0 like frexp does):
+// frexp()'s zero / infinity tests were five of the eight instructions of a renormalisation.
+__device__ __forceinline__ void lik_renorm(double &m, int &e) {
+    e += __builtin_amdgcn_frexp_exp(m);
+    m = __builtin_amdgcn_frexp_mant(m);
+}
 __device__ __forceinline__ bool lik_gt(double m1, int e1, double m2, int e2) {   // L1 > L2
     return m1 > 0.0 && (!(m2 > 0.0) || e1 > e2 || (e1 == e2 && m1 > m2));
 }
@@ -198,12 +205,12 @@ __device__ __forceinline__ void occ_eval(const double (&al)[K], double kappa, in
         }
         if (RN == 4 || ((i >> 2) & (RN / 4 - 1)) == RN / 4 - 1) {      // wave-uniform
 #pragma unroll
-            for (int k = 0; k < K; ++k) { int ex; m[k] = frexp(m[k], &ex); e[k] += ex; }
+            for (int k = 0; k < K; ++k) lik_renorm(m[k], e[k]);
         }
     }
     if (RN != 4) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) { int ex; m[k] = frexp(m[k], &ex); e[k] += ex; }
+        for (int k = 0; k < K; ++k) lik_renorm(m[k], e[k]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
