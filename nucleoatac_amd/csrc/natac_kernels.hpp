@@ -1281,8 +1281,8 @@ __global__ void __launch_bounds__(256) natac_occ_smooth_blk(ChunkTable ct, const
     bool wave_clean;
     {   // the wave's lanes reach blocks u = w0 .. w0 + 63 + NB - 1 of the staged strip (w0 = first lane's threadIdx)
         const int w0 = threadIdx.x & ~63, ln = threadIdx.x & 63;
-        bool bad = gv[w0 + ln] != gv[w0 + ln];
-        if (ln < NB) bad = bad || (gv[w0 + 64 + ln] != gv[w0 + 64 + ln]);
+        bool bad = false;
+        for (int u = ln; u < 64 + NB; u += 64) bad = bad || (gv[w0 + u] != gv[w0 + u]);      // NB may exceed 64 (step 1)
         // ... and the last block any lane reaches lies whole inside the chunk (a cut last block is not NaN, but its weights differ)
         wave_clean = __ballot(bad) == 0ull && (long long)(kb0 + w0 + 63 + (NB - 1 - nbh) + 1) * STEP <= L;
     }

@@ -30,9 +30,9 @@ def one_round(rng, par):
     else:
         vm = rng.random((R, 2 * w + 1)) * 0.01 + 1e-4
     occ_up = int(rng.choice([200, 251, min(vup, 256)]))      # the occupancy kernels hold size ranges up to 256
-    flank = int(rng.choice([45, 60, 75]))
-    step = int(rng.choice([3, 5, 7]))
-    n_alpha = int(rng.choice([101, 65]))
+    flank = int(rng.choice([33, 45, 60, 61, 62, 75]))        # round 5: any flank / odd step <= 9 / alpha grid <= 101 stays on the block-sum
+    step = int(rng.choice([1, 3, 5, 7, 9, 11]))              # kernels; 11 is the general kernel
+    n_alpha = int(rng.choice([101, 65, 37, 3]))
     sd = int(rng.choice([7, 10]))
     sizes = synth_size_distribution(max(vup, occ_up, 251))
     nucp, nfrp = synth_occ_distributions(251)

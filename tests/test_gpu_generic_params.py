@@ -91,7 +91,7 @@ def test_generic_occupancy_parameters():
 
 @pytest.mark.parametrize("step,flank,n_alpha,upper,zero", [
     (3, 60, 101, 251, None), (5, 61, 101, 251, None), (5, 62, 101, 251, None), (7, 62, 101, 251, None), (9, 44, 65, 200, None),
-    (1, 20, 37, 251, None), (5, 60, 95, 251, None), (9, 4, 11, 251, None), (3, 73, 2, 251, None),
+    (1, 20, 37, 251, None), (1, 61, 65, 237, None), (3, 120, 101, 251, None), (5, 60, 95, 251, None), (9, 4, 11, 251, None), (3, 73, 2, 251, None),
     (5, 60, 101, 251, "nfr"), (3, 61, 51, 251, "nfr"), (5, 60, 101, 251, "nuc"), (7, 33, 101, 251, "both sides")])
 def test_fast_occupancy_path_for_any_odd_step_and_flank(step, flank, n_alpha, upper, zero):
     """--step 3 or --flank 61 used to drop the whole stage to the sliding-window kernel (5x slower).  The block-sum
@@ -113,7 +113,9 @@ def test_fast_occupancy_path_for_any_odd_step_and_flank(step, flank, n_alpha, up
     nucp, nfrp = nucp / nucp.sum(), nfrp / nfrp.sum()
     alphas = np.linspace(0, 1, n_alpha)
     Lc = 1203
-    pk = make_synthetic_chunks(24, Lc, 330, seed=step * 100 + flank)
+    counts = np.full(24, 330, dtype=np.int64)
+    counts[7::8] = 14                       # sparse chunks: fragment-free stretches -> NaN blocks inside the smoothing windows
+    pk = make_synthetic_chunks(24, Lc, 330, seed=step * 100 + flank, counts=counts)
     out = {}
     for mode in ("fast", "general"):
         if mode == "general":
