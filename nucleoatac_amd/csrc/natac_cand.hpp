@@ -104,11 +104,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     // these loads is as long as the arithmetic of a trip and three waves per SIMD do not hide it
     struct PairT { double va0, va1, vb0, vb1, sa, sb; };
     const double hm = h2 ? 1.0 : 0.0;                          // idle second column: clamped (valid) address, zero template
+    const unsigned o1 = (unsigned)c1 * 8u, o2 = (unsigned)c2 * 8u;      // byte offsets of the lane's two template columns
     auto load_pair = [&](int k) {
         PairT t;
         t.sa = vm.srow[2 * k]; t.sb = vm.srow[2 * k + 1];
-        t.va0 = vmat[2 * k * W + c1]; t.va1 = vmat[2 * k * W + c2];
-        t.vb0 = vmat[(2 * k + 1) * W + c1]; t.vb1 = vmat[(2 * k + 1) * W + c2];
+        // uniform row base + the lane's byte offset (forcing the scalar-base form of the load -- an opaque 32-bit offset next to it --
+        // costs more in moves than the 64-bit address adds it saves: measured 2.25 against 2.19 ms per 20 k chunks)
+        const char *ra = (const char *)(vmat + (size_t)(2 * k) * (size_t)W), *rb = ra + (size_t)W * sizeof(double);
+        t.va0 = *(const double *)(ra + o1); t.va1 = *(const double *)(ra + o2);
+        t.vb0 = *(const double *)(rb + o1); t.vb1 = *(const double *)(rb + o2);
         return t;
     };
     // one pair: row a multiplies the carried factor `cin`, row b the newly read one, which is handed on in `cout`
@@ -136,6 +140,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     double carry2[Q][2];
     int k = 0;
     PairT t0 = load_pair(0), t1 = load_pair(min(1, npair - 1));
+    // four pairs per trip: two sets of template registers take turns and are loaded directly -- with two pairs per trip the prefetched
+    // values were copied into place, 8 v_mov_b64 per trip (9.5 -> 9.0 ms per configs[2] step)
+    for (; k + 4 <= npair; k += 4) {
+        const PairT u0 = load_pair(min(k + 2, npair - 1));
+        pair_step(t0, carry, carry2);
+        const PairT u1 = load_pair(min(k + 3, npair - 1));
+        pair_step(t1, carry2, carry);
+        t0 = load_pair(min(k + 4, npair - 1));
+        pair_step(u0, carry, carry2);
+        t1 = load_pair(min(k + 5, npair - 1));
+        pair_step(u1, carry2, carry);
+    }
     for (; k + 2 <= npair; k += 2) {                          // two pairs per trip: the carried factor ping-pongs, no copies
         const PairT u0 = load_pair(min(k + 2, npair - 1));
         pair_step(t0, carry, carry2);
