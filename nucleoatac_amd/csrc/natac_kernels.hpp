@@ -260,7 +260,10 @@ __global__ void __launch_bounds__(256 / NBL) natac_frag_gather(ChunkTable ct, co
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 d[q] = __builtin_amdgcn_readlane(cc, i + q) + goff;
-                v[q] = *(const GatherCols<NBL> *)(matp + (__builtin_amdgcn_readlane(oo, i + q) + d[q] - (NBL - 1)));
+                // byte offset in 32 bits (the padded template is < 4 GB): the load takes the table's scalar base + this offset, no
+                // sign extension and 64-bit address arithmetic per fragment
+                const unsigned off = (unsigned)(__builtin_amdgcn_readlane(oo, i + q) + d[q] - (NBL - 1)) * (unsigned)sizeof(double);
+                v[q] = *(const GatherCols<NBL> *)((const char *)matp + off);
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
