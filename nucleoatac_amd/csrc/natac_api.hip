@@ -494,7 +494,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     unsigned long long *d_pos = nullptr;
     TRYF(dev_alloc(&d_hist, (size_t)nd::NLL + nd::ND)); tmp.keep(d_hist);
     HIPCHK(hipMemsetAsync(d_hist, 0, (nd::NLL + nd::ND) * sizeof(unsigned int), c->stream));
-    // line segments per member -> offsets of the per-segment records the histogram pass leaves for the emit pass
+    // line segments per member -> offsets of the per-segment records pass A of the emit kernel leaves for its pass B
     unsigned int *d_nseg = nullptr;
     unsigned long long *d_segbase = nullptr;
     LaneRec *d_recs = nullptr;
@@ -504,13 +504,16 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
                        (long long)n_text, nblk, d_nseg);
     TRYF(dev_scan(c, d_nseg, nblk, d_segbase));
     TRYF(dev_alloc(&d_recs, (size_t)nlines + (size_t)nblk + 64)); tmp.keep(d_recs);      // every line once + one more per straddled member border
+    // token histogram of a sample of the members (every member of a small batch): natac_deflate.hpp, sample_stride
+    const int stride = nd::sample_stride(nblk);
+    const long long counted = (nblk + stride - 1) / stride;
     const size_t lds_count = 65536 + (nd::NLL + nd::ND) * sizeof(unsigned int);
-    hipLaunchKernelGGL(tz_count_tokens, dim3((unsigned)nblk), dim3(TZ_THREADS), lds_count, c->stream, d_text, (long long)n_text, d_line_off,
-                       (long long)nlines, d_segbase, d_recs, d_hist);
+    hipLaunchKernelGGL(tz_count_tokens, dim3((unsigned)counted), dim3(TZ_THREADS), lds_count, c->stream, d_text, (long long)n_text, d_line_off,
+                       (long long)nlines, stride, d_hist);
     unsigned int hist[nd::NLL + nd::ND];
     HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    hist[256] += (unsigned int)nblk;                        // one end-of-block per member
+    nd::finish_hist(hist, hist + nd::NLL, counted, stride);      // one end-of-block per counted member; a code for every symbol when sampled
     nd::Codes codes;
     if (!nd::build_codes(hist, hist + nd::NLL, codes)) return fail(NATAC_E_ARG, "format_track: Huffman table description too long");
     TRYF(dev_upload(c, &d_codes, &codes, 1)); tmp.keep(d_codes);

@@ -7,8 +7,8 @@
 //   tz_line_len       emitted? (NaN runs, zero runs, the reference's run-before-NaN rule) + length of the text line
 //   scan x2           line index, byte offset
 //   tz_write_lines    the text, line_off[]
-//   tz_count_tokens   token histogram of all members                      -> host builds ONE Huffman code per track (natac_deflate.hpp)
-//   tz_emit_members   one workgroup per 0xff00-byte member: tokens -> bits, CRC-32, BGZF framing
+//   tz_count_tokens   token histogram of a sample of the members (all of a small batch) -> host builds ONE Huffman code per track (natac_deflate.hpp)
+//   tz_emit_members   one workgroup per 0xff00-byte member: masks, tokens -> bits, CRC-32, BGZF framing
 //   tz_compact        members packed back to back
 #pragma once
 #include "natac_deflate.hpp"
@@ -484,7 +484,8 @@ __device__ __forceinline__ void parse_lane_line(const unsigned char *lds_text, c
     nd::greedy_tokens(me.eq0, me.eq1, me.eq2, me.c, me.seglen, [&](int i) -> unsigned char { return seg[i]; }, sink);
 }
 
-// what tz_count_tokens leaves per line segment for tz_emit_members (40 bytes): the masks phase runs once per track
+// what pass A of tz_emit_members leaves per line segment for its pass B (40 bytes, in device memory: a member has up to 8,161 segments,
+// too many for LDS next to its 64 KB of text): the masks phase runs once per line
 struct LaneRec {
     unsigned long long eq0, eq1, eq2;
     unsigned short d0, d1, d2, q0rel, seglen, pad0, pad1, pad2;
@@ -528,14 +529,14 @@ __device__ __forceinline__ void wave_range(const MemberGeom &g, int wave, long l
     *s1 = *s0 + per < g.nseg ? *s0 + per : g.nseg;
 }
 
+// token histogram of the sampled members: workgroup j takes member j * stride (natac_deflate.hpp: sample_stride)
 __global__ void __launch_bounds__(TZ_THREADS) tz_count_tokens(const unsigned char *__restrict__ text, long long n_text,
-                                                               const long long *__restrict__ line_off, long long nlines,
-                                                               const unsigned long long *__restrict__ seg_base, LaneRec *__restrict__ recs,
+                                                               const long long *__restrict__ line_off, long long nlines, int stride,
                                                                unsigned int *__restrict__ hist /* [NLL + ND] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_text = smem;
     unsigned int *h = (unsigned int *)(smem + 65536);
-    const MemberGeom g = member_geom(line_off, nlines, n_text, blockIdx.x);
+    const MemberGeom g = member_geom(line_off, nlines, n_text, (long long)blockIdx.x * stride);
     for (int i = threadIdx.x; i < nd::NLL + nd::ND; i += TZ_THREADS) h[i] = 0;
     load_member_text(lds_text, text, g);
     __syncthreads();
@@ -546,7 +547,6 @@ __global__ void __launch_bounds__(TZ_THREADS) tz_count_tokens(const unsigned cha
     for (long long base = s0; base < s1; base += 64) {
         const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
         const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
-        if (lane < cnt) recs[seg_base[blockIdx.x] + base + lane] = pack_rec(me);
         parse_lane_line(lds_text, me, sink);
     }
     __syncthreads();
@@ -618,7 +618,7 @@ __device__ __forceinline__ unsigned long long wave_excl_scan(unsigned long long 
 // region (so that the deflate payload, 18 bytes later, starts on a 32-bit word).  sizes[b] = member size in bytes.
 __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
                                                                const long long *__restrict__ line_off, long long nlines,
-                                                               const unsigned long long *__restrict__ seg_base, const LaneRec *__restrict__ recs,
+                                                               const unsigned long long *__restrict__ seg_base, LaneRec *__restrict__ recs,
                                                                const nd::Codes *__restrict__ codes_g, const nd::CrcTables *__restrict__ crc_g,
                                                                unsigned char *__restrict__ out_regions, unsigned int *__restrict__ sizes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -640,9 +640,10 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long s0, s1;
     wave_range(g, wave, &s0, &s1);
-    // pass A: bits of this wave's lines, from the records tz_count_tokens left (a wave holds at most 8 groups of 64 lines: a
-    // member has <= 8,161 segments); the per-lane counts stay in registers for pass B
-    const LaneRec *myrecs = recs + seg_base[blockIdx.x];
+    // pass A: masks + bits of this wave's lines (a wave holds at most 8 groups of 64 lines: a member has <= 8,161 segments); the per-lane
+    // counts stay in registers and the masks go to the member's records for pass B (round 5: the histogram pass only sees a sample of
+    // the members and leaves no records; forming the masks again in pass B instead measured 6.2 against 5.6 ms per 42-Mbp track)
+    LaneRec *myrecs = recs + seg_base[blockIdx.x];
     unsigned int lb[4] = {0, 0, 0, 0};              // eight 16-bit counts (a line is <= 160 characters x 15 bits)
     unsigned long long wave_bits = 0;
 #pragma unroll
@@ -650,10 +651,12 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
         const long long base = s0 + 64 * gi;
         if (base < s1) {
             unsigned int nbits = 0;
-            if (base + lane < s1) {
-                const LaneLine me = unpack_rec(myrecs[base + lane]);
+            {
+                const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
+                const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
+                if (lane < cnt) myrecs[base + lane] = pack_rec(me);
                 nd::BitCountSink bc{codes, 0};
-                parse_lane_line(lds_text, me, bc);
+                parse_lane_line(lds_text, me, bc);         // invalid lanes (past cnt): nothing
                 nbits = (unsigned int)bc.bits;
             }
             lb[gi >> 1] |= nbits << (16 * (gi & 1));
@@ -706,7 +709,7 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
                 unsigned long long tot;
                 const unsigned long long mine = wave_excl_scan((unsigned long long)((lb[gi >> 1] >> (16 * (gi & 1))) & 0xffffu), lane, &tot);
                 if (base + lane < s1) {
-                    const LaneLine me = unpack_rec(myrecs[base + lane]);
+                    const LaneLine me = unpack_rec(myrecs[base + lane]);      // this lane's own record of pass A
                     if (me.valid) {
                         DevBitWriter bw;
                         bw.init(words + 5, (long long)(pos + mine));
