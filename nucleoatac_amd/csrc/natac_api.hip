@@ -54,6 +54,9 @@ struct natac_ctx {
     hipDeviceProp_t prop;
     // constants
     double *d_vmat = nullptr, *d_vmat_pad = nullptr, *d_srow = nullptr, *d_sizes = nullptr;   // d_vmat_pad: VMatDev::matp
+    double *d_lrt = nullptr;         // VMatDev::lrt (natac_lr_table), formed for model generation lrt_gen
+    long long lrt_gen = -1;
+    size_t lrt_cap = 0;
     int vlower = 0, vupper = 0, vw = 0, R = 0, W = 0, sizes_upper = 0;
     bool have_vmat = false, have_sizes = false, srow_dirty = true;
     bool vmat_zero = false, srow_zero = false;
@@ -119,6 +122,7 @@ struct natac_batch {
     int n_tiles1k = 0;
     bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
+    long long *d_tile256_first = nullptr;   // [nc + 1] first 256-base tile of every chunk (the candidates' way into d_ranges256)
     int *d_order_occ = nullptr;      // natac_tile_heavy: {count, claims, list[HEAVY_CAP], flag bytes[n_tiles_occ]} of the occupancy tiles
     int ranges256_w = -1;
     int ranges_occ_key[3] = {-1, -1, -1};   // (step, halfstep, flank) the occupancy tiles' fragment ranges were formed for
@@ -306,7 +310,7 @@ static int choose_bg_G(const natac_batch *b, int W) {
 
 static void launch_candidates(natac_ctx *c, const ChunkTable &ct, const VMatDev &vm, const int *d_cc, const int *d_cp, long long n,
                               const double *nuc_cov, const double *norm, const double *bnum, const double *bcov, double *lr,
-                              double *var, double *z) {
+                              double *var, double *z, const long long *tile_first = nullptr, const int2 *ranges256 = nullptr) {
     const int EW = c->W + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
     const int ZN = (((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1) + 5 + 32) & ~1, ON = (c->W + 1) & ~1;
     const size_t lds4 = ((size_t)4 * CAND_PER_WAVE * ((EW + 1) & ~1) + ZN + ON) * sizeof(double);
@@ -314,16 +318,33 @@ static void launch_candidates(natac_ctx *c, const ChunkTable &ct, const VMatDev 
     // at least 64 columns wide (every lane's first column exists) and
     // a model without exact zeros (those take the per-cell zero test of natac_candidates4).  NATAC_CAND_OLD=1: validation.
     const size_t ldsp = (size_t)4 * CAND_PER_WAVE * CANDP_STRIDE * sizeof(double);
-    if (bnum && bcov && c->vlower >= 2 && (c->R & 1) == 0 && c->W >= 64 && !vm.has_zero && EW <= CANDP_STRIDE && !getenv("NATAC_CAND_FULL") &&
-        !getenv("NATAC_CAND_OLD")) {
+    bool paired = bnum && bcov && c->vlower >= 2 && (c->R & 1) == 0 && c->W >= 64 && !vm.has_zero && EW <= CANDP_STRIDE &&
+                  !getenv("NATAC_CAND_FULL") && !getenv("NATAC_CAND_OLD");
+    if (paired && (c->lrt_gen != c->model_gen || !c->d_lrt)) {      // log(V / s) of the current model, on the launch stream (natac_lr_table)
+        if (!c->d_lrt || c->lrt_cap < (size_t)c->R * c->W) {
+            dev_free(c->d_lrt);
+            c->d_lrt = nullptr;
+            c->lrt_cap = 0;
+            if (dev_alloc(&c->d_lrt, (size_t)c->R * c->W) == NATAC_OK) c->lrt_cap = (size_t)c->R * c->W;
+            else paired = false;                                     // out of memory: the per-cell kernel below needs no table
+        }
+        if (paired) {
+            hipLaunchKernelGGL(natac_lr_table, dim3((unsigned)((c->R * c->W + 255) / 256)), dim3(256), 0, c->stream, c->d_vmat, c->d_srow, c->R, c->W,
+                               c->d_lrt);
+            c->lrt_gen = c->model_gen;
+        }
+    }
+    if (paired) {
+        VMatDev vml = vm;
+        vml.lrt = c->d_lrt;
         const long long per_block = 4 * CAND_PER_WAVE;
         const dim3 grid((unsigned)((n + per_block - 1) / per_block));
         if (c->vlower & 1)
-            hipLaunchKernelGGL((natac_candidates_paired<true>), grid, dim3(256), ldsp, c->stream, ct, vm, d_cc, d_cp, (int)n, nuc_cov, norm,
-                               bnum, bcov, lr, var, z);
+            hipLaunchKernelGGL((natac_candidates_paired<true>), grid, dim3(256), ldsp, c->stream, ct, vml, d_cc, d_cp, (int)n, nuc_cov, norm,
+                               bnum, bcov, tile_first, ranges256, lr, var, z);
         else
-            hipLaunchKernelGGL((natac_candidates_paired<false>), grid, dim3(256), ldsp, c->stream, ct, vm, d_cc, d_cp, (int)n, nuc_cov, norm,
-                               bnum, bcov, lr, var, z);
+            hipLaunchKernelGGL((natac_candidates_paired<false>), grid, dim3(256), ldsp, c->stream, ct, vml, d_cc, d_cp, (int)n, nuc_cov, norm,
+                               bnum, bcov, tile_first, ranges256, lr, var, z);
         return;
     }
     if (lds4 <= 64 * 1024) {
@@ -638,7 +659,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
     prof_collect(c);
-    dev_free(c->d_vmat); dev_free(c->d_vmat_pad); dev_free(c->d_srow); dev_free(c->d_sizes);
+    dev_free(c->d_vmat); dev_free(c->d_vmat_pad); dev_free(c->d_srow); dev_free(c->d_sizes); dev_free(c->d_lrt);
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
     dev_free(c->d_win_nuc); dev_free(c->d_win_occ); dev_free(c->d_wb_occ);
     dev_free(c->d_fft_tw); dev_free(c->d_fft_k);
@@ -922,6 +943,7 @@ static VMatDev make_vmat(natac_ctx *c) {
     VMatDev v;
     v.mat = c->d_vmat; v.matp = c->d_vmat_pad; v.srow = c->d_srow; v.lower = c->vlower; v.upper = c->vupper; v.w = c->vw; v.R = c->R; v.W = c->W;
     v.has_zero = (c->vmat_zero || c->srow_zero) ? 1 : 0;
+    v.lrt = nullptr;
     return v;
 }
 static OccModelDev make_occ(natac_ctx *c) {
@@ -1000,6 +1022,11 @@ int natac_batch_create(natac_ctx *c, int32_t nc, const int32_t *chunk_len, const
         hipLaunchKernelGGL(natac_frag_centres, dim3(blocks), dim3(256), 0, c->stream, b->d_lpos, b->d_ilen, b->d_centre, nf);
     }
     TRY(build_tiles(b, 256, &b->d_tiles256, &b->n_tiles256));
+    {
+        std::vector<long long> first((size_t)nc + 1, 0);
+        for (int i = 0; i < nc; ++i) first[(size_t)i + 1] = first[i] + (chunk_len[i] + 255) / 256;
+        TRY(dev_upload(c, &b->d_tile256_first, first.data(), first.size()));
+    }
     e = hipStreamSynchronize(c->stream);  // host buffers may be released by the caller after return
     if (e != hipSuccess) { natac_batch_free(b); return fail(NATAC_E_HIP, "upload: %s", hipGetErrorString(e)); }
 #undef TRY
@@ -1055,6 +1082,7 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_ebias);
     dev_free(b->d_occ_minkey); dev_free(b->d_occ_nan); dev_free(b->d_tiles_os); dev_free(b->d_tiles1k);
     dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
+    dev_free(b->d_tile256_first);
     dev_free(b->d_order_occ);
     dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
@@ -1548,7 +1576,7 @@ int natac_run_candidates(natac_batch *b, int64_t n_cand, const int32_t *cand_chu
     launch_candidates(c, ct, vm, d_cc, d_cp, n_cand, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM],
                       b->nuc_gen == c->model_gen ? b->d_bnum : nullptr, b->nuc_gen == c->model_gen ? b->d_bcov : nullptr, d_out,
                       d_out + n_cand,
-                      d_out + 2 * n_cand);
+                      d_out + 2 * n_cand, b->ranges256_w == c->vw ? b->d_tile256_first : nullptr, b->ranges256_w == c->vw ? b->d_ranges256 : nullptr);
     prof_end(c, ev);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(lr, d_out, (size_t)n_cand * sizeof(double), hipMemcpyDeviceToHost, c->stream);
@@ -1749,7 +1777,8 @@ static int run_peaks_impl(natac_batch *b, const double *sig_a, const double *sig
             const VMatDev vm = make_vmat(c);
             launch_candidates(c, ct, vm, b->d_pk_chunk, b->d_pk_pos, total, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NORM],
                               b->nuc_gen == c->model_gen ? b->d_bnum : nullptr, b->nuc_gen == c->model_gen ? b->d_bcov : nullptr,
-                              b->d_pk_out, b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap);
+                              b->d_pk_out, b->d_pk_out + b->pk_cap, b->d_pk_out + 2 * b->pk_cap,
+                              b->ranges256_w == c->vw ? b->d_tile256_first : nullptr, b->ranges256_w == c->vw ? b->d_ranges256 : nullptr);
         }
     }
     b->pk_has_stats = with_stats;

@@ -38,6 +38,18 @@ __device__ __forceinline__ int row_lower_bound(const int *__restrict__ a, int lo
     return lo + __popc((unsigned)(__ballot(less) >> sh) & 0xffffu);
 }
 
+// Nucleosome.getLR (NucleosomeCalling.py:110-122) over the fragments f of a candidate's window:
+//     lr = sum_f log(V[r_f,c_f] B0_f / S_B0V) - sum_f log(s_{r_f} B0_f / S_B)  =  sum_f log(V[r_f,c_f] / s_{r_f})  -  n_f log(S_B0V / S_B):
+// the fragment's bias product B0_f is in both terms and drops out, what is left per fragment is a constant of the model.  This table
+// holds it (R x W doubles, formed once per V-plot / size distribution), so a fragment costs one lookup instead of two exp(bias) reads, two
+// divisions and two logarithms.  Models with exact zeros never get here (natac_candidates4 keeps the per-cell form); windows with an
+// exp(bias) of 0 or NaN give NaN as before (the zero-cell test below / S_B0V itself).
+__global__ void __launch_bounds__(256) natac_lr_table(const double *__restrict__ vmat, const double *__restrict__ srow, int R, int W,
+                                                        double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < R * W) out[i] = log(vmat[i] / srow[i / W]);
+}
+
 constexpr int CANDP_STRIDE = 376;   // doubles per candidate window in LDS (compile-time: every LDS address of the sweep is a
                                     // running base register + an immediate); V-plots with W + upper - 2 > 376 use natac_candidates4
 
@@ -47,7 +59,8 @@ template <bool LODD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) natac_candidates_paired(
     ChunkTable ct, VMatDev vm, const int *__restrict__ cand_chunk, const int *__restrict__ cand_pos, int ncand,
     const double *__restrict__ nuc_cov, const double *__restrict__ norm, const double *__restrict__ bnum,
-    const double *__restrict__ bcov, double *__restrict__ out_lr, double *__restrict__ out_var, double *__restrict__ out_z) {
+    const double *__restrict__ bcov, const long long *__restrict__ tile_first, const int2 *__restrict__ ranges256,
+    double *__restrict__ out_lr, double *__restrict__ out_var, double *__restrict__ out_z) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int Q = CAND_PER_WAVE;
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
@@ -201,28 +214,73 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int nfr = (int)(ct.frag_off[mych + 1] - ct.frag_off[mych]);
     const int *cen = ct.centre + ct.frag_off[mych];
     const int *iln = ct.ilen + ct.frag_off[mych];
-    const int f0 = row_lower_bound(cen, 0, nfr, myp - vm.w, l, sh);
-    const int f1 = row_lower_bound(cen, f0, nfr, myp + vm.w + 1, l, sh);
-    const double *e = Ew + row * EWP;
-    double nl = 0.0, ul = 0.0;
+    int f0, f1;
+    if (ranges256) {
+        // the gather's index over the fragment list (natac_tile_ranges256): the fragments whose centres lie within w of the candidate's
+        // 256-base tile.  The row counts the centres below the window's two ends among them -- one round of independent loads; the
+        // 16-ary searches over the whole chunk are three dependent rounds each (and were most of this kernel's tail)
+        const int2 tr = ranges256[tile_first[mych] + (myp >> 8)];
+        const int klo = myp - vm.w, khi = myp + vm.w + 1;
+        int below_lo = 0, below_hi = 0;
+        int span = tr.y - tr.x;                                 // rows iterate together
+        span = max(max(__builtin_amdgcn_readlane(span, 0), __builtin_amdgcn_readlane(span, 16)),
+                   max(__builtin_amdgcn_readlane(span, 32), __builtin_amdgcn_readlane(span, 48)));
+        for (int base = 0; base < span; base += 64) {
+            int cv[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int i = tr.x + base + 16 * it + l;
+                cv[it] = 0x7fffffff;
+                if (i < tr.y) cv[it] = cen[i];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                below_lo += __popc((unsigned)(__ballot(cv[it] < klo) >> sh) & 0xffffu);
+                below_hi += __popc((unsigned)(__ballot(cv[it] < khi) >> sh) & 0xffffu);
+            }
+        }
+        f0 = tr.x + below_lo;
+        f1 = tr.x + below_hi;
+    } else {
+        f0 = row_lower_bound(cen, 0, nfr, myp - vm.w, l, sh);
+        f1 = row_lower_bound(cen, f0, nfr, myp + vm.w + 1, l, sh);
+    }
+    // sum_f log(V / s) over the window's nucleosome-sized fragments (see natac_lr_table) and their number.  The sizes / centres of up to
+    // 64 fragments of the row's window (4 per lane) are requested together, then their table values: two memory round trips for the
+    // whole window instead of two per 16 fragments
+    const double *__restrict__ lrt = vm.lrt;
+    double acc = 0.0, cntf = 0.0;
     int fmax = f1 - f0;                                         // rows iterate together: longest window of the wave
     fmax = max(max(__builtin_amdgcn_readlane(fmax, 0), __builtin_amdgcn_readlane(fmax, 16)),
                max(__builtin_amdgcn_readlane(fmax, 32), __builtin_amdgcn_readlane(fmax, 48)));
-    for (int base = 0; base < fmax; base += 16) {
+    {
+        int nn[4], cc[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int f = f0 + 16 * it + l;
+            nn[it] = -1; cc[it] = 0;
+            if (f < f1) { nn[it] = iln[f]; cc[it] = cen[f]; }
+        }
+        double tv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            tv[it] = 0.0;
+            if (nn[it] >= vm.lower && nn[it] < vm.upper) tv[it] = lrt[(nn[it] - vm.lower) * W + (cc[it] - myp + vm.w)];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            if (nn[it] >= vm.lower && nn[it] < vm.upper) { acc += tv[it]; cntf += 1.0; }
+    }
+    for (int base = 64; base < fmax; base += 16) {             // windows with more than 64 fragments
         const int f = f0 + base + l;
         if (f < f1) {
             const int n = iln[f];
-            if (n >= vm.lower && n < vm.upper) {
-                const int r = n - vm.lower, c = cen[f] - myp + vm.w;
-                const int hl = floor_half(n - 1), hr = floor_half(n);
-                const double b0 = (hl == -hr) ? e[c + A] : e[c + A - hl] * e[c + A + hr];
-                nl += log((vmat[r * W + c] * b0) / myB0V);
-                ul += log((vm.srow[r] * b0) / tB);
-            }
+            if (n >= vm.lower && n < vm.upper) { acc += lrt[(n - vm.lower) * W + (cen[f] - myp + vm.w)]; cntf += 1.0; }
         }
     }
-    nl = row_sum(nl);
-    ul = row_sum(ul);
+    acc = row_sum(acc);
+    cntf = row_sum(cntf);                                       // small integers: exact
+    const double nl = acc, ul = cntf * log(myB0V / tB);
     if (l == 0 && k0 + row < ncand) {
         const double m1 = tBV / tB;
         const int reads = (int)nuc_cov[op];

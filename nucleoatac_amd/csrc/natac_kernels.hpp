@@ -36,6 +36,7 @@ struct VMatDev {
     const double *mat;   // R x W row-major
     const double *matp;  // R x (W + 2 VPAD): the same rows between VPAD zero columns
     const double *srow;  // [R] sizes[lower + r]
+    const double *lrt;   // R x W: log(V[r,c] / sizes[lower + r]) (natac_lr_table; models without exact zeros), or null
     int lower, upper, w, R, W;
     int has_zero;        // the template or srow holds an exact 0 (host-computed)
 };
