@@ -1,6 +1,9 @@
 // natac_api.hip -- C-ABI (include/natac.h) over the kernels in natac_kernels.hpp.
 // Host-side runtime: contexts, batches of packed chunks resident in HBM, tile tables, launches, profiling.
 #include "../../include/natac.h"
+#ifndef NATAC_GNBL
+#define NATAC_GNBL 2
+#endif
 #include "natac_kernels.hpp"
 #include "natac_fft_bg.hpp"
 #include "natac_occ_fast.hpp"
@@ -1179,7 +1182,8 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     // OccChunk.getCov = nuc_cov + nfr_cov when the occupancy model's window / size range are the V-plot's: written here too
     const bool cov_too = c->have_occ && c->flank == c->vw && c->occ_upper == c->vupper;
     if (cov_too && (rc = ensure_track(b, NATAC_T_OCC_COV))) return rc;
-    constexpr int GNBL = 2;      // adjacent bases per lane (4: 4.5 ms against 3.5; 1: 3.8)
+    constexpr int GNBL = NATAC_GNBL;      // adjacent bases per lane: 2.  Round 5, lanes outside a window reading one shared zero line:
+                                          // 0.63 ms per 20 k chunks against 0.79 with 4 and 0.85 with 1 (round 2: 3.5 / 4.5 / 3.8 ms per step)
     hipLaunchKernelGGL((natac_frag_gather<GNBL>), dim3(b->n_tiles256), dim3(256 / GNBL), 0, c->stream, ct, b->d_tiles256, b->d_ranges256, vm,
                        b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_NFR_COV], b->d_track[NATAC_T_RAW],
                        cov_too ? b->d_track[NATAC_T_OCC_COV] : nullptr);

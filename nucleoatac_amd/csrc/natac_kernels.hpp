@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256 / NBL) natac_frag_gather(ChunkTable ct, co
                                                                  double *__restrict__ nuc_cov, double *__restrict__ nfr_cov,
                                                                  double *__restrict__ raw, double *__restrict__ occ_cov) {
     constexpr int WB = 64 * NBL;                               // bases per wave
-    static_assert(WB <= VPAD, "template padding");
+    static_assert(NBL - 1 <= VPAD, "template padding");          // lanes that straddle a window's edge read NBL - 1 padding columns at most
     __shared__ int strip_s[256 / WB][3][64];
     const int2 t = tiles[blockIdx.x];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -263,7 +263,11 @@ __global__ void __launch_bounds__(256 / NBL) natac_frag_gather(ChunkTable ct, co
                 d[q] = __builtin_amdgcn_readlane(cc, i + q) + goff;
                 // byte offset in 32 bits (the padded template is < 4 GB): the load takes the table's scalar base + this offset, no
                 // sign extension and 64-bit address arithmetic per fragment
-                const unsigned off = (unsigned)(__builtin_amdgcn_readlane(oo, i + q) + d[q] - (NBL - 1)) * (unsigned)sizeof(double);
+                unsigned off = (unsigned)(__builtin_amdgcn_readlane(oo, i + q) + d[q] - (NBL - 1)) * (unsigned)sizeof(double);
+                // a lane whose NBL columns all lie outside the fragment's window reads zeros: from ONE place (the table's first bytes
+                // are padding) instead of the row's own padding -- those lanes are half of every visit (121 of ~249 columns matter),
+                // and the rows' paddings are 292 KB of zeros that had to come out of L2 like the values
+                if ((unsigned)d[q] >= (unsigned)(W + NBL - 1)) off = 0u;
                 v[q] = *(const GatherCols<NBL> *)((const char *)matp + off);
             }
 #pragma unroll
