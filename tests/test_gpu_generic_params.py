@@ -149,3 +149,40 @@ def test_fast_occupancy_path_for_any_odd_step_and_flank(step, flank, n_alpha, up
         assert_track(cov[sl], oc["cov"], "cov", exact=True)
         gap = np.isnan(pre[sl])
         assert np.array_equal(occ[sl][~gap], pre[sl][~gap])          # block-per-lane smoothing == one-base-per-lane smoothing, bit for bit
+
+
+def test_heavy_tiles_first_does_not_show_in_any_result():
+    """natac_occ_decide visits the tiles with more than max(256, 4 x mean) fragments first (natac_tile_heavy: a 10x denser chunk is a 10x
+    longer wave).  The order of the launch must not show anywhere: a batch with a few 12x denser chunks, run with the heavy-first slots and
+    with NATAC_OCC_ORDER=0 (chunk order), gives the same grid values, tracks and status words, bit for bit -- and matches the oracle on a
+    dense and an ordinary chunk (the dense tiles' fragments do not fit the LDS strip: global-memory path of the decision kernel)."""
+    import os
+    from nucleoatac_amd.device import Context
+    from oracle import natac_oracle as O
+    nucp, nfrp = synth_occ_distributions(251)
+    counts = np.full(60, 400, dtype=np.int64)
+    counts[[3, 17, 18, 44]] = 5000
+    counts[9] = 0
+    pk = make_synthetic_chunks(60, 2120, 400, seed=77, counts=counts)
+    out = {}
+    for order in ("1", "0"):
+        os.environ["NATAC_OCC_ORDER"] = order
+        try:
+            with Context(0) as c:
+                c.set_occ_model(nucp, nfrp, step=5, flank=60)
+                b = c.upload(pk)
+                b.run_occ()
+                out[order] = [b.grid(g) for g in (L.G_OCC, L.G_LOWER, L.G_UPPER)] + \
+                             [b.track(t) for t in (L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER, L.T_OCC_COV)] + [b.status()]
+                b.free()
+        finally:
+            os.environ.pop("NATAC_OCC_ORDER", None)
+    for a, g in zip(out["1"], out["0"]):
+        assert np.array_equal(a, g, equal_nan=a.dtype.kind == "f")
+    assert not out["1"][-1].any()
+    nk = len(range(2, 2120, 5))
+    for k in (3, 4, 9):
+        l, n = pk.chunk_frags(k)
+        oc = O.occ_chunk_tracks(l.astype(np.int64), n.astype(np.int64), 0, 2120, pk.chunk_bias(k), -246, nucp, nfrp)
+        for gi, key in enumerate(("occ", "occ_lower", "occ_upper")):
+            assert_track(expand_grid(out["1"][gi][k * nk:(k + 1) * nk], 2120, 5), oc[key], key, exact=True)
