@@ -150,6 +150,7 @@ def _control_plane_worker(rank, world, port, q, bam_ok, bam_bad):
     except Exception as e:      # noqa: BLE001
         failed2 = "%s: %s" % (type(e).__name__, e)
     failed = (failed, failed2, time.time() - t0)
+    shard.barrier()                 # the publisher removes its directory right after the gather: look only once every rank is past it
     left = [f for f in os.listdir("/dev/shm") if f.startswith("natac_frags_")] if os.path.isdir("/dev/shm") else []
     shard.barrier()
     q.put((rank, created, backend, t_init, reads, mapped, failed, t_fail, left))
