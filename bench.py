@@ -43,7 +43,9 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_BP = {"cfg3": 79.8, "cfg3-heavy": 79.8, "cfg4": 76.9, "cfg5": 79.8}   # 76 L + 8 F + 3,944 B per chunk
 FLOP_PER_BP_BG = 2 * 146 * 121   # fp64 flop per base of the background correlation evaluated directly (R x W FMA)
-# executed by the FFT kernel: 73 row pairs x 364 flop per lane (172 add + 72 mul + 60 fma) x 64 lanes per 392-base tile
+# executed by the FFT kernel: 73 row pairs x 364 flop per lane (172 add + 72 mul + 60 fma as of round 4; round 5 folds the 1/sqrt2
+# of dft8 into FMAs -- 132 add + 44 mul + 100 fma, 276 instructions instead of 304 for the same arithmetic -- and keeps this count)
+# x 64 lanes per 392-base tile
 FLOP_PER_BP_BG_FFT = 73 * 364 * 64 / 392.0
 KERNEL_LABEL = {"background": "natac_background_fft (dense bias x VMat correlation, fp64 FFT)",
                 "occ_mle": "natac_occ_gsum + natac_occ_decide (occupancy grid MLE)",
