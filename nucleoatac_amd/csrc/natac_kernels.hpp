@@ -2027,19 +2027,64 @@ __global__ void __launch_bounds__(BT) natac_peaks_chunk_reg(ChunkTable ct, const
         }
     }
     __syncthreads();
-    // maxima of the thread's bases, then one ordered compaction for all NJ rows (base order = row-major over (j, thread))
+    // maxima of the thread's bases, then one ordered compaction for all NJ rows (base order = row-major over (j, thread)).
+    // The test "larger than both neighbours at every distance up to `order`" leaves a lane after 1.5 comparisons on average, but a wave
+    // only when its last lane leaves -- and among 64 consecutive bases one nearly always stays to the end, so every row cost `order`
+    // trips.  Two phases (round 5): distances 1 and 2 for every base (thresholds first), the survivors -- about a fifth -- go into a
+    // per-wave list, and the remaining distances run over that dense list, 64 candidates at a time; the rows' masks are put back
+    // together in LDS.  The list lives where the chunk's peak lists go afterwards (not in use yet).
     unsigned long long bal[NJ];
+    {
+        const int region = pk_cap * (int)(sizeof(double) + sizeof(int) + 1);
+        const int stride = (region / NW) & ~7;
+        unsigned long long *wmask = (unsigned long long *)((unsigned char *)sig + wave * stride);     // [NJ] survivors of row j
+        unsigned short *wlist = (unsigned short *)(wmask + NJ);
+        const int cap = (stride - NJ * 8) / 2;
+        const bool two_phase = order > 2 && stride >= NJ * 8 + 2 * 128;      // room for a useful list (else: the direct test below)
+        if (lane < NJ) wmask[lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        int cnt = 0;
+        const int o1 = order < 2 ? order : 2;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int g = threadIdx.x + BT * j;
-        bool pk = g < L;
-        if (pk) {
-            const double y = ys[g + order];
-            for (int sft = 1; sft <= order && pk; ++sft) pk = (y > ys[g + order + sft]) && (y > ys[g + order - sft]);
+        for (int j = 0; j < NJ; ++j) {
+            const int g = threadIdx.x + BT * j;
+            bool pk = g < L && (v[j] >= min_signal) && (g >= boundary) && (g < L - boundary);
+            double y = 0.0;
+            if (pk) {
+                y = ys[g + order];
+                for (int sft = 1; sft <= o1 && pk; ++sft) pk = (y > ys[g + order + sft]) && (y > ys[g + order - sft]);
+            }
+            const unsigned long long m = __ballot(pk);
+            const int alive = __popcll(m);
+            if (two_phase && cnt + alive <= cap) {                      // wave-uniform
+                if (pk) wlist[cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
+                            (unsigned short)(j * 64 + lane);
+                cnt += alive;
+            } else {                                                    // no list (or full): finish the row here
+                if (pk)
+                    for (int sft = o1 + 1; sft <= order && pk; ++sft) pk = (y > ys[g + order + sft]) && (y > ys[g + order - sft]);
+                const unsigned long long mf = __ballot(pk);
+                if (lane == 0) wmask[j] = mf;
+            }
         }
-        pk = pk && (v[j] >= min_signal) && (g >= boundary) && (g < L - boundary);
-        bal[j] = __ballot(pk);
-        if (lane == 0) row_cnt[j * NW + wave] = __popcll(bal[j]);
+        __builtin_amdgcn_wave_barrier();
+        unsigned int *wm32 = (unsigned int *)wmask;
+        for (int idx = lane; idx - lane < cnt; idx += 64) {             // wave-uniform trip count
+            if (idx < cnt) {
+                const int e = wlist[idx], jj = e >> 6, ll = e & 63;
+                const int g = (wave << 6) + ll + BT * jj;
+                const double y = ys[g + order];
+                bool pk = true;
+                for (int sft = 3; sft <= order && pk; ++sft) pk = (y > ys[g + order + sft]) && (y > ys[g + order - sft]);
+                if (pk) atomicOr(&wm32[2 * jj + (ll >> 5)], 1u << (ll & 31));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bal[j] = wmask[j];
+            if (lane == 0) row_cnt[j * NW + wave] = __popcll(bal[j]);
+        }
     }
     __syncthreads();
     int n = 0;
