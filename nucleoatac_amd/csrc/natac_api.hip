@@ -65,7 +65,10 @@ struct natac_ctx {
     bool vmat_zero = false, srow_zero = false;
     long long model_gen = 0;         // bumped by natac_set_vmat / natac_set_sizes
     // FFT background path: twiddles (once) and template spectra (per V-plot)
-    double *d_fft_tw = nullptr, *d_fft_k = nullptr;
+    double *d_fft_tw = nullptr, *d_fft_k = nullptr, *d_fft_etab = nullptr;   // etab: natac_fft_edge_table (extended tiles)
+    double *d_fft_mtab = nullptr, *d_fft_swt = nullptr;   // natac_fft_edge_table_mfma
+    bool bg_edge_mfma = true;
+    bool bg_ext = true;              // NATAC_BG_EXT=0: no extended FFT tiles (A-B timing / validation of the edge pass)
     bool fft_dirty = true, bg_direct = false, occ_ordered = true, occ_zero_nfr = false;
     std::vector<double> h_sizes;
     double *d_nucp = nullptr, *d_nfrp = nullptr, *d_alphas = nullptr;
@@ -125,6 +128,9 @@ struct natac_batch {
     int n_tiles1k = 0;
     bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
+    int *d_ext_list = nullptr;                 // indices of the extended tiles in d_tiles_bg (natac_background_edge)
+    unsigned char *d_tile_direct = nullptr;    // [n_tiles_bg] 1 = natac_background_fft evaluated the tile by direct summation
+    int n_ext = 0;
     long long *d_tile256_first = nullptr;   // [nc + 1] first 256-base tile of every chunk (the candidates' way into d_ranges256)
     int *d_order_occ = nullptr;      // natac_tile_heavy: {count, claims, list[HEAVY_CAP], flag bytes[n_tiles_occ]} of the occupancy tiles
     int ranges256_w = -1;
@@ -648,6 +654,10 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
     {   // NATAC_BG_DIRECT=1 selects the direct-summation background kernel (validation / A-B timing of the FFT path)
         const char *e = getenv("NATAC_BG_DIRECT");
         c->bg_direct = e && e[0] == '1';
+        e = getenv("NATAC_BG_EXT");
+        c->bg_ext = !(e && e[0] == '0');
+        e = getenv("NATAC_BG_EDGE_MFMA");
+        c->bg_edge_mfma = !(e && e[0] == '0');
         e = getenv("NATAC_OCC_GENERAL");   // NATAC_OCC_GENERAL=1: every tile through natac_occ_mle (validation / A-B timing)
         c->occ_force_general = e && e[0] == '1';
         e = getenv("NATAC_OCC_ORDER");     // NATAC_OCC_ORDER=0: natac_occ_decide visits its tiles in chunk order (A-B timing of the ordering)
@@ -665,7 +675,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     dev_free(c->d_vmat); dev_free(c->d_vmat_pad); dev_free(c->d_srow); dev_free(c->d_sizes); dev_free(c->d_lrt);
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
     dev_free(c->d_win_nuc); dev_free(c->d_win_occ); dev_free(c->d_wb_occ);
-    dev_free(c->d_fft_tw); dev_free(c->d_fft_k);
+    dev_free(c->d_fft_tw); dev_free(c->d_fft_k); dev_free(c->d_fft_etab); dev_free(c->d_fft_mtab); dev_free(c->d_fft_swt);
     dev_free(c->d_occ_q4); dev_free(c->d_occ_rho);
     dev_free(c->d_p10); dev_free(c->d_crc);
     if (c->t0) (void)hipEventDestroy(c->t0);
@@ -869,8 +879,50 @@ static int ensure_srow(natac_ctx *c) {
 // single-cell special case (i == 1, handled by the generic kernel)
 static bool fft_bg_applicable(const natac_ctx *c) {
     if (c->bg_direct || c->W > 192 || c->vlower < 2) return false;
-    const int EW = natac::FFT_N + ((c->vupper - 2) >> 1) + ((c->vupper - 1) >> 1);
-    return ((size_t)((EW + 1) & ~1) + 2 * natac::FFT_LA) * sizeof(double) <= 64 * 1024;
+    return natac::bg_fft_lds_bytes(c->vupper) <= 64 * 1024;
+}
+
+// Extended tiles (natac_fft_bg.hpp): FFT_EXT more outputs on each side of a tile, finished by natac_background_edge.  The edge pass
+// costs ~9 % of a tile's transforms, so a chunk is tiled that way only where that buys at least 10 % of its tiles: 2,120 bases take 5
+// tiles instead of 6, 10,120 bases 24 instead of 26 (not enough: plain tiles).  The choice depends on the chunk's length alone --
+// results do not depend on the batch a chunk is in.
+static bool bg_ext_possible(const natac_ctx *c) {
+    if (!c->bg_ext || c->W < 2 * natac::FFT_EXT || natac::bg_edge_wlen(c->vlower, c->vupper) > natac::EDGE_WLMAX) return false;
+    return natac::bg_edge_lds_doubles_per_wave(c->vlower, c->vupper) * natac::EDGE_WAVES * sizeof(double) <= 64 * 1024;
+}
+static bool bg_chunk_extended(int L, int TV) {
+    const int TVX = TV + 2 * natac::FFT_EXT;
+    const long long n_std = (L + TV - 1) / TV, n_ext = (L + TVX - 1) / TVX;
+    return n_ext * 11 <= n_std * 10;
+}
+static int build_tiles_bg(natac_batch *b, int TV, bool ext_ok) {
+    std::vector<int2> tiles;
+    std::vector<int> ext_list;
+    tiles.reserve((size_t)(b->total_bp / TV) + b->nc);
+    const int TVX = TV + 2 * natac::FFT_EXT;
+    for (int i = 0; i < b->nc; ++i) {
+        const int n = b->h_len[i];
+        if (ext_ok && bg_chunk_extended(n, TV)) {
+            for (int x = 0; x < n; x += TVX) {       // outputs [x, x + TVX): the transform's exact ones start at x + FFT_EXT
+                ext_list.push_back((int)tiles.size());
+                tiles.push_back(make_int2(i, (x + natac::FFT_EXT) | natac::FFT_EXT_BIT));
+            }
+        } else {
+            for (int x = 0; x < n; x += TV) tiles.push_back(make_int2(i, x));
+        }
+    }
+    dev_free(b->d_tiles_bg); dev_free(b->d_ext_list); dev_free(b->d_tile_direct);
+    b->d_tiles_bg = nullptr; b->d_ext_list = nullptr; b->d_tile_direct = nullptr;
+    b->n_tiles_bg = (int)tiles.size();
+    b->n_ext = (int)ext_list.size();
+    int rc = dev_upload(b->ctx, &b->d_tiles_bg, tiles.data(), tiles.size());
+    if (rc) return rc;
+    if (b->n_ext) {
+        if ((rc = dev_upload(b->ctx, &b->d_ext_list, ext_list.data(), ext_list.size()))) return rc;
+        if ((rc = dev_alloc(&b->d_tile_direct, tiles.size()))) return rc;
+    }
+    HIPCHK(sync_all(b->ctx));  // `tiles` is a local
+    return NATAC_OK;
 }
 
 static int ensure_fft(natac_ctx *c) {
@@ -892,6 +944,19 @@ static int ensure_fft(natac_ctx *c) {
     const int npair = (c->R + 1) / 2;
     if ((rc = dev_alloc(&c->d_fft_k, (size_t)npair * 2 * natac::FFT_N))) return rc;
     hipLaunchKernelGGL(natac_fft_template, dim3(npair), dim3(64), 0, c->stream, c->d_vmat, c->d_srow, c->R, c->W, c->d_fft_tw, c->d_fft_k);
+    dev_free(c->d_fft_etab);
+    c->d_fft_etab = nullptr;
+    if (c->W >= natac::FFT_EXT) {
+        const int ne = c->R * 2 * natac::FFT_EXT;
+        if ((rc = dev_alloc(&c->d_fft_etab, (size_t)ne))) return rc;
+        hipLaunchKernelGGL(natac_fft_edge_table, dim3((ne + 255) / 256), dim3(256), 0, c->stream, c->d_vmat, c->d_srow, c->R, c->W, c->d_fft_etab);
+        dev_free(c->d_fft_mtab); dev_free(c->d_fft_swt);
+        c->d_fft_mtab = c->d_fft_swt = nullptr;
+        const int NJ = (c->R + 3) / 4;
+        if ((rc = dev_alloc(&c->d_fft_mtab, (size_t)2 * NJ * 64)) || (rc = dev_alloc(&c->d_fft_swt, (size_t)4 * NJ))) return rc;
+        hipLaunchKernelGGL(natac_fft_edge_table_mfma, dim3((2 * NJ * 64 + 255) / 256), dim3(256), 0, c->stream, c->d_vmat, c->d_srow, c->R, c->W, NJ,
+                           c->d_fft_mtab, c->d_fft_swt);
+    }
     HIPCHK(hipGetLastError());
     c->fft_dirty = false;
     return NATAC_OK;
@@ -1086,6 +1151,7 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_occ_minkey); dev_free(b->d_occ_nan); dev_free(b->d_tiles_os); dev_free(b->d_tiles1k);
     dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
     dev_free(b->d_tile256_first);
+    dev_free(b->d_ext_list); dev_free(b->d_tile_direct);
     dev_free(b->d_order_occ);
     dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
@@ -1156,9 +1222,11 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     if (use_fft) {
         if ((rc = ensure_fft(c))) return rc;
         const int TV = FFT_N - c->W + 1;
-        if (b->bgG != -TV) {
-            if ((rc = build_tiles(b, TV, &b->d_tiles_bg, &b->n_tiles_bg))) return rc;
-            b->bgG = -TV;
+        const bool ext_ok = bg_ext_possible(c);
+        const int key = -(TV + (ext_ok ? 4096 : 0));   // the tiling this batch's table was built for
+        if (b->bgG != key) {
+            if ((rc = build_tiles_bg(b, TV, ext_ok))) return rc;
+            b->bgG = key;
         }
     } else if (fast) {
         const int G = choose_bg_G(b, c->W);
@@ -1192,11 +1260,24 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     prof_begin(c, NATAC_K_BACKGROUND, ev);
     if ((rc = run_exp_bias(b, c->stream, false))) return rc;
     if (use_fft) {
-        const int EW = FFT_N + ((vm.upper - 2) >> 1) + ((vm.upper - 1) >> 1);
-        const size_t lds = ((size_t)((EW + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
+        const size_t lds = bg_fft_lds_bytes(vm.upper);
         hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
                            c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg);
+                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg, b->d_tile_direct, vm.srow);
+        if (b->n_ext && c->bg_edge_mfma) {     // the FFT_EXT outputs on each side of every extended tile
+            const int wd = (int)bg_edgem_lds_doubles_per_wave(vm.lower, vm.upper);
+            hipLaunchKernelGGL(natac_background_edge_mfma, dim3((b->n_ext + EDGEM_WAVES - 1) / EDGEM_WAVES), dim3(64 * EDGEM_WAVES),
+                               (size_t)wd * EDGEM_WAVES * sizeof(double), c->stream, ct, b->d_tiles_bg, b->d_ext_list, b->n_ext,
+                               b->d_tile_direct, vm, c->d_fft_mtab, c->d_fft_swt, (c->R + 3) / 4, b->d_track[NATAC_T_NUC_COV],
+                               b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND], b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, wd);
+        } else if (b->n_ext) {
+            const int wd = (int)bg_edge_lds_doubles_per_wave(vm.lower, vm.upper);
+            const int per_wg = EDGE_WAVES * EDGE_TPW;
+            hipLaunchKernelGGL(natac_background_edge, dim3((b->n_ext + per_wg - 1) / per_wg), dim3(64 * EDGE_WAVES),
+                               (size_t)wd * EDGE_WAVES * sizeof(double), c->stream, ct, b->d_tiles_bg, b->d_ext_list, b->n_ext,
+                               b->d_tile_direct, vm, c->d_fft_etab, vm.srow, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW],
+                               b->d_track[NATAC_T_BACKGROUND], b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, wd);
+        }
     } else if (fast) {
         switch (b->bgG) {
             case 7: launch_bg<7>(b, ct, vm); break;

@@ -23,6 +23,18 @@ namespace natac {
 constexpr int FFT_N = 512;
 constexpr int FFT_LA = 576;   // layout A: p + 8 * (p >> 6)
 constexpr int FFT_LB = 520;   // layout B: (p & 7) * 65 + (p >> 3)
+// Extended tiles (round 5).  A 512-point circular correlation holds, besides its TV = 512 - W + 1 exact outputs, FFT_EXT outputs on each
+// side that are wrong by a few terms only: output TV - 1 + m (m = 1..16) wraps its last m template columns onto the tile's first
+// samples, output -k (circular index 512 - k) its first k columns onto the tile's last samples.  natac_background_edge replaces those
+// m (k) wrapped products per row by the true ones -- 2 x 136 multiply-adds per row and tile, summed directly -- so a tile yields
+// TV + 2 FFT_EXT outputs: a 2,120-base chunk takes 5 transforms per row pair instead of 6.  Which chunks are tiled that way is the
+// host's decision (bg_tiles_build: only where the tile count drops by more than the edge pass costs); the flag travels in tiles[].y.
+constexpr int FFT_EXT = 16;
+constexpr int FFT_EXT_BIT = 1 << 30;
+// exp(bias) entries of a tile that feed bases of its chunk (the rest of the staged window is zero): ext = FFT_EXT or 0
+__device__ __forceinline__ int bg_tile_need(int TV, int W, int A, int Bh, int L, int x0, int ext) {
+    return ext + min(TV + ext, L - x0) + W - 1 + A + Bh;
+}
 
 // 8-point DFT in registers, natural order in and out.  INV: conjugate twiddles (unnormalised inverse).
 template <bool INV>
@@ -119,6 +131,9 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
 
 #ifndef NATAC_FFT_ABL
 #define NATAC_FFT_ABL 0
+#endif
+#ifndef NATAC_FFT_SROW_S
+#define NATAC_FFT_SROW_S 0     // the pair loop's size weights through a scalar load (tools/fft_ab.sh "0 1" NATAC_FFT_SROW_S)
 #endif
 // complex scratch of the transposes: interleaved double2 (two planes of doubles with 8-byte accesses measured 5 % slower)
 #define CST(p, i, xr, xi) do { (p)[(i)] = make_double2((xr), (xi)); } while (0)
@@ -241,22 +256,24 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
                                             const double *__restrict__ ktab, const double *__restrict__ nuc_cov,
                                             const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
                                             double *__restrict__ bnum, double *__restrict__ bcov, double *smem, FftTwiddles &tww,
-                                            const int lane) {
+                                            const int lane, unsigned char *__restrict__ tile_direct = nullptr, unsigned ti = 0,
+                                            const double *__restrict__ srow_s = nullptr) {
     const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
-    const int EW = FFT_N + A + Bh, EWP = (EW + 1) & ~1;
+    const int ext = (t.y & FFT_EXT_BIT) ? FFT_EXT : 0;   // extended tile: FFT_EXT more outputs on each side, finished by natac_background_edge
+    const int EW = FFT_N + A + Bh + 2 * ext, EWP = (FFT_N + A + Bh + 2 * FFT_EXT + 1) & ~1;
     double *Et = smem;
     double2 *ca = (double2 *)(Et + EWP), *cb = ca;     // complex scratch of the transposes; layouts A and B are never live together
     double *sar = (double *)ca, *sai = sar + FFT_LA;   // the same memory as two real arrays (epilogue)
-    const int chunk = t.x, x0 = t.y;
+    const int chunk = t.x, x0 = t.y & (FFT_EXT_BIT - 1);
     const int L = ct.chunk_len[chunk];
     bool use_fft;
-    {   // Et[u] <-> coordinate x0 - HW - A + u
+    {   // Et[u] <-> coordinate x0 - ext - HW - A + u
         const double *b = ct.bias ? ct.ebias + ct.bias_off[chunk] : nullptr;       // exp(bias), natac_exp_bias
         const int nb = L + ct.bias_left + ct.bias_right;
-        const int j0 = x0 - HW - A + ct.bias_left;
+        const int j0 = x0 - ext - HW - A + ct.bias_left;
         // only the first `need` entries feed bases of this chunk; the rest of the tile is padded with zeros
-        const int need = min(TV, L - x0) + W - 1 + A + Bh;
+        const int need = bg_tile_need(TV, W, A, Bh, L, x0, ext);
         double emax = 0.0, emin = 1e300;
         bool okl = true;
         for (int u = lane; u < EW; u += WAVE) {
@@ -275,11 +292,13 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
     }
     __builtin_amdgcn_wave_barrier();
     const long long ob = ct.out_off[chunk];
+    if (tile_direct && lane == 0) tile_direct[ti] = use_fft ? 0 : 1;
+    Et += ext;                   // Et[u] <-> coordinate x0 - HW - A + u from here on, as for a plain tile
     if (!use_fft) {
 #pragma unroll 1
-        for (int j = 0; j < 8; ++j) {
-            const int u = lane + 64 * j, g = x0 + u;
-            if (u >= TV || g >= L) continue;
+        for (int j = 0; j < 9; ++j) {
+            const int u = lane + 64 * j - ext, g = x0 + u;      // an extended tile's edge outputs too: the edge pass skips this tile
+            if (u >= TV + ext || g >= L) continue;
             double num = 0.0, cv = 0.0;
 #pragma unroll 1
             for (int r = 0; r < vm.R; ++r) {
@@ -348,7 +367,11 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         };
         issue_xy(0);
         for (int pair = 0; pair < npair; ++pair) {
+#if NATAC_FFT_SROW_S
+            const double sa = srow_s[2 * pair], sb = srow_s[2 * pair + 1];     // the kernel's restrict argument: one scalar load
+#else
             const double sa = vm.srow[2 * pair], sb = vm.srow[2 * pair + 1];
+#endif
             const double *k = ktab + (size_t)pair * 2 * FFT_N;
             double kr[8], ki[8], re[8], im[8];
             if (SYNC) __builtin_amdgcn_s_barrier();      // the waves of a workgroup walk the row pairs in step: one L2 fetch of a pair's spectrum per CU
@@ -454,29 +477,65 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
     for (int j = 0; j < 8; ++j) sar[lane + 64 * j] = q[j];
     sar[FFT_N + lane] = 0.0;
     __builtin_amdgcn_wave_barrier();
+    // both levels with the eight outputs of a lane inside the loop over the terms: eight independent reads per trip instead of one
+    // (every output still adds its terms in the same order: the same bits as with the loops the other way round)
+    {
+        double ts[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int u = lane + 64 * j;
-        double tsum = 0.0;
-        for (int c = 0; c < B; ++c) tsum += sar[u + c];
-        sai[u] = tsum;
+        for (int j = 0; j < 8; ++j) ts[j] = 0.0;
+        for (int c = 0; c < B; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ts[j] += sar[lane + 64 * j + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sai[lane + 64 * j] = ts[j];
     }
+    sai[FFT_N + lane] = 0.0;      // an extended tile's right edge sums past the tile's last sample: the samples out there are the edge pass's
     __builtin_amdgcn_wave_barrier();
+    double cvv[8];
+    {
+        int ub[8];                // outputs past the tile's last one read the last one's terms (in bounds, not used)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ub[j] = min(lane + 64 * j, TV + ext - 1); cvv[j] = 0.0; }
+        for (int k = 0; k < nbk; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cvv[j] += sai[ub[j] + B * k];
+        }
+        for (int c = B * nbk; c < W; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cvv[j] += sar[ub[j] + c];
+        }
+    }
+    // left edge of an extended tile: output x0 - k sits at the circular index 512 - k (register 7 of the last FFT_EXT lanes); of its window
+    // the tile holds samples 0 .. W - 1 - k: the window sum of output 0 (lane 0, register 0) less the last k samples of that window
+    double cvl = 0.0;
+    if (ext) {
+        const double full = __shfl(cvv[0], 0);
+        const int k = FFT_N - (lane + 64 * 7);
+        double suf = 0.0;
+#pragma unroll
+        for (int c = 0; c < FFT_EXT; ++c) { const double v = sar[W - 1 - c]; suf += c < k ? v : 0.0; }
+        cvl = full - suf;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int u = lane + 64 * j;
         const int g = x0 + u;
-        if (u < TV && g < L) {
-            double cv = 0.0;
-            for (int k = 0; k < nbk; ++k) cv += sai[u + B * k];
-            for (int c = B * nbk; c < W; ++c) cv += sar[u + c];
+        const bool core = u < TV && g < L;
+        if (core || (u < TV + ext && g < L)) {
             const long long o = ob + g;
-            const double num = accr[j] * (1.0 / FFT_N);
-            const double b = (num * nuc_cov[o]) / cv;
-            bg[o] = b;
-            norm[o] = raw[o] - b;
+            const double num = accr[j] * (1.0 / FFT_N), cv = cvv[j];
+            if (core) {
+                const double b = (num * nuc_cov[o]) / cv;
+                bg[o] = b;
+                norm[o] = raw[o] - b;
+            }
             bnum[o] = num;           // sum B V and sum B of the window at this base: reused by the candidate statistics
-            bcov[o] = cv;
+            bcov[o] = cv;            // (right edge of an extended tile: both without the samples past the tile, see natac_background_edge)
+        } else if (j == 7 && u >= FFT_N - ext && x0 - (FFT_N - u) < L) {
+            const long long o = ob + (x0 - (FFT_N - u));
+            bnum[o] = accr[j] * (1.0 / FFT_N);
+            bcov[o] = cvl;
         }
     }
 }
@@ -489,11 +548,192 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                                              const double *__restrict__ nuc_cov, const double *__restrict__ raw,
                                                              double *__restrict__ bg, double *__restrict__ norm,
                                                              double *__restrict__ bnum, double *__restrict__ bcov,
-                                                             unsigned n_tiles) {
+                                                             unsigned n_tiles, unsigned char *__restrict__ tile_direct,
+                                                             const double *__restrict__ srow) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const unsigned ti = blockIdx.x;
     FftTwiddles tww;
-    bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x);
+    bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x, tile_direct, ti, srow);
+}
+
+// LDS of one wave of natac_background_fft, in bytes (host): the exp(bias) window of an extended tile + the transposes' scratch
+__host__ __device__ inline size_t bg_fft_lds_bytes(int upper) {
+    const int EWX = FFT_N + ((upper - 2) >> 1) + ((upper - 1) >> 1) + 2 * FFT_EXT;
+    return ((size_t)((EWX + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
+}
+
+// ---- the edge pass of extended tiles -------------------------------------------------------------------------------------------
+// etab[r][side][i], i < FFT_EXT: the template columns an edge output can wrap, weighted like the spectra (s_r V_r[c]):
+//   side 0 (left edge, output x0 - k):        s_r V_r[i]          -- sample x0 - t' meets column k - t'
+//   side 1 (right edge, output TV - 1 + m):   s_r V_r[W - 1 - i]  -- sample 512 + t meets column W - m + t = W - 1 - (m - 1 - t)
+__global__ void natac_fft_edge_table(const double *__restrict__ vmat, const double *__restrict__ srow, int R, int W, double *__restrict__ etab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * 2 * FFT_EXT) return;
+    const int r = i / (2 * FFT_EXT), side = (i / FFT_EXT) & 1, c = i % FFT_EXT;
+    etab[i] = srow[r] * vmat[r * W + (side ? W - 1 - c : c)];
+}
+
+// window length of the edge pass: the left (right) factors of the FFT_EXT samples of one group over all rows
+__host__ __device__ inline int bg_edge_wlen(int lower, int upper) {
+    const int A = (upper - 2) >> 1, Bh = (upper - 1) >> 1;
+    const int dl = A - ((lower - 1) >> 1), dr = Bh - (lower >> 1);
+    const int wl = (dl > dr ? dl : dr) + FFT_EXT;
+    return wl + ((12 - wl % 8) % 8);     // = 4 (mod 8): the four tiles of a wave then sit 32 banks apart (conflict-free ds_read_b64)
+}
+constexpr int EDGE_TPW = 64 / FFT_EXT;     // tiles per wave
+constexpr int EDGE_WAVES = 4;              // waves per workgroup
+constexpr int EDGE_RS = FFT_EXT + 1;       // stride of a lane's partial sums in the reduction scratch
+constexpr int EDGE_WLMAX = 128;            // longest window the edge pass stages (bg_ext_possible)
+__host__ __device__ inline size_t bg_edge_lds_doubles_per_wave(int lower, int upper) {
+    const int w = 4 * EDGE_TPW * bg_edge_wlen(lower, upper), rdx = 64 * EDGE_RS;
+    return (size_t)(w > rdx ? w : rdx);
+}
+
+// One wave takes EDGE_TPW extended tiles; lane = (tile, t).  Per side the lane owns ONE sample outside the tile (`out`) and the sample
+// inside that the circular transform used in its place (`in`): D_r = P_r[out] - P_r[in] per row; every output that wraps this sample
+// receives D_r times a template column that depends on the output's distance from the lane's sample only, i.e. on a wave-uniform
+// value per accumulator (scalar operand): acc[i] += D_r etab[r][side][i].  The column sums' missing samples (sum_r s_r P_r[out]) come
+// out of the same products.  A second phase adds the lanes' accumulators per output, in a fixed order, and finishes the FFT_EXT
+// outputs of that side: num = the transform's value (left in bnum) + the correction, likewise the window sum (bcov), then
+// background and normalised signal exactly as natac_background_fft forms them.
+// Tiles evaluated by direct summation (tile_direct) have their edge outputs already.
+__global__ void __launch_bounds__(64 * EDGE_WAVES) natac_background_edge(ChunkTable ct, const int2 *__restrict__ tiles, const int *__restrict__ ext_list,
+                                                                          int n_ext, const unsigned char *__restrict__ tile_direct, VMatDev vm,
+                                                                          const double *__restrict__ etab, const double *__restrict__ srow,
+                                                                          const double *__restrict__ nuc_cov,
+                                                                          const double *__restrict__ raw, double *__restrict__ bg,
+                                                                          double *__restrict__ norm, double *__restrict__ bnum,
+                                                                          double *__restrict__ bcov, int wave_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *ws = smem + (size_t)wave * wave_doubles;
+    const int tl = lane / FFT_EXT, t = lane % FFT_EXT;
+    const int slot = (blockIdx.x * EDGE_WAVES + wave) * EDGE_TPW + tl;
+    const bool have = slot < n_ext;
+    const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
+    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
+    const int hl0 = floor_half(vm.lower - 1), hr0 = floor_half(vm.lower);
+    const int WL = bg_edge_wlen(vm.lower, vm.upper);
+    int chunk = 0, x0 = 0, L = 0, need = 0, nb = 0, j0 = 0;
+    bool live = false;
+    const double *b = nullptr;
+    if (have) {
+        const int ti = ext_list[slot];
+        const int2 tt = tiles[ti];
+        chunk = tt.x; x0 = tt.y & (FFT_EXT_BIT - 1);
+        L = ct.chunk_len[chunk];
+        live = !tile_direct[ti];
+        b = ct.bias ? ct.ebias + ct.bias_off[chunk] : nullptr;
+        nb = L + ct.bias_left + ct.bias_right;
+        j0 = x0 - FFT_EXT - HW - A + ct.bias_left;                  // the extended tile's window starts FFT_EXT samples early
+        need = bg_tile_need(TV, W, A, Bh, L, x0, FFT_EXT);
+    }
+    // entry e of the tile's exp(bias) window exactly as natac_background_fft staged it: zero from `need` on and outside the chunk's
+    // bias slice.  [elo, ehi) = the entries that are read; the load itself is unconditional (clamped index), all of a side's in flight
+    const int elo = b ? max(0, -j0) : 0, ehi = b ? min(need, nb - j0) : 0;
+    const double *bj = b ? b + j0 : nullptr;
+    auto E = [&](int e) -> double {
+        double v = (e >= 0 && e < need) ? 1.0 : 0.0;         // no bias track: exp(0)
+        if (bj) {
+            const double x = bj[min(max(e, elo), max(ehi, elo + 1) - 1)];
+            v = (e >= elo && e < ehi) ? x : 0.0;
+        }
+        return v;
+    };
+    const long long ob = have ? ct.out_off[chunk] : 0;
+    double *wl_o = ws + (size_t)(tl * 4 + 0) * WL, *wr_o = ws + (size_t)(tl * 4 + 1) * WL;
+    double *wl_i = ws + (size_t)(tl * 4 + 2) * WL, *wr_i = ws + (size_t)(tl * 4 + 3) * WL;
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        // samples (tile coordinates): left edge  out = -FFT_EXT + t, in = 512 - FFT_EXT + t;  right edge  out = 512 + t, in = t
+        const int uo = side ? FFT_N : -FFT_EXT, ui = side ? 0 : FFT_N - FFT_EXT;
+        // windows: left factor of sample u, row i: entry FFT_EXT + A - fh(i - 1) + u -> wl[(A - hl) + t'] with wl[w] = E(FFT_EXT + u0 + w);
+        //          right factor: entry FFT_EXT + A + fh(i) + u -> wr[(hr - hr0) + t'] with wr[w] = E(FFT_EXT + A + hr0 + u0 + w)
+        __builtin_amdgcn_wave_barrier();
+        {
+            constexpr int NS = EDGE_WLMAX / FFT_EXT;
+            double s0[NS], s1[NS], s2[NS], s3[NS];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const int w = t + FFT_EXT * n;
+                if (FFT_EXT * n >= WL) { s0[n] = s1[n] = s2[n] = s3[n] = 0.0; continue; }      // wave-uniform
+                s0[n] = E(FFT_EXT + uo + w);
+                s1[n] = E(FFT_EXT + A + hr0 + uo + w);
+                s2[n] = E(FFT_EXT + ui + w);
+                s3[n] = E(FFT_EXT + A + hr0 + ui + w);
+            }
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const int w = t + FFT_EXT * n;
+                if (w < WL) { wl_o[w] = s0[n]; wr_o[w] = s1[n]; wl_i[w] = s2[n]; wr_i[w] = s3[n]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        double acc[FFT_EXT], qx = 0.0;
+#pragma unroll
+        for (int i = 0; i < FFT_EXT; ++i) acc[i] = 0.0;
+        // rows two at a time, the operands of the next row requested before the current row's arithmetic (LDS values, the row's
+        // weight and its FFT_EXT template columns -- wave-uniform, scalar loads)
+        struct RowOps { double lo, ro, li, ri, s; double v[FFT_EXT]; };
+        auto fetch = [&](RowOps &o, int r) {
+            const int i = vm.lower + r;
+            const int dl = A - floor_half(i - 1), dr = floor_half(i) - hr0;       // wave-uniform
+            o.lo = wl_o[dl + t]; o.ro = wr_o[dr + t]; o.li = wl_i[dl + t]; o.ri = wr_i[dr + t];
+            o.s = srow[r];            // (= vm.srow, as a restrict argument: a scalar load, not a vector load the arithmetic then waits for)
+            const double *__restrict__ v = etab + (size_t)(r * 2 + side) * FFT_EXT;
+#pragma unroll
+            for (int k = 0; k < FFT_EXT; ++k) o.v[k] = v[k];
+        };
+        auto apply = [&](const RowOps &o) {
+            const double po = o.lo * o.ro, pi = o.li * o.ri;
+            const double d = po - pi;
+            qx = fma(o.s, po, qx);
+#pragma unroll
+            for (int k = 0; k < FFT_EXT; ++k) acc[k] = fma(d, o.v[k], acc[k]);
+        };
+        RowOps oa, ob2;
+        fetch(oa, 0);
+        int r = 0;
+        for (; r + 2 <= vm.R; r += 2) {
+            fetch(ob2, r + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            apply(oa);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(oa, min(r + 2, vm.R - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            apply(ob2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (r < vm.R) apply(oa);
+        // reduction scratch (the windows are dead): [lane][EDGE_RS] = acc[0..15], qx
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < FFT_EXT; ++k) ws[lane * EDGE_RS + k] = acc[k];
+        ws[lane * EDGE_RS + FFT_EXT] = qx;
+        __builtin_amdgcn_wave_barrier();
+        // this lane finishes output number t of the side:
+        //   right: m = t + 1, samples 512 + s for s < m, accumulator m - 1 - s of lane s
+        //   left:  k = FFT_EXT - t (output x0 - k), samples -t' for t' <= k i.e. lanes s = FFT_EXT - t' >= t, accumulator k - t' = s - t
+        double corr = 0.0, qc = 0.0;
+        const double *rs = ws + (size_t)(tl * FFT_EXT) * EDGE_RS;
+#pragma unroll
+        for (int s = 0; s < FFT_EXT; ++s) {      // fixed order; lanes the output does not reach add + 0.0
+            const int ix = side ? t - s : s - t;
+            const double a = rs[s * EDGE_RS + max(ix, 0)], qq = rs[s * EDGE_RS + FFT_EXT];
+            corr += ix >= 0 ? a : 0.0;
+            qc += ix >= 0 ? qq : 0.0;
+        }
+        const int g = side ? x0 + TV + t : x0 - FFT_EXT + t;
+        if (live && g >= 0 && g < L) {
+            const long long o = ob + g;
+            const double num = bnum[o] + corr, cv = bcov[o] + qc;
+            const double bb = (num * nuc_cov[o]) / cv;
+            bg[o] = bb;
+            norm[o] = raw[o] - bb;
+            bnum[o] = num;
+            bcov[o] = cv;
+        }
+    }
 }
 
 // experiment (tools/test_fft_bg.hip): NW waves per workgroup, one tile each, optionally stepping through the row pairs together
@@ -507,7 +747,176 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
     const unsigned ti = blockIdx.x * NW + wave;
     if (ti >= n_tiles) return;
     FftTwiddles tww;
-    bg_fft_tile<false, SYNC>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem + (size_t)wave * wave_doubles, tww, lane);
+    bg_fft_tile<false, SYNC>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem + (size_t)wave * wave_doubles, tww, lane, nullptr, ti,
+                             vm.srow);
+}
+
+
+// ---- the edge pass as a small matrix product (the one place of this library where the matrix pipe fits) ------------------------------
+// Per tile and side the corrections are OUT[t][i] = sum_r D_r[t] C_r[i]: D = the product differences of the side's 16 samples (per-lane
+// data), C = 16 template columns per row.  As an outer product on the vector pipe (natac_background_edge above) every lane needs the 16
+// C_r[i] of every row as uniform operands -- 146 x 2 x 128 bytes through the scalar cache per wave, and the counters show the waves
+// waiting on it for half of their time.  v_mfma_f64_16x16x4_f64 takes BOTH operands distributed over the lanes:
+// A[t = lane & 15][k = lane >> 4] = D of row 4 j + k, B[k][i = lane & 15] = one coalesced 512-byte load of the table per step; a tile
+// and side is ceil(R / 4) instructions and every D is formed once.  fp64 MFMA has no rate advantage over fp64 FMAs on gfx950
+// (profiles/r1/probe_fp64_mfma_vs_valu.txt); what it buys here is operand delivery.
+// mtab[side][j][lane] = C of row 4 j + (lane >> 4), column index lane & 15 (0 for rows past R); swt[4 j + k] = s_r (0 past R).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+__global__ void natac_fft_edge_table_mfma(const double *__restrict__ vmat, const double *__restrict__ srow, int R, int W, int NJ,
+                                          double *__restrict__ mtab, double *__restrict__ swt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NJ * 4) swt[i] = i < R ? srow[i] : 0.0;
+    if (i >= 2 * NJ * 64) return;
+    const int side = i / (NJ * 64), j = (i / 64) % NJ, lane = i % 64;
+    const int r = 4 * j + (lane >> 4), c = lane & 15;
+    mtab[i] = r < R ? srow[r] * vmat[r * W + (side ? W - 1 - c : c)] : 0.0;
+}
+constexpr int EDGEM_WAVES = 4;             // waves (= tiles) per workgroup
+constexpr int EDGEM_PAD = 2;               // rows past R in the last step index up to two entries outside a window (values not used)
+__host__ __device__ inline int bg_edgem_wlen(int lower, int upper) {       // entries of one window: both sides' 16 samples over all rows
+    const int A = (upper - 2) >> 1, Bh = (upper - 1) >> 1;
+    const int dl = A - ((lower - 1) >> 1), dr = Bh - (lower >> 1);
+    return (dl > dr ? dl : dr) + 2 * FFT_EXT + 2 * EDGEM_PAD;
+}
+__host__ __device__ inline size_t bg_edgem_lds_doubles_per_wave(int lower, int upper) {
+    const int NJ = (upper - lower + 3) / 4;
+    return (size_t)4 * bg_edgem_wlen(lower, upper) + FFT_EXT * EDGE_RS + 64 + FFT_EXT + 128 + (size_t)4 * NJ;
+}
+
+// One wave per extended tile.  Windows (entries of the tile's exp(bias) window as natac_background_fft staged it, E below):
+//   wl_lo[w] = E(w), wl_hi[w] = E(512 + w)                       left factors  (entry 16 + A - fh(i - 1) + u of sample u, row i)
+//   wr_lo[w] = E(A + hr0 + w), wr_hi[w] = E(512 + A + hr0 + w)   right factors (entry 16 + A + fh(i) + u)
+// left edge:  out = sample -16 + t -> wl_lo[dl + t] wr_lo[dr + t];  in = sample 496 + t -> wl_hi[dl + t] wr_hi[dr + t]
+// right edge: out = sample 512 + t -> wl_hi[16 + dl + t] wr_hi[16 + dr + t];  in = sample t -> wl_lo[16 + dl + t] wr_lo[16 + dr + t]
+// with dl = A - fh(i - 1), dr = fh(i) - hr0; a lane's rows are 4 j + k: dl falls and dr rises by 2 per step.
+// (waves_per_eu >= 4: with a register budget of <= 256 the compiler keeps the accumulators in VGPRs; left at 512 it picks the AGPR form
+// and copies all sixteen registers in and out around every pair of instructions)
+__global__ void __launch_bounds__(64 * EDGEM_WAVES) __attribute__((amdgpu_waves_per_eu(4))) natac_background_edge_mfma(ChunkTable ct, const int2 *__restrict__ tiles, const int *__restrict__ ext_list,
+                                                                                int n_ext, const unsigned char *__restrict__ tile_direct, VMatDev vm,
+                                                                                const double *__restrict__ mtab, const double *__restrict__ swt, int NJ,
+                                                                                const double *__restrict__ nuc_cov, const double *__restrict__ raw,
+                                                                                double *__restrict__ bg, double *__restrict__ norm,
+                                                                                double *__restrict__ bnum, double *__restrict__ bcov, int wave_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * EDGEM_WAVES + wave;
+    if (slot >= n_ext) return;                      // no workgroup barrier below
+    const int ti = ext_list[slot];
+    if (tile_direct[ti]) return;                    // evaluated by direct summation, edge outputs included
+    double *ws = smem + (size_t)wave * wave_doubles;
+    const int t = lane & (FFT_EXT - 1), k = lane >> 4;
+    const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
+    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
+    const int hr0 = floor_half(vm.lower);
+    const int WLm = bg_edgem_wlen(vm.lower, vm.upper);
+    const int2 tt = tiles[ti];
+    const int chunk = tt.x, x0 = tt.y & (FFT_EXT_BIT - 1);
+    const int L = ct.chunk_len[chunk];
+    const double *b = ct.bias ? ct.ebias + ct.bias_off[chunk] : nullptr;
+    const int nb = L + ct.bias_left + ct.bias_right;
+    const int j0 = x0 - FFT_EXT - HW - A + ct.bias_left;              // the extended tile's window starts FFT_EXT samples early
+    const int need = bg_tile_need(TV, W, A, Bh, L, x0, FFT_EXT);
+    // entry e of the tile's exp(bias) window exactly as natac_background_fft staged it: zero from `need` on and outside the chunk's
+    // bias slice.  [elo, ehi) = the entries that are read; the load itself is unconditional (clamped index)
+    const int elo = b ? max(0, -j0) : 0, ehi = b ? min(need, nb - j0) : 0;
+    const double *bj = b ? b + j0 : nullptr;
+    auto E = [&](int e) -> double {
+        double v = (e >= 0 && e < need) ? 1.0 : 0.0;         // no bias track: exp(0)
+        if (bj) {
+            const double x = bj[min(max(e, elo), max(ehi, elo + 1) - 1)];
+            v = (e >= elo && e < ehi) ? x : 0.0;
+        }
+        return v;
+    };
+    double *wl_lo = ws + EDGEM_PAD, *wl_hi = wl_lo + WLm, *wr_lo = wl_hi + WLm, *wr_hi = wr_lo + WLm;
+    double *sc = ws + 4 * WLm, *sq = sc + FFT_EXT * EDGE_RS, *sqt = sq + 64, *sp = sqt + FFT_EXT, *sws = sp + 128;
+    {
+        constexpr int NS = (EDGE_WLMAX + 2 * FFT_EXT + 63) / 64;
+        double s0[NS], s1[NS], s2[NS], s3[NS];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int w = lane + 64 * n - EDGEM_PAD;
+            if (64 * n >= WLm) { s0[n] = s1[n] = s2[n] = s3[n] = 0.0; continue; }      // wave-uniform
+            s0[n] = E(w); s1[n] = E(FFT_N + w); s2[n] = E(A + hr0 + w); s3[n] = E(FFT_N + A + hr0 + w);
+        }
+        for (int i = lane; i < 4 * NJ; i += WAVE) sws[i] = swt[i];       // the rows' weights, read back with immediate offsets
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int w = lane + 64 * n - EDGEM_PAD;
+            if (w < WLm - EDGEM_PAD) { wl_lo[w] = s0[n]; wl_hi[w] = s1[n]; wr_lo[w] = s2[n]; wr_hi[w] = s3[n]; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const long long ob = ct.out_off[chunk];
+    const int dl0 = A - floor_half(vm.lower + k - 1), dr0 = floor_half(vm.lower + k) - hr0;
+    const int NJf = vm.R / 4;                       // steps whose four rows all exist
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const double *pl_o = (side ? wl_hi + FFT_EXT : wl_lo) + dl0 + t, *pr_o = (side ? wr_hi + FFT_EXT : wr_lo) + dr0 + t;
+        const double *pl_i = (side ? wl_lo + FFT_EXT : wl_hi) + dl0 + t, *pr_i = (side ? wr_lo + FFT_EXT : wr_hi) + dr0 + t;
+        const double *mt = mtab + (size_t)side * NJ * 64 + lane;
+        const double *sw = sws + k;
+        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        double qx = 0.0;
+        // step u of a trip: rows 4 (j + u) + k; the pointers sit at step j
+#define NATAC_EDGE_STEP(u, acc)                                                                                  \
+        {                                                                                                        \
+            const double po = pl_o[-2 * (u)] * pr_o[2 * (u)], pi = pl_i[-2 * (u)] * pr_i[2 * (u)];             \
+            qx = fma(sw[4 * (u)], po, qx);                                                                       \
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(po - pi, mt[64 * (u)], acc, 0, 0, 0);                     \
+        }
+        int j = 0;
+        for (; j + 4 <= NJf; j += 4) {
+            NATAC_EDGE_STEP(0, acc0) NATAC_EDGE_STEP(1, acc1) NATAC_EDGE_STEP(2, acc0) NATAC_EDGE_STEP(3, acc1)
+            pl_o -= 8; pl_i -= 8; pr_o += 8; pr_i += 8; mt += 256; sw += 16;
+        }
+        for (; j < NJf; ++j) {
+            NATAC_EDGE_STEP(0, acc0)
+            pl_o -= 2; pl_i -= 2; pr_o += 2; pr_i += 2; mt += 64; sw += 4;
+        }
+#undef NATAC_EDGE_STEP
+        if (j < NJ) {                                // the last rows: lanes past R contribute zeros (their window entries are not the model's)
+            const bool valid = 4 * j + k < vm.R;
+            const double lo = pl_o[0], ro = pr_o[0], li = pl_i[0], ri = pr_i[0];
+            const double po = valid ? lo * ro : 0.0, pi = valid ? li * ri : 0.0;
+            qx = fma(sw[0], po, qx);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(po - pi, mt[0], acc1, 0, 0, 0);
+        }
+        const d4_t acc = acc0 + acc1;
+        // OUT[t' = k + 4 q][i = lane & 15] = acc[q]; a lane's column sums are partial over its rows
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sc[(k + 4 * q) * EDGE_RS + t] = acc[q];
+        sq[lane] = qx;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < FFT_EXT) sqt[lane] = ((sq[lane] + sq[16 + lane]) + sq[32 + lane]) + sq[48 + lane];     // the missing column sum of sample `lane`
+        __builtin_amdgcn_wave_barrier();
+        // output number o = t of the side (as natac_background_edge):
+        //   right: m = o + 1, samples 512 + s for s <= o, OUT[s][o - s];  left: output x0 - (16 - o), samples s >= o, OUT[s][s - o]
+        // lane (k, o) adds the samples s = k, k + 4, k + 8, k + 12; the four partial sums are added in the order of k
+        double corr = 0.0, qc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sidx = k + 4 * q, ix = side ? t - sidx : sidx - t;
+            const double a = sc[sidx * EDGE_RS + max(ix, 0)], qq = sqt[sidx];
+            corr += ix >= 0 ? a : 0.0;
+            qc += ix >= 0 ? qq : 0.0;
+        }
+        sp[lane] = corr; sp[64 + lane] = qc;
+        __builtin_amdgcn_wave_barrier();
+        const int g = side ? x0 + TV + t : x0 - FFT_EXT + t;
+        if (k == 0 && g >= 0 && g < L) {
+            corr = ((sp[t] + sp[16 + t]) + sp[32 + t]) + sp[48 + t];
+            qc = ((sp[64 + t] + sp[80 + t]) + sp[96 + t]) + sp[112 + t];
+            const long long o = ob + g;
+            const double num = bnum[o] + corr, cv = bcov[o] + qc;
+            const double bb = (num * nuc_cov[o]) / cv;
+            bg[o] = bb;
+            norm[o] = raw[o] - bb;
+            bnum[o] = num;
+            bcov[o] = cv;
+        }
+    }
 }
 
 }  // namespace natac

@@ -18,16 +18,34 @@ static void launch_wg(int nt, size_t lds, const ChunkTable &ct, int2 *d_t, const
                        (int)(lds / 8));
 }
 
-// variant: 0 = the product kernel (one wave per workgroup); NW * 10 + SYNC = natac_background_fft_wg<NW, SYNC>
+// variant: 0 = the product kernel (one wave per workgroup), plain tiles; 1 = the same with extended tiles + natac_background_edge
+// where the library would use them; NW * 10 + SYNC = natac_background_fft_wg<NW, SYNC>
 float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const double *d_tw, const double *d_k, double *d_a, double *d_b,
               double *d_o1, double *d_o2, int reps, int variant = 0) {
     const int TV = FFT_N - v.W + 1;
     std::vector<int2> tiles;
-    for (int i = 0; i < nc; ++i) for (int x = 0; x < L; x += TV) tiles.push_back(make_int2(i, x));
+    std::vector<int> ext_list;
+    const int TVX = TV + 2 * FFT_EXT;
+    const bool ext = (variant == 1 || variant == 2) && ((L + TVX - 1) / TVX) * 11 <= ((L + TV - 1) / TV) * 10;
+    for (int i = 0; i < nc; ++i) {
+        if (ext) for (int x = 0; x < L; x += TVX) { ext_list.push_back((int)tiles.size()); tiles.push_back(make_int2(i, (x + FFT_EXT) | FFT_EXT_BIT)); }
+        else for (int x = 0; x < L; x += TV) tiles.push_back(make_int2(i, x));
+    }
     int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2)));
     CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
-    const int EW = FFT_N + 249, EWP = (EW + 1) & ~1;
-    const size_t lds = (size_t)(EWP + 2 * FFT_LA) * 8;
+    int *d_ext = nullptr; unsigned char *d_dir = nullptr; double *d_etab = nullptr, *d_mtab = nullptr, *d_swt = nullptr;
+    const int NJ = (v.R + 3) / 4, wdm = (int)bg_edgem_lds_doubles_per_wave(v.lower, v.upper);
+    if (ext) {
+        CK(hipMalloc(&d_ext, ext_list.size() * 4)); CK(hipMemcpy(d_ext, ext_list.data(), ext_list.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&d_dir, tiles.size()));
+        const int ne = v.R * 2 * FFT_EXT;
+        CK(hipMalloc(&d_etab, ne * 8));
+        hipLaunchKernelGGL(natac_fft_edge_table, dim3((ne + 255) / 256), dim3(256), 0, 0, v.mat, v.srow, v.R, v.W, d_etab);
+        CK(hipMalloc(&d_mtab, 2 * NJ * 64 * 8)); CK(hipMalloc(&d_swt, 4 * NJ * 8));
+        hipLaunchKernelGGL(natac_fft_edge_table_mfma, dim3((2 * NJ * 64 + 255) / 256), dim3(256), 0, 0, v.mat, v.srow, v.R, v.W, NJ, d_mtab, d_swt);
+    }
+    const size_t lds = bg_fft_lds_bytes(v.upper);
+    const int wd = (int)bg_edge_lds_doubles_per_wave(v.lower, v.upper), per_wg = EDGE_WAVES * EDGE_TPW;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     const int nt = (int)tiles.size();
@@ -41,14 +59,25 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
             case 80: launch_wg<8, false>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
             case 81: launch_wg<8, true>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
             default:
-                hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt);
+                hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt, d_dir, v.srow);
+                if (ext) {
+                    if (it == reps) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float m0; CK(hipEventElapsedTime(&m0, e0, e1)); printf("  transforms alone %.3f ms\n", m0); }
+                    if (variant == 2)
+                        hipLaunchKernelGGL(natac_background_edge_mfma, dim3(((int)ext_list.size() + EDGEM_WAVES - 1) / EDGEM_WAVES), dim3(64 * EDGEM_WAVES),
+                                           (size_t)wdm * EDGEM_WAVES * 8, 0, ct, d_t, d_ext, (int)ext_list.size(), d_dir, v, d_mtab, d_swt, NJ, d_a, d_b,
+                                           d_o1, d_o2, g_x1, g_x2, wdm);
+                    else
+                    hipLaunchKernelGGL(natac_background_edge, dim3(((int)ext_list.size() + per_wg - 1) / per_wg), dim3(64 * EDGE_WAVES),
+                                       (size_t)wd * EDGE_WAVES * 8, 0, ct, d_t, d_ext, (int)ext_list.size(), d_dir, v, d_etab, v.srow, d_a, d_b, d_o1, d_o2, g_x1,
+                                       g_x2, wd);
+                }
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (it > 0 && ms < best) best = ms;
     }
     CK(hipGetLastError());
-    printf("FFT variant=%d tiles=%zu lds=%zu  %.3f ms  %.1f Mbp/s\n", variant, tiles.size(), lds, best, (double)nc * L / best / 1e3);
+    printf("FFT variant=%d tiles=%zu (extended %zu) lds=%zu  %.3f ms  %.1f Mbp/s\n", variant, tiles.size(), ext_list.size(), lds, best, (double)nc * L / best / 1e3);
     CK(hipFree(d_t));
     return best;
 }
@@ -70,7 +99,8 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&d_bias, bias.size() * 8)); CK(hipMalloc(&d_vm, vm.size() * 8)); CK(hipMalloc(&d_srow, R * 8));
     CK(hipMalloc(&d_a, nbp * 8)); CK(hipMalloc(&d_b, nbp * 8)); CK(hipMalloc(&d_o1, nbp * 8)); CK(hipMalloc(&d_o2, nbp * 8));
     CK(hipMalloc(&d_p1, nbp * 8)); CK(hipMalloc(&d_p2, nbp * 8));
-    double *d_x1, *d_x2; CK(hipMalloc(&d_x1, nbp * 8)); CK(hipMalloc(&d_x2, nbp * 8)); g_x1 = d_x1; g_x2 = d_x2;
+    double *d_x1, *d_x2; CK(hipMalloc(&d_x1, nbp * 8)); CK(hipMalloc(&d_x2, nbp * 8));
+    CK(hipMalloc(&g_x1, nbp * 8)); CK(hipMalloc(&g_x2, nbp * 8));     // the FFT run's bnum / bcov (the direct kernel's stay in d_x1 / d_x2)
     CK(hipMemcpy(d_a, ncov.data(), nbp * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_b, raw.data(), nbp * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_len, len.data(), nc * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_foff, foff.data(), (nc + 1) * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_boff, boff.data(), (nc + 1) * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ooff, ooff.data(), (nc + 1) * 8, hipMemcpyHostToDevice));
@@ -127,6 +157,14 @@ int main(int argc, char **argv) {
         }
         printf("bg: max rel err %.3e (at %zu: %.17g vs %.17g)  max abs %.3e  nan-mismatch %zu\n", maxrel, worst, x[worst], y[worst], maxabs, bad);
         printf("sample: %.6g %.6g | %.6g %.6g | %.6g %.6g\n", x[0], y[0], x[391], y[391], x[392], y[392]);
+        const double *pa[3] = {d_p2, d_x1, d_x2}, *pb[3] = {d_o2, g_x1, g_x2};
+        const char *nm[3] = {"norm", "bnum", "bcov"};
+        for (int k = 0; k < 3 && !(argc > 4); ++k) {
+            CK(hipMemcpy(x.data(), pa[k], nbp * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), pb[k], nbp * 8, hipMemcpyDeviceToHost));
+            double mr = 0; size_t w = 0;
+            for (size_t i = 0; i < nbp; ++i) { const double r = fabs(x[i] - y[i]) / (fabs(x[i]) + (k ? 1e-300 : 1e-3)); if (!(r <= mr)) { mr = r; w = i; } }
+            printf("%s: max rel err %.3e (at %zu = base %zu: %.17g vs %.17g)\n", nm[k], mr, w, w % L, x[w], y[w]);
+        }
     }
     return 0;
 }
