@@ -46,11 +46,28 @@ FLOP_PER_BP_BG = 2 * 146 * 121   # fp64 flop per base of the background correlat
 # executed by the FFT kernel: 73 row pairs x 364 flop per lane (172 add + 72 mul + 60 fma as of round 4; round 5 folds the 1/sqrt2
 # of dft8 into FMAs -- 132 add + 44 mul + 100 fma, 276 instructions instead of 304 for the same arithmetic -- and keeps this count)
 # x 64 lanes per 392-base tile
-FLOP_PER_BP_BG_FFT = 73 * 364 * 64 / 392.0
+FLOP_PER_BP_BG_FFT = 73 * 364 * 64 / 392.0     # plain tiles; a run's own figure comes from its chunks' tilings (bg_executed_flop)
+FLOP_PER_TILE_BG_FFT = 73 * 364 * 64
+# the edge pass of an extended tile (natac_background_edge_mfma): per side 37 steps of one 16 x 16 x 4 fp64 MFMA (2,048 flop, half of
+# the 16 x 16 products are outputs nobody reads: executed, not useful) + per lane 2 multiplications, 1 subtraction, 1 FMA
+FLOP_PER_TILE_BG_EDGE = 2 * 37 * (2048 + 64 * 5)
+
+
+def bg_executed_flop(ctx, subs):
+    """fp64 operations the background stage executes on these chunks: tiles and extended tiles as the library cuts them (natac_bg_tiling)"""
+    flop, tiles, ext_tiles = 0, 0, 0
+    for sub in subs:
+        lens, counts = np.unique(np.asarray(sub.chunk_len), return_counts=True)
+        for Lc, k in zip(lens.tolist(), counts.tolist()):
+            nt, ex = ctx.bg_tiling(int(Lc))
+            tiles += nt * k
+            ext_tiles += nt * k if ex else 0
+    flop = tiles * FLOP_PER_TILE_BG_FFT + ext_tiles * FLOP_PER_TILE_BG_EDGE
+    return flop, tiles, ext_tiles
 KERNEL_LABEL = {"background": "natac_background_fft (dense bias x VMat correlation, fp64 FFT)",
                 "occ_mle": "natac_occ_gsum + natac_occ_decide (occupancy grid MLE)",
                 "candidates": "natac_peaks_chunk_reg + natac_candidates_paired (candidate search; LR / variance / z)"}
-KERNEL_SYMBOL = {"background": "natac_background_fft", "occ_mle": "natac_occ_", "candidates": "natac_candidates_paired"}
+KERNEL_SYMBOL = {"background": "natac_background_", "occ_mle": "natac_occ_", "candidates": "natac_candidates_paired"}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 H2H_TRACKS = ("T_NORM", "T_SMOOTH", "T_OCC", "T_OCC_LOWER", "T_OCC_UPPER")   # what `nucleoatac run` writes by default
@@ -599,6 +616,7 @@ def main():
     shard = ResidentShard(ctx, subs, recycle={"auto": "auto", "on": True, "off": False}[a.recycle])
     t_up = time.time() - t_up
     batches, recycle, last_n = shard.batches, shard.recycle, shard.last_n
+    bg_flop, bg_tiles, bg_ext_tiles = bg_executed_flop(ctx, subs)
     stages = bench_stages()
     n_cand = [0]
 
@@ -717,7 +735,7 @@ def main():
         bg_ms, bg_n = prof["background"]
         bg_avg_s = (bg_ms / max(1, bg_n)) / 1e3
         direct_tflops = FLOP_PER_BP_BG * bp_per_launch / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
-        fft_tflops = FLOP_PER_BP_BG_FFT * bp_per_launch / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
+        fft_tflops = bg_flop / launches_per_step / bg_avg_s / 1e12 if bg_avg_s > 0 else 0.0
         step_gbs = ALG_BYTES_PER_BP[a.workload] * my_bp / (dt / a.steps) / 1e9
         valu = pmc_valu_issue() if a.workload == "cfg3" else None
         dom_issue = None
@@ -771,6 +789,9 @@ def main():
                          "background_fp64": {"avg_launch_ms": round(bg_avg_s * 1e3, 3),
                                              "direct_equivalent_tflops": round(direct_tflops, 2),
                                              "executed_tflops": round(fft_tflops, 2), "peak": FP64_PEAK_TFLOPS,
+                                             "executed_flop_per_bp": round(bg_flop / max(1, my_bp), 1),
+                                             "tiles": int(bg_tiles), "extended_tiles": int(bg_ext_tiles),
+                                             "kernels": "natac_background_fft + natac_background_edge_mfma (one timed region)",
                                              "unit": "TFLOP/s", "frac_executed": round(fft_tflops / FP64_PEAK_TFLOPS, 4)}},
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
             "per_rank": per_rank, "control_plane": a.dist_backend if dist is not None else None,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "natac_batch_create_from_seq": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i32, _i32, _pp]),
     "natac_batch_free": (None, [_vp]),
     "natac_batch_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "natac_bg_tiling": (C.c_int, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "natac_batch_release_outputs": (C.c_int, [_vp]),
     "natac_run_nuc": (C.c_int, [_vp, _f64]),
     "natac_run_occ": (C.c_int, [_vp]),

@@ -65,9 +65,8 @@ struct natac_ctx {
     bool vmat_zero = false, srow_zero = false;
     long long model_gen = 0;         // bumped by natac_set_vmat / natac_set_sizes
     // FFT background path: twiddles (once) and template spectra (per V-plot)
-    double *d_fft_tw = nullptr, *d_fft_k = nullptr, *d_fft_etab = nullptr;   // etab: natac_fft_edge_table (extended tiles)
-    double *d_fft_mtab = nullptr, *d_fft_swt = nullptr;   // natac_fft_edge_table_mfma
-    bool bg_edge_mfma = true;
+    double *d_fft_tw = nullptr, *d_fft_k = nullptr;
+    double *d_fft_mtab = nullptr, *d_fft_swt = nullptr;   // natac_fft_edge_table_mfma (extended tiles)
     bool bg_ext = true;              // NATAC_BG_EXT=0: no extended FFT tiles (A-B timing / validation of the edge pass)
     bool fft_dirty = true, bg_direct = false, occ_ordered = true, occ_zero_nfr = false;
     std::vector<double> h_sizes;
@@ -128,7 +127,7 @@ struct natac_batch {
     int n_tiles1k = 0;
     bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
-    int *d_ext_list = nullptr;                 // indices of the extended tiles in d_tiles_bg (natac_background_edge)
+    int *d_ext_list = nullptr;                 // indices of the extended tiles in d_tiles_bg (natac_background_edge_mfma)
     unsigned char *d_tile_direct = nullptr;    // [n_tiles_bg] 1 = natac_background_fft evaluated the tile by direct summation
     int n_ext = 0;
     long long *d_tile256_first = nullptr;   // [nc + 1] first 256-base tile of every chunk (the candidates' way into d_ranges256)
@@ -656,8 +655,6 @@ int natac_ctx_create(int device_id, natac_ctx **out) {
         c->bg_direct = e && e[0] == '1';
         e = getenv("NATAC_BG_EXT");
         c->bg_ext = !(e && e[0] == '0');
-        e = getenv("NATAC_BG_EDGE_MFMA");
-        c->bg_edge_mfma = !(e && e[0] == '0');
         e = getenv("NATAC_OCC_GENERAL");   // NATAC_OCC_GENERAL=1: every tile through natac_occ_mle (validation / A-B timing)
         c->occ_force_general = e && e[0] == '1';
         e = getenv("NATAC_OCC_ORDER");     // NATAC_OCC_ORDER=0: natac_occ_decide visits its tiles in chunk order (A-B timing of the ordering)
@@ -675,7 +672,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     dev_free(c->d_vmat); dev_free(c->d_vmat_pad); dev_free(c->d_srow); dev_free(c->d_sizes); dev_free(c->d_lrt);
     dev_free(c->d_nucp); dev_free(c->d_nfrp); dev_free(c->d_alphas);
     dev_free(c->d_win_nuc); dev_free(c->d_win_occ); dev_free(c->d_wb_occ);
-    dev_free(c->d_fft_tw); dev_free(c->d_fft_k); dev_free(c->d_fft_etab); dev_free(c->d_fft_mtab); dev_free(c->d_fft_swt);
+    dev_free(c->d_fft_tw); dev_free(c->d_fft_k); dev_free(c->d_fft_mtab); dev_free(c->d_fft_swt);
     dev_free(c->d_occ_q4); dev_free(c->d_occ_rho);
     dev_free(c->d_p10); dev_free(c->d_crc);
     if (c->t0) (void)hipEventDestroy(c->t0);
@@ -882,19 +879,34 @@ static bool fft_bg_applicable(const natac_ctx *c) {
     return natac::bg_fft_lds_bytes(c->vupper) <= 64 * 1024;
 }
 
-// Extended tiles (natac_fft_bg.hpp): FFT_EXT more outputs on each side of a tile, finished by natac_background_edge.  The edge pass
+// Extended tiles (natac_fft_bg.hpp): FFT_EXT more outputs on each side of a tile, finished by natac_background_edge_mfma.  The edge pass
 // costs ~9 % of a tile's transforms, so a chunk is tiled that way only where that buys at least 10 % of its tiles: 2,120 bases take 5
 // tiles instead of 6, 10,120 bases 24 instead of 26 (not enough: plain tiles).  The choice depends on the chunk's length alone --
 // results do not depend on the batch a chunk is in.
 static bool bg_ext_possible(const natac_ctx *c) {
-    if (!c->bg_ext || c->W < 2 * natac::FFT_EXT || natac::bg_edge_wlen(c->vlower, c->vupper) > natac::EDGE_WLMAX) return false;
-    return natac::bg_edge_lds_doubles_per_wave(c->vlower, c->vupper) * natac::EDGE_WAVES * sizeof(double) <= 64 * 1024;
+    if (!c->bg_ext || c->W < 2 * natac::FFT_EXT || natac::bg_edgem_wlen(c->vlower, c->vupper) > natac::EDGE_WLMAX + 2 * natac::FFT_EXT) return false;
+    return natac::bg_edgem_lds_doubles_per_wave(c->vlower, c->vupper) * natac::EDGEM_WAVES * sizeof(double) <= 64 * 1024;
 }
 static bool bg_chunk_extended(int L, int TV) {
     const int TVX = TV + 2 * natac::FFT_EXT;
     const long long n_std = (L + TV - 1) / TV, n_ext = (L + TVX - 1) / TVX;
     return n_ext * 11 <= n_std * 10;
 }
+int natac_bg_tiling(natac_ctx *c, int32_t chunk_len, int32_t *n_tiles, int32_t *extended) {
+    if (!c || chunk_len <= 0) return fail(NATAC_E_ARG, "natac_bg_tiling: context and a positive chunk length");
+    if (!c->d_vmat) return fail(NATAC_E_STATE, "natac_bg_tiling: set the V-plot first");
+    int nt = 0, ex = 0;
+    if (fft_bg_applicable(c)) {
+        const int TV = natac::FFT_N - c->W + 1;
+        ex = bg_ext_possible(c) && bg_chunk_extended(chunk_len, TV);
+        const int w = ex ? TV + 2 * natac::FFT_EXT : TV;
+        nt = (chunk_len + w - 1) / w;
+    }
+    if (n_tiles) *n_tiles = nt;
+    if (extended) *extended = ex;
+    return NATAC_OK;
+}
+
 static int build_tiles_bg(natac_batch *b, int TV, bool ext_ok) {
     std::vector<int2> tiles;
     std::vector<int> ext_list;
@@ -944,12 +956,7 @@ static int ensure_fft(natac_ctx *c) {
     const int npair = (c->R + 1) / 2;
     if ((rc = dev_alloc(&c->d_fft_k, (size_t)npair * 2 * natac::FFT_N))) return rc;
     hipLaunchKernelGGL(natac_fft_template, dim3(npair), dim3(64), 0, c->stream, c->d_vmat, c->d_srow, c->R, c->W, c->d_fft_tw, c->d_fft_k);
-    dev_free(c->d_fft_etab);
-    c->d_fft_etab = nullptr;
     if (c->W >= natac::FFT_EXT) {
-        const int ne = c->R * 2 * natac::FFT_EXT;
-        if ((rc = dev_alloc(&c->d_fft_etab, (size_t)ne))) return rc;
-        hipLaunchKernelGGL(natac_fft_edge_table, dim3((ne + 255) / 256), dim3(256), 0, c->stream, c->d_vmat, c->d_srow, c->R, c->W, c->d_fft_etab);
         dev_free(c->d_fft_mtab); dev_free(c->d_fft_swt);
         c->d_fft_mtab = c->d_fft_swt = nullptr;
         const int NJ = (c->R + 3) / 4;
@@ -1264,19 +1271,12 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
         hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
                            c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
                            b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg, b->d_tile_direct, vm.srow);
-        if (b->n_ext && c->bg_edge_mfma) {     // the FFT_EXT outputs on each side of every extended tile
+        if (b->n_ext) {     // the FFT_EXT outputs on each side of every extended tile
             const int wd = (int)bg_edgem_lds_doubles_per_wave(vm.lower, vm.upper);
             hipLaunchKernelGGL(natac_background_edge_mfma, dim3((b->n_ext + EDGEM_WAVES - 1) / EDGEM_WAVES), dim3(64 * EDGEM_WAVES),
                                (size_t)wd * EDGEM_WAVES * sizeof(double), c->stream, ct, b->d_tiles_bg, b->d_ext_list, b->n_ext,
                                b->d_tile_direct, vm, c->d_fft_mtab, c->d_fft_swt, (c->R + 3) / 4, b->d_track[NATAC_T_NUC_COV],
                                b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND], b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, wd);
-        } else if (b->n_ext) {
-            const int wd = (int)bg_edge_lds_doubles_per_wave(vm.lower, vm.upper);
-            const int per_wg = EDGE_WAVES * EDGE_TPW;
-            hipLaunchKernelGGL(natac_background_edge, dim3((b->n_ext + per_wg - 1) / per_wg), dim3(64 * EDGE_WAVES),
-                               (size_t)wd * EDGE_WAVES * sizeof(double), c->stream, ct, b->d_tiles_bg, b->d_ext_list, b->n_ext,
-                               b->d_tile_direct, vm, c->d_fft_etab, vm.srow, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW],
-                               b->d_track[NATAC_T_BACKGROUND], b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, wd);
         }
     } else if (fast) {
         switch (b->bgG) {

@@ -25,7 +25,7 @@ constexpr int FFT_LA = 576;   // layout A: p + 8 * (p >> 6)
 constexpr int FFT_LB = 520;   // layout B: (p & 7) * 65 + (p >> 3)
 // Extended tiles (round 5).  A 512-point circular correlation holds, besides its TV = 512 - W + 1 exact outputs, FFT_EXT outputs on each
 // side that are wrong by a few terms only: output TV - 1 + m (m = 1..16) wraps its last m template columns onto the tile's first
-// samples, output -k (circular index 512 - k) its first k columns onto the tile's last samples.  natac_background_edge replaces those
+// samples, output -k (circular index 512 - k) its first k columns onto the tile's last samples.  natac_background_edge_mfma replaces those
 // m (k) wrapped products per row by the true ones -- 2 x 136 multiply-adds per row and tile, summed directly -- so a tile yields
 // TV + 2 FFT_EXT outputs: a 2,120-base chunk takes 5 transforms per row pair instead of 6.  Which chunks are tiled that way is the
 // host's decision (bg_tiles_build: only where the tile count drops by more than the edge pass costs); the flag travels in tiles[].y.
@@ -251,7 +251,7 @@ constexpr double FFT_MAX_RANGE = 3e4;   // real Tn5 PWM log-bias spans <= 8.7 lo
 // one tile of the background through FFTs; `smem` = this wave's LDS (EWP + 2 FFT_LA doubles), `t` = (chunk, x0).
 // TW_LOADED: the caller holds the per-lane twiddles in `tww` (persistent kernel); otherwise they are loaded here, after the
 // conditioning test, exactly where the one-tile-per-workgroup kernel always loaded them.
-template <bool TW_LOADED, bool SYNC = false>
+template <bool TW_LOADED>
 __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, const VMatDev &vm, const double *__restrict__ tw,
                                             const double *__restrict__ ktab, const double *__restrict__ nuc_cov,
                                             const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
@@ -260,7 +260,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
                                             const double *__restrict__ srow_s = nullptr) {
     const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
-    const int ext = (t.y & FFT_EXT_BIT) ? FFT_EXT : 0;   // extended tile: FFT_EXT more outputs on each side, finished by natac_background_edge
+    const int ext = (t.y & FFT_EXT_BIT) ? FFT_EXT : 0;   // extended tile: FFT_EXT more outputs on each side, finished by natac_background_edge_mfma
     const int EW = FFT_N + A + Bh + 2 * ext, EWP = (FFT_N + A + Bh + 2 * FFT_EXT + 1) & ~1;
     double *Et = smem;
     double2 *ca = (double2 *)(Et + EWP), *cb = ca;     // complex scratch of the transposes; layouts A and B are never live together
@@ -374,7 +374,6 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
 #endif
             const double *k = ktab + (size_t)pair * 2 * FFT_N;
             double kr[8], ki[8], re[8], im[8];
-            if (SYNC) __builtin_amdgcn_s_barrier();      // the waves of a workgroup walk the row pairs in step: one L2 fetch of a pair's spectrum per CU
 #pragma unroll
             for (int m = 0; m < 8; ++m) { kr[m] = k[m * 64 + lane]; ki[m] = k[FFT_N + m * 64 + lane]; }
             __builtin_amdgcn_sched_barrier(0);
@@ -531,7 +530,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
                 norm[o] = raw[o] - b;
             }
             bnum[o] = num;           // sum B V and sum B of the window at this base: reused by the candidate statistics
-            bcov[o] = cv;            // (right edge of an extended tile: both without the samples past the tile, see natac_background_edge)
+            bcov[o] = cv;            // (right edge of an extended tile: both without the samples past the tile, see natac_background_edge_mfma)
         } else if (j == 7 && u >= FFT_N - ext && x0 - (FFT_N - u) < L) {
             const long long o = ob + (x0 - (FFT_N - u));
             bnum[o] = accr[j] * (1.0 / FFT_N);
@@ -562,201 +561,20 @@ __host__ __device__ inline size_t bg_fft_lds_bytes(int upper) {
     return ((size_t)((EWX + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
 }
 
-// ---- the edge pass of extended tiles -------------------------------------------------------------------------------------------
-// etab[r][side][i], i < FFT_EXT: the template columns an edge output can wrap, weighted like the spectra (s_r V_r[c]):
-//   side 0 (left edge, output x0 - k):        s_r V_r[i]          -- sample x0 - t' meets column k - t'
-//   side 1 (right edge, output TV - 1 + m):   s_r V_r[W - 1 - i]  -- sample 512 + t meets column W - m + t = W - 1 - (m - 1 - t)
-__global__ void natac_fft_edge_table(const double *__restrict__ vmat, const double *__restrict__ srow, int R, int W, double *__restrict__ etab) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * 2 * FFT_EXT) return;
-    const int r = i / (2 * FFT_EXT), side = (i / FFT_EXT) & 1, c = i % FFT_EXT;
-    etab[i] = srow[r] * vmat[r * W + (side ? W - 1 - c : c)];
-}
+constexpr int EDGE_RS = FFT_EXT + 1;       // stride of a sample's row in the reduction scratch
+constexpr int EDGE_WLMAX = 128;            // longest window (largest row offset + FFT_EXT) the edge pass stages
 
-// window length of the edge pass: the left (right) factors of the FFT_EXT samples of one group over all rows
-__host__ __device__ inline int bg_edge_wlen(int lower, int upper) {
-    const int A = (upper - 2) >> 1, Bh = (upper - 1) >> 1;
-    const int dl = A - ((lower - 1) >> 1), dr = Bh - (lower >> 1);
-    const int wl = (dl > dr ? dl : dr) + FFT_EXT;
-    return wl + ((12 - wl % 8) % 8);     // = 4 (mod 8): the four tiles of a wave then sit 32 banks apart (conflict-free ds_read_b64)
-}
-constexpr int EDGE_TPW = 64 / FFT_EXT;     // tiles per wave
-constexpr int EDGE_WAVES = 4;              // waves per workgroup
-constexpr int EDGE_RS = FFT_EXT + 1;       // stride of a lane's partial sums in the reduction scratch
-constexpr int EDGE_WLMAX = 128;            // longest window the edge pass stages (bg_ext_possible)
-__host__ __device__ inline size_t bg_edge_lds_doubles_per_wave(int lower, int upper) {
-    const int w = 4 * EDGE_TPW * bg_edge_wlen(lower, upper), rdx = 64 * EDGE_RS;
-    return (size_t)(w > rdx ? w : rdx);
-}
-
-// One wave takes EDGE_TPW extended tiles; lane = (tile, t).  Per side the lane owns ONE sample outside the tile (`out`) and the sample
-// inside that the circular transform used in its place (`in`): D_r = P_r[out] - P_r[in] per row; every output that wraps this sample
-// receives D_r times a template column that depends on the output's distance from the lane's sample only, i.e. on a wave-uniform
-// value per accumulator (scalar operand): acc[i] += D_r etab[r][side][i].  The column sums' missing samples (sum_r s_r P_r[out]) come
-// out of the same products.  A second phase adds the lanes' accumulators per output, in a fixed order, and finishes the FFT_EXT
-// outputs of that side: num = the transform's value (left in bnum) + the correction, likewise the window sum (bcov), then
-// background and normalised signal exactly as natac_background_fft forms them.
-// Tiles evaluated by direct summation (tile_direct) have their edge outputs already.
-__global__ void __launch_bounds__(64 * EDGE_WAVES) natac_background_edge(ChunkTable ct, const int2 *__restrict__ tiles, const int *__restrict__ ext_list,
-                                                                          int n_ext, const unsigned char *__restrict__ tile_direct, VMatDev vm,
-                                                                          const double *__restrict__ etab, const double *__restrict__ srow,
-                                                                          const double *__restrict__ nuc_cov,
-                                                                          const double *__restrict__ raw, double *__restrict__ bg,
-                                                                          double *__restrict__ norm, double *__restrict__ bnum,
-                                                                          double *__restrict__ bcov, int wave_doubles) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *ws = smem + (size_t)wave * wave_doubles;
-    const int tl = lane / FFT_EXT, t = lane % FFT_EXT;
-    const int slot = (blockIdx.x * EDGE_WAVES + wave) * EDGE_TPW + tl;
-    const bool have = slot < n_ext;
-    const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
-    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
-    const int hl0 = floor_half(vm.lower - 1), hr0 = floor_half(vm.lower);
-    const int WL = bg_edge_wlen(vm.lower, vm.upper);
-    int chunk = 0, x0 = 0, L = 0, need = 0, nb = 0, j0 = 0;
-    bool live = false;
-    const double *b = nullptr;
-    if (have) {
-        const int ti = ext_list[slot];
-        const int2 tt = tiles[ti];
-        chunk = tt.x; x0 = tt.y & (FFT_EXT_BIT - 1);
-        L = ct.chunk_len[chunk];
-        live = !tile_direct[ti];
-        b = ct.bias ? ct.ebias + ct.bias_off[chunk] : nullptr;
-        nb = L + ct.bias_left + ct.bias_right;
-        j0 = x0 - FFT_EXT - HW - A + ct.bias_left;                  // the extended tile's window starts FFT_EXT samples early
-        need = bg_tile_need(TV, W, A, Bh, L, x0, FFT_EXT);
-    }
-    // entry e of the tile's exp(bias) window exactly as natac_background_fft staged it: zero from `need` on and outside the chunk's
-    // bias slice.  [elo, ehi) = the entries that are read; the load itself is unconditional (clamped index), all of a side's in flight
-    const int elo = b ? max(0, -j0) : 0, ehi = b ? min(need, nb - j0) : 0;
-    const double *bj = b ? b + j0 : nullptr;
-    auto E = [&](int e) -> double {
-        double v = (e >= 0 && e < need) ? 1.0 : 0.0;         // no bias track: exp(0)
-        if (bj) {
-            const double x = bj[min(max(e, elo), max(ehi, elo + 1) - 1)];
-            v = (e >= elo && e < ehi) ? x : 0.0;
-        }
-        return v;
-    };
-    const long long ob = have ? ct.out_off[chunk] : 0;
-    double *wl_o = ws + (size_t)(tl * 4 + 0) * WL, *wr_o = ws + (size_t)(tl * 4 + 1) * WL;
-    double *wl_i = ws + (size_t)(tl * 4 + 2) * WL, *wr_i = ws + (size_t)(tl * 4 + 3) * WL;
-#pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
-        // samples (tile coordinates): left edge  out = -FFT_EXT + t, in = 512 - FFT_EXT + t;  right edge  out = 512 + t, in = t
-        const int uo = side ? FFT_N : -FFT_EXT, ui = side ? 0 : FFT_N - FFT_EXT;
-        // windows: left factor of sample u, row i: entry FFT_EXT + A - fh(i - 1) + u -> wl[(A - hl) + t'] with wl[w] = E(FFT_EXT + u0 + w);
-        //          right factor: entry FFT_EXT + A + fh(i) + u -> wr[(hr - hr0) + t'] with wr[w] = E(FFT_EXT + A + hr0 + u0 + w)
-        __builtin_amdgcn_wave_barrier();
-        {
-            constexpr int NS = EDGE_WLMAX / FFT_EXT;
-            double s0[NS], s1[NS], s2[NS], s3[NS];
-#pragma unroll
-            for (int n = 0; n < NS; ++n) {
-                const int w = t + FFT_EXT * n;
-                if (FFT_EXT * n >= WL) { s0[n] = s1[n] = s2[n] = s3[n] = 0.0; continue; }      // wave-uniform
-                s0[n] = E(FFT_EXT + uo + w);
-                s1[n] = E(FFT_EXT + A + hr0 + uo + w);
-                s2[n] = E(FFT_EXT + ui + w);
-                s3[n] = E(FFT_EXT + A + hr0 + ui + w);
-            }
-#pragma unroll
-            for (int n = 0; n < NS; ++n) {
-                const int w = t + FFT_EXT * n;
-                if (w < WL) { wl_o[w] = s0[n]; wr_o[w] = s1[n]; wl_i[w] = s2[n]; wr_i[w] = s3[n]; }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        double acc[FFT_EXT], qx = 0.0;
-#pragma unroll
-        for (int i = 0; i < FFT_EXT; ++i) acc[i] = 0.0;
-        // rows two at a time, the operands of the next row requested before the current row's arithmetic (LDS values, the row's
-        // weight and its FFT_EXT template columns -- wave-uniform, scalar loads)
-        struct RowOps { double lo, ro, li, ri, s; double v[FFT_EXT]; };
-        auto fetch = [&](RowOps &o, int r) {
-            const int i = vm.lower + r;
-            const int dl = A - floor_half(i - 1), dr = floor_half(i) - hr0;       // wave-uniform
-            o.lo = wl_o[dl + t]; o.ro = wr_o[dr + t]; o.li = wl_i[dl + t]; o.ri = wr_i[dr + t];
-            o.s = srow[r];            // (= vm.srow, as a restrict argument: a scalar load, not a vector load the arithmetic then waits for)
-            const double *__restrict__ v = etab + (size_t)(r * 2 + side) * FFT_EXT;
-#pragma unroll
-            for (int k = 0; k < FFT_EXT; ++k) o.v[k] = v[k];
-        };
-        auto apply = [&](const RowOps &o) {
-            const double po = o.lo * o.ro, pi = o.li * o.ri;
-            const double d = po - pi;
-            qx = fma(o.s, po, qx);
-#pragma unroll
-            for (int k = 0; k < FFT_EXT; ++k) acc[k] = fma(d, o.v[k], acc[k]);
-        };
-        RowOps oa, ob2;
-        fetch(oa, 0);
-        int r = 0;
-        for (; r + 2 <= vm.R; r += 2) {
-            fetch(ob2, r + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            apply(oa);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(oa, min(r + 2, vm.R - 1));
-            __builtin_amdgcn_sched_barrier(0);
-            apply(ob2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (r < vm.R) apply(oa);
-        // reduction scratch (the windows are dead): [lane][EDGE_RS] = acc[0..15], qx
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < FFT_EXT; ++k) ws[lane * EDGE_RS + k] = acc[k];
-        ws[lane * EDGE_RS + FFT_EXT] = qx;
-        __builtin_amdgcn_wave_barrier();
-        // this lane finishes output number t of the side:
-        //   right: m = t + 1, samples 512 + s for s < m, accumulator m - 1 - s of lane s
-        //   left:  k = FFT_EXT - t (output x0 - k), samples -t' for t' <= k i.e. lanes s = FFT_EXT - t' >= t, accumulator k - t' = s - t
-        double corr = 0.0, qc = 0.0;
-        const double *rs = ws + (size_t)(tl * FFT_EXT) * EDGE_RS;
-#pragma unroll
-        for (int s = 0; s < FFT_EXT; ++s) {      // fixed order; lanes the output does not reach add + 0.0
-            const int ix = side ? t - s : s - t;
-            const double a = rs[s * EDGE_RS + max(ix, 0)], qq = rs[s * EDGE_RS + FFT_EXT];
-            corr += ix >= 0 ? a : 0.0;
-            qc += ix >= 0 ? qq : 0.0;
-        }
-        const int g = side ? x0 + TV + t : x0 - FFT_EXT + t;
-        if (live && g >= 0 && g < L) {
-            const long long o = ob + g;
-            const double num = bnum[o] + corr, cv = bcov[o] + qc;
-            const double bb = (num * nuc_cov[o]) / cv;
-            bg[o] = bb;
-            norm[o] = raw[o] - bb;
-            bnum[o] = num;
-            bcov[o] = cv;
-        }
-    }
-}
-
-// experiment (tools/test_fft_bg.hip): NW waves per workgroup, one tile each, optionally stepping through the row pairs together
-template <int NW, bool SYNC>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) natac_background_fft_wg(
-    ChunkTable ct, const int2 *__restrict__ tiles, VMatDev vm, const double *__restrict__ tw, const double *__restrict__ ktab,
-    const double *__restrict__ nuc_cov, const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
-    double *__restrict__ bnum, double *__restrict__ bcov, unsigned n_tiles, int wave_doubles) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned ti = blockIdx.x * NW + wave;
-    if (ti >= n_tiles) return;
-    FftTwiddles tww;
-    bg_fft_tile<false, SYNC>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem + (size_t)wave * wave_doubles, tww, lane, nullptr, ti,
-                             vm.srow);
-}
-
-
-// ---- the edge pass as a small matrix product (the one place of this library where the matrix pipe fits) ------------------------------
-// Per tile and side the corrections are OUT[t][i] = sum_r D_r[t] C_r[i]: D = the product differences of the side's 16 samples (per-lane
-// data), C = 16 template columns per row.  As an outer product on the vector pipe (natac_background_edge above) every lane needs the 16
-// C_r[i] of every row as uniform operands -- 146 x 2 x 128 bytes through the scalar cache per wave, and the counters show the waves
-// waiting on it for half of their time.  v_mfma_f64_16x16x4_f64 takes BOTH operands distributed over the lanes:
+// ---- the edge pass of extended tiles: a small matrix product (the one place of this library where the matrix pipe fits) --------------
+// Side 0 = left edge (outputs x0 - 16 .. x0 - 1), side 1 = right edge (outputs x0 + TV .. x0 + TV + 15).  Sample s of a side (lane
+// t = s): the sample outside the tile that the outputs need (`out`: -16 + s on the left, 512 + s on the right) and the sample inside
+// that the circular transform used in its place (`in`: 496 + s, s).  D_r[s] = P_r[out] - P_r[in] per row; output number o of the side
+// is short of  sum_r sum_s D_r[s] C_r[i]  with i = the distance between output and sample (right: o - s for s <= o; left: s - o for
+// s >= o) and C_r[i] = s_r V_r[W - 1 - i] (right), s_r V_r[i] (left) -- the template column that sample meets -- and its window sum
+// of  sum_r s_r P_r[out]  over the same samples.  So per tile and side OUT[s][i] = sum_r D_r[s] C_r[i], a 16 x R by R x 16 product,
+// and the outputs are sums along its anti-diagonals.  Round 5 built this first as an outer product on the vector pipe (every lane
+// needs the 16 C_r[i] of every row as uniform operands: 146 x 2 x 128 bytes through the scalar cache per wave, the counters showed
+// the waves waiting on it for half of their time: 0.78 ms per 100 k tiles).  v_mfma_f64_16x16x4_f64 takes BOTH operands distributed
+// over the lanes (0.57 ms):
 // A[t = lane & 15][k = lane >> 4] = D of row 4 j + k, B[k][i = lane & 15] = one coalesced 512-byte load of the table per step; a tile
 // and side is ceil(R / 4) instructions and every D is formed once.  fp64 MFMA has no rate advantage over fp64 FMAs on gfx950
 // (profiles/r1/probe_fp64_mfma_vs_valu.txt); what it buys here is operand delivery.
@@ -891,7 +709,7 @@ __global__ void __launch_bounds__(64 * EDGEM_WAVES) __attribute__((amdgpu_waves_
         __builtin_amdgcn_wave_barrier();
         if (lane < FFT_EXT) sqt[lane] = ((sq[lane] + sq[16 + lane]) + sq[32 + lane]) + sq[48 + lane];     // the missing column sum of sample `lane`
         __builtin_amdgcn_wave_barrier();
-        // output number o = t of the side (as natac_background_edge):
+        // output number o = t of the side:
         //   right: m = o + 1, samples 512 + s for s <= o, OUT[s][o - s];  left: output x0 - (16 - o), samples s >= o, OUT[s][s - o]
         // lane (k, o) adds the samples s = k, k + 4, k + 8, k + 12; the four partial sums are added in the order of k
         double corr = 0.0, qc = 0.0;

@@ -177,6 +177,12 @@ class Context(object):
         L.check(self._lib.natac_set_vmat(self._h, _ptr(mat), int(lower), int(upper), mat.shape[1] // 2))
         self.vmat_shape = mat.shape
 
+    def bg_tiling(self, chunk_len):
+        """(tiles, extended) of the background stage for a chunk of this length with the V-plot that is set (natac_bg_tiling)."""
+        nt, ex = C.c_int32(0), C.c_int32(0)
+        L.check(self._lib.natac_bg_tiling(self._h, int(chunk_len), C.byref(nt), C.byref(ex)))
+        return nt.value, bool(ex.value)
+
     def set_sizes(self, sizes):
         """global insert-size distribution over [0, len(sizes)) (pyatac/chunkmat2d.py:154-156)."""
         sizes = _f64(sizes)

@@ -9,67 +9,43 @@ using namespace natac;
 static double *g_x1 = nullptr, *g_x2 = nullptr;   // the kernels' bnum / bcov outputs
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int NW, bool SYNC>
-static void launch_wg(int nt, size_t lds, const ChunkTable &ct, int2 *d_t, const VMatDev &v, const double *d_tw, const double *d_k, double *d_a,
-                      double *d_b, double *d_o1, double *d_o2) {
-    auto kp = natac_background_fft_wg<NW, SYNC>;
-    CK(hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NW * lds)));
-    hipLaunchKernelGGL(kp, dim3((nt + NW - 1) / NW), dim3(64 * NW), NW * lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt,
-                       (int)(lds / 8));
-}
-
-// variant: 0 = the product kernel (one wave per workgroup), plain tiles; 1 = the same with extended tiles + natac_background_edge
-// where the library would use them; NW * 10 + SYNC = natac_background_fft_wg<NW, SYNC>
+// variant: 0 = the product kernel (one wave per workgroup), plain tiles; 1 = the same with extended tiles + natac_background_edge_mfma
+// where the library would use them.  (Round 5's multi-wave workgroup variants natac_background_fft_wg<NW, SYNC> -- measured slower,
+// profiles/r5/fft_hfold_and_multiwave_workgroups.txt -- left the sources with commit 8c075d2's successor.)
 float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const double *d_tw, const double *d_k, double *d_a, double *d_b,
               double *d_o1, double *d_o2, int reps, int variant = 0) {
     const int TV = FFT_N - v.W + 1;
     std::vector<int2> tiles;
     std::vector<int> ext_list;
     const int TVX = TV + 2 * FFT_EXT;
-    const bool ext = (variant == 1 || variant == 2) && ((L + TVX - 1) / TVX) * 11 <= ((L + TV - 1) / TV) * 10;
+    const bool ext = variant == 1 && ((L + TVX - 1) / TVX) * 11 <= ((L + TV - 1) / TV) * 10;
     for (int i = 0; i < nc; ++i) {
         if (ext) for (int x = 0; x < L; x += TVX) { ext_list.push_back((int)tiles.size()); tiles.push_back(make_int2(i, (x + FFT_EXT) | FFT_EXT_BIT)); }
         else for (int x = 0; x < L; x += TV) tiles.push_back(make_int2(i, x));
     }
     int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2)));
     CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
-    int *d_ext = nullptr; unsigned char *d_dir = nullptr; double *d_etab = nullptr, *d_mtab = nullptr, *d_swt = nullptr;
+    int *d_ext = nullptr; unsigned char *d_dir = nullptr; double *d_mtab = nullptr, *d_swt = nullptr;
     const int NJ = (v.R + 3) / 4, wdm = (int)bg_edgem_lds_doubles_per_wave(v.lower, v.upper);
     if (ext) {
         CK(hipMalloc(&d_ext, ext_list.size() * 4)); CK(hipMemcpy(d_ext, ext_list.data(), ext_list.size() * 4, hipMemcpyHostToDevice));
         CK(hipMalloc(&d_dir, tiles.size()));
-        const int ne = v.R * 2 * FFT_EXT;
-        CK(hipMalloc(&d_etab, ne * 8));
-        hipLaunchKernelGGL(natac_fft_edge_table, dim3((ne + 255) / 256), dim3(256), 0, 0, v.mat, v.srow, v.R, v.W, d_etab);
         CK(hipMalloc(&d_mtab, 2 * NJ * 64 * 8)); CK(hipMalloc(&d_swt, 4 * NJ * 8));
         hipLaunchKernelGGL(natac_fft_edge_table_mfma, dim3((2 * NJ * 64 + 255) / 256), dim3(256), 0, 0, v.mat, v.srow, v.R, v.W, NJ, d_mtab, d_swt);
     }
     const size_t lds = bg_fft_lds_bytes(v.upper);
-    const int wd = (int)bg_edge_lds_doubles_per_wave(v.lower, v.upper), per_wg = EDGE_WAVES * EDGE_TPW;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     const int nt = (int)tiles.size();
     for (int it = 0; it < reps + 1; ++it) {
         CK(hipEventRecord(e0));
-        switch (variant) {
-            case 20: launch_wg<2, false>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
-            case 21: launch_wg<2, true>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
-            case 40: launch_wg<4, false>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
-            case 41: launch_wg<4, true>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
-            case 80: launch_wg<8, false>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
-            case 81: launch_wg<8, true>(nt, lds, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2); break;
-            default:
+        {
                 hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt, d_dir, v.srow);
                 if (ext) {
                     if (it == reps) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float m0; CK(hipEventElapsedTime(&m0, e0, e1)); printf("  transforms alone %.3f ms\n", m0); }
-                    if (variant == 2)
-                        hipLaunchKernelGGL(natac_background_edge_mfma, dim3(((int)ext_list.size() + EDGEM_WAVES - 1) / EDGEM_WAVES), dim3(64 * EDGEM_WAVES),
-                                           (size_t)wdm * EDGEM_WAVES * 8, 0, ct, d_t, d_ext, (int)ext_list.size(), d_dir, v, d_mtab, d_swt, NJ, d_a, d_b,
-                                           d_o1, d_o2, g_x1, g_x2, wdm);
-                    else
-                    hipLaunchKernelGGL(natac_background_edge, dim3(((int)ext_list.size() + per_wg - 1) / per_wg), dim3(64 * EDGE_WAVES),
-                                       (size_t)wd * EDGE_WAVES * 8, 0, ct, d_t, d_ext, (int)ext_list.size(), d_dir, v, d_etab, v.srow, d_a, d_b, d_o1, d_o2, g_x1,
-                                       g_x2, wd);
+                    hipLaunchKernelGGL(natac_background_edge_mfma, dim3(((int)ext_list.size() + EDGEM_WAVES - 1) / EDGEM_WAVES), dim3(64 * EDGEM_WAVES),
+                                       (size_t)wdm * EDGEM_WAVES * 8, 0, ct, d_t, d_ext, (int)ext_list.size(), d_dir, v, d_mtab, d_swt, NJ, d_a, d_b,
+                                       d_o1, d_o2, g_x1, g_x2, wdm);
                 }
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
