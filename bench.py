@@ -61,7 +61,7 @@ def bg_executed_flop(ctx, subs):
         for Lc, k in zip(lens.tolist(), counts.tolist()):
             nt, ex = ctx.bg_tiling(int(Lc))
             tiles += nt * k
-            ext_tiles += nt * k if ex else 0
+            ext_tiles += ex * k
     flop = tiles * FLOP_PER_TILE_BG_FFT + ext_tiles * FLOP_PER_TILE_BG_EDGE
     return flop, tiles, ext_tiles
 KERNEL_LABEL = {"background": "natac_background_fft (dense bias x VMat correlation, fp64 FFT)",

@@ -124,9 +124,9 @@ int natac_batch_create_from_seq(natac_ctx *ctx, int32_t n_chunks, const int32_t 
 void natac_batch_free(natac_batch *b);
 int natac_batch_info(natac_batch *b, int64_t *total_bp, int64_t *total_grid, int64_t *n_frags);
 /* How the background stage (NucleosomeCalling.py:49-64, the dense correlation of the bias matrix with the V-plot) tiles a chunk of
- * chunk_len bases with the V-plot that is set: n_tiles 512-point transforms per row pair, extended = 1 when the tiles yield 16 more
- * outputs on each side (finished by an edge pass) because that saves more than a tenth of the chunk's transforms.  0 tiles = the
- * FFT path does not apply to this V-plot (direct summation).  A function of the chunk's length and the model alone. */
+ * chunk_len bases with the V-plot that is set: n_tiles 512-point transforms per row pair, of which the first `extended` yield 16 more
+ * outputs on each side (finished by an edge pass; chosen where that saves whole tiles).  0 tiles = the FFT path does not apply to
+ * this V-plot (direct summation).  A function of the chunk's length and the model alone. */
 int natac_bg_tiling(natac_ctx *ctx, int32_t chunk_len, int32_t *n_tiles, int32_t *extended);
 /* Drop every output of the batch (per-base tracks, grid arrays, candidate / peak arrays) but keep its packed inputs resident:
  * for workloads whose outputs do not fit in HBM all at once (BASELINE configs[3] on one GPU: 3 Gbp x ~160 B/bp); the blocks go

@@ -879,29 +879,33 @@ static bool fft_bg_applicable(const natac_ctx *c) {
     return natac::bg_fft_lds_bytes(c->vupper) <= 64 * 1024;
 }
 
-// Extended tiles (natac_fft_bg.hpp): FFT_EXT more outputs on each side of a tile, finished by natac_background_edge_mfma.  The edge pass
-// costs ~9 % of a tile's transforms, so a chunk is tiled that way only where that buys at least 10 % of its tiles: 2,120 bases take 5
-// tiles instead of 6, 10,120 bases 24 instead of 26 (not enough: plain tiles).  The choice depends on the chunk's length alone --
-// results do not depend on the batch a chunk is in.
+// Extended tiles (natac_fft_bg.hpp): FFT_EXT more outputs on each side of a tile, finished by natac_background_edge_mfma.  An extended
+// tile costs ~11 % more than a plain one (edge pass 8 %, its own longer epilogue 3 %: profiles/r5), so a chunk gets the cheapest
+// mix of n tiles of which the first k are extended, 100 n + 11 k smallest with 392 n + 32 k >= L: 2,120 bases take 5 extended tiles
+// instead of 6 plain ones, 2,000 bases 5 tiles of which 2 are extended, 10,120 bases stay at 26 plain tiles (25 would need 10 extended
+// ones).  The choice depends on the chunk's length alone -- results do not depend on the batch a chunk is in.
 static bool bg_ext_possible(const natac_ctx *c) {
     if (!c->bg_ext || c->W < 2 * natac::FFT_EXT || natac::bg_edgem_wlen(c->vlower, c->vupper) > natac::EDGE_WLMAX + 2 * natac::FFT_EXT) return false;
     return natac::bg_edgem_lds_doubles_per_wave(c->vlower, c->vupper) * natac::EDGEM_WAVES * sizeof(double) <= 64 * 1024;
 }
-static bool bg_chunk_extended(int L, int TV) {
-    const int TVX = TV + 2 * natac::FFT_EXT;
-    const long long n_std = (L + TV - 1) / TV, n_ext = (L + TVX - 1) / TVX;
-    return n_ext * 11 <= n_std * 10;
+static void bg_chunk_tiling(int L, int TV, bool ext_ok, int *n_tiles, int *n_extended) {
+    const int E2 = 2 * natac::FFT_EXT;
+    const int n_std = (L + TV - 1) / TV;
+    int best_n = n_std, best_k = 0;
+    long long best = 100LL * n_std;
+    for (int n = n_std - 1; ext_ok && n >= 1 && (long long)n * (TV + E2) >= L; --n) {
+        const int k = (int)((L - (long long)n * TV + E2 - 1) / E2);
+        const long long cost = 100LL * n + 11LL * k;
+        if (cost < best) { best = cost; best_n = n; best_k = k; }
+    }
+    *n_tiles = best_n;
+    *n_extended = best_k;
 }
 int natac_bg_tiling(natac_ctx *c, int32_t chunk_len, int32_t *n_tiles, int32_t *extended) {
     if (!c || chunk_len <= 0) return fail(NATAC_E_ARG, "natac_bg_tiling: context and a positive chunk length");
     if (!c->d_vmat) return fail(NATAC_E_STATE, "natac_bg_tiling: set the V-plot first");
     int nt = 0, ex = 0;
-    if (fft_bg_applicable(c)) {
-        const int TV = natac::FFT_N - c->W + 1;
-        ex = bg_ext_possible(c) && bg_chunk_extended(chunk_len, TV);
-        const int w = ex ? TV + 2 * natac::FFT_EXT : TV;
-        nt = (chunk_len + w - 1) / w;
-    }
+    if (fft_bg_applicable(c)) bg_chunk_tiling(chunk_len, natac::FFT_N - c->W + 1, bg_ext_possible(c), &nt, &ex);
     if (n_tiles) *n_tiles = nt;
     if (extended) *extended = ex;
     return NATAC_OK;
@@ -914,13 +918,18 @@ static int build_tiles_bg(natac_batch *b, int TV, bool ext_ok) {
     const int TVX = TV + 2 * natac::FFT_EXT;
     for (int i = 0; i < b->nc; ++i) {
         const int n = b->h_len[i];
-        if (ext_ok && bg_chunk_extended(n, TV)) {
-            for (int x = 0; x < n; x += TVX) {       // outputs [x, x + TVX): the transform's exact ones start at x + FFT_EXT
+        int nt, k;
+        bg_chunk_tiling(n, TV, ext_ok, &nt, &k);
+        int x = 0;
+        for (int t = 0; t < nt; ++t) {
+            if (t < k) {       // outputs [x, x + TVX): the transform's exact ones start at x + FFT_EXT
                 ext_list.push_back((int)tiles.size());
                 tiles.push_back(make_int2(i, (x + natac::FFT_EXT) | natac::FFT_EXT_BIT));
+                x += TVX;
+            } else {
+                tiles.push_back(make_int2(i, x));
+                x += TV;
             }
-        } else {
-            for (int x = 0; x < n; x += TV) tiles.push_back(make_int2(i, x));
         }
     }
     dev_free(b->d_tiles_bg); dev_free(b->d_ext_list); dev_free(b->d_tile_direct);

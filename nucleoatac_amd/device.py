@@ -178,10 +178,11 @@ class Context(object):
         self.vmat_shape = mat.shape
 
     def bg_tiling(self, chunk_len):
-        """(tiles, extended) of the background stage for a chunk of this length with the V-plot that is set (natac_bg_tiling)."""
+        """(tiles, extended tiles among them) of the background stage for a chunk of this length with the V-plot that is set
+        (natac_bg_tiling)."""
         nt, ex = C.c_int32(0), C.c_int32(0)
         L.check(self._lib.natac_bg_tiling(self._h, int(chunk_len), C.byref(nt), C.byref(ex)))
-        return nt.value, bool(ex.value)
+        return nt.value, ex.value
 
     def set_sizes(self, sizes):
         """global insert-size distribution over [0, len(sizes)) (pyatac/chunkmat2d.py:154-156)."""

@@ -18,10 +18,22 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
     std::vector<int2> tiles;
     std::vector<int> ext_list;
     const int TVX = TV + 2 * FFT_EXT;
-    const bool ext = variant == 1 && ((L + TVX - 1) / TVX) * 11 <= ((L + TV - 1) / TV) * 10;
+    // the library's rule (natac_api.hip, bg_chunk_tiling): n tiles of which the first k are extended, 100 n + 11 k smallest
+    int bn = (L + TV - 1) / TV, bk = 0;
+    if (variant == 1) {
+        long long best = 100LL * bn;
+        for (int n = bn - 1; n >= 1 && (long long)n * TVX >= L; --n) {
+            const int k = (int)((L - (long long)n * TV + 2 * FFT_EXT - 1) / (2 * FFT_EXT));
+            if (100LL * n + 11LL * k < best) { best = 100LL * n + 11LL * k; bn = n; bk = k; }
+        }
+    }
+    const bool ext = bk > 0;
     for (int i = 0; i < nc; ++i) {
-        if (ext) for (int x = 0; x < L; x += TVX) { ext_list.push_back((int)tiles.size()); tiles.push_back(make_int2(i, (x + FFT_EXT) | FFT_EXT_BIT)); }
-        else for (int x = 0; x < L; x += TV) tiles.push_back(make_int2(i, x));
+        int x = 0;
+        for (int t = 0; t < bn; ++t) {
+            if (t < bk) { ext_list.push_back((int)tiles.size()); tiles.push_back(make_int2(i, (x + FFT_EXT) | FFT_EXT_BIT)); x += TVX; }
+            else { tiles.push_back(make_int2(i, x)); x += TV; }
+        }
     }
     int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2)));
     CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
