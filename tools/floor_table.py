@@ -30,7 +30,7 @@ def main():
     for k, c in per.items():
         if k not in avg or avg[k] < 2e5 or "GRBM_GUI_ACTIVE" not in c or "kernel_ns_under_pmc" not in c or k.startswith("natac_clock"):
             continue
-        if any(x in k for x in ("tile_ranges", "frag_centres", "tile_heavy", "fft_template", "lr_table")):
+        if any(x in k for x in ("tile_ranges", "frag_centres", "tile_heavy", "fft_template", "fft_edge_table", "lr_table")):
             continue            # indexes over the (immutable) inputs and model tables: formed once per batch / model, not per step
         ghz = c["GRBM_GUI_ACTIVE"] / 8.0 / c["kernel_ns_under_pmc"]
         t_valu = c.get("SQ_INSTS_VALU", 0.0) * 4.0 / 1024.0 / ghz / 1e6
