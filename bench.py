@@ -48,7 +48,7 @@ FLOP_PER_BP_BG = 2 * 146 * 121   # fp64 flop per base of the background correlat
 # x 64 lanes per 392-base tile
 FLOP_PER_BP_BG_FFT = 73 * 364 * 64 / 392.0     # plain tiles; a run's own figure comes from its chunks' tilings (bg_executed_flop)
 FLOP_PER_TILE_BG_FFT = 73 * 364 * 64
-# the edge pass of an extended tile (natac_background_edge_mfma): per side 37 steps of one 16 x 16 x 4 fp64 MFMA (2,048 flop, half of
+# the edge pass of an extended tile (natac_fft_bg.hpp, bg_edge_side): per side 37 steps of one 16 x 16 x 4 fp64 MFMA (2,048 flop, half of
 # the 16 x 16 products are outputs nobody reads: executed, not useful) + per lane 2 multiplications, 1 subtraction, 1 FMA
 FLOP_PER_TILE_BG_EDGE = 2 * 37 * (2048 + 64 * 5)
 
@@ -67,7 +67,7 @@ def bg_executed_flop(ctx, subs):
 KERNEL_LABEL = {"background": "natac_background_fft (dense bias x VMat correlation, fp64 FFT)",
                 "occ_mle": "natac_occ_gsum + natac_occ_decide (occupancy grid MLE)",
                 "candidates": "natac_peaks_chunk_reg + natac_candidates_paired (candidate search; LR / variance / z)"}
-KERNEL_SYMBOL = {"background": "natac_background_", "occ_mle": "natac_occ_", "candidates": "natac_candidates_paired"}
+KERNEL_SYMBOL = {"background": "natac_background_fft", "occ_mle": "natac_occ_", "candidates": "natac_candidates_paired"}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6          # MI355X fp64 vector peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 H2H_TRACKS = ("T_NORM", "T_SMOOTH", "T_OCC", "T_OCC_LOWER", "T_OCC_UPPER")   # what `nucleoatac run` writes by default
@@ -791,7 +791,7 @@ def main():
                                              "executed_tflops": round(fft_tflops, 2), "peak": FP64_PEAK_TFLOPS,
                                              "executed_flop_per_bp": round(bg_flop / max(1, my_bp), 1),
                                              "tiles": int(bg_tiles), "extended_tiles": int(bg_ext_tiles),
-                                             "kernels": "natac_background_fft + natac_background_edge_mfma (one timed region)",
+                                             "kernels": "natac_background_fft (transforms + the edge pass of its extended tiles)",
                                              "unit": "TFLOP/s", "frac_executed": round(fft_tflops / FP64_PEAK_TFLOPS, 4)}},
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
             "per_rank": per_rank, "control_plane": a.dist_backend if dist is not None else None,

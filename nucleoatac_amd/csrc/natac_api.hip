@@ -66,7 +66,7 @@ struct natac_ctx {
     long long model_gen = 0;         // bumped by natac_set_vmat / natac_set_sizes
     // FFT background path: twiddles (once) and template spectra (per V-plot)
     double *d_fft_tw = nullptr, *d_fft_k = nullptr;
-    double *d_fft_mtab = nullptr, *d_fft_swt = nullptr;   // natac_fft_edge_table_mfma (extended tiles)
+    double *d_fft_mtab = nullptr, *d_fft_swt = nullptr;   // natac_fft_edge_table_mfma (the edge pass of extended tiles)
     bool bg_ext = true;              // NATAC_BG_EXT=0: no extended FFT tiles (A-B timing / validation of the edge pass)
     bool fft_dirty = true, bg_direct = false, occ_ordered = true, occ_zero_nfr = false;
     std::vector<double> h_sizes;
@@ -127,9 +127,6 @@ struct natac_batch {
     int n_tiles1k = 0;
     bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
-    int *d_ext_list = nullptr;                 // indices of the extended tiles in d_tiles_bg (natac_background_edge_mfma)
-    unsigned char *d_tile_direct = nullptr;    // [n_tiles_bg] 1 = natac_background_fft evaluated the tile by direct summation
-    int n_ext = 0;
     long long *d_tile256_first = nullptr;   // [nc + 1] first 256-base tile of every chunk (the candidates' way into d_ranges256)
     int *d_order_occ = nullptr;      // natac_tile_heavy: {count, claims, list[HEAVY_CAP], flag bytes[n_tiles_occ]} of the occupancy tiles
     int ranges256_w = -1;
@@ -879,14 +876,15 @@ static bool fft_bg_applicable(const natac_ctx *c) {
     return natac::bg_fft_lds_bytes(c->vupper) <= 64 * 1024;
 }
 
-// Extended tiles (natac_fft_bg.hpp): FFT_EXT more outputs on each side of a tile, finished by natac_background_edge_mfma.  An extended
+// Extended tiles (natac_fft_bg.hpp): FFT_EXT more outputs on each side of a tile, finished by an edge pass at the end of the tile's wave.  An extended
 // tile costs ~11 % more than a plain one (edge pass 8 %, its own longer epilogue 3 %: profiles/r5), so a chunk gets the cheapest
 // mix of n tiles of which the first k are extended, 100 n + 11 k smallest with 392 n + 32 k >= L: 2,120 bases take 5 extended tiles
 // instead of 6 plain ones, 2,000 bases 5 tiles of which 2 are extended, 10,120 bases stay at 26 plain tiles (25 would need 10 extended
 // ones).  The choice depends on the chunk's length alone -- results do not depend on the batch a chunk is in.
 static bool bg_ext_possible(const natac_ctx *c) {
-    if (!c->bg_ext || c->W < 2 * natac::FFT_EXT || natac::bg_edgem_wlen(c->vlower, c->vupper) > natac::EDGE_WLMAX + 2 * natac::FFT_EXT) return false;
-    return natac::bg_edgem_lds_doubles_per_wave(c->vlower, c->vupper) * natac::EDGEM_WAVES * sizeof(double) <= 64 * 1024;
+    // the edge pass's scratch (partial outputs, reduction scratch, the rows' weights) lives in the transposes' LDS region
+    return c->bg_ext && c->W >= 2 * natac::FFT_EXT &&
+           4 * natac::FFT_EXT + natac::EDGE_SCRATCH + 4 * ((c->R + 3) / 4) <= 2 * natac::FFT_LA;
 }
 static void bg_chunk_tiling(int L, int TV, bool ext_ok, int *n_tiles, int *n_extended) {
     const int E2 = 2 * natac::FFT_EXT;
@@ -913,17 +911,14 @@ int natac_bg_tiling(natac_ctx *c, int32_t chunk_len, int32_t *n_tiles, int32_t *
 
 static int build_tiles_bg(natac_batch *b, int TV, bool ext_ok) {
     std::vector<int2> tiles;
-    std::vector<int> ext_list;
     tiles.reserve((size_t)(b->total_bp / TV) + b->nc);
     const int TVX = TV + 2 * natac::FFT_EXT;
     for (int i = 0; i < b->nc; ++i) {
-        const int n = b->h_len[i];
         int nt, k;
-        bg_chunk_tiling(n, TV, ext_ok, &nt, &k);
+        bg_chunk_tiling(b->h_len[i], TV, ext_ok, &nt, &k);
         int x = 0;
         for (int t = 0; t < nt; ++t) {
             if (t < k) {       // outputs [x, x + TVX): the transform's exact ones start at x + FFT_EXT
-                ext_list.push_back((int)tiles.size());
                 tiles.push_back(make_int2(i, (x + natac::FFT_EXT) | natac::FFT_EXT_BIT));
                 x += TVX;
             } else {
@@ -932,16 +927,11 @@ static int build_tiles_bg(natac_batch *b, int TV, bool ext_ok) {
             }
         }
     }
-    dev_free(b->d_tiles_bg); dev_free(b->d_ext_list); dev_free(b->d_tile_direct);
-    b->d_tiles_bg = nullptr; b->d_ext_list = nullptr; b->d_tile_direct = nullptr;
+    dev_free(b->d_tiles_bg);
+    b->d_tiles_bg = nullptr;
     b->n_tiles_bg = (int)tiles.size();
-    b->n_ext = (int)ext_list.size();
     int rc = dev_upload(b->ctx, &b->d_tiles_bg, tiles.data(), tiles.size());
     if (rc) return rc;
-    if (b->n_ext) {
-        if ((rc = dev_upload(b->ctx, &b->d_ext_list, ext_list.data(), ext_list.size()))) return rc;
-        if ((rc = dev_alloc(&b->d_tile_direct, tiles.size()))) return rc;
-    }
     HIPCHK(sync_all(b->ctx));  // `tiles` is a local
     return NATAC_OK;
 }
@@ -1167,7 +1157,6 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_occ_minkey); dev_free(b->d_occ_nan); dev_free(b->d_tiles_os); dev_free(b->d_tiles1k);
     dev_free(b->d_tiles256); dev_free(b->d_tiles_bg); dev_free(b->d_tiles_occ); dev_free(b->d_ranges_occ); dev_free(b->d_ranges256);
     dev_free(b->d_tile256_first);
-    dev_free(b->d_ext_list); dev_free(b->d_tile_direct);
     dev_free(b->d_order_occ);
     dev_free(b->d_jitter); dev_free(b->d_pk_out); dev_free(b->d_cap_off);
     dev_free(b->d_pk_offs); dev_free(b->d_slot); dev_free(b->d_pk_count); dev_free(b->d_pk_chunk); dev_free(b->d_pk_pos);
@@ -1279,14 +1268,8 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
         const size_t lds = bg_fft_lds_bytes(vm.upper);
         hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
                            c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg, b->d_tile_direct, vm.srow);
-        if (b->n_ext) {     // the FFT_EXT outputs on each side of every extended tile
-            const int wd = (int)bg_edgem_lds_doubles_per_wave(vm.lower, vm.upper);
-            hipLaunchKernelGGL(natac_background_edge_mfma, dim3((b->n_ext + EDGEM_WAVES - 1) / EDGEM_WAVES), dim3(64 * EDGEM_WAVES),
-                               (size_t)wd * EDGEM_WAVES * sizeof(double), c->stream, ct, b->d_tiles_bg, b->d_ext_list, b->n_ext,
-                               b->d_tile_direct, vm, c->d_fft_mtab, c->d_fft_swt, (c->R + 3) / 4, b->d_track[NATAC_T_NUC_COV],
-                               b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND], b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, wd);
-        }
+                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg, vm.srow, c->d_fft_mtab,
+                           c->d_fft_swt, (c->R + 3) / 4);
     } else if (fast) {
         switch (b->bgG) {
             case 7: launch_bg<7>(b, ct, vm); break;

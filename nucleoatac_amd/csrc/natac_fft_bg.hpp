@@ -25,10 +25,10 @@ constexpr int FFT_LA = 576;   // layout A: p + 8 * (p >> 6)
 constexpr int FFT_LB = 520;   // layout B: (p & 7) * 65 + (p >> 3)
 // Extended tiles (round 5).  A 512-point circular correlation holds, besides its TV = 512 - W + 1 exact outputs, FFT_EXT outputs on each
 // side that are wrong by a few terms only: output TV - 1 + m (m = 1..16) wraps its last m template columns onto the tile's first
-// samples, output -k (circular index 512 - k) its first k columns onto the tile's last samples.  natac_background_edge_mfma replaces those
-// m (k) wrapped products per row by the true ones -- 2 x 136 multiply-adds per row and tile, summed directly -- so a tile yields
-// TV + 2 FFT_EXT outputs: a 2,120-base chunk takes 5 transforms per row pair instead of 6.  Which chunks are tiled that way is the
-// host's decision (bg_tiles_build: only where the tile count drops by more than the edge pass costs); the flag travels in tiles[].y.
+// samples, output -k (circular index 512 - k) its first k columns onto the tile's last samples.  The edge pass at the end of bg_fft_tile
+// (bg_edge_side) replaces those m (k) wrapped products per row by the true ones -- 2 x 136 multiply-adds per row and tile, summed
+// directly -- so a tile yields TV + 2 FFT_EXT outputs: a 2,120-base chunk takes 5 transforms per row pair instead of 6.  Which tiles of
+// a chunk are extended is the host's decision (natac_api.hip, bg_chunk_tiling: the cheapest mix); the flag travels in tiles[].y.
 constexpr int FFT_EXT = 16;
 constexpr int FFT_EXT_BIT = 1 << 30;
 // exp(bias) entries of a tile that feed bases of its chunk (the rest of the staged window is zero): ext = FFT_EXT or 0
@@ -113,6 +113,99 @@ __device__ __forceinline__ void lds_wait16(double (&x)[8], double (&y)[8]) {
                    "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7])
                  :
                  : "memory");
+}
+
+// ---- the edge pass of extended tiles: a small matrix product (the one place of this library where the matrix pipe fits) --------------
+// Side 0 = left edge (outputs x0 - 16 .. x0 - 1), side 1 = right edge (outputs x0 + TV .. x0 + TV + 15).  Sample s of a side (lane
+// t = s): the sample outside the tile that the outputs need (`out`: -16 + s on the left, 512 + s on the right) and the sample inside
+// that the circular transform used in its place (`in`: 496 + s, s).  D_r[s] = P_r[out] - P_r[in] per row; output number o of the side
+// is short of  sum_r sum_s D_r[s] C_r[i]  with i = the distance between output and sample (right: o - s for s <= o; left: s - o for
+// s >= o) and C_r[i] = s_r V_r[W - 1 - i] (right), s_r V_r[i] (left) -- the template column that sample meets -- and its window sum
+// of  sum_r s_r P_r[out]  over the same samples.  So per tile and side OUT[s][i] = sum_r D_r[s] C_r[i], a 16 x R by R x 16 product,
+// and the outputs are sums along its anti-diagonals.  Round 5 built this first as an outer product on the vector pipe (every lane
+// needs the 16 C_r[i] of every row as uniform operands: 146 x 2 x 128 bytes through the scalar cache per wave, the counters showed
+// the waves waiting on it for half of their time: 0.78 ms per 100 k tiles).  v_mfma_f64_16x16x4_f64 takes BOTH operands distributed
+// over the lanes (0.57 ms as a kernel of its own, one wave per tile with the windows staged again; 0.45 ms here, at the end of the wave
+// that just transformed the tile and still has its exp(bias) window in LDS):
+// A[t = lane & 15][k = lane >> 4] = D of row 4 j + k, B[k][i = lane & 15] = one coalesced 512-byte load of the table per step; a tile
+// and side is ceil(R / 4) instructions and every D is formed once.  fp64 MFMA has no rate advantage over fp64 FMAs on gfx950
+// (profiles/r1/probe_fp64_mfma_vs_valu.txt); what it buys here is operand delivery.
+// bg_edge_side: one side for one tile, by one wave: returns (lanes 0..15: output number lane & 15 of the side) the correction of the
+// numerator and of the window sum.  Windows (entry e of the tile's staged exp(bias) window, E):
+//   wl_lo[w] = E(w), wl_hi[w] = E(512 + w)                       left factors  (entry 16 + A - fh(i - 1) + u of sample u, row i)
+//   wr_lo[w] = E(A + hr0 + w), wr_hi[w] = E(512 + A + hr0 + w)   right factors (entry 16 + A + fh(i) + u)
+// left edge:  out = sample -16 + t -> wl_lo[dl + t] wr_lo[dr + t];  in = sample 496 + t -> wl_hi[dl + t] wr_hi[dr + t]
+// right edge: out = sample 512 + t -> wl_hi[16 + dl + t] wr_hi[16 + dr + t];  in = sample t -> wl_lo[16 + dl + t] wr_lo[16 + dr + t]
+// with dl = A - fh(i - 1), dr = fh(i) - hr0; a lane's rows are 4 j + k: dl falls and dr rises by 2 per step (rows past R in the last
+// step index up to two entries outside a window: read, not used).  sws = the rows' weights (4 NJ doubles, zero past R), sc =
+// EDGE_SCRATCH doubles of LDS, mtab = natac_fft_edge_table_mfma's table.  (The accumulators stay in VGPRs because the kernel's register
+// budget is <= 256: with 512 the compiler picks the AGPR form and copies sixteen registers around every pair of instructions.)
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int EDGE_RS = FFT_EXT + 1;       // stride of a sample's row in the reduction scratch
+constexpr int EDGE_SCRATCH = FFT_EXT * EDGE_RS + 64 + FFT_EXT + 128;
+__device__ __forceinline__ void bg_edge_side(const int side, const double *wl_lo, const double *wl_hi, const double *wr_lo, const double *wr_hi,
+                                             const double *sws, double *sc, const double *__restrict__ mtab, const int NJ, const int R,
+                                             const int lower, const int A, const int hr0, const int lane, double &corr_out, double &qc_out) {
+    const int t = lane & (FFT_EXT - 1), k = lane >> 4;
+    double *sq = sc + FFT_EXT * EDGE_RS, *sqt = sq + 64, *sp = sqt + FFT_EXT;
+    const int dl0 = A - floor_half(lower + k - 1), dr0 = floor_half(lower + k) - hr0;
+    const int NJf = R / 4;                       // steps whose four rows all exist
+    {
+        const double *pl_o = (side ? wl_hi + FFT_EXT : wl_lo) + dl0 + t, *pr_o = (side ? wr_hi + FFT_EXT : wr_lo) + dr0 + t;
+        const double *pl_i = (side ? wl_lo + FFT_EXT : wl_hi) + dl0 + t, *pr_i = (side ? wr_lo + FFT_EXT : wr_hi) + dr0 + t;
+        const double *mt = mtab + (size_t)side * NJ * 64 + lane;
+        const double *sw = sws + k;
+        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        double qx = 0.0;
+        // step u of a trip: rows 4 (j + u) + k; the pointers sit at step j
+#define NATAC_EDGE_STEP(u, acc)                                                                                  \
+        {                                                                                                        \
+            const double po = pl_o[-2 * (u)] * pr_o[2 * (u)], pi = pl_i[-2 * (u)] * pr_i[2 * (u)];             \
+            qx = fma(sw[4 * (u)], po, qx);                                                                       \
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(po - pi, mt[64 * (u)], acc, 0, 0, 0);                     \
+        }
+        int j = 0;
+        for (; j + 4 <= NJf; j += 4) {
+            NATAC_EDGE_STEP(0, acc0) NATAC_EDGE_STEP(1, acc1) NATAC_EDGE_STEP(2, acc0) NATAC_EDGE_STEP(3, acc1)
+            pl_o -= 8; pl_i -= 8; pr_o += 8; pr_i += 8; mt += 256; sw += 16;
+        }
+        for (; j < NJf; ++j) {
+            NATAC_EDGE_STEP(0, acc0)
+            pl_o -= 2; pl_i -= 2; pr_o += 2; pr_i += 2; mt += 64; sw += 4;
+        }
+#undef NATAC_EDGE_STEP
+        if (j < NJ) {                                // the last rows: lanes past R contribute zeros (their window entries are not the model's)
+            const bool valid = 4 * j + k < R;
+            const double lo = pl_o[0], ro = pr_o[0], li = pl_i[0], ri = pr_i[0];
+            const double po = valid ? lo * ro : 0.0, pi = valid ? li * ri : 0.0;
+            qx = fma(sw[0], po, qx);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(po - pi, mt[0], acc1, 0, 0, 0);
+        }
+        const d4_t acc = acc0 + acc1;
+        // OUT[t' = k + 4 q][i = lane & 15] = acc[q]; a lane's column sums are partial over its rows
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sc[(k + 4 * q) * EDGE_RS + t] = acc[q];
+        sq[lane] = qx;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < FFT_EXT) sqt[lane] = ((sq[lane] + sq[16 + lane]) + sq[32 + lane]) + sq[48 + lane];     // the missing column sum of sample `lane`
+        __builtin_amdgcn_wave_barrier();
+        // output number o = t of the side:
+        //   right: m = o + 1, samples 512 + s for s <= o, OUT[s][o - s];  left: output x0 - (16 - o), samples s >= o, OUT[s][s - o]
+        // lane (k, o) adds the samples s = k, k + 4, k + 8, k + 12; the four partial sums are added in the order of k
+        double corr = 0.0, qc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sidx = k + 4 * q, ix = side ? t - sidx : sidx - t;
+            const double a = sc[sidx * EDGE_RS + max(ix, 0)], qq = sqt[sidx];
+            corr += ix >= 0 ? a : 0.0;
+            qc += ix >= 0 ? qq : 0.0;
+        }
+        sp[lane] = corr; sp[64 + lane] = qc;
+        __builtin_amdgcn_wave_barrier();
+        corr_out = ((sp[t] + sp[16 + t]) + sp[32 + t]) + sp[48 + t];
+        qc_out = ((sp[64 + t] + sp[80 + t]) + sp[96 + t]) + sp[112 + t];
+    }
 }
 
 struct FftTwiddles {            // per-lane twiddles, loaded once per kernel
@@ -256,11 +349,11 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
                                             const double *__restrict__ ktab, const double *__restrict__ nuc_cov,
                                             const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
                                             double *__restrict__ bnum, double *__restrict__ bcov, double *smem, FftTwiddles &tww,
-                                            const int lane, unsigned char *__restrict__ tile_direct = nullptr, unsigned ti = 0,
-                                            const double *__restrict__ srow_s = nullptr) {
+                                            const int lane, const double *__restrict__ srow_s = nullptr, const double *__restrict__ mtab = nullptr,
+                                            const double *__restrict__ swt = nullptr, const int NJ = 0) {
     const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
-    const int ext = (t.y & FFT_EXT_BIT) ? FFT_EXT : 0;   // extended tile: FFT_EXT more outputs on each side, finished by natac_background_edge_mfma
+    const int ext = (t.y & FFT_EXT_BIT) ? FFT_EXT : 0;   // extended tile: FFT_EXT more outputs on each side, finished by the edge pass below
     const int EW = FFT_N + A + Bh + 2 * ext, EWP = (FFT_N + A + Bh + 2 * FFT_EXT + 1) & ~1;
     double *Et = smem;
     double2 *ca = (double2 *)(Et + EWP), *cb = ca;     // complex scratch of the transposes; layouts A and B are never live together
@@ -292,12 +385,11 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
     }
     __builtin_amdgcn_wave_barrier();
     const long long ob = ct.out_off[chunk];
-    if (tile_direct && lane == 0) tile_direct[ti] = use_fft ? 0 : 1;
     Et += ext;                   // Et[u] <-> coordinate x0 - HW - A + u from here on, as for a plain tile
     if (!use_fft) {
 #pragma unroll 1
         for (int j = 0; j < 9; ++j) {
-            const int u = lane + 64 * j - ext, g = x0 + u;      // an extended tile's edge outputs too: the edge pass skips this tile
+            const int u = lane + 64 * j - ext, g = x0 + u;      // an extended tile's edge outputs too
             if (u >= TV + ext || g >= L) continue;
             double num = 0.0, cv = 0.0;
 #pragma unroll 1
@@ -516,6 +608,8 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         for (int c = 0; c < FFT_EXT; ++c) { const double v = sar[W - 1 - c]; suf += c < k ? v : 0.0; }
         cvl = full - suf;
     }
+    double *pe = sar;                   // [side][output][numerator, window sum] of the edge outputs, as far as the tile holds them
+    __builtin_amdgcn_wave_barrier();    // the sums above are done with sar / sai
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int u = lane + 64 * j;
@@ -529,12 +623,41 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
                 bg[o] = b;
                 norm[o] = raw[o] - b;
             }
-            bnum[o] = num;           // sum B V and sum B of the window at this base: reused by the candidate statistics
-            bcov[o] = cv;            // (right edge of an extended tile: both without the samples past the tile, see natac_background_edge_mfma)
-        } else if (j == 7 && u >= FFT_N - ext && x0 - (FFT_N - u) < L) {
-            const long long o = ob + (x0 - (FFT_N - u));
-            bnum[o] = accr[j] * (1.0 / FFT_N);
-            bcov[o] = cvl;
+            if (core) {
+                bnum[o] = num;       // sum B V and sum B of the window at this base: reused by the candidate statistics
+                bcov[o] = cv;
+            } else {                 // right edge of an extended tile: both without the samples past the tile, finished below
+                pe[2 * (FFT_EXT + u - TV)] = num; pe[2 * (FFT_EXT + u - TV) + 1] = cv;
+            }
+        } else if (j == 7 && u >= FFT_N - ext && x0 - (FFT_N - u) < L) {      // left edge
+            pe[2 * (u - (FFT_N - FFT_EXT))] = accr[j] * (1.0 / FFT_N); pe[2 * (u - (FFT_N - FFT_EXT)) + 1] = cvl;
+        }
+    }
+    if (ext) {
+        // The edge pass (see bg_edge_side): the windows are ranges of the exp(bias) window this wave staged.  Entry e of that window
+        // (coordinate x0 - 16 - HW - A + e; zero from `need` on and outside the chunk's bias slice):
+        //   wl_lo[w] = E(w), wl_hi[w] = E(512 + w)                       left factors  (entry 16 + A - fh(i - 1) + u of sample u, row i)
+        //   wr_lo[w] = E(A + hr0 + w), wr_hi[w] = E(512 + A + hr0 + w)   right factors (entry 16 + A + fh(i) + u)
+        const double *Ea = Et - ext;
+        const int hr0 = floor_half(vm.lower);
+        double *sc = pe + 4 * FFT_EXT, *sws = sc + EDGE_SCRATCH;
+        for (int i = lane; i < 4 * NJ; i += WAVE) sws[i] = swt[i];
+        __builtin_amdgcn_wave_barrier();
+        const int t = lane & (FFT_EXT - 1);
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            double corr, qc;
+            bg_edge_side(side, Ea, Ea + FFT_N, Ea + A + hr0, Ea + FFT_N + A + hr0, sws, sc, mtab, NJ, vm.R, vm.lower, A, hr0, lane, corr, qc);
+            const int g = side ? x0 + TV + t : x0 - FFT_EXT + t;
+            if (lane < FFT_EXT && g >= 0 && g < L) {
+                const long long o = ob + g;
+                const double num = pe[2 * (FFT_EXT * side + t)] + corr, cv = pe[2 * (FFT_EXT * side + t) + 1] + qc;
+                const double bb = (num * nuc_cov[o]) / cv;
+                bg[o] = bb;
+                norm[o] = raw[o] - bb;
+                bnum[o] = num;
+                bcov[o] = cv;
+            }
         }
     }
 }
@@ -547,12 +670,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                                              const double *__restrict__ nuc_cov, const double *__restrict__ raw,
                                                              double *__restrict__ bg, double *__restrict__ norm,
                                                              double *__restrict__ bnum, double *__restrict__ bcov,
-                                                             unsigned n_tiles, unsigned char *__restrict__ tile_direct,
-                                                             const double *__restrict__ srow) {
+                                                             unsigned n_tiles, const double *__restrict__ srow, const double *__restrict__ mtab,
+                                                             const double *__restrict__ swt, int NJ) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const unsigned ti = blockIdx.x;
     FftTwiddles tww;
-    bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x, tile_direct, ti, srow);
+    bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x, srow, mtab, swt, NJ);
 }
 
 // LDS of one wave of natac_background_fft, in bytes (host): the exp(bias) window of an extended tile + the transposes' scratch
@@ -561,25 +684,8 @@ __host__ __device__ inline size_t bg_fft_lds_bytes(int upper) {
     return ((size_t)((EWX + 1) & ~1) + 2 * FFT_LA) * sizeof(double);
 }
 
-constexpr int EDGE_RS = FFT_EXT + 1;       // stride of a sample's row in the reduction scratch
-constexpr int EDGE_WLMAX = 128;            // longest window (largest row offset + FFT_EXT) the edge pass stages
-
-// ---- the edge pass of extended tiles: a small matrix product (the one place of this library where the matrix pipe fits) --------------
-// Side 0 = left edge (outputs x0 - 16 .. x0 - 1), side 1 = right edge (outputs x0 + TV .. x0 + TV + 15).  Sample s of a side (lane
-// t = s): the sample outside the tile that the outputs need (`out`: -16 + s on the left, 512 + s on the right) and the sample inside
-// that the circular transform used in its place (`in`: 496 + s, s).  D_r[s] = P_r[out] - P_r[in] per row; output number o of the side
-// is short of  sum_r sum_s D_r[s] C_r[i]  with i = the distance between output and sample (right: o - s for s <= o; left: s - o for
-// s >= o) and C_r[i] = s_r V_r[W - 1 - i] (right), s_r V_r[i] (left) -- the template column that sample meets -- and its window sum
-// of  sum_r s_r P_r[out]  over the same samples.  So per tile and side OUT[s][i] = sum_r D_r[s] C_r[i], a 16 x R by R x 16 product,
-// and the outputs are sums along its anti-diagonals.  Round 5 built this first as an outer product on the vector pipe (every lane
-// needs the 16 C_r[i] of every row as uniform operands: 146 x 2 x 128 bytes through the scalar cache per wave, the counters showed
-// the waves waiting on it for half of their time: 0.78 ms per 100 k tiles).  v_mfma_f64_16x16x4_f64 takes BOTH operands distributed
-// over the lanes (0.57 ms):
-// A[t = lane & 15][k = lane >> 4] = D of row 4 j + k, B[k][i = lane & 15] = one coalesced 512-byte load of the table per step; a tile
-// and side is ceil(R / 4) instructions and every D is formed once.  fp64 MFMA has no rate advantage over fp64 FMAs on gfx950
-// (profiles/r1/probe_fp64_mfma_vs_valu.txt); what it buys here is operand delivery.
+// the edge pass's table (bg_edge_side):
 // mtab[side][j][lane] = C of row 4 j + (lane >> 4), column index lane & 15 (0 for rows past R); swt[4 j + k] = s_r (0 past R).
-typedef double d4_t __attribute__((ext_vector_type(4)));
 __global__ void natac_fft_edge_table_mfma(const double *__restrict__ vmat, const double *__restrict__ srow, int R, int W, int NJ,
                                           double *__restrict__ mtab, double *__restrict__ swt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -589,152 +695,4 @@ __global__ void natac_fft_edge_table_mfma(const double *__restrict__ vmat, const
     const int r = 4 * j + (lane >> 4), c = lane & 15;
     mtab[i] = r < R ? srow[r] * vmat[r * W + (side ? W - 1 - c : c)] : 0.0;
 }
-constexpr int EDGEM_WAVES = 4;             // waves (= tiles) per workgroup
-constexpr int EDGEM_PAD = 2;               // rows past R in the last step index up to two entries outside a window (values not used)
-__host__ __device__ inline int bg_edgem_wlen(int lower, int upper) {       // entries of one window: both sides' 16 samples over all rows
-    const int A = (upper - 2) >> 1, Bh = (upper - 1) >> 1;
-    const int dl = A - ((lower - 1) >> 1), dr = Bh - (lower >> 1);
-    return (dl > dr ? dl : dr) + 2 * FFT_EXT + 2 * EDGEM_PAD;
-}
-__host__ __device__ inline size_t bg_edgem_lds_doubles_per_wave(int lower, int upper) {
-    const int NJ = (upper - lower + 3) / 4;
-    return (size_t)4 * bg_edgem_wlen(lower, upper) + FFT_EXT * EDGE_RS + 64 + FFT_EXT + 128 + (size_t)4 * NJ;
-}
-
-// One wave per extended tile.  Windows (entries of the tile's exp(bias) window as natac_background_fft staged it, E below):
-//   wl_lo[w] = E(w), wl_hi[w] = E(512 + w)                       left factors  (entry 16 + A - fh(i - 1) + u of sample u, row i)
-//   wr_lo[w] = E(A + hr0 + w), wr_hi[w] = E(512 + A + hr0 + w)   right factors (entry 16 + A + fh(i) + u)
-// left edge:  out = sample -16 + t -> wl_lo[dl + t] wr_lo[dr + t];  in = sample 496 + t -> wl_hi[dl + t] wr_hi[dr + t]
-// right edge: out = sample 512 + t -> wl_hi[16 + dl + t] wr_hi[16 + dr + t];  in = sample t -> wl_lo[16 + dl + t] wr_lo[16 + dr + t]
-// with dl = A - fh(i - 1), dr = fh(i) - hr0; a lane's rows are 4 j + k: dl falls and dr rises by 2 per step.
-// (waves_per_eu >= 4: with a register budget of <= 256 the compiler keeps the accumulators in VGPRs; left at 512 it picks the AGPR form
-// and copies all sixteen registers in and out around every pair of instructions)
-__global__ void __launch_bounds__(64 * EDGEM_WAVES) __attribute__((amdgpu_waves_per_eu(4))) natac_background_edge_mfma(ChunkTable ct, const int2 *__restrict__ tiles, const int *__restrict__ ext_list,
-                                                                                int n_ext, const unsigned char *__restrict__ tile_direct, VMatDev vm,
-                                                                                const double *__restrict__ mtab, const double *__restrict__ swt, int NJ,
-                                                                                const double *__restrict__ nuc_cov, const double *__restrict__ raw,
-                                                                                double *__restrict__ bg, double *__restrict__ norm,
-                                                                                double *__restrict__ bnum, double *__restrict__ bcov, int wave_doubles) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * EDGEM_WAVES + wave;
-    if (slot >= n_ext) return;                      // no workgroup barrier below
-    const int ti = ext_list[slot];
-    if (tile_direct[ti]) return;                    // evaluated by direct summation, edge outputs included
-    double *ws = smem + (size_t)wave * wave_doubles;
-    const int t = lane & (FFT_EXT - 1), k = lane >> 4;
-    const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
-    const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
-    const int hr0 = floor_half(vm.lower);
-    const int WLm = bg_edgem_wlen(vm.lower, vm.upper);
-    const int2 tt = tiles[ti];
-    const int chunk = tt.x, x0 = tt.y & (FFT_EXT_BIT - 1);
-    const int L = ct.chunk_len[chunk];
-    const double *b = ct.bias ? ct.ebias + ct.bias_off[chunk] : nullptr;
-    const int nb = L + ct.bias_left + ct.bias_right;
-    const int j0 = x0 - FFT_EXT - HW - A + ct.bias_left;              // the extended tile's window starts FFT_EXT samples early
-    const int need = bg_tile_need(TV, W, A, Bh, L, x0, FFT_EXT);
-    // entry e of the tile's exp(bias) window exactly as natac_background_fft staged it: zero from `need` on and outside the chunk's
-    // bias slice.  [elo, ehi) = the entries that are read; the load itself is unconditional (clamped index)
-    const int elo = b ? max(0, -j0) : 0, ehi = b ? min(need, nb - j0) : 0;
-    const double *bj = b ? b + j0 : nullptr;
-    auto E = [&](int e) -> double {
-        double v = (e >= 0 && e < need) ? 1.0 : 0.0;         // no bias track: exp(0)
-        if (bj) {
-            const double x = bj[min(max(e, elo), max(ehi, elo + 1) - 1)];
-            v = (e >= elo && e < ehi) ? x : 0.0;
-        }
-        return v;
-    };
-    double *wl_lo = ws + EDGEM_PAD, *wl_hi = wl_lo + WLm, *wr_lo = wl_hi + WLm, *wr_hi = wr_lo + WLm;
-    double *sc = ws + 4 * WLm, *sq = sc + FFT_EXT * EDGE_RS, *sqt = sq + 64, *sp = sqt + FFT_EXT, *sws = sp + 128;
-    {
-        constexpr int NS = (EDGE_WLMAX + 2 * FFT_EXT + 63) / 64;
-        double s0[NS], s1[NS], s2[NS], s3[NS];
-#pragma unroll
-        for (int n = 0; n < NS; ++n) {
-            const int w = lane + 64 * n - EDGEM_PAD;
-            if (64 * n >= WLm) { s0[n] = s1[n] = s2[n] = s3[n] = 0.0; continue; }      // wave-uniform
-            s0[n] = E(w); s1[n] = E(FFT_N + w); s2[n] = E(A + hr0 + w); s3[n] = E(FFT_N + A + hr0 + w);
-        }
-        for (int i = lane; i < 4 * NJ; i += WAVE) sws[i] = swt[i];       // the rows' weights, read back with immediate offsets
-#pragma unroll
-        for (int n = 0; n < NS; ++n) {
-            const int w = lane + 64 * n - EDGEM_PAD;
-            if (w < WLm - EDGEM_PAD) { wl_lo[w] = s0[n]; wl_hi[w] = s1[n]; wr_lo[w] = s2[n]; wr_hi[w] = s3[n]; }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const long long ob = ct.out_off[chunk];
-    const int dl0 = A - floor_half(vm.lower + k - 1), dr0 = floor_half(vm.lower + k) - hr0;
-    const int NJf = vm.R / 4;                       // steps whose four rows all exist
-#pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
-        const double *pl_o = (side ? wl_hi + FFT_EXT : wl_lo) + dl0 + t, *pr_o = (side ? wr_hi + FFT_EXT : wr_lo) + dr0 + t;
-        const double *pl_i = (side ? wl_lo + FFT_EXT : wl_hi) + dl0 + t, *pr_i = (side ? wr_lo + FFT_EXT : wr_hi) + dr0 + t;
-        const double *mt = mtab + (size_t)side * NJ * 64 + lane;
-        const double *sw = sws + k;
-        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        double qx = 0.0;
-        // step u of a trip: rows 4 (j + u) + k; the pointers sit at step j
-#define NATAC_EDGE_STEP(u, acc)                                                                                  \
-        {                                                                                                        \
-            const double po = pl_o[-2 * (u)] * pr_o[2 * (u)], pi = pl_i[-2 * (u)] * pr_i[2 * (u)];             \
-            qx = fma(sw[4 * (u)], po, qx);                                                                       \
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(po - pi, mt[64 * (u)], acc, 0, 0, 0);                     \
-        }
-        int j = 0;
-        for (; j + 4 <= NJf; j += 4) {
-            NATAC_EDGE_STEP(0, acc0) NATAC_EDGE_STEP(1, acc1) NATAC_EDGE_STEP(2, acc0) NATAC_EDGE_STEP(3, acc1)
-            pl_o -= 8; pl_i -= 8; pr_o += 8; pr_i += 8; mt += 256; sw += 16;
-        }
-        for (; j < NJf; ++j) {
-            NATAC_EDGE_STEP(0, acc0)
-            pl_o -= 2; pl_i -= 2; pr_o += 2; pr_i += 2; mt += 64; sw += 4;
-        }
-#undef NATAC_EDGE_STEP
-        if (j < NJ) {                                // the last rows: lanes past R contribute zeros (their window entries are not the model's)
-            const bool valid = 4 * j + k < vm.R;
-            const double lo = pl_o[0], ro = pr_o[0], li = pl_i[0], ri = pr_i[0];
-            const double po = valid ? lo * ro : 0.0, pi = valid ? li * ri : 0.0;
-            qx = fma(sw[0], po, qx);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(po - pi, mt[0], acc1, 0, 0, 0);
-        }
-        const d4_t acc = acc0 + acc1;
-        // OUT[t' = k + 4 q][i = lane & 15] = acc[q]; a lane's column sums are partial over its rows
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sc[(k + 4 * q) * EDGE_RS + t] = acc[q];
-        sq[lane] = qx;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < FFT_EXT) sqt[lane] = ((sq[lane] + sq[16 + lane]) + sq[32 + lane]) + sq[48 + lane];     // the missing column sum of sample `lane`
-        __builtin_amdgcn_wave_barrier();
-        // output number o = t of the side:
-        //   right: m = o + 1, samples 512 + s for s <= o, OUT[s][o - s];  left: output x0 - (16 - o), samples s >= o, OUT[s][s - o]
-        // lane (k, o) adds the samples s = k, k + 4, k + 8, k + 12; the four partial sums are added in the order of k
-        double corr = 0.0, qc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int sidx = k + 4 * q, ix = side ? t - sidx : sidx - t;
-            const double a = sc[sidx * EDGE_RS + max(ix, 0)], qq = sqt[sidx];
-            corr += ix >= 0 ? a : 0.0;
-            qc += ix >= 0 ? qq : 0.0;
-        }
-        sp[lane] = corr; sp[64 + lane] = qc;
-        __builtin_amdgcn_wave_barrier();
-        const int g = side ? x0 + TV + t : x0 - FFT_EXT + t;
-        if (k == 0 && g >= 0 && g < L) {
-            corr = ((sp[t] + sp[16 + t]) + sp[32 + t]) + sp[48 + t];
-            qc = ((sp[64 + t] + sp[80 + t]) + sp[96 + t]) + sp[112 + t];
-            const long long o = ob + g;
-            const double num = bnum[o] + corr, cv = bcov[o] + qc;
-            const double bb = (num * nuc_cov[o]) / cv;
-            bg[o] = bb;
-            norm[o] = raw[o] - bb;
-            bnum[o] = num;
-            bcov[o] = cv;
-        }
-    }
-}
-
 }  // namespace natac

@@ -1,5 +1,5 @@
-"""Extended tiles of the FFT background kernel (natac_fft_bg.hpp: 16 more outputs on each side of a 512-point tile, finished by
-natac_background_edge_mfma) against direct summation, the plain tiling and the oracle (NucleosomeCalling.py:49-64)."""
+"""Extended tiles of the FFT background kernel (natac_fft_bg.hpp: 16 more outputs on each side of a 512-point tile, finished by the
+edge pass at the end of the tile's wave) against direct summation, the plain tiling and the oracle (NucleosomeCalling.py:49-64)."""
 import os
 import subprocess
 import sys
@@ -117,7 +117,7 @@ def test_extended_tiles_equal_direct_summation_and_plain_tiles(bias_kind):
 
 def test_extended_tiles_with_damaged_bias_match_oracle_and_direct():
     """a NaN, a zero and a huge dynamic range next to the borders of extended tiles: the tiles whose windows hold them are evaluated by
-    direct summation, edge outputs included (the edge pass skips them); NaNs sit exactly where the reference's dense correlation has them"""
+    direct summation, edge outputs included; NaNs sit exactly where the reference's dense correlation has them"""
     from oracle import natac_oracle as O
     par = golden("params_example")
     sizes = synth_size_distribution(251)

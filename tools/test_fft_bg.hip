@@ -9,7 +9,7 @@ using namespace natac;
 static double *g_x1 = nullptr, *g_x2 = nullptr;   // the kernels' bnum / bcov outputs
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-// variant: 0 = the product kernel (one wave per workgroup), plain tiles; 1 = the same with extended tiles + natac_background_edge_mfma
+// variant: 0 = the product kernel (one wave per workgroup), plain tiles; 1 = the same with extended tiles (edge pass at the end of the tile's wave)
 // where the library would use them.  (Round 5's multi-wave workgroup variants natac_background_fft_wg<NW, SYNC> -- measured slower,
 // profiles/r5/fft_hfold_and_multiwave_workgroups.txt -- left the sources with commit 8c075d2's successor.)
 float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const double *d_tw, const double *d_k, double *d_a, double *d_b,
@@ -37,11 +37,9 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
     }
     int2 *d_t; CK(hipMalloc(&d_t, tiles.size() * sizeof(int2)));
     CK(hipMemcpy(d_t, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
-    int *d_ext = nullptr; unsigned char *d_dir = nullptr; double *d_mtab = nullptr, *d_swt = nullptr;
-    const int NJ = (v.R + 3) / 4, wdm = (int)bg_edgem_lds_doubles_per_wave(v.lower, v.upper);
+    double *d_mtab = nullptr, *d_swt = nullptr;
+    const int NJ = (v.R + 3) / 4;
     if (ext) {
-        CK(hipMalloc(&d_ext, ext_list.size() * 4)); CK(hipMemcpy(d_ext, ext_list.data(), ext_list.size() * 4, hipMemcpyHostToDevice));
-        CK(hipMalloc(&d_dir, tiles.size()));
         CK(hipMalloc(&d_mtab, 2 * NJ * 64 * 8)); CK(hipMalloc(&d_swt, 4 * NJ * 8));
         hipLaunchKernelGGL(natac_fft_edge_table_mfma, dim3((2 * NJ * 64 + 255) / 256), dim3(256), 0, 0, v.mat, v.srow, v.R, v.W, NJ, d_mtab, d_swt);
     }
@@ -52,13 +50,7 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
     for (int it = 0; it < reps + 1; ++it) {
         CK(hipEventRecord(e0));
         {
-                hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt, d_dir, v.srow);
-                if (ext) {
-                    if (it == reps) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float m0; CK(hipEventElapsedTime(&m0, e0, e1)); printf("  transforms alone %.3f ms\n", m0); }
-                    hipLaunchKernelGGL(natac_background_edge_mfma, dim3(((int)ext_list.size() + EDGEM_WAVES - 1) / EDGEM_WAVES), dim3(64 * EDGEM_WAVES),
-                                       (size_t)wdm * EDGEM_WAVES * 8, 0, ct, d_t, d_ext, (int)ext_list.size(), d_dir, v, d_mtab, d_swt, NJ, d_a, d_b,
-                                       d_o1, d_o2, g_x1, g_x2, wdm);
-                }
+                hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt, v.srow, d_mtab, d_swt, NJ);
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
