@@ -877,7 +877,7 @@ static bool fft_bg_applicable(const natac_ctx *c) {
 }
 
 // Extended tiles (natac_fft_bg.hpp): FFT_EXT more outputs on each side of a tile, finished by an edge pass at the end of the tile's wave.  An extended
-// tile costs ~11 % more than a plain one (edge pass 8 %, its own longer epilogue 3 %: profiles/r5), so a chunk gets the cheapest
+// tile costs ~10 % more than a plain one (edge pass 6-7 %, its own longer epilogue 3 %: profiles/r5; the rule prices it at 11), so a chunk gets the cheapest
 // mix of n tiles of which the first k are extended, 100 n + 11 k smallest with 392 n + 32 k >= L: 2,120 bases take 5 extended tiles
 // instead of 6 plain ones, 2,000 bases 5 tiles of which 2 are extended, 10,120 bases stay at 26 plain tiles (25 would need 10 extended
 // ones).  The choice depends on the chunk's length alone -- results do not depend on the batch a chunk is in.
@@ -1268,7 +1268,7 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
         const size_t lds = bg_fft_lds_bytes(vm.upper);
         hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
                            c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
-                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg, vm.srow, c->d_fft_mtab,
+                           b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg, c->d_fft_mtab,
                            c->d_fft_swt, (c->R + 3) / 4);
     } else if (fast) {
         switch (b->bgG) {

@@ -225,9 +225,6 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
 #ifndef NATAC_FFT_ABL
 #define NATAC_FFT_ABL 0
 #endif
-#ifndef NATAC_FFT_SROW_S
-#define NATAC_FFT_SROW_S 0     // the pair loop's size weights through a scalar load (tools/fft_ab.sh "0 1" NATAC_FFT_SROW_S)
-#endif
 // complex scratch of the transposes: interleaved double2 (two planes of doubles with 8-byte accesses measured 5 % slower)
 #define CST(p, i, xr, xi) do { (p)[(i)] = make_double2((xr), (xi)); } while (0)
 #define CLD(p, i, xr, xi) do { const double2 v_ = (p)[(i)]; (xr) = v_.x; (xi) = v_.y; } while (0)
@@ -349,8 +346,8 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
                                             const double *__restrict__ ktab, const double *__restrict__ nuc_cov,
                                             const double *__restrict__ raw, double *__restrict__ bg, double *__restrict__ norm,
                                             double *__restrict__ bnum, double *__restrict__ bcov, double *smem, FftTwiddles &tww,
-                                            const int lane, const double *__restrict__ srow_s = nullptr, const double *__restrict__ mtab = nullptr,
-                                            const double *__restrict__ swt = nullptr, const int NJ = 0) {
+                                            const int lane, const double *__restrict__ mtab = nullptr, const double *__restrict__ swt = nullptr,
+                                            const int NJ = 0) {
     const int W = vm.W, HW = W / 2, TV = FFT_N - W + 1;
     const int A = (vm.upper - 2) >> 1, Bh = (vm.upper - 1) >> 1;
     const int ext = (t.y & FFT_EXT_BIT) ? FFT_EXT : 0;   // extended tile: FFT_EXT more outputs on each side, finished by the edge pass below
@@ -459,11 +456,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         };
         issue_xy(0);
         for (int pair = 0; pair < npair; ++pair) {
-#if NATAC_FFT_SROW_S
-            const double sa = srow_s[2 * pair], sb = srow_s[2 * pair + 1];     // the kernel's restrict argument: one scalar load
-#else
-            const double sa = vm.srow[2 * pair], sb = vm.srow[2 * pair + 1];
-#endif
+            const double sa = vm.srow[2 * pair], sb = vm.srow[2 * pair + 1];     // (as one scalar load instead: measured, no difference)
             const double *k = ktab + (size_t)pair * 2 * FFT_N;
             double kr[8], ki[8], re[8], im[8];
 #pragma unroll
@@ -670,12 +663,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                                              const double *__restrict__ nuc_cov, const double *__restrict__ raw,
                                                              double *__restrict__ bg, double *__restrict__ norm,
                                                              double *__restrict__ bnum, double *__restrict__ bcov,
-                                                             unsigned n_tiles, const double *__restrict__ srow, const double *__restrict__ mtab,
+                                                             unsigned n_tiles, const double *__restrict__ mtab,
                                                              const double *__restrict__ swt, int NJ) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const unsigned ti = blockIdx.x;
     FftTwiddles tww;
-    bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x, srow, mtab, swt, NJ);
+    bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x, mtab, swt, NJ);
 }
 
 // LDS of one wave of natac_background_fft, in bytes (host): the exp(bias) window of an extended tile + the transposes' scratch

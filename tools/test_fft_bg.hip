@@ -50,7 +50,7 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
     for (int it = 0; it < reps + 1; ++it) {
         CK(hipEventRecord(e0));
         {
-                hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt, v.srow, d_mtab, d_swt, NJ);
+                hipLaunchKernelGGL(natac_background_fft, dim3(nt), dim3(64), lds, 0, ct, d_t, v, d_tw, d_k, d_a, d_b, d_o1, d_o2, g_x1, g_x2, (unsigned)nt, d_mtab, d_swt, NJ);
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
