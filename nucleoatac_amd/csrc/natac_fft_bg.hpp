@@ -225,6 +225,12 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
 #ifndef NATAC_FFT_ABL
 #define NATAC_FFT_ABL 0
 #endif
+#ifndef NATAC_FFT_TW_EARLY
+#define NATAC_FFT_TW_EARLY 1       // the per-lane twiddles requested in front of the window staging instead of behind the conditioning test
+#endif                             // (both switches, tools/r5_ext6.sh, 100 k extended tiles, five runs each: 7.51 -> 7.44 -> 7.39 ms)
+#ifndef NATAC_FFT_EPI_PREFETCH
+#define NATAC_FFT_EPI_PREFETCH 1   // the epilogue's nuc_cov / raw inputs requested before the inverse transform (tools/fft_ab.sh "0 1" NATAC_FFT_EPI_PREFETCH)
+#endif
 // complex scratch of the transposes: interleaved double2 (two planes of doubles with 8-byte accesses measured 5 % slower)
 #define CST(p, i, xr, xi) do { (p)[(i)] = make_double2((xr), (xi)); } while (0)
 #define CLD(p, i, xr, xi) do { const double2 v_ = (p)[(i)]; (xr) = v_.x; (xi) = v_.y; } while (0)
@@ -357,6 +363,9 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
     double *sar = (double *)ca, *sai = sar + FFT_LA;   // the same memory as two real arrays (epilogue)
     const int chunk = t.x, x0 = t.y & (FFT_EXT_BIT - 1);
     const int L = ct.chunk_len[chunk];
+    // the per-lane twiddles requested in front of the window staging (one round trip to L2 that nothing waits for); the rare tile that
+    // falls back to direct summation has loaded them for nothing
+    if (!TW_LOADED && NATAC_FFT_TW_EARLY) fft_load_twiddles(tww, tw, lane);
     bool use_fft;
     {   // Et[u] <-> coordinate x0 - ext - HW - A + u
         const double *b = ct.bias ? ct.ebias + ct.bias_off[chunk] : nullptr;       // exp(bias), natac_exp_bias
@@ -411,7 +420,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         }
         return;
     }
-    if (!TW_LOADED) fft_load_twiddles(tww, tw, lane);
+    if (!TW_LOADED && !NATAC_FFT_TW_EARLY) fft_load_twiddles(tww, tw, lane);
     double accr[8], acci[8], q[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) { accr[m] = 0.0; acci[m] = 0.0; q[m] = 0.0; }
@@ -551,6 +560,18 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
             acci[m] = fma(im[m], kr[m], fma(-re[m], ki[m], acci[m]));
         }
     }
+#if NATAC_FFT_EPI_PREFETCH
+    // the epilogue's two inputs per output, requested before the inverse transform: behind the barriers and asm waits below the compiler
+    // cannot move the loads up, and every one of the eight output rows then waited for its own round trip to HBM
+    double pf_cov[8], pf_raw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int u = lane + 64 * j, g = x0 + u;
+        const bool core = u < TV && g < L;
+        pf_cov[j] = core ? nuc_cov[ob + g] : 0.0;
+        pf_raw[j] = core ? raw[ob + g] : 0.0;
+    }
+#endif
     fft512_inv(accr, acci, tww, ca, cb, lane);
     // covB: W-wide box sum of Q (both rows of every pair already added), two levels: T[u] = sum of B consecutive Q,
     // cov[u] = sum of nb strided T + the remainder  (B = 11, nb = 11 for W = 121: 23 LDS reads per base instead of 121)
@@ -612,9 +633,15 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
             const long long o = ob + g;
             const double num = accr[j] * (1.0 / FFT_N), cv = cvv[j];
             if (core) {
+#if NATAC_FFT_EPI_PREFETCH
+                const double b = (num * pf_cov[j]) / cv;
+                bg[o] = b;
+                norm[o] = pf_raw[j] - b;
+#else
                 const double b = (num * nuc_cov[o]) / cv;
                 bg[o] = b;
                 norm[o] = raw[o] - b;
+#endif
             }
             if (core) {
                 bnum[o] = num;       // sum B V and sum B of the window at this base: reused by the candidate statistics
