@@ -208,6 +208,43 @@ __device__ __forceinline__ void bg_edge_side(const int side, const double *wl_lo
     }
 }
 
+// ---- explicit LDS instructions of the skewed pair loop (NATAC_FFT_SKEW, bg_fft_tile) ---------------------------------------------------
+// The skewed loop keeps two transforms of one wave in flight, so its waits must name HOW MANY of the wave's LDS instructions may still
+// be outstanding (LDS instructions of a wave execute and return in issue order; lgkmcnt counts them).  The compiler counts only the LDS
+// instructions it emitted itself, so every LDS access of that loop is inline asm and every wait is written out.
+typedef double d2v __attribute__((ext_vector_type(2)));
+#ifndef NATAC_SKEW_ABL
+#define NATAC_SKEW_ABL 0     // harness only (tools/r6_skew3.sh; wrong results): 1 = no transpose stores, 2 = no transpose loads, 4 = no template-spectrum loads, 8 = no operand reads
+#endif
+template <int OFF> __device__ __forceinline__ void ds_st128(unsigned a, double xr, double xi) {
+    const d2v v = {xr, xi};
+    if (NATAC_SKEW_ABL & 1) { asm volatile("" : : "v"(a), "v"(v) : "memory"); return; }
+    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(a), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void ds_ld128(d2v &v, unsigned a) {
+    if (NATAC_SKEW_ABL & 2) { asm volatile("" : "=v"(v) : "v"(a) : "memory"); return; }
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+}
+// eight complex values a + STRIDE j (bytes)
+template <int STRIDE> __device__ __forceinline__ void ds_ld128x8(d2v (&v)[8], unsigned a) {
+    ds_ld128<0 * STRIDE>(v[0], a); ds_ld128<1 * STRIDE>(v[1], a); ds_ld128<2 * STRIDE>(v[2], a); ds_ld128<3 * STRIDE>(v[3], a);
+    ds_ld128<4 * STRIDE>(v[4], a); ds_ld128<5 * STRIDE>(v[5], a); ds_ld128<6 * STRIDE>(v[6], a); ds_ld128<7 * STRIDE>(v[7], a);
+}
+// wait until at most N of the wave's LDS instructions are outstanding; the operands tie every later use of the eight values to it
+template <int N> __device__ __forceinline__ void lds_wait_c8(d2v (&v)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void lds_wait16n(double (&x)[8], double (&y)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%16)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7])
+                 : "n"(N)
+                 : "memory");
+}
+
 struct FftTwiddles {            // per-lane twiddles, loaded once per kernel
     double w1r[8], w1i[8];      // W_512^(lane * m)
     double w2r[8], w2i[8];      // W_64^((lane & 7) * m)
@@ -224,6 +261,23 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
 
 #ifndef NATAC_FFT_ABL
 #define NATAC_FFT_ABL 0
+#endif
+#ifndef NATAC_FFT_SKEW
+#define NATAC_FFT_SKEW 1           // the pair loop with two row pairs in flight per wave (see "the skewed pair loop" in bg_fft_tile)
+#endif
+#ifndef NATAC_FFT_KX4
+#define NATAC_FFT_KX4 1            // template spectra as [pair][m][lane][re, im]: a lane's two values of a bin in ONE 16-byte load (8 instead of 16 requests per pair)
+#endif
+#if NATAC_FFT_KX4
+#define NATAC_FFT_KIDX(m, lane, c) (((m) * 64 + (lane)) * 2 + (c))
+#else
+#define NATAC_FFT_KIDX(m, lane, c) ((c) * FFT_N + (m) * 64 + (lane))
+#endif
+#ifndef NATAC_FFT_SKEW_XYWAIT
+#define NATAC_FFT_SKEW_XYWAIT 8    // the skewed loop's wait for the next pair's operands: 0 = in front of W2's stores, 8 = behind them (in front of R2's loads)
+#endif
+#ifndef NATAC_FFT_SKEW_K
+#define NATAC_FFT_SKEW_K 3         // where the skewed loop requests a pair's template spectrum: 1 = a whole trip ahead, 2 = at the top of its trip, 3 = after S1 of the next pair, 4 = after that S1's products
 #endif
 #ifndef NATAC_FFT_TW_EARLY
 #define NATAC_FFT_TW_EARLY 1       // the per-lane twiddles requested in front of the window staging instead of behind the conditioning test
@@ -315,7 +369,51 @@ __device__ __forceinline__ void fft512_inv(double (&re)[8], double (&im)[8], con
     __builtin_amdgcn_wave_barrier();
 }
 
-// K[pair] = FFT(s_a V_a + i s_b V_b) in the layout fft512_fwd produces; kout[pair][re/im][m][lane].  One wave per pair.
+// ---- the skewed pair loop's pieces (NATAC_FFT_SKEW) -------------------------------------------------------------------------------------
+// Same transform as fft512_fwd -- the same operations on the same values in the same order, so the same bits -- cut at its two transposes
+// so that bg_fft_tile can put ANOTHER row pair's arithmetic between a transpose's store + read-back and the first use of what comes back:
+//   S1 = products + column sums + first DFT + twiddle 1        -> W1 (8 stores, layout A), R1 (8 loads)
+//   S2 = second DFT + twiddle 2                                 -> W2 (8 stores, layout B), R2 (8 loads)
+//   S3 = third DFT + acc += Z conj(K)
+// Byte addresses (LDS offsets) of a lane, `c` = the wave's complex scratch:
+//   W1: c + 16 (lane + 72 m)          R1: c + 16 (72 m2 + n1 + 8 j)        W2: c + 16 (65 n1 + 8 m2 + m)        R2: c + 16 (65 n + lane)
+__device__ __forceinline__ void skew_tw1(double (&re)[8], double (&im)[8], const FftTwiddles &t) {
+#pragma unroll
+    for (int m = 1; m < 8; ++m) {
+        const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])), xi = fma(re[m], t.w1i[m], im[m] * t.w1r[m]);
+        re[m] = xr; im[m] = xi;
+    }
+}
+__device__ __forceinline__ void skew_w1(const double (&re)[8], const double (&im)[8], unsigned a) {
+    ds_st128<0 * 1152>(a, re[0], im[0]); ds_st128<1 * 1152>(a, re[1], im[1]); ds_st128<2 * 1152>(a, re[2], im[2]); ds_st128<3 * 1152>(a, re[3], im[3]);
+    ds_st128<4 * 1152>(a, re[4], im[4]); ds_st128<5 * 1152>(a, re[5], im[5]); ds_st128<6 * 1152>(a, re[6], im[6]); ds_st128<7 * 1152>(a, re[7], im[7]);
+}
+// second DFT of the values R1 brought (skew_s2), then twiddle 2 and W2 (skew_w2)
+__device__ __forceinline__ void skew_s2(const d2v (&A)[8], double (&re)[8], double (&im)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { re[j] = A[j].x; im[j] = A[j].y; }
+    dft8<false>(re, im);
+}
+__device__ __forceinline__ void skew_w2(const double (&re)[8], const double (&im)[8], const FftTwiddles &t, unsigned a) {
+#define NATAC_SKEW_W2(m) { const double xr = fma(re[m], t.w2r[m], -(im[m] * t.w2i[m])), xi = fma(re[m], t.w2i[m], im[m] * t.w2r[m]); ds_st128<16 * (m)>(a, xr, xi); }
+    ds_st128<0>(a, re[0], im[0]);
+    NATAC_SKEW_W2(1) NATAC_SKEW_W2(2) NATAC_SKEW_W2(3) NATAC_SKEW_W2(4) NATAC_SKEW_W2(5) NATAC_SKEW_W2(6) NATAC_SKEW_W2(7)
+#undef NATAC_SKEW_W2
+}
+// third DFT of the values R2 brought and acc += Z conj(K)
+__device__ __forceinline__ void skew_s3(const d2v (&B)[8], const double (&kr)[8], const double (&ki)[8], double (&accr)[8], double (&acci)[8]) {
+    double re[8], im[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { re[j] = B[j].x; im[j] = B[j].y; }
+    dft8<false>(re, im);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        accr[m] = fma(re[m], kr[m], fma(im[m], ki[m], accr[m]));
+        acci[m] = fma(im[m], kr[m], fma(-re[m], ki[m], acci[m]));
+    }
+}
+
+// K[pair] = FFT(s_a V_a + i s_b V_b) in the layout fft512_fwd produces; kout[pair][m][lane][re, im] (NATAC_FFT_KIDX).  One wave per pair.
 // The insert-size weights s_r (BiasMat2D.normByInsertDist, chunkmat2d.py:154-156) are folded into the template: the
 // correlation is linear, so sum_r (s_r B0_r) * V_r = sum_r B0_r * (s_r V_r) and the kernel transforms the unweighted products.
 __global__ void __launch_bounds__(64) natac_fft_template(const double *__restrict__ vmat, const double *__restrict__ srow, int R, int W,
@@ -335,7 +433,7 @@ __global__ void __launch_bounds__(64) natac_fft_template(const double *__restric
     fft512_fwd(re, im, t, sa, sb, lane);
     double *o = kout + (size_t)pair * 2 * FFT_N;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) { o[m * 64 + lane] = re[m]; o[FFT_N + m * 64 + lane] = im[m]; }
+    for (int m = 0; m < 8; ++m) { o[NATAC_FFT_KIDX(m, lane, 0)] = re[m]; o[NATAC_FFT_KIDX(m, lane, 1)] = im[m]; }
 }
 
 // background + normalised signal for tiles of TV = 512 - W + 1 bases; one tile per wave, one wave per workgroup.
@@ -440,7 +538,108 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) carry[j] = c0[lane + 64 * j];
     }
-    if (pairs_full && NATAC_FFT_ABL == 0) {
+    if (pairs_full && NATAC_FFT_ABL == 0 && NATAC_FFT_SKEW) {
+        // The skewed pair loop (round 6).  A transform is S1 -> W1 R1 -> S2 -> W2 R2 -> S3 (skew_* above); a wave that runs them in that
+        // order sits out two LDS round trips per row pair (8 stores at 13 cycles, 8 loads, the queue of the CU's seven other waves in
+        // front of them), and the SIMD's second wave covered only part of that (round 5: 23.5 ms of fp64 issue + 18.3 ms of LDS array time
+        // overlapped by 4.5 ms).  Here the wave has TWO row pairs in flight, p (second half) and p + 1 (first half):
+        //     wait R1(p) | x,y(p+1) requested | S2(p)  W2(p)  R2(p) requested | S1(p+1) | K(p) requested  W1(p+1)  R1(p+1) requested |
+        //     wait R2(p) | S3(p)
+        // so R2(p) travels under S1(p+1) (112 fp64 instructions) and R1(p+1) under S3(p) (84).  One scratch region is enough: a wave's LDS
+        // instructions execute in issue order, R2(p) is issued before W1(p+1) overwrites what it reads.  Registers: while S1(p+1) runs, R2's
+        // eight complex targets are the only extra live values (the template spectrum K(p) is requested after it); while S3(p) runs, R1's.
+        // Every value is computed by the same operations in the same order as in fft512_fwd: bit-identical outputs.
+        const unsigned cbase = (unsigned)(uintptr_t)ca;
+        const int m2 = lane >> 3, n1 = lane & 7;
+        const unsigned aw1 = cbase + 16u * lane, ar1 = cbase + 16u * (72 * m2 + n1), aw2 = cbase + 16u * (65 * n1 + 8 * m2), ar2 = aw1;
+        // One form for an odd and for an even first insert size: with X = the factor both rows of a pair share and Y = row b's other factor
+        // (odd: X = left factor, Y = right factor of b, carried = right factor of a; even: X = right factor, Y = left factor of b, carried =
+        // left factor of a) the products are  re = X carried, im = X Y, carried' = Y  either way -- only the ADDRESSES differ (a product does
+        // not depend on the order of its factors, so these are the bits of the loop that tested `lodd` per trip).  Left factors move down
+        // by one sample per pair, right factors up.
+        double x[8], y[8], tr[8], ti[8];
+        d2v Av[8], Bv[8];
+        const double *px = (lodd ? Et + (A - floor_half(vm.lower - 1)) : Et + (A + floor_half(vm.lower))) + lane;
+        const double *py = (lodd ? Et + (A + floor_half(vm.lower + 1)) : Et + (A - floor_half(vm.lower))) + lane;
+        const int dx = lodd ? -1 : 1;
+        auto issue_xy = [&](int pair) {
+            if (NATAC_SKEW_ABL & 8) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) { asm volatile("" : "=v"(x[jj])); asm volatile("" : "=v"(y[jj])); }
+            } else {
+                lds_read8_b64(x, px + dx * pair);
+                lds_read8_b64(y, py - dx * pair);
+            }
+        };
+        auto s1 = [&](const double sa, const double sb) {     // x, y, carry -> products, column sums
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                tr[j] = x[j] * carry[j];
+                ti[j] = x[j] * y[j];
+                carry[j] = y[j];
+                q[j] = fma(sb, ti[j], fma(sa, tr[j], q[j]));
+            }
+        };
+        auto s1b = [&]() {
+            dft8<false>(tr, ti);
+            skew_tw1(tr, ti, tww);
+        };
+        double kr[8], ki[8];
+        auto load_k = [&](int pair) {
+            const double *k = ktab + (size_t)pair * 2 * FFT_N;
+            if (NATAC_SKEW_ABL & 4) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { asm volatile("" : "=v"(kr[m])); asm volatile("" : "=v"(ki[m])); }
+                return;
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { kr[m] = k[NATAC_FFT_KIDX(m, lane, 0)]; ki[m] = k[NATAC_FFT_KIDX(m, lane, 1)]; }
+        };
+        issue_xy(0);
+        lds_wait16n<0>(x, y);
+        s1(vm.srow[0], vm.srow[1]);
+        s1b();
+        skew_w1(tr, ti, aw1);
+        ds_ld128x8<128>(Av, ar1);
+        if (NATAC_FFT_SKEW_K == 1) load_k(0);
+        double ur[8], ui[8];
+        for (int pair = 0; pair + 1 < npair; ++pair) {
+            lds_wait_c8<0>(Av);                        // R1(pair)
+            issue_xy(pair + 1);
+            const double sa = vm.srow[2 * pair + 2], sb = vm.srow[2 * pair + 3];     // requested a phase ahead of their use in S1
+            if (NATAC_FFT_SKEW_K == 2) load_k(pair);
+            __builtin_amdgcn_sched_barrier(0);
+            skew_s2(Av, ur, ui);
+            __builtin_amdgcn_sched_barrier(0);
+#if NATAC_FFT_SKEW_XYWAIT == 0
+            lds_wait16n<0>(x, y);
+#endif
+            skew_w2(ur, ui, tww, aw2);
+#if NATAC_FFT_SKEW_XYWAIT == 8
+            lds_wait16n<8>(x, y);                     // the operands, with W2's eight stores outstanding but BEFORE R2 is requested: lgkmcnt is a 4-bit
+#endif                                                // counter, a wait behind R2 could not leave all 16 outstanding and would sit out the first store
+            ds_ld128x8<1040>(Bv, ar2);                // R2(pair)
+            __builtin_amdgcn_sched_barrier(0);
+            s1(sa, sb);
+            if (NATAC_FFT_SKEW_K == 4) { __builtin_amdgcn_sched_barrier(0); load_k(pair); __builtin_amdgcn_sched_barrier(0); }
+            s1b();
+            __builtin_amdgcn_sched_barrier(0);
+            if (NATAC_FFT_SKEW_K == 3) load_k(pair);
+            skew_w1(tr, ti, aw1);
+            lds_wait_c8<8>(Bv);                       // R2(pair): only W1's eight stores may still be outstanding; R1 is requested behind the wait
+            ds_ld128x8<128>(Av, ar1);                  // R1(pair + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            skew_s3(Bv, kr, ki, accr, acci);
+            if (NATAC_FFT_SKEW_K == 1) { __builtin_amdgcn_sched_barrier(0); load_k(pair + 1); }
+        }
+        lds_wait_c8<0>(Av);
+        skew_s2(Av, ur, ui);
+        skew_w2(ur, ui, tww, aw2);
+        ds_ld128x8<1040>(Bv, ar2);
+        if (NATAC_FFT_SKEW_K != 1) load_k(npair - 1);
+        lds_wait_c8<0>(Bv);
+        skew_s3(Bv, kr, ki, accr, acci);
+    } else if (pairs_full && NATAC_FFT_ABL == 0) {
         // Measured in round 5 and not kept (tools/test_fft_bg.hip on 20 k chunks, 8.25-8.30 ms as it stands): (1) the short last tile of a
         // chunk (2,120 bases leave 280 points of 512 for the sixth tile) with the zero blocks' operand reads, products, column sums and
         // first-stage additions left out -- same bits, 13 % fewer fp64 instructions in one tile of six -- 8.31 ms: a second copy of this
@@ -469,7 +668,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
             const double *k = ktab + (size_t)pair * 2 * FFT_N;
             double kr[8], ki[8], re[8], im[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) { kr[m] = k[m * 64 + lane]; ki[m] = k[FFT_N + m * 64 + lane]; }
+            for (int m = 0; m < 8; ++m) { kr[m] = k[NATAC_FFT_KIDX(m, lane, 0)]; ki[m] = k[NATAC_FFT_KIDX(m, lane, 1)]; }
             __builtin_amdgcn_sched_barrier(0);
             lds_wait16(x, y);
             if (lodd) {       // carry = right factor of a
@@ -553,7 +752,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         }
         fft512_fwd(re, im, tww, ca, cb, lane);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { kr[m] = NATAC_FFT_ABL == 2 ? 0.5 + m : k[m * 64 + lane]; ki[m] = NATAC_FFT_ABL == 2 ? 0.25 * m : k[FFT_N + m * 64 + lane]; }
+        for (int m = 0; m < 8; ++m) { kr[m] = NATAC_FFT_ABL == 2 ? 0.5 + m : k[NATAC_FFT_KIDX(m, lane, 0)]; ki[m] = NATAC_FFT_ABL == 2 ? 0.25 * m : k[NATAC_FFT_KIDX(m, lane, 1)]; }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
             accr[m] = fma(re[m], kr[m], fma(im[m], ki[m], accr[m]));

@@ -47,6 +47,7 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     const int nt = (int)tiles.size();
+    if (getenv("NATAC_HARNESS_REPS")) reps = atoi(getenv("NATAC_HARNESS_REPS"));     // many back-to-back launches (tools/r6_power.sh samples power and clock under them)
     for (int it = 0; it < reps + 1; ++it) {
         CK(hipEventRecord(e0));
         {
@@ -64,7 +65,7 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
 
 int main(int argc, char **argv) {
     int nc = argc > 1 ? atoi(argv[1]) : 20000, L = argc > 2 ? atoi(argv[2]) : 2120;
-    const int R = 146, W = 121, lo = 105, up = 251, bl = 246, br = 247;
+    const int R = 146, W = 121, lo = getenv("NATAC_HARNESS_LO") ? atoi(getenv("NATAC_HARNESS_LO")) : 105, up = lo + R, bl = 246, br = 247;   // NATAC_HARNESS_LO=104: an even first insert size
     std::vector<int> len(nc, L); std::vector<long long> foff(nc + 1, 0), boff(nc + 1), ooff(nc + 1);
     for (int i = 0; i <= nc; ++i) { boff[i] = (long long)i * (L + bl + br); ooff[i] = (long long)i * L; }
     std::vector<double> bias((size_t)nc * (L + bl + br)); for (auto &x : bias) x = (rand() / (double)RAND_MAX - 0.5) * 3.0 - 4.0;
@@ -137,6 +138,17 @@ int main(int argc, char **argv) {
         }
         printf("bg: max rel err %.3e (at %zu: %.17g vs %.17g)  max abs %.3e  nan-mismatch %zu\n", maxrel, worst, x[worst], y[worst], maxabs, bad);
         printf("sample: %.6g %.6g | %.6g %.6g | %.6g %.6g\n", x[0], y[0], x[391], y[391], x[392], y[392]);
+        {   // the FFT run's four outputs as one 64-bit FNV-1a hash: equal between two builds <=> bit-identical outputs
+            const double *pp[4] = {d_o1, d_o2, g_x1, g_x2};
+            unsigned long long h = 1469598103934665603ull;
+            std::vector<double> z(nbp);
+            for (int k = 0; k < 4; ++k) {
+                CK(hipMemcpy(z.data(), pp[k], nbp * 8, hipMemcpyDeviceToHost));
+                const unsigned long long *u = (const unsigned long long *)z.data();
+                for (size_t i = 0; i < nbp; ++i) { h ^= u[i]; h *= 1099511628211ull; }
+            }
+            printf("outputs fnv1a64 %016llx\n", h);
+        }
         const double *pa[3] = {d_p2, d_x1, d_x2}, *pb[3] = {d_o2, g_x1, g_x2};
         const char *nm[3] = {"norm", "bnum", "bcov"};
         for (int k = 0; k < 3 && !(argc > 4); ++k) {
