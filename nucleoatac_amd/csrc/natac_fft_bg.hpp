@@ -273,11 +273,11 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
 #else
 #define NATAC_FFT_KIDX(m, lane, c) ((c) * FFT_N + (m) * 64 + (lane))
 #endif
-#ifndef NATAC_FFT_SKEW_XYWAIT
-#define NATAC_FFT_SKEW_XYWAIT 8    // the skewed loop's wait for the next pair's operands: 0 = in front of W2's stores, 8 = behind them (in front of R2's loads)
+#ifndef NATAC_FFT_SKEW_PP
+#define NATAC_FFT_SKEW_PP 1        // the skewed loop unrolled by two, the carried operand factor alternating between two buffers (no register copies)
 #endif
 #ifndef NATAC_FFT_SKEW_K
-#define NATAC_FFT_SKEW_K 3         // where the skewed loop requests a pair's template spectrum: 1 = a whole trip ahead, 2 = at the top of its trip, 3 = after S1 of the next pair, 4 = after that S1's products
+#define NATAC_FFT_SKEW_K 3         // where the skewed loop requests a pair's template spectrum: 3 = after S1 of the next pair, 4 = after that S1's products (earlier: spills)
 #endif
 #ifndef NATAC_FFT_TW_EARLY
 #define NATAC_FFT_TW_EARLY 1       // the per-lane twiddles requested in front of the window staging instead of behind the conditioning test
@@ -562,21 +562,22 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         const double *px = (lodd ? Et + (A - floor_half(vm.lower - 1)) : Et + (A + floor_half(vm.lower))) + lane;
         const double *py = (lodd ? Et + (A + floor_half(vm.lower + 1)) : Et + (A - floor_half(vm.lower))) + lane;
         const int dx = lodd ? -1 : 1;
-        auto issue_xy = [&](int pair) {
+        // yn = where the pair's Y goes, yo = the Y of the pair before (the carried factor).  With NATAC_FFT_SKEW_PP the loop is unrolled by two
+        // and the two buffers swap roles from trip to trip; without it yo is `carry` and every trip ends with eight register copies.
+        auto issue_xy = [&](int pair, double (&yn)[8]) {
             if (NATAC_SKEW_ABL & 8) {
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) { asm volatile("" : "=v"(x[jj])); asm volatile("" : "=v"(y[jj])); }
+                for (int jj = 0; jj < 8; ++jj) { asm volatile("" : "=v"(x[jj])); asm volatile("" : "=v"(yn[jj])); }
             } else {
                 lds_read8_b64(x, px + dx * pair);
-                lds_read8_b64(y, py - dx * pair);
+                lds_read8_b64(yn, py - dx * pair);
             }
         };
-        auto s1 = [&](const double sa, const double sb) {     // x, y, carry -> products, column sums
+        auto s1 = [&](const double sa, const double sb, const double (&yn)[8], const double (&yo)[8]) {     // x, Y, carried Y -> products, column sums
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                tr[j] = x[j] * carry[j];
-                ti[j] = x[j] * y[j];
-                carry[j] = y[j];
+                tr[j] = x[j] * yo[j];
+                ti[j] = x[j] * yn[j];
                 q[j] = fma(sb, ti[j], fma(sa, tr[j], q[j]));
             }
         };
@@ -595,32 +596,20 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
 #pragma unroll
             for (int m = 0; m < 8; ++m) { kr[m] = k[NATAC_FFT_KIDX(m, lane, 0)]; ki[m] = k[NATAC_FFT_KIDX(m, lane, 1)]; }
         };
-        issue_xy(0);
-        lds_wait16n<0>(x, y);
-        s1(vm.srow[0], vm.srow[1]);
-        s1b();
-        skew_w1(tr, ti, aw1);
-        ds_ld128x8<128>(Av, ar1);
-        if (NATAC_FFT_SKEW_K == 1) load_k(0);
         double ur[8], ui[8];
-        for (int pair = 0; pair + 1 < npair; ++pair) {
+        // one trip: second half of `pair`, first half of pair + 1 (whose Y goes to yn; yo = pair's Y)
+        auto trip = [&](int pair, double (&yn)[8], double (&yo)[8]) {
             lds_wait_c8<0>(Av);                        // R1(pair)
-            issue_xy(pair + 1);
+            issue_xy(pair + 1, yn);
             const double sa = vm.srow[2 * pair + 2], sb = vm.srow[2 * pair + 3];     // requested a phase ahead of their use in S1
-            if (NATAC_FFT_SKEW_K == 2) load_k(pair);
             __builtin_amdgcn_sched_barrier(0);
             skew_s2(Av, ur, ui);
             __builtin_amdgcn_sched_barrier(0);
-#if NATAC_FFT_SKEW_XYWAIT == 0
-            lds_wait16n<0>(x, y);
-#endif
             skew_w2(ur, ui, tww, aw2);
-#if NATAC_FFT_SKEW_XYWAIT == 8
-            lds_wait16n<8>(x, y);                     // the operands, with W2's eight stores outstanding but BEFORE R2 is requested: lgkmcnt is a 4-bit
-#endif                                                // counter, a wait behind R2 could not leave all 16 outstanding and would sit out the first store
-            ds_ld128x8<1040>(Bv, ar2);                // R2(pair)
+            lds_wait16n<8>(x, yn);                    // the operands, with W2's eight stores outstanding but BEFORE R2 is requested: lgkmcnt is a 4-bit
+            ds_ld128x8<1040>(Bv, ar2);                // counter, a wait behind R2 could not leave all 16 outstanding and would sit out the first store
             __builtin_amdgcn_sched_barrier(0);
-            s1(sa, sb);
+            s1(sa, sb, yn, yo);
             if (NATAC_FFT_SKEW_K == 4) { __builtin_amdgcn_sched_barrier(0); load_k(pair); __builtin_amdgcn_sched_barrier(0); }
             s1b();
             __builtin_amdgcn_sched_barrier(0);
@@ -630,13 +619,34 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
             ds_ld128x8<128>(Av, ar1);                  // R1(pair + 1)
             __builtin_amdgcn_sched_barrier(0);
             skew_s3(Bv, kr, ki, accr, acci);
-            if (NATAC_FFT_SKEW_K == 1) { __builtin_amdgcn_sched_barrier(0); load_k(pair + 1); }
+        };
+        issue_xy(0, y);
+        lds_wait16n<0>(x, y);
+        s1(vm.srow[0], vm.srow[1], y, carry);
+        s1b();
+        skew_w1(tr, ti, aw1);
+        ds_ld128x8<128>(Av, ar1);
+        {
+            int pair = 0;
+#if NATAC_FFT_SKEW_PP
+            for (; pair + 2 < npair; pair += 2) {
+                trip(pair, carry, y);
+                trip(pair + 1, y, carry);
+            }
+            if (pair + 1 < npair) trip(pair, carry, y);
+#else
+            for (; pair + 1 < npair; ++pair) {
+                trip(pair, carry, y);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) y[jj] = carry[jj];
+            }
+#endif
         }
         lds_wait_c8<0>(Av);
         skew_s2(Av, ur, ui);
         skew_w2(ur, ui, tww, aw2);
         ds_ld128x8<1040>(Bv, ar2);
-        if (NATAC_FFT_SKEW_K != 1) load_k(npair - 1);
+        load_k(npair - 1);
         lds_wait_c8<0>(Bv);
         skew_s3(Bv, kr, ki, accr, acci);
     } else if (pairs_full && NATAC_FFT_ABL == 0) {
