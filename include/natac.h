@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define NATAC_ABI_VERSION 1
+/* bumped whenever an entry point is added, removed or changes meaning (2: round 5 removed natac_run_nuc_occ, added natac_bg_tiling /
+ * natac_store_set_budget / natac_store_declined, gave natac_store_adopt's n_hard == -1 a meaning); the binding refuses another version */
+#define NATAC_ABI_VERSION 2
 
 enum {
     NATAC_OK = 0,

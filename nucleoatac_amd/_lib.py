@@ -7,6 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2      # NATAC_ABI_VERSION of include/natac.h (tests/test_abi.py compares the two)
 LIB_PATH = os.environ.get("NATAC_LIB") or os.path.join(_HERE, "libnatac_hip.so")   # NATAC_LIB: A/B builds of the same ABI
 
 # enums of include/natac.h
@@ -164,8 +165,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.natac_abi_version() != 1:
-        raise ImportError("libnatac_hip.so ABI version mismatch")
+    if lib.natac_abi_version() != ABI_VERSION:
+        raise ImportError("libnatac_hip.so ABI version %d, this binding is for %d: rebuild (python __graft_entry__.py)" % (lib.natac_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -945,6 +945,12 @@ static int ensure_fft(natac_ctx *c) {
             tw[2 * k] = std::cos(a);
             tw[2 * k + 1] = -std::sin(a);
         }
+        // fault injection for the test suite's own sensitivity check (tests/test_gpu_tight_tier.py): NATAC_FAULT_TWIDDLE="k:delta" adds delta
+        // to cos(2 pi k / 512).  The parity tests must FAIL with k = 37, delta = 1e-9 -- a tolerance that lets this through is not a test.
+        if (const char *e = getenv("NATAC_FAULT_TWIDDLE")) {
+            int k = 0; double dlt = 0.0;
+            if (sscanf(e, "%d:%lf", &k, &dlt) == 2 && k >= 0 && k < natac::FFT_N) tw[2 * (size_t)k] += dlt;
+        }
         if ((rc = dev_upload(c, &c->d_fft_tw, tw.data(), tw.size()))) return rc;
         HIPCHK(sync_all(c));
     }

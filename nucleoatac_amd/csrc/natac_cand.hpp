@@ -280,6 +280,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
     acc = row_sum(acc);
     cntf = row_sum(cntf);                                       // small integers: exact
+    // LR = sum_f log(V / s)[r_f, c_f] - n_f log(S_B0V / S_B): Nucleosome.getLR's sum of log(V b0 / (b ...)) with the per-fragment bias
+    // product cancelled.  Algebraically equal; it DEVIATES from the reference only where a single fragment's V * b0 under- or overflows
+    // in the reference (it returns -inf / NaN there, this form stays finite; `myzero` keeps the reference's NaN for exact zeros), and
+    // it rounds differently at ~1e-13 relative (tests hold lr to the oracle at 1e-10).
     const double nl = acc, ul = cntf * log(myB0V / tB);
     if (l == 0 && k0 + row < ncand) {
         const double m1 = tBV / tB;

@@ -94,7 +94,7 @@ __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
 
 // eight doubles base[64 j], j = 0..7, as eight ds_read_b64 (2 LDS cycles each).  Left to the compiler these become four
 // ds_read2st64_b64, which move the same bytes at half the rate (MI355X_MICROARCH.md, LDS table: 8 cycles per 1 KiB against
-// 2 x 2) -- and the FFT kernel is bound by the LDS pipe.  The values are only valid after lds_wait16().
+// 2 x 2) -- and the FFT kernel is bound by the LDS pipe.  The values are only valid after lds_wait16n<N>().
 __device__ __forceinline__ void lds_read8_b64(double (&v)[8], const double *base) {
     const unsigned a = (unsigned)(uintptr_t)base;     // LDS offset = low half of the generic pointer
     asm volatile("ds_read_b64 %0, %1" : "=v"(v[0]) : "v"(a));
@@ -106,15 +106,6 @@ __device__ __forceinline__ void lds_read8_b64(double (&v)[8], const double *base
     asm volatile("ds_read_b64 %0, %1 offset:3072" : "=v"(v[6]) : "v"(a));
     asm volatile("ds_read_b64 %0, %1 offset:3584" : "=v"(v[7]) : "v"(a));
 }
-// wait for the reads above; the operands tie every later use of the 16 values to this point
-__device__ __forceinline__ void lds_wait16(double (&x)[8], double (&y)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
-                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7])
-                 :
-                 : "memory");
-}
-
 // ---- the edge pass of extended tiles: a small matrix product (the one place of this library where the matrix pipe fits) --------------
 // Side 0 = left edge (outputs x0 - 16 .. x0 - 1), side 1 = right edge (outputs x0 + TV .. x0 + TV + 15).  Sample s of a side (lane
 // t = s): the sample outside the tile that the outputs need (`out`: -16 + s on the left, 512 + s on the right) and the sample inside
@@ -137,7 +128,7 @@ __device__ __forceinline__ void lds_wait16(double (&x)[8], double (&y)[8]) {
 // left edge:  out = sample -16 + t -> wl_lo[dl + t] wr_lo[dr + t];  in = sample 496 + t -> wl_hi[dl + t] wr_hi[dr + t]
 // right edge: out = sample 512 + t -> wl_hi[16 + dl + t] wr_hi[16 + dr + t];  in = sample t -> wl_lo[16 + dl + t] wr_lo[16 + dr + t]
 // with dl = A - fh(i - 1), dr = fh(i) - hr0; a lane's rows are 4 j + k: dl falls and dr rises by 2 per step (rows past R in the last
-// step index up to two entries outside a window: read, not used).  sws = the rows' weights (4 NJ doubles, zero past R), sc =
+// step would index up to two entries outside a window: their loads are predicated off).  sws = the rows' weights (4 NJ doubles, zero past R), sc =
 // EDGE_SCRATCH doubles of LDS, mtab = natac_fft_edge_table_mfma's table.  (The accumulators stay in VGPRs because the kernel's register
 // budget is <= 256: with 512 the compiler picks the AGPR form and copies sixteen registers around every pair of instructions.)
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -175,9 +166,10 @@ __device__ __forceinline__ void bg_edge_side(const int side, const double *wl_lo
         }
 #undef NATAC_EDGE_STEP
         if (j < NJ) {                                // the last rows: lanes past R contribute zeros (their window entries are not the model's)
-            const bool valid = 4 * j + k < R;
-            const double lo = pl_o[0], ro = pr_o[0], li = pl_i[0], ri = pr_i[0];
-            const double po = valid ? lo * ro : 0.0, pi = valid ? li * ri : 0.0;
+            const bool valid = 4 * j + k < R;      // rows past R would index up to two entries below / above the windows: not read at all
+            double lo = 0.0, ro = 0.0, li = 0.0, ri = 0.0;
+            if (valid) { lo = pl_o[0]; ro = pr_o[0]; li = pl_i[0]; ri = pr_i[0]; }
+            const double po = lo * ro, pi = li * ri;
             qx = fma(sw[0], po, qx);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(po - pi, mt[0], acc1, 0, 0, 0);
         }
@@ -208,21 +200,16 @@ __device__ __forceinline__ void bg_edge_side(const int side, const double *wl_lo
     }
 }
 
-// ---- explicit LDS instructions of the skewed pair loop (NATAC_FFT_SKEW, bg_fft_tile) ---------------------------------------------------
+// ---- explicit LDS instructions of the skewed pair loop (bg_fft_tile) -----------------------------------------------------------------
 // The skewed loop keeps two transforms of one wave in flight, so its waits must name HOW MANY of the wave's LDS instructions may still
 // be outstanding (LDS instructions of a wave execute and return in issue order; lgkmcnt counts them).  The compiler counts only the LDS
 // instructions it emitted itself, so every LDS access of that loop is inline asm and every wait is written out.
 typedef double d2v __attribute__((ext_vector_type(2)));
-#ifndef NATAC_SKEW_ABL
-#define NATAC_SKEW_ABL 0     // harness only (tools/r6_skew3.sh; wrong results): 1 = no transpose stores, 2 = no transpose loads, 4 = no template-spectrum loads, 8 = no operand reads
-#endif
 template <int OFF> __device__ __forceinline__ void ds_st128(unsigned a, double xr, double xi) {
     const d2v v = {xr, xi};
-    if (NATAC_SKEW_ABL & 1) { asm volatile("" : : "v"(a), "v"(v) : "memory"); return; }
     asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(a), "v"(v), "n"(OFF) : "memory");
 }
 template <int OFF> __device__ __forceinline__ void ds_ld128(d2v &v, unsigned a) {
-    if (NATAC_SKEW_ABL & 2) { asm volatile("" : "=v"(v) : "v"(a) : "memory"); return; }
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
 }
 // eight complex values a + STRIDE j (bytes)
@@ -259,26 +246,8 @@ __device__ __forceinline__ void fft_load_twiddles(FftTwiddles &t, const double *
     }
 }
 
-#ifndef NATAC_FFT_ABL
-#define NATAC_FFT_ABL 0
-#endif
-#ifndef NATAC_FFT_SKEW
-#define NATAC_FFT_SKEW 1           // the pair loop with two row pairs in flight per wave (see "the skewed pair loop" in bg_fft_tile)
-#endif
-#ifndef NATAC_FFT_KX4
-#define NATAC_FFT_KX4 1            // template spectra as [pair][m][lane][re, im]: a lane's two values of a bin in ONE 16-byte load (8 instead of 16 requests per pair)
-#endif
-#if NATAC_FFT_KX4
+// template spectra as [pair][m][lane][re, im]: a lane's two values of a bin arrive in ONE 16-byte load (8 instead of 16 requests per pair)
 #define NATAC_FFT_KIDX(m, lane, c) (((m) * 64 + (lane)) * 2 + (c))
-#else
-#define NATAC_FFT_KIDX(m, lane, c) ((c) * FFT_N + (m) * 64 + (lane))
-#endif
-#ifndef NATAC_FFT_SKEW_PP
-#define NATAC_FFT_SKEW_PP 1        // the skewed loop unrolled by two, the carried operand factor alternating between two buffers (no register copies)
-#endif
-#ifndef NATAC_FFT_SKEW_K
-#define NATAC_FFT_SKEW_K 3         // where the skewed loop requests a pair's template spectrum: 3 = after S1 of the next pair, 4 = after that S1's products (earlier: spills)
-#endif
 #ifndef NATAC_FFT_TW_EARLY
 #define NATAC_FFT_TW_EARLY 1       // the per-lane twiddles requested in front of the window staging instead of behind the conditioning test
 #endif                             // (both switches, tools/r5_ext6.sh, 100 k extended tiles, five runs each: 7.51 -> 7.44 -> 7.39 ms)
@@ -321,20 +290,8 @@ __device__ __forceinline__ void fft512_fwd_rest(double (&re)[8], double (&im)[8]
 // forward 512-point FFT of the wave's data (lane n, register j <-> element n + 64 j); result: lane b, register m holds the
 // bin of "stage-3 butterfly b, output m" (a fixed permutation of the frequencies, identical for signal and template).
 // sa / sb: the wave's LDS scratch, FFT_LA and FFT_LB doubles for the real and for the imaginary parts each.
-// NATAC_FFT_ABL (tools/test_fft_bg.hip only): 1 = no LDS transposes (wrong results; what the round trips cost),
-// 2 = no template-spectrum loads, 3 = no exp(bias) operand reads
-
 __device__ __forceinline__ void fft512_fwd(double (&re)[8], double (&im)[8], const FftTwiddles &t, double2 *sa, double2 *sb, int lane) {
     dft8<false>(re, im);
-    if (NATAC_FFT_ABL == 1) {
-#pragma unroll
-        for (int m = 1; m < 8; ++m) { const double xr = fma(re[m], t.w1r[m], -(im[m] * t.w1i[m])); im[m] = fma(re[m], t.w1i[m], im[m] * t.w1r[m]); re[m] = xr; }
-        dft8<false>(re, im);
-#pragma unroll
-        for (int m = 1; m < 8; ++m) { const double xr = fma(re[m], t.w2r[m], -(im[m] * t.w2i[m])); im[m] = fma(re[m], t.w2i[m], im[m] * t.w2r[m]); re[m] = xr; }
-        dft8<false>(re, im);
-        return;
-    }
     fft512_fwd_t1(re, im, t, sa, lane);
     fft512_fwd_rest(re, im, t, sb, lane);
 }
@@ -369,7 +326,7 @@ __device__ __forceinline__ void fft512_inv(double (&re)[8], double (&im)[8], con
     __builtin_amdgcn_wave_barrier();
 }
 
-// ---- the skewed pair loop's pieces (NATAC_FFT_SKEW) -------------------------------------------------------------------------------------
+// ---- the skewed pair loop's pieces ------------------------------------------------------------------------------------------------------
 // Same transform as fft512_fwd -- the same operations on the same values in the same order, so the same bits -- cut at its two transposes
 // so that bg_fft_tile can put ANOTHER row pair's arithmetic between a transpose's store + read-back and the first use of what comes back:
 //   S1 = products + column sums + first DFT + twiddle 1        -> W1 (8 stores, layout A), R1 (8 loads)
@@ -538,17 +495,23 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) carry[j] = c0[lane + 64 * j];
     }
-    if (pairs_full && NATAC_FFT_ABL == 0 && NATAC_FFT_SKEW) {
+    if (pairs_full) {
         // The skewed pair loop (round 6).  A transform is S1 -> W1 R1 -> S2 -> W2 R2 -> S3 (skew_* above); a wave that runs them in that
         // order sits out two LDS round trips per row pair (8 stores at 13 cycles, 8 loads, the queue of the CU's seven other waves in
         // front of them), and the SIMD's second wave covered only part of that (round 5: 23.5 ms of fp64 issue + 18.3 ms of LDS array time
-        // overlapped by 4.5 ms).  Here the wave has TWO row pairs in flight, p (second half) and p + 1 (first half):
-        //     wait R1(p) | x,y(p+1) requested | S2(p)  W2(p)  R2(p) requested | S1(p+1) | K(p) requested  W1(p+1)  R1(p+1) requested |
-        //     wait R2(p) | S3(p)
+        // overlapped by 4.5 ms).  Here the wave has TWO row pairs in flight, p (second half) and p + 1 (first half); one trip is
+        //     wait R1(p) | X,Y(p+1) requested | S2(p) | W2(p) | wait X,Y | R2(p) requested | S1(p+1) | K(p) requested | W1(p+1) |
+        //     wait R2(p) | R1(p+1) requested | S3(p)
         // so R2(p) travels under S1(p+1) (112 fp64 instructions) and R1(p+1) under S3(p) (84).  One scratch region is enough: a wave's LDS
-        // instructions execute in issue order, R2(p) is issued before W1(p+1) overwrites what it reads.  Registers: while S1(p+1) runs, R2's
-        // eight complex targets are the only extra live values (the template spectrum K(p) is requested after it); while S3(p) runs, R1's.
-        // Every value is computed by the same operations in the same order as in fft512_fwd: bit-identical outputs.
+        // instructions execute in issue order, R2(p) is issued before W1(p+1) overwrites what it reads.  Both waits inside the trip sit
+        // where only the eight stores just issued are behind them: lgkmcnt is a 4-bit counter, a wait with 8 stores + 8 loads behind it can
+        // name at most 15 and then sits out the first store's trip through the LDS queue (measured: that alone gave the gain back).
+        // Registers: while S1(p+1) runs, R2's eight complex targets are the only extra live values (the template spectrum K(p) is requested
+        // after it: a phase earlier the loop spills); while S3(p) runs, R1's.  244 VGPRs, no scratch.
+        // Every value is computed by the same operations in the same order as in fft512_fwd: the outputs are bit-identical to round 5's
+        // loop (tools/test_fft_bg.hip prints a hash of the four output arrays; profiles/r6/fft_skew_session*.txt).  Measured, same box,
+        // 100 k extended tiles: 7.65 -> 7.12 ms; in the configs[2] step 40.4 -> 37.4 ms (profiles/r6/bench_ab_*).  The ablation builds
+        // behind these numbers (stores / loads / template spectra / operands removed one by one) are commits 0c98ab4 and 1054b69.
         const unsigned cbase = (unsigned)(uintptr_t)ca;
         const int m2 = lane >> 3, n1 = lane & 7;
         const unsigned aw1 = cbase + 16u * lane, ar1 = cbase + 16u * (72 * m2 + n1), aw2 = cbase + 16u * (65 * n1 + 8 * m2), ar2 = aw1;
@@ -562,16 +525,11 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         const double *px = (lodd ? Et + (A - floor_half(vm.lower - 1)) : Et + (A + floor_half(vm.lower))) + lane;
         const double *py = (lodd ? Et + (A + floor_half(vm.lower + 1)) : Et + (A - floor_half(vm.lower))) + lane;
         const int dx = lodd ? -1 : 1;
-        // yn = where the pair's Y goes, yo = the Y of the pair before (the carried factor).  With NATAC_FFT_SKEW_PP the loop is unrolled by two
-        // and the two buffers swap roles from trip to trip; without it yo is `carry` and every trip ends with eight register copies.
+        // yn = where the pair's Y goes, yo = the Y of the pair before (the carried factor).  The loop is unrolled by two and the two buffers swap
+        // roles from trip to trip (as one buffer + `carry` every trip ended with eight register copies).
         auto issue_xy = [&](int pair, double (&yn)[8]) {
-            if (NATAC_SKEW_ABL & 8) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) { asm volatile("" : "=v"(x[jj])); asm volatile("" : "=v"(yn[jj])); }
-            } else {
-                lds_read8_b64(x, px + dx * pair);
-                lds_read8_b64(yn, py - dx * pair);
-            }
+            lds_read8_b64(x, px + dx * pair);
+            lds_read8_b64(yn, py - dx * pair);
         };
         auto s1 = [&](const double sa, const double sb, const double (&yn)[8], const double (&yo)[8]) {     // x, Y, carried Y -> products, column sums
 #pragma unroll
@@ -588,11 +546,6 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         double kr[8], ki[8];
         auto load_k = [&](int pair) {
             const double *k = ktab + (size_t)pair * 2 * FFT_N;
-            if (NATAC_SKEW_ABL & 4) {
-#pragma unroll
-                for (int m = 0; m < 8; ++m) { asm volatile("" : "=v"(kr[m])); asm volatile("" : "=v"(ki[m])); }
-                return;
-            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) { kr[m] = k[NATAC_FFT_KIDX(m, lane, 0)]; ki[m] = k[NATAC_FFT_KIDX(m, lane, 1)]; }
         };
@@ -610,10 +563,9 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
             ds_ld128x8<1040>(Bv, ar2);                // counter, a wait behind R2 could not leave all 16 outstanding and would sit out the first store
             __builtin_amdgcn_sched_barrier(0);
             s1(sa, sb, yn, yo);
-            if (NATAC_FFT_SKEW_K == 4) { __builtin_amdgcn_sched_barrier(0); load_k(pair); __builtin_amdgcn_sched_barrier(0); }
             s1b();
             __builtin_amdgcn_sched_barrier(0);
-            if (NATAC_FFT_SKEW_K == 3) load_k(pair);
+            load_k(pair);                             // K(pair), after S1: requested earlier it does not fit the register file (spills)
             skew_w1(tr, ti, aw1);
             lds_wait_c8<8>(Bv);                       // R2(pair): only W1's eight stores may still be outstanding; R1 is requested behind the wait
             ds_ld128x8<128>(Av, ar1);                  // R1(pair + 1)
@@ -628,19 +580,11 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         ds_ld128x8<128>(Av, ar1);
         {
             int pair = 0;
-#if NATAC_FFT_SKEW_PP
             for (; pair + 2 < npair; pair += 2) {
                 trip(pair, carry, y);
                 trip(pair + 1, y, carry);
             }
             if (pair + 1 < npair) trip(pair, carry, y);
-#else
-            for (; pair + 1 < npair; ++pair) {
-                trip(pair, carry, y);
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) y[jj] = carry[jj];
-            }
-#endif
         }
         lds_wait_c8<0>(Av);
         skew_s2(Av, ur, ui);
@@ -649,120 +593,26 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
         load_k(npair - 1);
         lds_wait_c8<0>(Bv);
         skew_s3(Bv, kr, ki, accr, acci);
-    } else if (pairs_full && NATAC_FFT_ABL == 0) {
-        // Measured in round 5 and not kept (tools/test_fft_bg.hip on 20 k chunks, 8.25-8.30 ms as it stands): (1) the short last tile of a
-        // chunk (2,120 bases leave 280 points of 512 for the sixth tile) with the zero blocks' operand reads, products, column sums and
-        // first-stage additions left out -- same bits, 13 % fewer fp64 instructions in one tile of six -- 8.31 ms: a second copy of this
-        // loop, 256 VGPRs; (2) two pairs per trip with the carried factor ping-ponging between two buffers instead of the eight
-        // v_mov_b64 per trip below -- 8.86 ms: 256 VGPRs + 28 bytes of scratch; (3) even moving this loop into a generic lambda
-        // cost 0.25 ms of the 41 in the step; (4) the size weights sa / sb requested one trip ahead (their load sits in front of the 16
-        // template loads and the column sums wait for it): 8.21 against 8.15 ms, the other wave of the SIMD already covers that wait.
-        // The loop sits at the register limit of two waves per SIMD; leave its shape alone.
-        // Software pipeline of a row pair: the template spectrum is requested at the top of the trip (the whole transform covers
-        // its L2 round trip; left to the compiler the loads sit right before the last DFT) and the exp(bias) operands of the
-        // NEXT pair after the last DFT, so that the accumulation covers their LDS round trip.
-        double x[8], y[8];
-        auto issue_xy = [&](int pair) {
-            const int ia = vm.lower + 2 * pair, ib = ia + 1;
-            if (lodd) {       // shared left factor x; y = right factor of b
-                lds_read8_b64(x, Et + (A - floor_half(ia - 1)) + lane);
-                lds_read8_b64(y, Et + (A + floor_half(ib)) + lane);
-            } else {          // shared right factor y; x = left factor of b
-                lds_read8_b64(x, Et + (A - floor_half(ib - 1)) + lane);
-                lds_read8_b64(y, Et + (A + floor_half(ia)) + lane);
-            }
-        };
-        issue_xy(0);
-        for (int pair = 0; pair < npair; ++pair) {
-            const double sa = vm.srow[2 * pair], sb = vm.srow[2 * pair + 1];     // (as one scalar load instead: measured, no difference)
-            const double *k = ktab + (size_t)pair * 2 * FFT_N;
-            double kr[8], ki[8], re[8], im[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) { kr[m] = k[NATAC_FFT_KIDX(m, lane, 0)]; ki[m] = k[NATAC_FFT_KIDX(m, lane, 1)]; }
-            __builtin_amdgcn_sched_barrier(0);
-            lds_wait16(x, y);
-            if (lodd) {       // carry = right factor of a
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    re[j] = x[j] * carry[j];
-                    im[j] = x[j] * y[j];
-                    carry[j] = y[j];
-                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
-                }
-            } else {          // carry = left factor of a
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    re[j] = carry[j] * y[j];
-                    im[j] = x[j] * y[j];
-                    carry[j] = x[j];
-                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
-                }
-            }
-            fft512_fwd(re, im, tww, ca, cb, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_xy(min(pair + 1, npair - 1));
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
-                accr[m] = fma(re[m], kr[m], fma(im[m], ki[m], accr[m]));
-                acci[m] = fma(im[m], kr[m], fma(-re[m], ki[m], acci[m]));
-            }
-        }
-        lds_wait16(x, y);     // the re-read of the last trip
-    } else   // odd row count (or an ablation build): the plain loop
+    } else   // odd row count: the plain loop, one transform after the other (the missing row reads row a's window with weight 0)
     for (int pair = 0; pair < npair; ++pair) {
         const int ra = 2 * pair, rb = ra + 1;
-        const int ia = vm.lower + ra, ib = (rb < vm.R) ? ia + 1 : ia;   // odd R: the missing row reads row a's (valid) window with weight 0
+        const int ia = vm.lower + ra, ib = (rb < vm.R) ? ia + 1 : ia;
         const double sa = vm.srow[ra], sb = (rb < vm.R) ? vm.srow[rb] : 0.0;
         double re[8], im[8];
         const double *k = ktab + (size_t)pair * 2 * FFT_N;
         double kr[8], ki[8];
-        if (pairs_full) {
-            double x[8], y[8];
-            if (NATAC_FFT_ABL == 3) {
+        const double *ela = Et + (A - floor_half(ia - 1)), *era = Et + (A + floor_half(ia));
+        const double *elb = Et + (A - floor_half(ib - 1)), *erb = Et + (A + floor_half(ib));
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { x[j] = 1.0 + 1e-3 * (pair + j); y[j] = 1.0 - 1e-3 * (lane + j); }
-            }
-            if (lodd) {       // shared left factor x; y = right factor of b; carry = right factor of a
-                if (NATAC_FFT_ABL != 3) {
-                    lds_read8_b64(x, Et + (A - floor_half(ia - 1)) + lane);
-                    lds_read8_b64(y, Et + (A + floor_half(ib)) + lane);
-                    lds_wait16(x, y);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    re[j] = x[j] * carry[j];
-                    im[j] = x[j] * y[j];
-                    carry[j] = y[j];
-                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
-                }
-            } else {          // shared right factor y; x = left factor of b; carry = left factor of a
-                if (NATAC_FFT_ABL != 3) {
-                    lds_read8_b64(x, Et + (A - floor_half(ib - 1)) + lane);
-                    lds_read8_b64(y, Et + (A + floor_half(ia)) + lane);
-                    lds_wait16(x, y);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    re[j] = carry[j] * y[j];
-                    im[j] = x[j] * y[j];
-                    carry[j] = x[j];
-                    q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
-                }
-            }
-        } else {
-            const double *ela = Et + (A - floor_half(ia - 1)), *era = Et + (A + floor_half(ia));
-            const double *elb = Et + (A - floor_half(ib - 1)), *erb = Et + (A + floor_half(ib));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int u = lane + 64 * j;
-                re[j] = ela[u] * era[u];
-                im[j] = elb[u] * erb[u];
-                q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int u = lane + 64 * j;
+            re[j] = ela[u] * era[u];
+            im[j] = elb[u] * erb[u];
+            q[j] = fma(sb, im[j], fma(sa, re[j], q[j]));
         }
         fft512_fwd(re, im, tww, ca, cb, lane);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { kr[m] = NATAC_FFT_ABL == 2 ? 0.5 + m : k[NATAC_FFT_KIDX(m, lane, 0)]; ki[m] = NATAC_FFT_ABL == 2 ? 0.25 * m : k[NATAC_FFT_KIDX(m, lane, 1)]; }
+        for (int m = 0; m < 8; ++m) { kr[m] = k[NATAC_FFT_KIDX(m, lane, 0)]; ki[m] = k[NATAC_FFT_KIDX(m, lane, 1)]; }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {                 // acc += Z * conj(K)
             accr[m] = fma(re[m], kr[m], fma(im[m], ki[m], accr[m]));

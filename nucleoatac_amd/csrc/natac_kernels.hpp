@@ -2041,6 +2041,21 @@ __global__ void __launch_bounds__(BT) natac_peaks_chunk_reg(ChunkTable ct, const
         unsigned short *wlist = (unsigned short *)(wmask + NJ);
         const int cap = (stride - NJ * 8) / 2;
         const bool two_phase = order > 2 && stride >= NJ * 8 + 2 * 128;      // room for a useful list (else: the direct test below)
+        if (stride < NJ * 8) {
+            // a large `order` shrinks the peak lists (pk_cap = maxL / (order + 1)) below even the NJ masks of a wave (maxL 4,096, order 150:
+            // 104 bytes for 128): the masks then stay in registers, every row takes the direct test
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int g = threadIdx.x + BT * j;
+                bool pk = g < L && (v[j] >= min_signal) && (g >= boundary) && (g < L - boundary);
+                if (pk) {
+                    const double y = ys[g + order];
+                    for (int sft = 1; sft <= order && pk; ++sft) pk = (y > ys[g + order + sft]) && (y > ys[g + order - sft]);
+                }
+                bal[j] = __ballot(pk);
+                if (lane == 0) row_cnt[j * NW + wave] = __popcll(bal[j]);
+            }
+        } else {
         if (lane < NJ) wmask[lane] = 0ull;
         __builtin_amdgcn_wave_barrier();
         int cnt = 0;
@@ -2084,6 +2099,7 @@ __global__ void __launch_bounds__(BT) natac_peaks_chunk_reg(ChunkTable ct, const
         for (int j = 0; j < NJ; ++j) {
             bal[j] = wmask[j];
             if (lane == 0) row_cnt[j * NW + wave] = __popcll(bal[j]);
+        }
         }
     }
     __syncthreads();

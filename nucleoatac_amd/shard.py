@@ -217,8 +217,8 @@ def shared_fragment_store(bam):
                     FragmentStore.register(bam, st)
                 except (OSError, ValueError):                               # not visible from here after all: decode it ourselves
                     st = FragmentStore.open(bam)
-            except BaseException as e:      # noqa: BLE001 -- announced below: no rank may be left waiting in a barrier for this one
-                map_err = e
+            except Exception as e:      # noqa: BLE001 -- announced below: no rank may be left waiting in the gather for this one (KeyboardInterrupt /
+                map_err = e             # SystemExit are NOT caught: an interrupted rank must leave at once, not enter a collective first)
         # every rank has mapped the files (or says that it could not): the publisher unlinks them (the mappings stay valid).  The
         # gather is the barrier; a rank that failed here raises its own error and every other rank raises with it.
         oks = [None] * world

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import assert_track, golden  # noqa: E402
+from helpers import assert_track, cancel_scale, golden  # noqa: E402
 from nucleoatac_amd import _lib as L  # noqa: E402
 from nucleoatac_amd.device import Context  # noqa: E402
 from nucleoatac_amd.packing import PackedChunks  # noqa: E402
@@ -85,8 +85,8 @@ def one_round(ctx, rng, par, sizes, nucp, nfrp, rnd):
         assert_track(tr[L.T_NFR_COV][k], nt["nfr_cov"], "nfr_cov", exact=True)
         assert_track(tr[L.T_RAW][k], nt["raw"], "raw")
         assert_track(tr[L.T_BACKGROUND][k], nt["bg"], "bg")
-        assert_track(tr[L.T_NORM][k], nt["norm"], "norm", atol=1e-8)
-        assert_track(tr[L.T_SMOOTH][k], nt["smoothed"], "smoothed", atol=1e-8)
+        assert_track(tr[L.T_NORM][k], nt["norm"], "norm", scale=cancel_scale(nt["raw"], nt["bg"]))
+        assert_track(tr[L.T_SMOOTH][k], nt["smoothed"], "smoothed", scale=cancel_scale(nt["raw"], nt["bg"]))
         assert np.array_equal(tr[L.T_INS][k], O.get_insertions(l, n, 0, Lc).astype(np.int32))
         if not (st[k] & 1):
             oc = O.occ_chunk_tracks(l, n, 0, Lc, bias_k, -246, nucp, nfrp)

@@ -7,12 +7,20 @@ from nucleoatac_amd.packing import PackedChunks, sort_by_centre
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# float tracks: north-star tolerance 1e-5 relative (BASELINE.json) plus ONE absolute floor, 1e-9.  The
-# floor covers values that are exactly 0 in one implementation and ~1e-17 in the other (FFT vs direct sums).  norm = raw - bg
-# (and its smoothing) is a difference of two larger numbers: its floor is 1e-9 relative to the scale of the operands,
-# `scale` = max(1, max|raw|, max|bg|) -- 1 for ordinary data, larger only for the crowded / extreme-bias edge cases.
+# Float tracks.  The north-star tolerance is 1e-5 relative (BASELINE.json); it is the CEILING, not what the parity tests assert.
+# Round 6: the kernels agree with the reference-generated goldens / the oracle to 1e-13 ... 5e-10 (the FFT background against
+# the reference's own scipy FFT, different summation orders; profiles/r6/achieved_differences_gpu_suite.txt lists every assertion), so a
+# numerics regression of six orders -- a mis-folded twiddle, a dropped compensation, a wrong edge column at 1e-7 -- must not pass at 1e-5.
+# assert_track's DEFAULT is therefore the TIGHT tier: |d| <= 1e-12 * scale + 1e-10 * |ref|.  `scale` = 1 for ordinary data; norm = raw - bg
+# (and its smoothing) is a difference of two larger numbers: its absolute floor is relative to the operands, cancel_scale(raw, bg).
+# Values that went through the text files ('%.12g', as the reference's str(float)): TEXT tier, 1e-9 relative + 1e-11 -- one unit of the
+# twelfth digit on a value that is itself a difference.  1e-5 (RTOL / ATOL, tier="north_star") stays only where the assertion says why.
 RTOL = 1e-5
 ATOL = 1e-9
+TIGHT_RTOL = 1e-10
+TIGHT_ATOL = 1e-12
+TEXT_RTOL = 1e-9
+TEXT_ATOL = 1e-11
 
 
 def cancel_scale(*operands):
@@ -54,11 +62,33 @@ def packed_from_golden(g, with_bias=True):
                         bias_log=np.concatenate(bvals) if with_bias else None)
 
 
-def assert_track(got, ref, name, exact=False, rtol=RTOL, atol=ATOL, scale=1.0):
+def _log_stats(name, got, ref, m, scale):
+    path = os.environ.get("NATAC_TRACK_STATS")       # development: the achieved differences per assertion (tools/r6_tight_probe.sh)
+    if not path or not m.any():
+        return
+    d = np.abs(got[m] - ref[m])
+    i = int(np.argmax(d))
+    rel = d / np.maximum(np.abs(ref[m]), 1e-300)
+    big = np.abs(ref[m]) > 1e-6 * max(1.0, float(np.abs(ref[m]).max()))
+    with open(path, "a") as f:
+        f.write("%s\tmax_abs=%.3e\tat_ref=%.3e\tmax_rel_where_|ref|>1e-6max=%.3e\tscale=%.3g\tn=%d\n" % (
+            name, float(d[i]), float(np.abs(ref[m][i])), float(rel[big].max()) if big.any() else 0.0, scale, int(m.sum())))
+
+
+def assert_text_close(got, ref, msg=""):
+    """values parsed from the text outputs (12 significant digits on both sides): the TEXT tier"""
+    np.testing.assert_allclose(got, ref, rtol=TEXT_RTOL, atol=TEXT_ATOL, err_msg=msg)
+
+
+def assert_track(got, ref, name, exact=False, rtol=None, atol=None, scale=1.0, tier="tight"):
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, "%s: shape %s vs %s" % (name, got.shape, ref.shape)
     assert np.array_equal(np.isnan(got), np.isnan(ref)), "%s: NaN pattern differs" % name
     m = ~np.isnan(ref)
+    tiers = {"tight": (TIGHT_RTOL, TIGHT_ATOL), "text": (TEXT_RTOL, TEXT_ATOL), "north_star": (RTOL, ATOL)}
+    rtol = tiers[tier][0] if rtol is None else rtol
+    atol = tiers[tier][1] if atol is None else atol
+    _log_stats(name, got, ref, m, scale)
     if exact:
         assert np.array_equal(got[m], ref[m]), "%s: not bit-exact (max |d| = %g)" % (name, np.max(np.abs(got[m] - ref[m])))
     else:

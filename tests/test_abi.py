@@ -32,7 +32,8 @@ def test_library_exports_every_symbol(lib):
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in header_functions():
         assert hasattr(so, name), name
-    assert so.natac_abi_version() == 1
+    hdr_version = int(re.search(r"#define NATAC_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "natac.h")).read()).group(1))
+    assert so.natac_abi_version() == hdr_version == lib.ABI_VERSION
 
 
 def test_enums_match_header(lib):

@@ -137,5 +137,8 @@ def test_extended_tiles_with_damaged_bias_match_oracle_and_direct():
         mine = bg_e[off[k]:off[k + 1]]
         assert np.array_equal(np.isnan(mine), np.isnan(nt["bg"])), k
         good = ~np.isnan(mine)
+        # north-star tolerance here on purpose: next to e^25 entries the ORACLE's dense FFT correlation (scipy, as the reference's) carries
+        # an error relative to the window's largest product into the small outputs; the kernel's own check is the 1e-9 comparison with
+        # direct summation above
         np.testing.assert_allclose(mine[good], nt["bg"][good], rtol=1e-5, atol=1e-9)
     assert 0 < np.isnan(bg_e[:2120]).sum() < 400

@@ -94,11 +94,11 @@ def test_candidate_lr_var_z(ctx, case, with_bias):
         ref.append(rec)
     ref = np.concatenate(ref)
     lr, var, z = b.run_candidates(cc, cp)
-    assert_track(lr, ref[:, 1], "lr", rtol=1e-5, atol=1e-7)
+    assert_track(lr, ref[:, 1], "lr")
     ok = ref[:, 4] > 0
     assert ok.sum() > 0
-    assert_track(var[ok], ref[ok, 2], "var", rtol=1e-5, atol=1e-12)
-    assert_track(z[ok], ref[ok, 3], "z", rtol=1e-5, atol=1e-7)
+    assert_track(var[ok], ref[ok, 2], "var")
+    assert_track(z[ok], ref[ok, 3], "z")
     b.free()
 
 

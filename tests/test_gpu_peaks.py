@@ -86,6 +86,21 @@ def test_device_peaks_large_ragged_batch(ctx):
     b.free()
 
 
+@pytest.mark.parametrize("length,order", [(2048, 150), (4000, 150), (2120, 255), (3500, 97), (2120, 40)])
+def test_device_peaks_with_a_large_order(ctx, length, order):
+    """a large `order` (--redundant_sep up to 511) shrinks the LDS peak lists (pk_cap = maxL / (order + 1)) below the room the
+    per-wave row masks of natac_peaks_chunk_reg need (maxL 4,096, order 150: 104 bytes for 128); the masks then stay in registers."""
+    pk = make_synthetic_chunks(40, length, 600, seed=length + order)
+    b = ctx.upload(pk)
+    b.run_nuc(10)
+    kw = dict(min_signal=0, sep=25, boundary=60, order=order)
+    cc, cp, lr, var, z = b.run_peaks(**kw)
+    hc, hp = _host_peaks(b, pk, **kw)
+    assert len(cc) > 40 and np.array_equal(cc, hc) and np.array_equal(cp, hp)
+    assert not b.status().any()
+    b.free()
+
+
 def test_run_peaks_argument_errors(ctx):
     pk = make_synthetic_chunks(2, 500, 50, seed=1)
     b = ctx.upload(pk)

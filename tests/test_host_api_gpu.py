@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_track, golden, synth_stores
+from helpers import assert_text_close, assert_track, golden, synth_stores
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,7 @@ def test_occ_helper_matches_reference(case, seed, holes, use_fasta):
         assert [p.start - chunks[k].start for p in peaks] == list(ref_pk)
         pv = g["c%d_occ_peak_vals" % k]
         for p, row in zip(peaks, pv):
-            np.testing.assert_allclose([p.occ, p.occ_lower, p.occ_upper, p.reads], row, rtol=1e-5)
+            np.testing.assert_allclose([p.occ, p.occ_lower, p.occ_upper, p.reads], row, rtol=1e-10, atol=1e-12)
         assert_track(nuc_dist, g["c%d_occ_nuc_dist" % k], "nuc_dist", rtol=1e-9, atol=1e-12)
 
 
@@ -74,7 +74,7 @@ def test_nuc_helper_matches_reference(case, seed, holes, use_fasta):
         assert [n.start - chunks[k].start for n in r["nucpos"]] == [int(x) for x in ref[:, 0]]
         for n, row in zip(r["nucpos"], ref):
             np.testing.assert_allclose([n.z, n.lr, n.norm_signal, n.nuc_signal, n.nuc_cov, n.nfr_cov],
-                                       row[[1, 2, 4, 5, 6, 7]], rtol=1e-5, atol=1e-8)
+                                       row[[1, 2, 4, 5, 6, 7]], rtol=1e-10, atol=1e-11)
             assert abs(n.fuzz - row[3]) < 1e-3 * max(1.0, row[3])    # L-BFGS fit on the host, same start / bounds
             assert len(n.asBed().split("\t")) == 13
         assert [n.start - chunks[k].start for n in r["nucpos.redundant"]] == [int(x) for x in g["c%d_nucpos_redundant" % k]]
@@ -140,7 +140,7 @@ def test_cli_occ_then_nuc(tmp_path):
                    ("nucleoatac_raw", "c2_raw"), ("nucleoatac_background", "c2_bg")):
         t = Track("chrS", s_, e_)
         t.read_track(out + "." + f + ".bedgraph.gz")
-        np.testing.assert_allclose(t.vals, g[key], rtol=1e-5, atol=1e-9)
+        assert_text_close(t.vals, g[key], f)      # through the text file: 12 significant digits
     # the same tracks through a linear scan (no index) give the same values as through the tabix index
     import shutil
     shutil.copy(out + ".nucleoatac_signal.bedgraph.gz", out + ".noindex.bedgraph.gz")

@@ -3,7 +3,7 @@
 workload and the profiled launches are laid over its time axis.  Prints the mean clock per kernel class and a 1-ms-binned series
 of the last step as one JSON line.
 
-usage (GPU box):  NATAC_CORUN=0|1 python tools/clock_trace.py [n_chunks] [steps] > gpurun_out/clock_trace.json
+usage (GPU box):  python tools/clock_trace.py [n_chunks] [steps] > gpurun_out/clock_trace.json
 """
 import json
 import os
@@ -47,7 +47,7 @@ def main():
     m = mid >= t_last
     bins = np.floor(mid[m] - t_last).astype(int)
     series = [round(float(np.nanmean(tr["ghz"][m][bins == b])), 3) for b in range(int(bins.max()) + 1)] if m.any() else []
-    out = dict(corun=os.environ.get("NATAC_CORUN", "default"), chunks=nc, steps=steps, samples=int(len(tr["t_ms"])),
+    out = dict(chunks=nc, steps=steps, samples=int(len(tr["t_ms"])),
                clock_ghz_per_kernel={k: round(v, 3) for k, v in tr["per_kernel"].items()},
                kernels_ms_per_step={k: round(v[0] / steps, 3) for k, v in prof.items()},
                last_step_intervals=[(k, round(a - t_last, 3), round(b - t_last, 3)) for k, a, b in iv if a >= t_last - 1e-6],
