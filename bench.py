@@ -93,6 +93,9 @@ def parse():
     ap.add_argument("--no-h2h", action="store_true", help="skip the pipelined host-to-host measurement")
     ap.add_argument("--h2h-sub", type=int, default=2500, help="chunks per pipelined sub-batch")
     ap.add_argument("--h2h-threads", type=int, default=6, help="contexts (host threads) of the host-to-host pipeline")
+    ap.add_argument("--h2h-ranks", action="store_true", help="N > 1: every rank also runs the host-to-host pipeline on (a part of) its shard, "
+                    "all ranks at once; the rates are reported per rank")
+    ap.add_argument("--h2h-rank-chunks", type=int, default=20000, help="chunks of a rank's shard the --h2h-ranks leg runs on")
     ap.add_argument("--cli-chunks", type=int, default=10000, help="chunks of the CLI end-to-end measurement (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
@@ -250,7 +253,7 @@ def pmc_source():
     """where the committed counter numbers come from: newest profiles/*/pmc_summary.csv, the source stamp it was collected
     with (tools/pmc_summarize.py) and whether that stamp matches the sources of this run"""
     import glob
-    from nucleoatac_amd._lib import csrc_sha16
+    from nucleoatac_amd._lib import profile_sha16
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.csv")))
     if not files:
         return None
@@ -259,10 +262,11 @@ def pmc_source():
         for l in fh:
             if l.startswith("# source_sha16="):
                 stamp = l.split("=", 1)[1].split()[0]
-    cur = csrc_sha16()
+    cur = profile_sha16()
     return {"file": os.path.relpath(files[-1], ROOT), "collected_at_source_sha16": stamp, "current_source_sha16": cur,
             "stale": stamp != cur,
-            "note": "counters are read from the committed rocprofv3 --pmc summary, not measured in this run"}
+            "note": "counters are read from the committed rocprofv3 --pmc summary, not measured in this run; the stamp covers the library's "
+                    "sources, nucleoatac_amd/synth.py and bench.py's workload builder"}
 
 
 def pmc_traffic_bytes(kernel_substr):
@@ -446,6 +450,36 @@ def bench_stages(tracks=()):
 
 
 # ------------------------------------------------------------------------------------------------ host-to-host pipeline
+def placement(pci):
+    """where this rank's host side sits relative to its GPU: the CPUs the process may run on, their NUMA node(s), the GPU's NUMA node
+    (sysfs).  The pinned slots of the host-to-host pipeline are allocated by these CPUs; on a two-socket node a rank whose CPUs are on
+    the other socket than its GPU pays the inter-socket link on every transfer -- printed per rank so that a scaling run shows it."""
+    def _cpulist(txt):
+        out = set()
+        for part in txt.strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                out.update(range(int(lo), int(hi or lo) + 1))
+        return out
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    nodes = {}
+    try:
+        for d in sorted(os.listdir("/sys/devices/system/node")):
+            if d.startswith("node") and d[4:].isdigit():
+                nodes[int(d[4:])] = _cpulist(open("/sys/devices/system/node/%s/cpulist" % d).read())
+    except OSError:
+        pass
+    cpu_nodes = sorted(n for n, cs in nodes.items() if cs & set(cpus))
+    gpu_node = None
+    try:
+        gpu_node = int(open("/sys/bus/pci/devices/%s/numa_node" % str(pci).lower()).read())
+    except (OSError, ValueError):
+        pass
+    rng = "%d-%d" % (cpus[0], cpus[-1]) if cpus and cpus[-1] - cpus[0] + 1 == len(cpus) else ",".join(str(c) for c in cpus[:64])
+    return dict(cpus_allowed=len(cpus), cpu_list=rng, cpu_numa_nodes=cpu_nodes, gpu_numa_node=gpu_node,
+                gpu_local_to_cpus=None if gpu_node is None or gpu_node < 0 or not cpu_nodes else gpu_node in cpu_nodes)
+
+
 def host_to_host(pk, device, par, sizes, nucp, nfrp, steps, sub_chunks, n_threads, as_text=False):
     """SURVEY.md section 8(d)'s boundary: packed inputs in host memory -> per-base tracks back in host memory, through the
     product's own executor (nucleoatac_amd/executor.py::PipelinedExecutor, the class `nucleoatac occ` / `nuc` run on): the
@@ -654,7 +688,7 @@ def main():
         rows = [None] * world
         dist.all_gather_object(rows, dict(rank=rank, generate_s=round(t_gen, 2), upload_s=round(t_up, 2),
                                           ms_per_step=round(my_dt / a.steps * 1e3, 3), bp=my_bp, fragments=my_frags,
-                                          device=local_rank, hip_device=hip_dev, pci_bus_id=pci))
+                                          device=local_rank, hip_device=hip_dev, pci_bus_id=pci, placement=placement(pci)))
         per_rank = rows
     prof = ctx.profile()
     ms_per_step = dt / a.steps * 1e3
@@ -710,6 +744,19 @@ def main():
                          reference="the device's literal O(N^2) fp64 pair sum (the .pyx's own terms); tests pin it to the oracle's C restatement")
     shard.close()
     h2h = None
+    if world > 1 and a.h2h_ranks and a.workload != "cfg4":
+        # first contact of the host-to-host pipeline with SEVERAL ranks on one host (pinned slots, six contexts per rank, the ranks'
+        # executors next to each other): every rank runs the float64 form on its own shard at the same time; the rates go into per_rank.
+        # Not part of the driver's N > 1 line by default (--h2h-ranks): the contract's value is the HBM-resident step above.
+        ctx.close()
+        ctx = None
+        dshard.barrier(sync_cuda=False)
+        mine = host_to_host(subs[0].subset(0, min(subs[0].n_chunks, a.h2h_rank_chunks)), local_rank, par, sizes, nucp, nfrp,
+                            max(1, min(a.steps, 3)), a.h2h_sub, a.h2h_threads)
+        rows = [None] * world
+        dist.all_gather_object(rows, (rank, mine["host_to_host_mbp_s"], mine["pcie_gbs_down"], mine["seconds"]))
+        for r, v, g, sec in rows:
+            per_rank[r].update(host_to_host_mbp_s=v, host_to_host_pcie_gbs_down=g, host_to_host_seconds=sec)
     if rank == 0 and world == 1 and not a.no_h2h and a.workload != "cfg4":
         ctx.close()
         ctx = None
@@ -794,7 +841,7 @@ def main():
                                              "kernels": "natac_background_fft (transforms + the edge pass of its extended tiles)",
                                              "unit": "TFLOP/s", "frac_executed": round(fft_tflops / FP64_PEAK_TFLOPS, 4)}},
             "kernels_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in prof.items()},
-            "per_rank": per_rank, "control_plane": a.dist_backend if dist is not None else None,
+            "per_rank": per_rank, "placement": placement(pci), "control_plane": a.dist_backend if dist is not None else None,
             "valu_issue_from_committed_pmc": valu,
             "host": {"generate_s": round(t_gen, 2), "upload_s": round(t_up, 2),
                      "download_5_tracks_and_candidates_s": None if t_dn is None else round(t_dn, 2),

@@ -52,7 +52,8 @@ enum {
     NATAC_T_NUC_COV = 0,    /* CoverageTrack rows [vlower,vupper)   NucleosomeCalling.py:257-260 */
     NATAC_T_NFR_COV = 1,    /* CoverageTrack rows [0,vlower)        NucleosomeCalling.py:271-273 */
     NATAC_T_RAW = 2,        /* SignalTrack.calculateSignal           NucleosomeCalling.py:29-36  (nucleoatac_raw) */
-    NATAC_T_BACKGROUND = 3, /* BiasTrack.calculateBackgroundSignal   NucleosomeCalling.py:49-64  (nucleoatac_background) */
+    NATAC_T_BACKGROUND = 3, /* BiasTrack.calculateBackgroundSignal   NucleosomeCalling.py:49-64  (nucleoatac_background; an output only with
+                             * --write_all: after the FFT kernel it is formed on the first download / track_ptr / writer request) */
     NATAC_T_NORM = 4,       /* NormSignalTrack                       NucleosomeCalling.py:38-43  (nucleoatac_signal) */
     NATAC_T_SMOOTH = 5,     /* NucChunk.smoothSignal                 NucleosomeCalling.py:274-283 (nucleoatac_signal.smooth) */
     NATAC_T_OCC = 6,        /* OccupancyTrack.smoothed_vals AFTER call_peaks' in-place NaN fill (Occupancy.py:147-153, utils.py:86-91) */

@@ -141,6 +141,27 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def profile_sha16(synth_path=None, bench_path=None):
+    """stamp of a committed counter summary (profiles/*/pmc_summary.csv): the library's sources (csrc_sha16) AND the input the counters
+    were collected on -- nucleoatac_amd/synth.py (the generator) and bench.py's workload builder (make_workload and the defaults of the
+    arguments it reads).  A change of either makes bench.py report `traffic_source.stale: true`.  The two paths are parameters for
+    tests/test_host_logic.py."""
+    import hashlib
+    import re
+    root = os.path.dirname(_HERE)
+    h = hashlib.sha256(csrc_sha16().encode())
+    with open(synth_path or os.path.join(_HERE, "synth.py"), "rb") as fh:
+        h.update(fh.read())
+    with open(bench_path or os.path.join(root, "bench.py")) as fh:
+        src = fh.read()
+    m = re.search(r"^def make_workload\(.*?(?=^def |\Z)", src, flags=re.S | re.M)
+    h.update((m.group(0) if m else "").encode())
+    for arg in ("--workload", "--chunks", "--chunk-len", "--frags-per-chunk", "--seed", "--sub-chunks"):
+        m = re.search(r"add_argument\(\"%s\".*" % re.escape(arg), src)
+        h.update((m.group(0) if m else "").encode())
+    return h.hexdigest()[:16]
+
+
 class NatacError(RuntimeError):
     """error reported by libnatac_hip.so (negative return code of the C-ABI)"""
 

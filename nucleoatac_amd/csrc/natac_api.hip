@@ -126,6 +126,7 @@ struct natac_batch {
     int2 *d_tiles_os = nullptr, *d_tiles1k = nullptr;
     int n_tiles1k = 0;
     bool prefill_valid = false;                   // OCC_PREFILL holds this run's values (written by the generic path or on demand)
+    bool bg_valid = false;                        // BACKGROUND holds this run's values (the FFT path leaves it to materialise_bg)
     int2 *d_tiles256 = nullptr, *d_tiles_bg = nullptr, *d_tiles_occ = nullptr, *d_ranges_occ = nullptr, *d_ranges256 = nullptr;
     long long *d_tile256_first = nullptr;   // [nc + 1] first 256-base tile of every chunk (the candidates' way into d_ranges256)
     int *d_order_occ = nullptr;      // natac_tile_heavy: {count, claims, list[HEAVY_CAP], flag bytes[n_tiles_occ]} of the occupancy tiles
@@ -1189,7 +1190,7 @@ int natac_batch_release_outputs(natac_batch *b) {
     b->d_pk_chunk = b->d_pk_pos = b->d_opk_keep = nullptr;
     dev_free(b->d_fmt_out); b->d_fmt_out = nullptr; b->fmt_bytes = -1;
     b->pk_cap = 0; b->pk_n = -1; b->opk_cap = 0; b->opk_n = -1;
-    b->nuc_done = b->occ_done = b->ins_done = b->cov_from_nuc = b->prefill_valid = false;
+    b->nuc_done = b->occ_done = b->ins_done = b->cov_from_nuc = b->prefill_valid = b->bg_valid = false;
     // the per-chunk status words describe the outputs that were just dropped
     HIPCHK(hipMemsetAsync(b->d_status, 0, (size_t)b->nc * sizeof(int), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1224,11 +1225,15 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     for (int i = 0; i < b->nc; ++i)
         if (b->h_len[i] < M) return fail(NATAC_E_ARG, "chunk %d shorter (%d) than the smoothing window (%d)", i, b->h_len[i], M);
     if ((rc = ensure_window(c, &c->d_win_nuc, &c->win_nuc_M, &c->win_nuc_sd, M, smooth_sd, &c->win_nuc_sum))) return rc;
-    for (int t : {NATAC_T_NUC_COV, NATAC_T_NFR_COV, NATAC_T_RAW, NATAC_T_BACKGROUND, NATAC_T_NORM, NATAC_T_SMOOTH})
+    const bool use_fft = fft_bg_applicable(c);
+    // The background track itself is an output only with --write_all (run_nuc.py:22-39: _nucHelper returns it, run_nuc writes it only
+    // then); the FFT kernel leaves its two factors per base (bnum, bcov: the candidates read them) and T_BACKGROUND is formed from them
+    // on the first request (materialise_bg) -- the same expression, the same bits, 8 bytes per base less written per step.
+    for (int t : {NATAC_T_NUC_COV, NATAC_T_NFR_COV, NATAC_T_RAW, NATAC_T_NORM, NATAC_T_SMOOTH})
         if ((rc = ensure_track(b, t))) return rc;
+    if (!use_fft && (rc = ensure_track(b, NATAC_T_BACKGROUND))) return rc;
     if (!b->d_bnum && (rc = dev_alloc(&b->d_bnum, (size_t)b->total_bp))) return rc;
     if (!b->d_bcov && (rc = dev_alloc(&b->d_bcov, (size_t)b->total_bp))) return rc;
-    const bool use_fft = fft_bg_applicable(c);
     const bool fast = !use_fft && (c->W == 121 && c->vlower >= 2);
     if (use_fft) {
         if ((rc = ensure_fft(c))) return rc;
@@ -1273,9 +1278,10 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
     if (use_fft) {
         const size_t lds = bg_fft_lds_bytes(vm.upper);
         hipLaunchKernelGGL(natac_background_fft, dim3(b->n_tiles_bg), dim3(64), lds, c->stream, ct, b->d_tiles_bg, vm, c->d_fft_tw,
-                           c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
+                           c->d_fft_k, b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], (double *)nullptr,
                            b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov, (unsigned)b->n_tiles_bg, c->d_fft_mtab,
                            c->d_fft_swt, (c->R + 3) / 4);
+        b->bg_valid = false;
     } else if (fast) {
         switch (b->bgG) {
             case 7: launch_bg<7>(b, ct, vm); break;
@@ -1283,10 +1289,12 @@ int natac_run_nuc(natac_batch *b, double smooth_sd) {
             case 13: launch_bg<13>(b, ct, vm); break;
             default: launch_bg<17>(b, ct, vm); break;
         }
+        b->bg_valid = true;
     } else {
         hipLaunchKernelGGL(natac_background_generic, dim3(b->n_tiles256), dim3(256), 0, c->stream, ct, b->d_tiles256, vm,
                            b->d_track[NATAC_T_NUC_COV], b->d_track[NATAC_T_RAW], b->d_track[NATAC_T_BACKGROUND],
                            b->d_track[NATAC_T_NORM], b->d_bnum, b->d_bcov);
+        b->bg_valid = true;
     }
     prof_end(c, ev);
     prof_begin(c, NATAC_K_SMOOTH_NUC, ev);
@@ -1365,6 +1373,20 @@ static int ensure_block_weights(natac_ctx *c, int M, double sd, int NB) {
     return NATAC_OK;
 }
 
+// BACKGROUND after the FFT kernel: (bnum * nuc_cov) / bcov per base, the expression of the kernel's own epilogue (natac_fft_bg.hpp)
+static int materialise_bg(natac_batch *b) {
+    if (b->bg_valid) return NATAC_OK;
+    natac_ctx *c = b->ctx;
+    int rc = ensure_track(b, NATAC_T_BACKGROUND);
+    if (rc) return rc;
+    const int blocks = (int)std::min<long long>((b->total_bp + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(natac_bg_from_factors, dim3(blocks), dim3(256), 0, c->stream, b->d_bnum, b->d_track[NATAC_T_NUC_COV], b->d_bcov,
+                       b->d_track[NATAC_T_BACKGROUND], b->total_bp);
+    HIPCHK(hipGetLastError());
+    b->bg_valid = true;
+    return NATAC_OK;
+}
+
 // OCC_PREFILL (smoothed_vals before call_peaks' NaN fill) is not part of the default pass: written on the first request
 static int materialise_prefill(natac_batch *b) {
     if (b->prefill_valid) return NATAC_OK;
@@ -1376,6 +1398,13 @@ static int materialise_prefill(natac_batch *b) {
     launch_occ_smooth_generic(b, ct, om, 2 * c->flank + 1, b->d_track[NATAC_T_OCC_PREFILL], nullptr, nullptr);
     HIPCHK(hipGetLastError());
     b->prefill_valid = true;
+    return NATAC_OK;
+}
+
+// tracks that are formed on the first request
+static int materialise_track(natac_batch *b, int track) {
+    if (track == NATAC_T_OCC_PREFILL && b->occ_done) return materialise_prefill(b);
+    if (track == NATAC_T_BACKGROUND && b->nuc_done) return materialise_bg(b);
     return NATAC_OK;
 }
 
@@ -1886,6 +1915,8 @@ int natac_run_track_peaks(natac_batch *b, int track, double min_signal, int sep,
     if (track == NATAC_T_INS) return fail(NATAC_E_ARG, "peak search needs a float64 track");
     int rc = track_ready(b, track);
     if (rc) return rc;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    if ((rc = materialise_track(b, track))) return rc;
     return run_peaks_impl(b, b->d_track[track], nullptr, false, min_signal, sep, boundary, order, jitter, n_jitter, n_peaks);
 }
 
@@ -2001,7 +2032,7 @@ int natac_batch_download(natac_batch *b, int track, void *dst, size_t dst_bytes)
     const size_t need = (size_t)b->total_bp * (track == NATAC_T_INS ? sizeof(int) : sizeof(double));
     if (dst_bytes != need) return fail(NATAC_E_ARG, "destination holds %zu bytes, track needs %zu", dst_bytes, need);
     HIPCHK(hipSetDevice(b->ctx->device));
-    if (track == NATAC_T_OCC_PREFILL && (rc = materialise_prefill(b))) return rc;
+    if ((rc = materialise_track(b, track))) return rc;
     HIPCHK(hipMemcpyAsync(dst, b->d_track[track], need, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(sync_all(b->ctx));
     prof_collect(b->ctx);
@@ -2031,7 +2062,7 @@ int natac_batch_set_track(natac_batch *b, int track, const double *vals, size_t 
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(b->d_track[track], vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (track <= NATAC_T_SMOOTH) b->nuc_done = true;            // the stage flags only gate downloads / the writer
+    if (track <= NATAC_T_SMOOTH) { b->nuc_done = true; if (track == NATAC_T_BACKGROUND) b->bg_valid = true; }   // the stage flags only gate downloads / the writer
     else { b->occ_done = true; if (track == NATAC_T_OCC_PREFILL) b->prefill_valid = true; }
     return NATAC_OK;
 }
@@ -2048,9 +2079,9 @@ int natac_batch_status(natac_batch *b, int32_t *dst, size_t dst_bytes) {
 int natac_batch_track_ptr(natac_batch *b, int track, void **dptr) {
     if (!b || !dptr) return fail(NATAC_E_ARG, "null argument");
     if (track < 0 || track >= NATAC_T_COUNT) return fail(NATAC_E_ARG, "bad track id");
-    if (track == NATAC_T_OCC_PREFILL && b->occ_done) {
+    if ((track == NATAC_T_OCC_PREFILL && b->occ_done) || (track == NATAC_T_BACKGROUND && b->nuc_done)) {
         HIPCHK(hipSetDevice(b->ctx->device));
-        int rc = materialise_prefill(b);
+        int rc = materialise_track(b, track);
         if (rc) return rc;
     }
     *dptr = b->d_track[track];
@@ -2356,7 +2387,7 @@ int natac_batch_format_track(natac_batch *b, int track, const int32_t *chrom_id,
     natac_ctx *c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(sync_all(c));
-    if (track == NATAC_T_OCC_PREFILL && (rc = materialise_prefill(b))) return rc;
+    if ((rc = materialise_track(b, track))) return rc;
     if (track != NATAC_T_INS)
         return format_values(b, b->d_track[track], chrom_id, names, n_names, chunk_start, write_zero, compress, n_bytes, n_text_bytes, n_lines,
                              n_hard);
@@ -2984,6 +3015,7 @@ int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const in
     for (int i = 0; i < n_tracks; ++i) {
         if (tracks[i] == NATAC_T_INS) return fail(NATAC_E_ARG, "float64 tracks only");
         if ((rc = track_ready(b, tracks[i]))) return rc;
+        if ((rc = materialise_track(b, tracks[i]))) return rc;
     }
     if (b->total_bp >= 0xffffffffLL) return fail(NATAC_E_ARG, "batch too long (%lld bases)", b->total_bp);
     {   // budget first: nothing is launched or allocated for a segment the store will not keep

@@ -468,7 +468,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
             }
             const long long o = ob + g;
             const double bgv = (num * nuc_cov[o]) / cv;
-            bg[o] = bgv;
+            if (bg) bg[o] = bgv;
             norm[o] = raw[o] - bgv;
             bnum[o] = num;
             bcov[o] = cv;
@@ -694,11 +694,11 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
             if (core) {
 #if NATAC_FFT_EPI_PREFETCH
                 const double b = (num * pf_cov[j]) / cv;
-                bg[o] = b;
+                if (bg) bg[o] = b;       // null: the track is formed from bnum / bcov on request (natac_bg_from_factors)
                 norm[o] = pf_raw[j] - b;
 #else
                 const double b = (num * nuc_cov[o]) / cv;
-                bg[o] = b;
+                if (bg) bg[o] = b;
                 norm[o] = raw[o] - b;
 #endif
             }
@@ -732,7 +732,7 @@ __device__ __forceinline__ void bg_fft_tile(const ChunkTable &ct, const int2 t, 
                 const long long o = ob + g;
                 const double num = pe[2 * (FFT_EXT * side + t)] + corr, cv = pe[2 * (FFT_EXT * side + t) + 1] + qc;
                 const double bb = (num * nuc_cov[o]) / cv;
-                bg[o] = bb;
+                if (bg) bg[o] = bb;
                 norm[o] = raw[o] - bb;
                 bnum[o] = num;
                 bcov[o] = cv;
@@ -755,6 +755,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned ti = blockIdx.x;
     FftTwiddles tww;
     bg_fft_tile<false>(ct, tiles[ti], vm, tw, ktab, nuc_cov, raw, bg, norm, bnum, bcov, smem, tww, (int)threadIdx.x, mtab, swt, NJ);
+}
+
+// T_BACKGROUND on request (natac_api.hip: materialise_bg): the epilogue's own expression from the two factors it leaves per base
+__global__ void __launch_bounds__(256) natac_bg_from_factors(const double *__restrict__ bnum, const double *__restrict__ nuc_cov,
+                                                             const double *__restrict__ bcov, double *__restrict__ bg, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) bg[i] = (bnum[i] * nuc_cov[i]) / bcov[i];
 }
 
 // LDS of one wave of natac_background_fft, in bytes (host): the exp(bias) window of an extended tile + the transposes' scratch

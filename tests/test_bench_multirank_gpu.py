@@ -42,6 +42,24 @@ def test_gpus_flag_starts_its_own_ranks():
     assert d["config"]["chunks_total"] == 8000 and d["config"]["chunks_this_rank"] == 4000 and d["value"] > 0
 
 
+def test_two_ranks_run_the_host_to_host_pipeline_side_by_side():
+    """the host-to-host pipeline (pinned slots, six contexts per rank) with more than one rank on a host -- every rank
+    runs it on its own shard at the same time (`--h2h-ranks`) and the line carries a rate and the host placement (CPUs allowed, their
+    NUMA nodes, the GPU's NUMA node) per rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--chunks", "4000",
+                          "--no-cpu-baseline", "--steps", "2", "--warmup", "1", "--h2h-ranks", "--h2h-rank-chunks", "3000", "--h2h-sub", "1000"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and len(d["per_rank"]) == 2
+    for r in d["per_rank"]:
+        assert r["host_to_host_mbp_s"] > 0 and r["host_to_host_pcie_gbs_down"] > 0
+        pl = r["placement"]
+        assert pl["cpus_allowed"] >= 1 and pl["cpu_list"] and isinstance(pl["cpu_numa_nodes"], list)
+    assert "placement" in d
+
+
 def test_single_rank_default_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chunks", "3000", "--cpu-chunks", "32",
                           "--cpu-literal-chunks", "16", "--h2h-sub", "1000", "--cli-chunks", "400"], capture_output=True, text=True, timeout=900, cwd=ROOT)

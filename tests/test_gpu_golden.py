@@ -102,6 +102,32 @@ def test_candidate_lr_var_z(ctx, case, with_bias):
     b.free()
 
 
+def test_background_is_formed_on_request(ctx):
+    """round 6: the FFT kernel no longer writes T_BACKGROUND (an output only with --write_all, run_nuc.py:22-39); the first request forms
+    it from the kernel's two factors per base with the epilogue's own expression.  Requested late (after occ, ins and the candidate
+    search), twice, and through the device writer: the reference's values every time, and norm == raw - background bit for bit."""
+    g = golden("chunks_basic")
+    pk = packed_from_golden(g, True)
+    b = ctx.upload(pk)
+    b.run_nuc(smooth_sd=10)
+    b.run_occ()
+    b.run_ins(0, 2000)
+    b.run_peaks(min_signal=0, sep=25, boundary=60, order=12)
+    bg1 = b.track(L.T_BACKGROUND)
+    bg2 = b.track(L.T_BACKGROUND)
+    assert np.array_equal(bg1, bg2, equal_nan=True)
+    raw, norm = b.track(L.T_RAW), b.track(L.T_NORM)
+    assert np.array_equal(norm, raw - bg1, equal_nan=True)
+    for k, part in enumerate(b.split(bg1)):
+        assert_track(part, g["c%d_bg" % k], "background")
+    text, info = b.format_track(L.T_BACKGROUND, ["chrS"] * pk.n_chunks, pk.chunk_start, compress=False)
+    assert info["lines"] > 0
+    # a second pass over the same batch invalidates and re-forms it
+    b.run_nuc(smooth_sd=10)
+    assert np.array_equal(b.track(L.T_BACKGROUND), bg1, equal_nan=True)
+    b.free()
+
+
 def test_cython_dropins_edge_cases(ctx):
     g = golden("ins_edge")
     l, n, s, e = g["l"], g["n"], int(g["start"]), int(g["end"])

@@ -402,3 +402,34 @@ def test_bench_gpus_flag_means_ranks(tmp_path):
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 2 and "WORLD_SIZE=4" in out.stderr and not out.stdout.strip()
+
+
+def test_profile_stamp_covers_the_workload(tmp_path):
+    """bench.py's `traffic_source.stale` must flip when the INPUT the committed counters were collected on changes,
+    not only when the kernels do: the stamp hashes nucleoatac_amd/synth.py and bench.py's workload builder too."""
+    import os
+    import shutil
+    from nucleoatac_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = _lib.profile_sha16()
+    assert base == _lib.profile_sha16() and len(base) == 16
+    synth = tmp_path / "synth.py"
+    shutil.copy(os.path.join(root, "nucleoatac_amd", "synth.py"), synth)
+    assert _lib.profile_sha16(synth_path=str(synth)) == base                 # a copy: the same stamp
+    with open(synth, "a") as f:
+        f.write("\n# another fragment-size mixture\n")
+    assert _lib.profile_sha16(synth_path=str(synth)) != base                 # the generator changed: stale
+    bench = tmp_path / "bench.py"
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "F = a.frags_per_chunk or 500" in src
+    bench.write_text(src.replace("F = a.frags_per_chunk or 500", "F = a.frags_per_chunk or 600"))
+    assert _lib.profile_sha16(bench_path=str(bench)) != base                 # the workload's constants changed: stale
+    bench.write_text(src.replace("def pmc_source():", "def pmc_source():  # edited"))
+    assert _lib.profile_sha16(bench_path=str(bench)) == base                 # the rest of bench.py is not the workload
+    # and bench.py reports it
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    src_info = bm.pmc_source()
+    assert src_info is None or src_info["current_source_sha16"] == base

@@ -34,9 +34,9 @@ def main():
         fh.write("# values of the LAST dispatch of each kernel (the timed step). FETCH_SIZE / WRITE_SIZE in KiB as reported; on gfx950 "
                  "FETCH_SIZE\n# under-counts wide streaming reads 2x (MI355X_MICROARCH.md, HBM section). GRBM_GUI_ACTIVE is summed over "
                  "the 8 XCDs:\n# effective clock = value / 8 / kernel_ns_under_pmc\n")
-        from nucleoatac_amd._lib import csrc_sha16
-        fh.write("# source_sha16=%s (sha256 of nucleoatac_amd/csrc/* + include/natac.h at collection time; bench.py compares it with "
-                 "the current sources)\n" % csrc_sha16())
+        from nucleoatac_amd._lib import profile_sha16
+        fh.write("# source_sha16=%s (sha256 of nucleoatac_amd/csrc/* + include/natac.h + nucleoatac_amd/synth.py + bench.py's workload builder at "
+                 "collection time; bench.py compares it with the current ones)\n" % profile_sha16())
         fh.write("kernel,counter,sum_over_dispatches,dispatches\n")
         for (k, c), v in last.items():
             fh.write('"%s",%s,%.1f,1\n' % (k, c, v))
