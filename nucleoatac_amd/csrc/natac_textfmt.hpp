@@ -78,9 +78,30 @@ NATAC_HD inline int digits_i64(long long v) {
     return v < 0 ? 1 + digits_u64((uint64_t)(-(v + 1)) + 1) : digits_u64((uint64_t)v);
 }
 
-// python-2 str(float) of a non-NaN double: '%.12g' + ".0" for integral text.  Returns the end pointer; *hard is incremented
+// Where the characters of a value go.  PtrSink: a byte buffer (host writer, tests).  RegSink: three 64-bit words held in registers --
+// on the device a `char buf[24]` written at run-time positions lives in scratch memory (32 bytes per lane in tz_line_len and
+// tz_format_values until round 6); here a character is OR-ed into the word its position selects.
+struct PtrSink {
+    char *p;
+    NATAC_HD void put(char c) { *p++ = c; }
+};
+struct RegSink {
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
+    int n = 0;
+    NATAC_HD void put(char c) {
+        const uint64_t v = (uint64_t)(unsigned char)c << ((n & 7) * 8);
+        const int k = n >> 3;
+        w0 |= k == 0 ? v : 0ull;
+        w1 |= k == 1 ? v : 0ull;
+        w2 |= k == 2 ? v : 0ull;
+        ++n;
+    }
+};
+
+// python-2 str(float) of a non-NaN double: '%.12g' + ".0" for integral text, character by character into `out`.  *hard is incremented
 // when the rounding could not be decided from the truncated table entry (see the header).  tab = the P10 table.
-NATAC_HD inline char *fmt_py2_float(char *p, double v, const P10 *tab, int *hard) {
+template <class Sink>
+NATAC_HD inline void fmt_py2_float_to(Sink &out, double v, const P10 *tab, int *hard) {
     union { double d; uint64_t u; } cv;
     cv.d = v;
     const uint64_t bits = cv.u;
@@ -88,13 +109,13 @@ NATAC_HD inline char *fmt_py2_float(char *p, double v, const P10 *tab, int *hard
     const int ef = (int)((bits >> 52) & 0x7ff);
     const uint64_t frac = bits & 0xfffffffffffffull;
     if (ef == 0x7ff) {
-        if (frac) { *p++ = 'n'; *p++ = 'a'; *p++ = 'n'; return p; }
-        if (neg) *p++ = '-';
-        *p++ = 'i'; *p++ = 'n'; *p++ = 'f';
-        return p;
+        if (frac) { out.put('n'); out.put('a'); out.put('n'); return; }
+        if (neg) out.put('-');
+        out.put('i'); out.put('n'); out.put('f');
+        return;
     }
-    if (neg) *p++ = '-';
-    if (ef == 0 && frac == 0) { *p++ = '0'; *p++ = '.'; *p++ = '0'; return p; }
+    if (neg) out.put('-');
+    if (ef == 0 && frac == 0) { out.put('0'); out.put('.'); out.put('0'); return; }
     uint64_t m = ef ? (frac | (1ull << 52)) : frac;
     int e2 = ef ? ef - 1075 : -1074;
     const int lz = clz64(m);
@@ -128,30 +149,43 @@ NATAC_HD inline char *fmt_py2_float(char *p, double v, const P10 *tab, int *hard
         if (D >= 1000000000000ull) { D = 100000000000ull; ++e10; }   // 999999999999.5+ rounded up to 10^12
         break;
     }
-    char dg[12];
-    for (int i = 11; i >= 0; --i) { dg[i] = (char)('0' + (int)(D % 10)); D /= 10; }
+    // the twelve digits as one packed word, digit i (0 = first) in bits [4 (11 - i), 4 (11 - i) + 4): no indexed array
+    uint64_t bcd = 0;
+    {
+        const uint32_t hi6 = (uint32_t)(D / 1000000ull), lo6 = (uint32_t)(D - (uint64_t)hi6 * 1000000ull);     // two 6-digit halves: 32-bit divisions
+        uint32_t u = lo6;
+        for (int i = 0; i < 6; ++i) { const uint32_t q = u / 10u; bcd |= (uint64_t)(u - q * 10u) << (4 * i); u = q; }
+        u = hi6;
+        for (int i = 6; i < 12; ++i) { const uint32_t q = u / 10u; bcd |= (uint64_t)(u - q * 10u) << (4 * i); u = q; }
+    }
+    auto dg = [&](int i) -> char { return (char)('0' + (int)((bcd >> (4 * (11 - i))) & 0xf)); };
     int nd = 12;
-    while (nd > 1 && dg[nd - 1] == '0') --nd;            // %g strips trailing zeros
+    while (nd > 1 && ((bcd >> (4 * (12 - nd))) & 0xf) == 0) --nd;            // %g strips trailing zeros
     if (e10 < -4 || e10 >= 12) {                         // scientific: d[.ddd]e+XX (at least two exponent digits); has an 'e': no ".0"
-        *p++ = dg[0];
-        if (nd > 1) { *p++ = '.'; for (int i = 1; i < nd; ++i) *p++ = dg[i]; }
-        *p++ = 'e';
+        out.put(dg(0));
+        if (nd > 1) { out.put('.'); for (int i = 1; i < nd; ++i) out.put(dg(i)); }
+        out.put('e');
         int x = e10;
-        if (x < 0) { *p++ = '-'; x = -x; } else *p++ = '+';
-        if (x >= 100) { *p++ = (char)('0' + x / 100); x %= 100; *p++ = (char)('0' + x / 10); *p++ = (char)('0' + x % 10); }
-        else { *p++ = (char)('0' + x / 10); *p++ = (char)('0' + x % 10); }
+        if (x < 0) { out.put('-'); x = -x; } else out.put('+');
+        if (x >= 100) { out.put((char)('0' + x / 100)); x %= 100; out.put((char)('0' + x / 10)); out.put((char)('0' + x % 10)); }
+        else { out.put((char)('0' + x / 10)); out.put((char)('0' + x % 10)); }
     } else if (e10 >= 0) {
         const int ni = e10 + 1;                          // integer digits
-        for (int i = 0; i < ni; ++i) *p++ = (i < nd) ? dg[i] : '0';
-        *p++ = '.';
-        if (nd > ni) { for (int i = ni; i < nd; ++i) *p++ = dg[i]; }
-        else *p++ = '0';                                 // integral text gets ".0"
+        for (int i = 0; i < ni; ++i) out.put((i < nd) ? dg(i) : '0');
+        out.put('.');
+        if (nd > ni) { for (int i = ni; i < nd; ++i) out.put(dg(i)); }
+        else out.put('0');                               // integral text gets ".0"
     } else {
-        *p++ = '0'; *p++ = '.';
-        for (int i = 0; i < -e10 - 1; ++i) *p++ = '0';
-        for (int i = 0; i < nd; ++i) *p++ = dg[i];
+        out.put('0'); out.put('.');
+        for (int i = 0; i < -e10 - 1; ++i) out.put('0');
+        for (int i = 0; i < nd; ++i) out.put(dg(i));
     }
-    return p;
+}
+// into a byte buffer; returns the end pointer
+NATAC_HD inline char *fmt_py2_float(char *p, double v, const P10 *tab, int *hard) {
+    PtrSink s{p};
+    fmt_py2_float_to(s, v, tab, hard);
+    return s.p;
 }
 
 constexpr int MAX_VALUE_CHARS = 24;     // "-1.23456789012e-308" is 19

@@ -205,12 +205,11 @@ __global__ void __launch_bounds__(256) tz_line_len(TextJob job, long long nruns,
     const RunInfo r = run_info(job, k, nruns, R, C);
     int n = 0, hard = 0;
     if (r.emitted) {
-        union { char c[VTXT]; unsigned long long w[VTXT / 8]; } v;
-#pragma unroll
-        for (int i = 0; i < VTXT / 8; ++i) v.w[i] = 0;
-        const int nv = (int)(natac_text::fmt_py2_float(v.c, r.v, job.p10, &hard) - v.c);
-#pragma unroll
-        for (int i = 0; i < VTXT / 8; ++i) vtxt[(VTXT / 8) * k + i] = v.w[i];
+        natac_text::RegSink v;                              // the text in three registers (a char[24] here was 32 bytes of scratch per lane)
+        natac_text::fmt_py2_float_to(v, r.v, job.p10, &hard);
+        const int nv = v.n;
+        static_assert(VTXT == 24, "RegSink holds 24 characters");
+        vtxt[3 * k] = v.w0; vtxt[3 * k + 1] = v.w1; vtxt[3 * k + 2] = v.w2;
         const int cid = job.chrom_id[r.chunk];
         const long long s = job.chunk_start[r.chunk];
         n = (job.name_off[cid + 1] - job.name_off[cid]) + natac_text::digits_i64(s + r.a_rel) + natac_text::digits_i64(s + r.b_rel) + nv + 4;
@@ -329,11 +328,13 @@ __global__ void __launch_bounds__(256) tz_format_values(const double *__restrict
                                                          char *__restrict__ out, int *__restrict__ len, int *__restrict__ hard_total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    char buf[natac_text::MAX_VALUE_CHARS];
     int hard = 0;
-    const int m = (int)(natac_text::fmt_py2_float(buf, v[i], p10, &hard) - buf);
-    for (int k = 0; k < m; ++k) out[i * natac_text::MAX_VALUE_CHARS + k] = buf[k];
-    len[i] = m;
+    natac_text::RegSink t;
+    natac_text::fmt_py2_float_to(t, v[i], p10, &hard);
+    static_assert(natac_text::MAX_VALUE_CHARS == 24, "RegSink holds 24 characters");
+    unsigned long long *o = (unsigned long long *)(out + i * natac_text::MAX_VALUE_CHARS);      // 24-byte slots of an aligned buffer
+    o[0] = t.w0; o[1] = t.w1; o[2] = t.w2;
+    len[i] = t.n;
     if (hard) atomicAdd(hard_total, hard);
 }
 
@@ -640,30 +641,27 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long s0, s1;
     wave_range(g, wave, &s0, &s1);
-    // pass A: masks + bits of this wave's lines (a wave holds at most 8 groups of 64 lines: a member has <= 8,161 segments); the per-lane
-    // counts stay in registers and the masks go to the member's records for pass B (round 5: the histogram pass only sees a sample of
+    // pass A: masks + bits of this wave's lines; the masks and the bit count of a line go to the member's records for pass B (round 5: the histogram pass only sees a sample of
     // the members and leaves no records; forming the masks again in pass B instead measured 6.2 against 5.6 ms per 42-Mbp track)
     LaneRec *myrecs = recs + seg_base[blockIdx.x];
-    unsigned int lb[4] = {0, 0, 0, 0};              // eight 16-bit counts (a line is <= 160 characters x 15 bits)
     unsigned long long wave_bits = 0;
-#pragma unroll
-    for (int gi = 0; gi < 8; ++gi) {
-        const long long base = s0 + 64 * gi;
-        if (base < s1) {
-            unsigned int nbits = 0;
-            {
-                const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
-                const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
-                if (lane < cnt) myrecs[base + lane] = pack_rec(me);
-                nd::BitCountSink bc{codes, 0};
-                parse_lane_line(lds_text, me, bc);         // invalid lanes (past cnt): nothing
-                nbits = (unsigned int)bc.bits;
-            }
-            lb[gi >> 1] |= nbits << (16 * (gi & 1));
-            unsigned long long tot;
-            (void)wave_excl_scan((unsigned long long)nbits, lane, &tot);
-            wave_bits += tot;
+    // (round 6: a line's bit count travels in its record -- the 16 spare bits -- instead of eight packed counts per lane kept in registers
+    // across both passes, and the loops over a wave's groups are not unrolled: 64 VGPRs without the 68 bytes of scratch round 5 had)
+#pragma unroll 1
+    for (long long base = s0; base < s1; base += 64) {
+        const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
+        const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
+        nd::BitCountSink bc{codes, 0};
+        parse_lane_line(lds_text, me, bc);         // invalid lanes (past cnt): nothing
+        const unsigned int nbits = (unsigned int)bc.bits;
+        if (lane < cnt) {
+            LaneRec r = pack_rec(me);
+            r.pad0 = (unsigned short)nbits;        // a line is <= 160 characters x 15 bits
+            myrecs[base + lane] = r;
         }
+        unsigned long long tot;
+        (void)wave_excl_scan((unsigned long long)nbits, lane, &tot);
+        wave_bits += tot;
     }
     if (lane == 0) wbits[wave] = wave_bits;
     // CRC-32: my 64-byte slice, shifted to the start of the last slice (natac_deflate.hpp: CrcTables), XOR-reduced over the workgroup
@@ -702,24 +700,24 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
         for (int i = threadIdx.x; i < hw; i += TZ_THREADS) words[5 + i] = codes->hdr[i];
         if (threadIdx.x == 0 && hr) atomicOr(&words[5 + hw], codes->hdr[hw]);
         unsigned long long pos = (unsigned long long)codes->hdr_bits + my_start;      // bit position of this wave's next group
-#pragma unroll
-        for (int gi = 0; gi < 8; ++gi) {
-            const long long base = s0 + 64 * gi;
-            if (base < s1) {
-                unsigned long long tot;
-                const unsigned long long mine = wave_excl_scan((unsigned long long)((lb[gi >> 1] >> (16 * (gi & 1))) & 0xffffu), lane, &tot);
-                if (base + lane < s1) {
-                    const LaneLine me = unpack_rec(myrecs[base + lane]);      // this lane's own record of pass A
-                    if (me.valid) {
-                        DevBitWriter bw;
-                        bw.init(words + 5, (long long)(pos + mine));
-                        DevEmitSink es{codes, &bw};
-                        parse_lane_line(lds_text, me, es);
-                        bw.finish();
-                    }
+#pragma unroll 1
+        for (long long base = s0; base < s1; base += 64) {
+            LaneRec r;
+            r.seglen = 0; r.pad0 = 0;
+            if (base + lane < s1) r = myrecs[base + lane];                // this lane's own record of pass A
+            unsigned long long tot;
+            const unsigned long long mine = wave_excl_scan((unsigned long long)r.pad0, lane, &tot);
+            if (base + lane < s1) {
+                const LaneLine me = unpack_rec(r);
+                if (me.valid) {
+                    DevBitWriter bw;
+                    bw.init(words + 5, (long long)(pos + mine));
+                    DevEmitSink es{codes, &bw};
+                    parse_lane_line(lds_text, me, es);
+                    bw.finish();
                 }
-                pos += tot;
             }
+            pos += tot;
         }
         if (threadIdx.x == 0) {                               // end of block after the last token
             DevBitWriter bw;

@@ -19,6 +19,14 @@ int main(int argc, char **argv) {
         char *eb = natac_writer::fmt_py2_float(b, v);
         hard_total += hard;
         ++n;
+        {   // the register sink the kernels use (three 64-bit words) holds the same bytes as the pointer sink
+            natac_text::RegSink rs;
+            int h2 = 0;
+            natac_text::fmt_py2_float_to(rs, v, natac_text::H_P10, &h2);
+            char c[24];
+            std::memcpy(c, &rs.w0, 8); std::memcpy(c + 8, &rs.w1, 8); std::memcpy(c + 16, &rs.w2, 8);
+            if (rs.n != ea - a || std::memcmp(c, a, rs.n)) { if (bad < 20) std::printf("REG-SINK MISMATCH %.17g\n", v); ++bad; }
+        }
         if (hard) return;
         if (ea - a != eb - b || std::memcmp(a, b, ea - a)) {
             if (bad < 20) { *ea = 0; *eb = 0; std::printf("MISMATCH %.17g: device-fmt '%s' vs native '%s'\n", v, a, b); }
