@@ -524,13 +524,15 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     // line segments per member -> offsets of the per-segment records pass A of the emit kernel leaves for its pass B
     unsigned int *d_nseg = nullptr;
     unsigned long long *d_segbase = nullptr;
-    LaneRec *d_recs = nullptr;
+    unsigned int *d_stage = nullptr;
+    unsigned short *d_segbits = nullptr;
     TRYF(dev_alloc(&d_nseg, (size_t)nblk)); tmp.keep(d_nseg);
     TRYF(dev_alloc(&d_segbase, (size_t)nblk + 1)); tmp.keep(d_segbase);
     hipLaunchKernelGGL(tz_member_nseg, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->stream, d_line_off, (long long)nlines,
                        (long long)n_text, nblk, d_nseg);
     TRYF(dev_scan(c, d_nseg, nblk, d_segbase));
-    TRYF(dev_alloc(&d_recs, (size_t)nlines + (size_t)nblk + 64)); tmp.keep(d_recs);      // every line once + one more per straddled member border
+    TRYF(dev_alloc(&d_segbits, (size_t)nlines + (size_t)nblk + 64)); tmp.keep(d_segbits);  // every line once + one more per straddled member border
+    TRYF(dev_alloc(&d_stage, (size_t)nblk * STAGE_WORDS)); tmp.keep(d_stage);             // the lines' finished bits between the emit kernel's two passes
     // token histogram of a sample of the members (every member of a small batch): natac_deflate.hpp, sample_stride
     const int stride = nd::sample_stride(nblk);
     const long long counted = (nblk + stride - 1) / stride;
@@ -550,7 +552,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_pos, (size_t)nblk + 1)); tmp.keep(d_pos);
     const size_t lds_emit = 65536 + ((sizeof(nd::Codes) + 15) & ~(size_t)15);
     hipLaunchKernelGGL(tz_emit_members, dim3((unsigned)nblk), dim3(TZ_THREADS), lds_emit, c->stream, d_text, (long long)n_text, d_line_off,
-                       (long long)nlines, d_segbase, d_recs, d_codes, c->d_crc, d_regions, d_sizes);
+                       (long long)nlines, d_segbase, d_stage, d_segbits, d_codes, c->d_crc, d_regions, d_sizes);
     HIPCHK(hipGetLastError());
     TRYF(dev_scan(c, d_sizes, nblk, d_pos));
     b->fmt_member_pos.resize((size_t)nblk + 1);

@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(256) tz_format_values(const double *__restrict
 //           token loop -- the bulk of the instructions -- runs 64 lines wide.
 constexpr int TZ_THREADS = 1024, TZ_WAVES = TZ_THREADS / 64;
 
+
 struct DevCountSink {              // LDS histogram
     unsigned int *ll, *d;
     __device__ void literal(unsigned char c) { atomicAdd(&ll[c], 1u); }
@@ -485,28 +486,43 @@ __device__ __forceinline__ void parse_lane_line(const unsigned char *lds_text, c
     nd::greedy_tokens(me.eq0, me.eq1, me.eq2, me.c, me.seglen, [&](int i) -> unsigned char { return seg[i]; }, sink);
 }
 
-// what pass A of tz_emit_members leaves per line segment for its pass B (40 bytes, in device memory: a member has up to 8,161 segments,
-// too many for LDS next to its 64 KB of text): the masks phase runs once per line
-struct LaneRec {
-    unsigned long long eq0, eq1, eq2;
-    unsigned short d0, d1, d2, q0rel, seglen, pad0, pad1, pad2;
+// What pass A of tz_emit_members leaves per line segment for its pass B (round 6): the line's FINISHED bits, from bit 0 of a private
+// range of 32-bit words in a staging buffer, and their count.  Pass B only shifts them to where the prefix sums put the line -- it does
+// not parse again (until round 6 pass A left the three masks, 40 bytes per line, and pass B repeated the greedy parse: 2 of the kernel's
+// 5 ms).  A token never takes more than 16 bits per character it covers (a literal <= 15; a match of >= 3 characters <= 15 + 5 + 15 + 13),
+// so segment k of a member (starting q0rel bytes into it) owns the words [(q0rel + k + 1) >> 1, (q0rel' + k + 2) >> 1) -- at least
+// ceil(seglen / 2) of them: the ranges cannot overlap and STAGE_WORDS per member hold them all (a line is >= 8 characters).
+constexpr int STAGE_WORDS = (nd::BLK + nd::BLK / 8 + 4) / 2 + 4;
+__device__ __forceinline__ int stage_offset(int q0rel, int k) { return (q0rel + k + 1) >> 1; }
+struct DevStageWriter {            // LSB-first bit stream from bit 0 of its own words: plain stores
+    unsigned int *wp, *w0;
+    unsigned long long acc;
+    int nacc;
+    __device__ void init(unsigned int *w) { wp = w0 = w; acc = 0; nacc = 0; }
+    __device__ void put(unsigned int v, int nb) {
+        acc |= (unsigned long long)v << nacc;
+        nacc += nb;
+        if (nacc >= 32) { *wp++ = (unsigned int)acc; acc >>= 32; nacc -= 32; }
+    }
+    __device__ unsigned int finish() {          // returns the number of bits written
+        if (nacc > 0) *wp = (unsigned int)acc;
+        return (unsigned int)(wp - w0) * 32u + (unsigned int)nacc;
+    }
 };
-__device__ __forceinline__ LaneRec pack_rec(const LaneLine &me) {
-    LaneRec r;
-    r.eq0 = me.eq0; r.eq1 = me.eq1; r.eq2 = me.eq2;
-    r.d0 = (unsigned short)me.c.d0; r.d1 = (unsigned short)me.c.d1; r.d2 = (unsigned short)me.c.d2;     // distances <= 32768
-    r.q0rel = (unsigned short)me.q0rel; r.seglen = (unsigned short)(me.valid ? me.seglen : 0);
-    r.pad0 = r.pad1 = r.pad2 = 0;
-    return r;
-}
-__device__ __forceinline__ LaneLine unpack_rec(const LaneRec &r) {
-    LaneLine me;
-    me.valid = r.seglen > 0;
-    me.q0rel = r.q0rel; me.seglen = r.seglen;
-    me.c.d0 = r.d0; me.c.d1 = r.d1; me.c.d2 = r.d2;
-    me.eq0 = r.eq0; me.eq1 = r.eq1; me.eq2 = r.eq2;
-    return me;
-}
+struct DevStageSink {
+    const nd::Codes *c;
+    const unsigned int *lit;       // LDS: ll_code | ll_len << 16 per literal / length symbol -- one lookup per literal instead of two
+    DevStageWriter *w;
+    __device__ void literal(unsigned char ch) { const unsigned int e = lit[ch]; w->put(e & 0xffffu, (int)(e >> 16)); }
+    __device__ void match(int L, int dist) {
+        int s, eb, ev;
+        nd::len_symbol(L, &s, &eb, &ev);
+        const unsigned int e = lit[s];
+        w->put((e & 0xffffu) | ((unsigned int)ev << (e >> 16)), (int)(e >> 16) + eb);
+        nd::dist_symbol(dist, &s, &eb, &ev);
+        w->put(c->d_code[s] | ((unsigned int)ev << c->d_len[s]), c->d_len[s] + eb);
+    }
+};
 // number of line segments of every member (for the offsets of the records above)
 __global__ void __launch_bounds__(256) tz_member_nseg(const long long *__restrict__ line_off, long long nlines, long long n_text,
                                                        long long nblk, unsigned int *__restrict__ nseg) {
@@ -556,48 +572,32 @@ __global__ void __launch_bounds__(TZ_THREADS) tz_count_tokens(const unsigned cha
 }
 
 struct DevBitWriter {              // LSB-first bit stream into zero-initialised 32-bit words; words shared with a neighbour are OR-ed
-    unsigned int *words;
-    long long bitpos;              // next bit to write
-    unsigned long long acc;        // pending bits, acc bit 0 = stream bit (bitpos - nacc)
+    unsigned int *wp;              // the word the pending bits belong to (a member's stream is < 2^19 bits: 32-bit arithmetic throughout)
+    unsigned long long acc;        // pending bits, acc bit 0 = bit 0 of *wp
     int nacc;
     bool first;                    // the next flushed word is the first one of this writer (may be shared with the previous line)
-    __device__ void init(unsigned int *w, long long start_bit) {
-        words = w;
-        bitpos = start_bit;
+    __device__ void init(unsigned int *w, unsigned int start_bit) {
+        wp = w + (start_bit >> 5);
         acc = 0;
-        nacc = (int)(start_bit & 31);   // the bits below the start in the first word are pending zeros: OR-ing zeros is harmless
+        nacc = (int)(start_bit & 31u);  // the bits below the start in the first word are pending zeros: OR-ing zeros is harmless
         first = true;
     }
     __device__ void put(unsigned int v, int nb) {
         acc |= (unsigned long long)v << nacc;
         nacc += nb;
-        bitpos += nb;
         if (nacc >= 32) {
-            unsigned int *dst = &words[(bitpos - nacc) >> 5];
-            if (first) { atomicOr(dst, (unsigned int)acc); first = false; }
-            else *dst = (unsigned int)acc;
+            if (first) { atomicOr(wp, (unsigned int)acc); first = false; }
+            else *wp = (unsigned int)acc;
+            ++wp;
             acc >>= 32;
             nacc -= 32;
         }
     }
     __device__ void finish() {
-        if (nacc > 0) atomicOr(&words[(bitpos - nacc) >> 5], (unsigned int)acc);
+        if (nacc > 0) atomicOr(wp, (unsigned int)acc);
         nacc = 0;
     }
 };
-struct DevEmitSink {
-    const nd::Codes *c;
-    DevBitWriter *w;
-    __device__ void literal(unsigned char ch) { w->put(c->ll_code[ch], c->ll_len[ch]); }
-    __device__ void match(int L, int dist) {
-        int s, eb, ev;
-        nd::len_symbol(L, &s, &eb, &ev);
-        w->put(c->ll_code[s] | ((unsigned int)ev << c->ll_len[s]), c->ll_len[s] + eb);
-        nd::dist_symbol(dist, &s, &eb, &ev);
-        w->put(c->d_code[s] | ((unsigned int)ev << c->d_len[s]), c->d_len[s] + eb);
-    }
-};
-
 __device__ __forceinline__ void or_bytes(unsigned int *words, long long byte_off, unsigned long long value, int nbytes) {
     for (int i = 0; i < nbytes; ++i) {
         const long long o = byte_off + i;
@@ -619,7 +619,7 @@ __device__ __forceinline__ unsigned long long wave_excl_scan(unsigned long long 
 // region (so that the deflate payload, 18 bytes later, starts on a 32-bit word).  sizes[b] = member size in bytes.
 __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
                                                                const long long *__restrict__ line_off, long long nlines,
-                                                               const unsigned long long *__restrict__ seg_base, LaneRec *__restrict__ recs,
+                                                               const unsigned long long *__restrict__ seg_base, unsigned int *__restrict__ stage, unsigned short *__restrict__ seg_bits,
                                                                const nd::Codes *__restrict__ codes_g, const nd::CrcTables *__restrict__ crc_g,
                                                                unsigned char *__restrict__ out_regions, unsigned int *__restrict__ sizes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -628,12 +628,14 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ unsigned long long wbits[TZ_WAVES];
     __shared__ unsigned int crc_w[TZ_WAVES];
     __shared__ unsigned int crc_tab[256];
+    __shared__ unsigned int lit32[nd::NLL];
     const MemberGeom g = member_geom(line_off, nlines, n_text, blockIdx.x);
     {
         const unsigned int *src = (const unsigned int *)codes_g;
         unsigned int *dst = (unsigned int *)codes;
         for (int i = threadIdx.x; i < (int)(sizeof(nd::Codes) / 4); i += TZ_THREADS) dst[i] = src[i];
         for (int i = threadIdx.x; i < 256; i += TZ_THREADS) crc_tab[i] = crc_g->table[i];
+        for (int i = threadIdx.x; i < nd::NLL; i += TZ_THREADS) lit32[i] = (unsigned int)codes_g->ll_code[i] | ((unsigned int)codes_g->ll_len[i] << 16);
     }
     load_member_text(lds_text, text, g);
     __syncthreads();
@@ -641,24 +643,23 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long s0, s1;
     wave_range(g, wave, &s0, &s1);
-    // pass A: masks + bits of this wave's lines; the masks and the bit count of a line go to the member's records for pass B (round 5: the histogram pass only sees a sample of
-    // the members and leaves no records; forming the masks again in pass B instead measured 6.2 against 5.6 ms per 42-Mbp track)
-    LaneRec *myrecs = recs + seg_base[blockIdx.x];
+    // pass A: masks + ONE greedy parse per line, the line's bits into its staging words, their count into seg_bits
+    unsigned int *mystage = stage + (size_t)blockIdx.x * STAGE_WORDS;
+    unsigned short *mybits = seg_bits + seg_base[blockIdx.x];
     unsigned long long wave_bits = 0;
-    // (round 6: a line's bit count travels in its record -- the 16 spare bits -- instead of eight packed counts per lane kept in registers
-    // across both passes, and the loops over a wave's groups are not unrolled: 64 VGPRs without the 68 bytes of scratch round 5 had)
 #pragma unroll 1
     for (long long base = s0; base < s1; base += 64) {
         const int cnt = (int)(s1 - base < 64 ? s1 - base : 64);
         const LaneLine me = group_masks(lds_text, g, line_off, nlines, n_text, base, cnt, lane);
-        nd::BitCountSink bc{codes, 0};
-        parse_lane_line(lds_text, me, bc);         // invalid lanes (past cnt): nothing
-        const unsigned int nbits = (unsigned int)bc.bits;
-        if (lane < cnt) {
-            LaneRec r = pack_rec(me);
-            r.pad0 = (unsigned short)nbits;        // a line is <= 160 characters x 15 bits
-            myrecs[base + lane] = r;
+        unsigned int nbits = 0;
+        if (me.valid) {
+            DevStageWriter sw;
+            sw.init(mystage + stage_offset(me.q0rel, (int)(base + lane)));
+            DevStageSink ss{codes, lit32, &sw};
+            parse_lane_line(lds_text, me, ss);
+            nbits = sw.finish();
         }
+        if (lane < cnt) mybits[base + lane] = (unsigned short)nbits;       // a line is <= 160 characters x 15 bits
         unsigned long long tot;
         (void)wave_excl_scan((unsigned long long)nbits, lane, &tot);
         wave_bits += tot;
@@ -702,26 +703,34 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
         unsigned long long pos = (unsigned long long)codes->hdr_bits + my_start;      // bit position of this wave's next group
 #pragma unroll 1
         for (long long base = s0; base < s1; base += 64) {
-            LaneRec r;
-            r.seglen = 0; r.pad0 = 0;
-            if (base + lane < s1) r = myrecs[base + lane];                // this lane's own record of pass A
+            const bool have = base + lane < s1;
+            const unsigned int nbits = have ? mybits[base + lane] : 0u;
             unsigned long long tot;
-            const unsigned long long mine = wave_excl_scan((unsigned long long)r.pad0, lane, &tot);
-            if (base + lane < s1) {
-                const LaneLine me = unpack_rec(r);
-                if (me.valid) {
-                    DevBitWriter bw;
-                    bw.init(words + 5, (long long)(pos + mine));
-                    DevEmitSink es{codes, &bw};
-                    parse_lane_line(lds_text, me, es);
-                    bw.finish();
+            const unsigned long long mine = wave_excl_scan((unsigned long long)nbits, lane, &tot);
+            if (nbits) {
+                // this lane's line: its staged words shifted to bit (pos + mine) of the member's stream.  The first and the last word it
+                // touches may be shared with the neighbouring lines (OR-ed); the words in between have one owner (plain stores).
+                const long long kk = g.k0 + base + lane;
+                const long long ls = line_off[kk];
+                const int q0rel = (int)((ls > g.bs ? ls : g.bs) - g.bs);
+                const unsigned int *src = mystage + stage_offset(q0rel, (int)(base + lane));
+                const unsigned int P = (unsigned int)(pos + mine), sh = P & 31u;
+                unsigned int *dst = words + 5 + (P >> 5);
+                const int nw = (int)((nbits + 31u) >> 5), nout = (int)((sh + nbits + 31u) >> 5);
+                unsigned int prev = 0;
+                for (int j = 0; j < nout; ++j) {
+                    const unsigned int cur = j < nw ? src[j] : 0u;
+                    const unsigned int w = sh ? (cur << sh) | (prev >> (32u - sh)) : cur;
+                    prev = cur;
+                    if (j == 0 || j == nout - 1) atomicOr(dst + j, w);
+                    else dst[j] = w;
                 }
             }
             pos += tot;
         }
         if (threadIdx.x == 0) {                               // end of block after the last token
             DevBitWriter bw;
-            bw.init(words + 5, (long long)((unsigned long long)codes->hdr_bits + total_tok_bits));
+            bw.init(words + 5, (unsigned int)((unsigned long long)codes->hdr_bits + total_tok_bits));
             bw.put(codes->ll_code[256], eob_len);
             bw.finish();
         }
