@@ -440,8 +440,18 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
         cat.insert(cat.end(), names[i], names[i] + l);
         noff.push_back((int)cat.size());
     }
-    for (int i = 0; i < b->nc; ++i)
+    // longest line this call can form: name + two coordinates + value text + 4 separators.  tz_write_lines stages the 256 lines of a
+    // workgroup in LDS; sized for THIS bound (typically ~52 bytes per line) instead of the format's 160 it keeps 8 waves per SIMD
+    // resident instead of 3.
+    size_t max_name = 0;
+    long long max_coord = 0, min_coord = 0;
+    for (int i = 0; i < b->nc; ++i) {
         if (chrom_id[i] < 0 || chrom_id[i] >= n_names) return fail(NATAC_E_ARG, "chunk %d: chromosome id %d out of range", i, chrom_id[i]);
+        max_name = std::max(max_name, (size_t)(noff[chrom_id[i] + 1] - noff[chrom_id[i]]));
+        max_coord = std::max<long long>(max_coord, (long long)chunk_start[i] + b->h_len[i]);
+        min_coord = std::min<long long>(min_coord, (long long)chunk_start[i]);
+    }
+    const int line_cap = std::min<int>(MAX_LINE, (int)max_name + 2 * std::max(natac_text::digits_i64(max_coord), natac_text::digits_i64(min_coord)) + VTXT + 4);
     if (b->total_bp >= 0xffffffffLL) return fail(NATAC_E_ARG, "batch too long for the device writer (%lld bases)", b->total_bp);
     TmpFree tmp;
     char *d_names = nullptr;
@@ -502,7 +512,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
         TRYF(dev_alloc(&d_lbeg, (size_t)nlines)); tmp.keep(d_lbeg);
         TRYF(dev_alloc(&d_lend, (size_t)nlines)); tmp.keep(d_lend);
     }
-    hipLaunchKernelGGL(tz_write_lines, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_boff, d_lidx, d_vtxt, d_text,
+    hipLaunchKernelGGL(tz_write_lines, dim3(rb), dim3(256), (size_t)256 * line_cap + 32, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_boff, d_lidx, d_vtxt, d_text,
                        d_line_off, d_lcid, d_lbeg, d_lend);
     if (!compress) {
         hipError_t e = hipStreamSynchronize(c->stream);

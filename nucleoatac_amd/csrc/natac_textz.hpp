@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) tz_write_lines(TextJob job, long long nru
                                                        const unsigned long long *__restrict__ line_idx, const unsigned long long *__restrict__ vtxt,
                                                        unsigned char *__restrict__ text, long long *__restrict__ line_off, int *__restrict__ l_cid,
                                                        long long *__restrict__ l_beg, long long *__restrict__ l_end) {
-    __shared__ __attribute__((aligned(16))) unsigned char stage[256 * MAX_LINE + 32];
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage[];      // 256 x (the longest line of this call) + 32 bytes (host)
     const long long k0 = (long long)blockIdx.x * 256, k = k0 + threadIdx.x;
     const long long k1 = k0 + 256 < nruns ? k0 + 256 : nruns;
     const unsigned long long base = byte_off[k0], end = byte_off[k1];          // byte_off has nruns + 1 entries
