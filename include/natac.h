@@ -35,8 +35,9 @@ extern "C" {
 #endif
 
 /* bumped whenever an entry point is added, removed or changes meaning (2: round 5 removed natac_run_nuc_occ, added natac_bg_tiling /
- * natac_store_set_budget / natac_store_declined, gave natac_store_adopt's n_hard == -1 a meaning); the binding refuses another version */
-#define NATAC_ABI_VERSION 2
+ * natac_store_set_budget / natac_store_declined, gave natac_store_adopt's n_hard == -1 a meaning; 3: round 6 added natac_batch_format_fetch_begin / _wait);
+ * the binding refuses another version */
+#define NATAC_ABI_VERSION 3
 
 enum {
     NATAC_OK = 0,
@@ -266,6 +267,13 @@ int natac_batch_format_track(natac_batch *b, int track, const int32_t *chrom_id,
                              const int64_t *chunk_start, int write_zero, int compress, int64_t *n_bytes, int64_t *n_text_bytes,
                              int64_t *n_lines, int32_t *n_hard);
 int natac_batch_format_fetch(natac_batch *b, void *dst, size_t dst_bytes);
+/* The same without waiting: _begin starts the copy of the last natac_batch_format_track result into `dst` (pinned host memory) on a
+ * second stream and returns; the batch may format its next track at once (the reference's writer processes likewise take track after
+ * track, run_occ.py:130-136).  `dst` holds the result after natac_batch_format_fetch_wait, which waits for every copy begun on the
+ * batch; natac_batch_free and natac_batch_release_outputs wait too.  The tabix records of a result (natac_batch_format_index_*) must be
+ * fetched before the next natac_batch_format_track, as with the blocking fetch. */
+int natac_batch_format_fetch_begin(natac_batch *b, void *dst, size_t dst_bytes);
+int natac_batch_format_fetch_wait(natac_batch *b);
 /* The .tbi of a file assembled from natac_batch_format_track(compress) results, WITHOUT re-reading the file (the reference runs
  * pysam.tabix_index(..., preset="bed") over every finished file, run_occ.py:136-139).  The device reduces the lines of a result to runs
  * of records per 16-kb leaf bin (one per ~16 kb instead of one per base): natac_batch_format_index_size / _fetch return the runs

@@ -7,7 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2      # NATAC_ABI_VERSION of include/natac.h (tests/test_abi.py compares the two)
+# The pipelined executor runs six contexts with two streams each (stages + the copies of finished results).  The HIP runtime maps streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise: with the default the bedGraph.gz
+# host-to-host leg measured 550 Mbp/s, with 8 queues 567-592 (profiles/r6/README.md).  Read once when the runtime initialises, so it is set
+# here, before the library is loaded; an explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ABI_VERSION = 3      # NATAC_ABI_VERSION of include/natac.h (tests/test_abi.py compares the two)
 LIB_PATH = os.environ.get("NATAC_LIB") or os.path.join(_HERE, "libnatac_hip.so")   # NATAC_LIB: A/B builds of the same ABI
 
 # enums of include/natac.h
@@ -81,6 +86,8 @@ SIGNATURES = {
     "natac_batch_format_track": (C.c_int, [_vp, C.c_int, _vp, _vp, _i32, _vp, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64),
                                  C.POINTER(_i64), C.POINTER(_i32)]),
     "natac_batch_format_fetch": (C.c_int, [_vp, _vp, _sz]),
+    "natac_batch_format_fetch_begin": (C.c_int, [_vp, _vp, _sz]),
+    "natac_batch_format_fetch_wait": (C.c_int, [_vp]),
     "natac_tbi_create": (C.c_int, [_pp]),
     "natac_tbi_free": (None, [_vp]),
     "natac_batch_format_index_size": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),

@@ -54,6 +54,7 @@ static int fail(int code, const char *fmt, ...) {
 struct natac_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // every stage, uploads, drop-ins: one stream
+    hipStream_t copy_stream = nullptr;   // natac_batch_format_fetch_begin: a finished result leaves the device while the next track is formatted
     hipDeviceProp_t prop;
     // constants
     double *d_vmat = nullptr, *d_vmat_pad = nullptr, *d_srow = nullptr, *d_sizes = nullptr;   // d_vmat_pad: VMatDev::matp
@@ -161,6 +162,7 @@ struct natac_batch {
     int nuc_w = -1, nuc_upper = -1;   // V-plot geometry natac_run_nuc ran with (coverage tracks depend on it)
     double *d_bnum = nullptr, *d_bcov = nullptr;   // per-base sum B V / sum B of the background kernel (candidate statistics)
     unsigned char *d_fmt_out = nullptr;            // result of the last natac_batch_format_track (text or BGZF members)
+    std::vector<std::pair<unsigned char *, hipEvent_t>> fmt_pending;   // results on their way to the host (natac_batch_format_fetch_begin)
     long long fmt_bytes = -1;
     // tabix records of that result (compress mode): runs of lines per leaf bin, member offsets, chromosome names
     std::vector<natac_textz::GroupRec> fmt_groups;
@@ -173,6 +175,7 @@ struct natac_batch {
 static hipError_t sync_all(natac_ctx *c) { return hipStreamSynchronize(c->stream); }
 
 static int track_ready(natac_batch *b, int t);
+static int fmt_pending_wait(natac_batch *b);
 
 static void prof_begin(natac_ctx *c, int k, natac_ctx::Ev &ev, hipStream_t st = nullptr) {
     ev.k = k;
@@ -394,28 +397,30 @@ static int ensure_text_tables(natac_ctx *c) {
     return NATAC_OK;
 }
 
-// exclusive scan of in[0..n) into out[0..n], out[n] = total (device arrays; n > 0)
-template <class T>
-static int dev_scan(natac_ctx *c, const T *in, long long n, unsigned long long *out) {
-    using namespace natac_textz;
-    const long long nblk = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
-    unsigned long long *sums = nullptr;
-    int rc = dev_alloc(&sums, (size_t)nblk + 1);
-    if (rc) return rc;
-    hipLaunchKernelGGL((tz_scan_block_sums<T>), dim3((unsigned)nblk), dim3(256), 0, c->stream, in, n, sums);
-    hipLaunchKernelGGL(tz_scan_sums, dim3(1), dim3(1024), 0, c->stream, sums, nblk);
-    hipLaunchKernelGGL((tz_scan_final<T>), dim3((unsigned)nblk), dim3(256), 0, c->stream, in, n, sums, out);
-    hipError_t e = hipStreamSynchronize(c->stream);
-    dev_free(sums);
-    if (e != hipSuccess) return fail(NATAC_E_HIP, "scan: %s", hipGetErrorString(e));
-    return NATAC_OK;
-}
-
 struct TmpFree {               // frees device temporaries at scope exit
     std::vector<void *> v;
     ~TmpFree() { for (void *p : v) dev_free(p); }
     template <class T> T *keep(T *p) { v.push_back((void *)p); return p; }
 };
+
+// exclusive scan of in[0..n) into out[0..n], out[n] = total (device arrays; n > 0).  The block sums are a temporary of the CALLER's scope
+// (`tmp`, freed after the caller's last synchronisation): freeing them here needed a stream synchronisation per scan -- six per formatted
+// track -- because the pool may hand a freed block to another context at once.
+template <class T>
+static int dev_scan(natac_ctx *c, const T *in, long long n, unsigned long long *out, TmpFree &tmp) {
+    using namespace natac_textz;
+    const long long nblk = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    unsigned long long *sums = nullptr;
+    int rc = dev_alloc(&sums, (size_t)nblk + 1);
+    if (rc) return rc;
+    tmp.keep(sums);
+    hipLaunchKernelGGL((tz_scan_block_sums<T>), dim3((unsigned)nblk), dim3(256), 0, c->stream, in, n, sums);
+    hipLaunchKernelGGL(tz_scan_sums, dim3(1), dim3(1024), 0, c->stream, sums, nblk);
+    hipLaunchKernelGGL((tz_scan_final<T>), dim3((unsigned)nblk), dim3(256), 0, c->stream, in, n, sums, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "scan: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
 
 // text / BGZF of a device array of per-base values laid out like the batch's tracks.  Result stays in b->d_fmt_out.
 static int format_values(natac_batch *b, const double *d_vals, const int32_t *chrom_id, const char *const *names, int32_t n_names,
@@ -475,7 +480,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_tc, (size_t)nt)); tmp.keep(d_tc);
     TRYF(dev_alloc(&d_tb, (size_t)nt + 1)); tmp.keep(d_tb);
     hipLaunchKernelGGL(tz_flags_count, dim3(nt), dim3(256), 0, c->stream, job, d_tc);
-    TRYF(dev_scan(c, d_tc, (long long)nt, d_tb));
+    TRYF(dev_scan(c, d_tc, (long long)nt, d_tb, tmp));
     unsigned long long nruns = 0;
     HIPCHK(hipMemcpyAsync(&nruns, d_tb + nt, sizeof nruns, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -490,8 +495,8 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     hipLaunchKernelGGL(tz_line_len, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_isl, d_hard, d_vtxt);
     TRYF(dev_alloc(&d_boff, (size_t)nruns + 1)); tmp.keep(d_boff);
     TRYF(dev_alloc(&d_lidx, (size_t)nruns + 1)); tmp.keep(d_lidx);
-    TRYF(dev_scan(c, d_len8, (long long)nruns, d_boff));
-    TRYF(dev_scan(c, d_isl, (long long)nruns, d_lidx));
+    TRYF(dev_scan(c, d_len8, (long long)nruns, d_boff, tmp));
+    TRYF(dev_scan(c, d_isl, (long long)nruns, d_lidx, tmp));
     unsigned long long n_text = 0, nlines = 0;
     int hard = 0;
     HIPCHK(hipMemcpyAsync(&n_text, d_boff + nruns, sizeof n_text, hipMemcpyDeviceToHost, c->stream));
@@ -540,7 +545,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_segbase, (size_t)nblk + 1)); tmp.keep(d_segbase);
     hipLaunchKernelGGL(tz_member_nseg, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->stream, d_line_off, (long long)nlines,
                        (long long)n_text, nblk, d_nseg);
-    TRYF(dev_scan(c, d_nseg, nblk, d_segbase));
+    TRYF(dev_scan(c, d_nseg, nblk, d_segbase, tmp));
     TRYF(dev_alloc(&d_segbits, (size_t)nlines + (size_t)nblk + 64)); tmp.keep(d_segbits);  // every line once + one more per straddled member border
     TRYF(dev_alloc(&d_stage, (size_t)nblk * STAGE_WORDS)); tmp.keep(d_stage);             // the lines' finished bits between the emit kernel's two passes
     // token histogram of a sample of the members (every member of a small batch): natac_deflate.hpp, sample_stride
@@ -564,7 +569,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     hipLaunchKernelGGL(tz_emit_members, dim3((unsigned)nblk), dim3(TZ_THREADS), lds_emit, c->stream, d_text, (long long)n_text, d_line_off,
                        (long long)nlines, d_segbase, d_stage, d_segbits, d_codes, c->d_crc, d_regions, d_sizes);
     HIPCHK(hipGetLastError());
-    TRYF(dev_scan(c, d_sizes, nblk, d_pos));
+    TRYF(dev_scan(c, d_sizes, nblk, d_pos, tmp));
     b->fmt_member_pos.resize((size_t)nblk + 1);
     HIPCHK(hipMemcpyAsync(b->fmt_member_pos.data(), d_pos, ((size_t)nblk + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     {   // tabix records: runs of lines per leaf bin (tz_group_*)
@@ -576,7 +581,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
         TRYF(dev_alloc(&d_gf, (size_t)nlines)); tmp.keep(d_gf);
         TRYF(dev_alloc(&d_gidx, (size_t)nlines + 1)); tmp.keep(d_gidx);
         hipLaunchKernelGGL(tz_group_flags, dim3(lb), dim3(256), 0, c->stream, (long long)nlines, d_lcid, d_lbeg, d_lend, d_gf);
-        TRYF(dev_scan(c, d_gf, (long long)nlines, d_gidx));
+        TRYF(dev_scan(c, d_gf, (long long)nlines, d_gidx, tmp));
         unsigned long long ngroups = 0;
         HIPCHK(hipMemcpyAsync(&ngroups, d_gidx + nlines, sizeof ngroups, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -690,6 +695,7 @@ void natac_ctx_destroy(natac_ctx *c) {
     if (c->ck_stream) (void)hipStreamDestroy(c->ck_stream);
     if (c->ck_start) (void)hipEventDestroy(c->ck_start);
     if (c->d_ck) (void)hipFree(c->d_ck);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1182,6 +1188,7 @@ void natac_batch_free(natac_batch *b) {
     dev_free(b->d_pk_big);
     for (int i = 0; i < NATAC_T_COUNT; ++i) dev_free(b->d_track[i]);
     dev_free(b->d_bnum); dev_free(b->d_bcov); dev_free(b->d_fmt_out);
+    (void)fmt_pending_wait(b);
     dev_free(b->d_blk_off); dev_free(b->d_gsum); dev_free(b->d_tiles_gs); dev_free(b->d_defer);
     dev_free(b->d_opk_vals); dev_free(b->d_nuc_dist); dev_free(b->d_opk_keep);
     for (int i = 0; i < 3; ++i) dev_free(b->d_grid[i]);
@@ -1201,6 +1208,7 @@ int natac_batch_release_outputs(natac_batch *b) {
     b->d_bnum = b->d_bcov = b->d_gsum = b->d_pk_out = b->d_opk_vals = b->d_nuc_dist = nullptr;
     b->d_pk_chunk = b->d_pk_pos = b->d_opk_keep = nullptr;
     dev_free(b->d_fmt_out); b->d_fmt_out = nullptr; b->fmt_bytes = -1;
+    (void)fmt_pending_wait(b);
     b->pk_cap = 0; b->pk_n = -1; b->opk_cap = 0; b->opk_n = -1;
     b->nuc_done = b->occ_done = b->ins_done = b->cov_from_nuc = b->prefill_valid = b->bg_valid = false;
     // the per-chunk status words describe the outputs that were just dropped
@@ -2413,11 +2421,52 @@ int natac_batch_format_track(natac_batch *b, int track, const int32_t *chrom_id,
     return rc;
 }
 
+// results handed to natac_batch_format_fetch_begin: wait for their copies, give the device buffers back
+static int fmt_pending_wait(natac_batch *b) {
+    hipError_t first = hipSuccess;
+    for (auto &p : b->fmt_pending) {
+        hipError_t e = hipEventSynchronize(p.second);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+        (void)hipEventDestroy(p.second);
+        dev_free(p.first);
+    }
+    b->fmt_pending.clear();
+    if (first != hipSuccess) return fail(NATAC_E_HIP, "format_fetch: %s", hipGetErrorString(first));
+    return NATAC_OK;
+}
+
+int natac_batch_format_fetch_begin(natac_batch *b, void *dst, size_t dst_bytes) {
+    if (!b || (!dst && dst_bytes)) return fail(NATAC_E_ARG, "null argument");
+    if (b->fmt_bytes < 0) return fail(NATAC_E_STATE, "natac_batch_format_track has not run");
+    if ((long long)dst_bytes < b->fmt_bytes) return fail(NATAC_E_ARG, "destination holds %zu bytes, result has %lld", dst_bytes, b->fmt_bytes);
+    if (b->fmt_bytes == 0) return NATAC_OK;
+    if (!b->d_fmt_out) return fail(NATAC_E_STATE, "the result has already been handed to natac_batch_format_fetch_begin");
+    natac_ctx *c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // natac_batch_format_track returns with its stream drained: the result is complete, the copy needs no event from it
+    hipEvent_t ev = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipMemcpyAsync(dst, b->d_fmt_out, (size_t)b->fmt_bytes, hipMemcpyDeviceToHost, c->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(ev, c->copy_stream);
+    if (e != hipSuccess) { (void)hipEventDestroy(ev); return fail(NATAC_E_HIP, "format_fetch_begin: %s", hipGetErrorString(e)); }
+    b->fmt_pending.emplace_back(b->d_fmt_out, ev);       // the buffer is the copy's until natac_batch_format_fetch_wait
+    b->d_fmt_out = nullptr;          // fmt_bytes stays: the result's tabix records are still to be fetched; a second fetch of the bytes is refused below
+    return NATAC_OK;
+}
+
+int natac_batch_format_fetch_wait(natac_batch *b) {
+    if (!b) return fail(NATAC_E_ARG, "batch is NULL");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    return fmt_pending_wait(b);
+}
+
 int natac_batch_format_fetch(natac_batch *b, void *dst, size_t dst_bytes) {
     if (!b || (!dst && dst_bytes)) return fail(NATAC_E_ARG, "null argument");
     if (b->fmt_bytes < 0) return fail(NATAC_E_STATE, "natac_batch_format_track has not run");
     if ((long long)dst_bytes < b->fmt_bytes) return fail(NATAC_E_ARG, "destination holds %zu bytes, result has %lld", dst_bytes, b->fmt_bytes);
     if (b->fmt_bytes == 0) return NATAC_OK;
+    if (!b->d_fmt_out) return fail(NATAC_E_STATE, "the result has already been handed to natac_batch_format_fetch_begin");
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipMemcpyAsync(dst, b->d_fmt_out, (size_t)b->fmt_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
@@ -3065,7 +3114,7 @@ int natac_store_adopt(natac_store *s, natac_batch *b, int32_t n_tracks, const in
         job.chrom_id = nullptr; job.chunk_start = nullptr; job.names = nullptr; job.name_off = nullptr; job.p10 = c->d_p10;
         job.write_zero = write_zero & 1; job.keep_before_nan = (write_zero >> 1) & 1;
         hipLaunchKernelGGL(tz_flags_count, dim3(nt), dim3(256), 0, c->stream, job, d_tc);
-        TRYS(dev_scan(c, d_tc, (long long)nt, d_tb));
+        TRYS(dev_scan(c, d_tc, (long long)nt, d_tb, tmp));
         unsigned long long nruns = 0;
         if ((e = hipMemcpyAsync(&nruns, d_tb + nt, sizeof nruns, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;

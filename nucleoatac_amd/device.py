@@ -518,18 +518,27 @@ class DeviceBatch(object):
         L.check(self._lib.natac_download_nuc_dist(self._h, _ptr(nd), nd.nbytes))
         return cc, cp, occ, lo, up, rd, keep, nd
 
-    def format_track(self, t, chroms, chunk_start, write_zero=True, compress=True, keep_runs_before_nan=False, out=None):
+    def format_track(self, t, chroms, chunk_start, write_zero=True, compress=True, keep_runs_before_nan=False, out=None, wait=True):
         """Track.write_track of per-base track `t` for every chunk ON THE DEVICE (natac_batch_format_track): returns
         (bytes as a uint8 array -- bedGraph text, or BGZF members when `compress` --, info dict).  `chroms`: one chromosome name
-        per chunk; `out`: a function n_bytes -> uint8 buffer (e.g. a pinned slot) that receives the result."""
+        per chunk; `out`: a function n_bytes -> uint8 buffer (e.g. a pinned slot) that receives the result.  `wait=False`: the copy into
+        `out`'s (pinned) buffer is only STARTED (natac_batch_format_fetch_begin) so that the next track can be formatted meanwhile; the
+        bytes are valid after `format_wait()`."""
         nc = self.packed.n_chunks
         if len(chroms) != nc or len(chunk_start) != nc:
             raise ValueError("one chromosome name and start per chunk")
-        names = sorted(set(str(c) for c in chroms))
-        idx = {c: i for i, c in enumerate(names)}
-        cid = np.array([idx[str(c)] for c in chroms], dtype=np.int32)
-        cs = np.ascontiguousarray(chunk_start, dtype=np.int64)
-        arr = (C.c_char_p * len(names))(*[c.encode("ascii") for c in names])
+        # the name table of a batch is formed once, not once per track: a per-chunk Python loop here (str(), a dict lookup) holds the GIL for
+        # ~2 ms per 2,500 chunks -- with five tracks per sub-batch and six executor threads that serialised the whole bedGraph.gz
+        # pipeline on the interpreter (round 6: kernels busy 55 % of the leg's wall time)
+        key = (id(chroms), id(chunk_start))
+        cached = getattr(self, "_fmt_names", None)
+        if cached is None or cached[0] != key:
+            uniq, inv = np.unique(np.asarray(chroms, dtype=str), return_inverse=True)      # sorted, like sorted(set(...))
+            names = [str(c) for c in uniq]
+            cached = (key, names, np.ascontiguousarray(inv, dtype=np.int32), np.ascontiguousarray(chunk_start, dtype=np.int64),
+                      (C.c_char_p * len(names))(*[c.encode("ascii") for c in names]), chroms, chunk_start)   # (the two objects are kept alive: id() stays theirs)
+            self._fmt_names = cached
+        _, names, cid, cs, arr = cached[:5]
         nb, nt, nl, hard = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int32(0)
         L.check(self._lib.natac_batch_format_track(self._h, int(t), _ptr(cid), arr, len(names), _ptr(cs),
                                                    (1 if write_zero else 0) | (2 if keep_runs_before_nan else 0), 1 if compress else 0,
@@ -537,7 +546,10 @@ class DeviceBatch(object):
         buf = out(nb.value) if out is not None else np.empty(nb.value, dtype=np.uint8)
         if buf.dtype != np.uint8 or buf.size < nb.value:
             raise ValueError("out must give a uint8 buffer of at least %d bytes" % nb.value)
-        L.check(self._lib.natac_batch_format_fetch(self._h, _ptr(buf), buf.nbytes))
+        if wait:
+            L.check(self._lib.natac_batch_format_fetch(self._h, _ptr(buf), buf.nbytes))
+        else:
+            L.check(self._lib.natac_batch_format_fetch_begin(self._h, _ptr(buf), buf.nbytes))
         info = dict(bytes=nb.value, text_bytes=nt.value, lines=nl.value, hard=hard.value)
         if compress:
             # tabix records of this result (runs of lines per 16-kb leaf bin) for writer.TbiBuilder.push
@@ -551,6 +563,10 @@ class DeviceBatch(object):
                                                              _ptr(rec["t0"]), _ptr(rec["t1"]), _ptr(rec["member_pos"])))
             info["index"] = rec
         return buf[:nb.value], info
+
+    def format_wait(self):
+        """wait for every result whose copy `format_track(..., wait=False)` started"""
+        L.check(self._lib.natac_batch_format_fetch_wait(self._h))
 
     def set_track(self, t, vals):
         """overwrite float64 per-base track `t` with host values (natac_batch_set_track), e.g. to send an externally computed

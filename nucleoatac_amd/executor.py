@@ -183,8 +183,9 @@ class PipelinedExecutor(object):
             r.text, r.text_index = {}, {}
             for t in st.text_tracks:
                 # Track.write_track + bgzip on the device: BGZF members straight into the pinned slot
+                # (the copy of a finished track into the pinned slot runs while the next track is formatted: wait=False + format_wait below)
                 buf, info = b.format_track(t, packed.chroms, packed.chunk_start, compress=True,
-                                           out=lambda nbytes, t=t: slot.view(("z", t), nbytes, np.uint8))
+                                           out=lambda nbytes, t=t: slot.view(("z", t), nbytes, np.uint8), wait=False)
                 if info["hard"]:        # a value whose 12th digit the device table cannot decide (|v| >= 1e12 ties): host formatter
                     if t not in r.tracks:
                         dt = np.int32 if t == L.T_INS else np.float64
@@ -193,6 +194,8 @@ class PipelinedExecutor(object):
                 else:
                     r.text[t] = buf
                     r.text_index[t] = info["index"]      # tabix records of these members (writer.TbiBuilder)
+            if st.text_tracks:
+                b.format_wait()
             r.peaks = b.download_peaks(n) if st.peaks is not None else None
             r.occ_peaks = b.run_occ_peaks(**st.occ_peaks) if st.occ_peaks is not None else None
             r.status = b.status()

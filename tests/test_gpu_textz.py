@@ -282,3 +282,39 @@ def test_device_writer_on_random_tracks(ctx, tmp_path):
         out, info = b.format_track(L.T_OCC, ["c"] * 3, pk.chunk_start, compress=comp)
         assert len(out) == 0 and info["lines"] == 0
     b.free()
+
+
+def test_results_fetched_while_the_next_track_is_formatted(ctx):
+    """round 6: natac_batch_format_fetch_begin / _wait -- the copy of a finished result into pinned memory runs on a second stream while
+    the batch formats its next track (what executor.PipelinedExecutor does with its five text tracks).  Same bytes and the same tabix
+    records as the blocking fetch, for every track, in any interleaving; a batch freed with copies still in flight waits for them."""
+    from nucleoatac_amd.device import pinned_empty
+    pk = make_synthetic_chunks(600, 2120, 500, seed=17)
+    chroms = ["chr%d" % (1 + k // 200) for k in range(pk.n_chunks)]
+    b = ctx.upload(pk)
+    b.run_nuc(10)
+    b.run_occ()
+    tracks = (L.T_NORM, L.T_SMOOTH, L.T_OCC, L.T_OCC_LOWER, L.T_OCC_UPPER)
+    ref = {}
+    for t in tracks:
+        z, info = b.format_track(t, chroms, pk.chunk_start, compress=True)
+        ref[t] = (z.copy(), info)
+    slots = {t: pinned_empty(len(ref[t][0]) + 4096, np.uint8) for t in tracks}
+    for s in slots.values():
+        s[:] = 0xee
+    got = {}
+    for t in tracks:                                     # five copies begun, none waited for
+        z, info = b.format_track(t, chroms, pk.chunk_start, compress=True, out=lambda n, t=t: slots[t][:n], wait=False)
+        got[t] = (z, info)
+    b.format_wait()
+    for t in tracks:
+        z, info = got[t]
+        assert np.array_equal(z, ref[t][0]), t
+        assert info["bytes"] == ref[t][1]["bytes"] and info["lines"] == ref[t][1]["lines"]
+        for k in ("cid", "beg", "end", "count", "t0", "t1", "member_pos"):
+            assert np.array_equal(info["index"][k], ref[t][1]["index"][k]), (t, k)
+        assert (slots[t][len(z):] == 0xee).all()          # nothing written past the result
+    b.format_wait()                                      # nothing pending: a no-op
+    z, info = b.format_track(L.T_NORM, chroms, pk.chunk_start, compress=True, out=lambda n: slots[L.T_NORM][:n], wait=False)
+    b.free()                                             # waits for the copy it still owns
+    assert np.array_equal(z, ref[L.T_NORM][0])
