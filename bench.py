@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--no-h2h", action="store_true", help="skip the pipelined host-to-host measurement")
     ap.add_argument("--h2h-sub", type=int, default=2500, help="chunks per pipelined sub-batch")
     ap.add_argument("--h2h-threads", type=int, default=6, help="contexts (host threads) of the host-to-host pipeline")
+    ap.add_argument("--h2h-text-sub", type=int, default=0, help="chunks per sub-batch of the bedGraph.gz form (0: 5000, or --h2h-sub if that is given)")
+    ap.add_argument("--h2h-text-threads", type=int, default=0, help="contexts of the bedGraph.gz form (0: 10, or --h2h-threads if that is given)")
     ap.add_argument("--h2h-ranks", action="store_true", help="N > 1: every rank also runs the host-to-host pipeline on (a part of) its shard, "
                     "all ranks at once; the rates are reported per rank")
     ap.add_argument("--h2h-rank-chunks", type=int, default=20000, help="chunks of a rank's shard the --h2h-ranks leg runs on")
@@ -761,7 +763,14 @@ def main():
         ctx.close()
         ctx = None
         h2h = host_to_host(subs[0], local_rank, par, sizes, nucp, nfrp, a.steps, a.h2h_sub, a.h2h_threads)
-        h2h["as_bedgraph_gz"] = host_to_host(subs[0], local_rank, par, sizes, nucp, nfrp, a.steps, a.h2h_sub, a.h2h_threads, as_text=True)
+        # the two forms are bound by different things (float64: the PCIe link; bedGraph.gz: ~25 small launches and a few synchronisations per
+        # track, which more contexts with larger sub-batches hide better -- profiles/r6/README.md, the sweeps), so each runs with the executor
+        # parameters that suit it; both are printed in the form's own `contexts` / `chunks_per_sub_batch`.  An explicit --h2h-sub /
+        # --h2h-threads applies to both forms.
+        explicit = any(x.startswith(("--h2h-sub", "--h2h-threads")) for x in sys.argv[1:])
+        t_sub = a.h2h_text_sub or (a.h2h_sub if explicit else 5000)
+        t_thr = a.h2h_text_threads or (a.h2h_threads if explicit else 10)
+        h2h["as_bedgraph_gz"] = host_to_host(subs[0], local_rank, par, sizes, nucp, nfrp, a.steps, t_sub, t_thr, as_text=True)
     e2e = None
     if rank == 0 and world == 1 and a.cli_chunks > 0 and a.workload == "cfg3":
         if ctx is not None:
