@@ -142,3 +142,43 @@ def test_extended_tiles_with_damaged_bias_match_oracle_and_direct():
         # direct summation above
         np.testing.assert_allclose(mine[good], nt["bg"][good], rtol=1e-5, atol=1e-9)
     assert 0 < np.isnan(bg_e[:2120]).sum() < 400
+
+
+CODE_GEOM = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_bg_ext import _ragged_batch, LENGTHS
+from nucleoatac_amd import _lib as L
+from nucleoatac_amd.device import Context
+from nucleoatac_amd.synth import synth_size_distribution
+lo, up = int(sys.argv[2]), int(sys.argv[3])
+rng = np.random.default_rng(lo * 1000 + up)
+vm = rng.random((up - lo, 121)) * 0.01 + 1e-4
+c = Context(0); c.set_vmat(vm, lo, up); c.set_sizes(synth_size_distribution(up))
+pk, fr = _ragged_batch(LENGTHS, 11, "normal")
+b = c.upload(pk); b.run_nuc(10)
+np.savez(sys.argv[1], tracks=np.stack([b.track(L.T_BACKGROUND), b.track(L.T_NORM), b.track(L.T_RAW)]))
+b.free(); c.close()
+''' % (ROOT, HERE)
+
+
+@pytest.mark.parametrize("lower,upper", [(105, 251), (104, 250), (105, 253), (104, 252), (105, 252), (106, 251), (61, 121)])
+def test_pair_loop_variants_equal_direct_summation(lower, upper):
+    """round 6: the skewed pair loop of natac_background_fft for an odd and an even first insert size (they differ in the ADDRESSES of the
+    two operand streams only), an odd and an even number of row pairs (the loop is unrolled by two: 74 pairs leave one trip over), and an
+    odd row count (the plain loop) -- each against the direct-summation kernel on the ragged batch, extended and plain tiles mixed."""
+    def run(env_extra, tag, td):
+        env = dict(os.environ)
+        env.pop("NATAC_BG_DIRECT", None)
+        env.pop("NATAC_BG_EXT", None)
+        env.update(env_extra)
+        path = os.path.join(td, tag + ".npz")
+        subprocess.run([sys.executable, "-c", CODE_GEOM, path, str(lower), str(upper)], check=True, env=env)
+        return np.load(path)["tracks"]
+    with tempfile.TemporaryDirectory() as td:
+        fft = run({}, "fft", td)
+        direct = run({"NATAC_BG_DIRECT": "1"}, "direct", td)
+    assert np.array_equal(fft[2], direct[2])                                  # raw does not go through the FFT
+    assert np.isfinite(direct[0]).all() and np.abs(direct[0]).max() > 0
+    np.testing.assert_allclose(fft[0], direct[0], rtol=1e-10, atol=1e-13)      # background
+    np.testing.assert_allclose(fft[1], direct[1], rtol=1e-10, atol=1e-12)      # norm = raw - bg
