@@ -422,6 +422,23 @@ static int dev_scan(natac_ctx *c, const T *in, long long n, unsigned long long *
     return NATAC_OK;
 }
 
+// the two scans over a track's runs (byte offsets and indices of its lines) in one pass over the length array (tz_scan2_*)
+static int dev_scan2(natac_ctx *c, const unsigned char *in, long long n, unsigned long long *out_sum, unsigned long long *out_cnt, TmpFree &tmp) {
+    using namespace natac_textz;
+    const long long nblk = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    unsigned long long *sums = nullptr;
+    int rc = dev_alloc(&sums, 2 * ((size_t)nblk + 1));
+    if (rc) return rc;
+    tmp.keep(sums);
+    hipLaunchKernelGGL(tz_scan2_block_sums, dim3((unsigned)nblk), dim3(256), 0, c->stream, in, n, nblk, sums);
+    hipLaunchKernelGGL(tz_scan_sums, dim3(1), dim3(1024), 0, c->stream, sums, nblk);
+    hipLaunchKernelGGL(tz_scan_sums, dim3(1), dim3(1024), 0, c->stream, sums + nblk + 1, nblk);
+    hipLaunchKernelGGL(tz_scan2_final, dim3((unsigned)nblk), dim3(256), 0, c->stream, in, n, nblk, sums, out_sum, out_cnt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NATAC_E_HIP, "scan: %s", hipGetErrorString(e));
+    return NATAC_OK;
+}
+
 // text / BGZF of a device array of per-base values laid out like the batch's tracks.  Result stays in b->d_fmt_out.
 static int format_values(natac_batch *b, const double *d_vals, const int32_t *chrom_id, const char *const *names, int32_t n_names,
                          const int64_t *chunk_start, int write_zero, int compress, int64_t *n_bytes, int64_t *n_text_bytes, int64_t *n_lines,
@@ -464,7 +481,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     long long *d_cs = nullptr, *d_line_off = nullptr;
     unsigned long long *d_tb = nullptr, *d_boff = nullptr, *d_lidx = nullptr;
     unsigned int *d_R = nullptr;
-    unsigned char *d_len8 = nullptr, *d_isl = nullptr, *d_text = nullptr;
+    unsigned char *d_len8 = nullptr, *d_text = nullptr;
 #define TRYF(x) do { if ((rc = (x)) != NATAC_OK) return rc; } while (0)
     TRYF(dev_upload(c, &d_names, cat.data(), cat.size())); tmp.keep(d_names);
     TRYF(dev_upload(c, &d_noff, noff.data(), noff.size())); tmp.keep(d_noff);
@@ -488,15 +505,13 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_C, (size_t)nruns)); tmp.keep(d_C);
     hipLaunchKernelGGL(tz_scatter_runs, dim3(nt), dim3(256), 0, c->stream, job, d_tb, d_R, d_C);
     TRYF(dev_alloc(&d_len8, (size_t)nruns)); tmp.keep(d_len8);
-    TRYF(dev_alloc(&d_isl, (size_t)nruns)); tmp.keep(d_isl);
     const unsigned rb = (unsigned)((nruns + 255) / 256);
     unsigned long long *d_vtxt = nullptr;             // text of every run's value (tz_line_len -> tz_write_lines)
     TRYF(dev_alloc(&d_vtxt, (size_t)nruns * (natac_textz::VTXT / 8))); tmp.keep(d_vtxt);
-    hipLaunchKernelGGL(tz_line_len, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_isl, d_hard, d_vtxt);
+    hipLaunchKernelGGL(tz_line_len, dim3(rb), dim3(256), 0, c->stream, job, (long long)nruns, d_R, d_C, d_len8, d_hard, d_vtxt);
     TRYF(dev_alloc(&d_boff, (size_t)nruns + 1)); tmp.keep(d_boff);
     TRYF(dev_alloc(&d_lidx, (size_t)nruns + 1)); tmp.keep(d_lidx);
-    TRYF(dev_scan(c, d_len8, (long long)nruns, d_boff, tmp));
-    TRYF(dev_scan(c, d_isl, (long long)nruns, d_lidx, tmp));
+    TRYF(dev_scan2(c, d_len8, (long long)nruns, d_boff, d_lidx, tmp));
     unsigned long long n_text = 0, nlines = 0;
     int hard = 0;
     HIPCHK(hipMemcpyAsync(&n_text, d_boff + nruns, sizeof n_text, hipMemcpyDeviceToHost, c->stream));
@@ -541,10 +556,12 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     unsigned long long *d_segbase = nullptr;
     unsigned int *d_stage = nullptr;
     unsigned short *d_segbits = nullptr;
+    long long *d_k0 = nullptr;
     TRYF(dev_alloc(&d_nseg, (size_t)nblk)); tmp.keep(d_nseg);
     TRYF(dev_alloc(&d_segbase, (size_t)nblk + 1)); tmp.keep(d_segbase);
+    TRYF(dev_alloc(&d_k0, (size_t)nblk)); tmp.keep(d_k0);
     hipLaunchKernelGGL(tz_member_nseg, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, c->stream, d_line_off, (long long)nlines,
-                       (long long)n_text, nblk, d_nseg);
+                       (long long)n_text, nblk, d_nseg, d_k0);
     TRYF(dev_scan(c, d_nseg, nblk, d_segbase, tmp));
     TRYF(dev_alloc(&d_segbits, (size_t)nlines + (size_t)nblk + 64)); tmp.keep(d_segbits);  // every line once + one more per straddled member border
     TRYF(dev_alloc(&d_stage, (size_t)nblk * STAGE_WORDS)); tmp.keep(d_stage);             // the lines' finished bits between the emit kernel's two passes
@@ -553,7 +570,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     const long long counted = (nblk + stride - 1) / stride;
     const size_t lds_count = 65536 + (nd::NLL + nd::ND) * sizeof(unsigned int);
     hipLaunchKernelGGL(tz_count_tokens, dim3((unsigned)counted), dim3(TZ_THREADS), lds_count, c->stream, d_text, (long long)n_text, d_line_off,
-                       (long long)nlines, stride, d_hist);
+                       (long long)nlines, stride, d_nseg, d_k0, d_hist);
     unsigned int hist[nd::NLL + nd::ND];
     HIPCHK(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -567,7 +584,7 @@ static int format_values(natac_batch *b, const double *d_vals, const int32_t *ch
     TRYF(dev_alloc(&d_pos, (size_t)nblk + 1)); tmp.keep(d_pos);
     const size_t lds_emit = 65536 + ((sizeof(nd::Codes) + 15) & ~(size_t)15);
     hipLaunchKernelGGL(tz_emit_members, dim3((unsigned)nblk), dim3(TZ_THREADS), lds_emit, c->stream, d_text, (long long)n_text, d_line_off,
-                       (long long)nlines, d_segbase, d_stage, d_segbits, d_codes, c->d_crc, d_regions, d_sizes);
+                       (long long)nlines, d_nseg, d_k0, d_segbase, d_stage, d_segbits, d_codes, c->d_crc, d_regions, d_sizes);
     HIPCHK(hipGetLastError());
     TRYF(dev_scan(c, d_sizes, nblk, d_pos, tmp));
     b->fmt_member_pos.resize((size_t)nblk + 1);

@@ -147,6 +147,54 @@ __global__ void __launch_bounds__(256) tz_scan_final(const T *__restrict__ in, l
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = before;     // total
 }
 
+// Two exclusive scans of one byte array in one pass: out_sum = scan of in[i] (byte offsets of the lines), out_cnt = scan of (in[i] != 0)
+// (indices of the lines: a run that writes no line has length 0).  sums[0..nblk] / sums[nblk + 1 ..] hold the two sets of block sums.
+__global__ void __launch_bounds__(256) tz_scan2_block_sums(const unsigned char *__restrict__ in, long long n, long long nblk,
+                                                            unsigned long long *__restrict__ sums) {
+    __shared__ unsigned long long red[8];
+    const long long base = (long long)blockIdx.x * SCAN_PER_BLOCK;
+    unsigned long long s = 0, c = 0;
+    for (int j = 0; j < 8; ++j) {
+        const long long i = base + threadIdx.x * 8 + j;
+        if (i < n) { const unsigned int v = in[i]; s += v; c += v ? 1u : 0u; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); c += __shfl_xor(c, off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) { sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3]; sums[nblk + 1 + blockIdx.x] = red[4] + red[5] + red[6] + red[7]; }
+}
+__global__ void __launch_bounds__(256) tz_scan2_final(const unsigned char *__restrict__ in, long long n, long long nblk,
+                                                       const unsigned long long *__restrict__ sums, unsigned long long *__restrict__ out_sum,
+                                                       unsigned long long *__restrict__ out_cnt) {
+    __shared__ unsigned long long wtot[8];
+    const long long base = (long long)blockIdx.x * SCAN_PER_BLOCK;
+    unsigned int v[8];
+    unsigned long long s = 0, c = 0;
+    for (int j = 0; j < 8; ++j) {
+        const long long i = base + threadIdx.x * 8 + j;
+        v[j] = i < n ? (unsigned int)in[i] : 0u;
+        s += v[j];
+        c += v[j] ? 1u : 0u;
+    }
+    unsigned long long incs = s, incc = c;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long os = __shfl_up(incs, off), oc = __shfl_up(incc, off);
+        if (lane >= off) { incs += os; incc += oc; }
+    }
+    if (lane == 63) { wtot[threadIdx.x >> 6] = incs; wtot[4 + (threadIdx.x >> 6)] = incc; }
+    __syncthreads();
+    unsigned long long bs = sums[blockIdx.x] + incs - s, bc = sums[nblk + 1 + blockIdx.x] + incc - c;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) { bs += wtot[k]; bc += wtot[4 + k]; }
+    for (int j = 0; j < 8; ++j) {
+        const long long i = base + threadIdx.x * 8 + j;
+        if (i < n) { out_sum[i] = bs; out_cnt[i] = bc; }
+        bs += v[j];
+        bc += v[j] ? 1u : 0u;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) { out_sum[n] = bs; out_cnt[n] = bc; }     // totals
+}
+
 // ---- lines ------------------------------------------------------------------------------------------------------------
 struct RunInfo {
     long long a_rel, b_rel;        // run = [a_rel, b_rel) relative to the chunk start
@@ -198,7 +246,7 @@ constexpr int VTXT = 24;           // bytes kept per run for the text of its val
 // The value's text is the expensive part of a line (exact '%.12g': ~2,000 instructions): tz_line_len forms it once and leaves it in
 // vtxt[VTXT / 8 * k ...] for tz_write_lines, which only adds the name and the two coordinates.
 __global__ void __launch_bounds__(256) tz_line_len(TextJob job, long long nruns, const unsigned int *__restrict__ R, const int *__restrict__ C,
-                                                    unsigned char *__restrict__ len8, unsigned char *__restrict__ is_line, int *__restrict__ hard_total,
+                                                    unsigned char *__restrict__ len8, int *__restrict__ hard_total,
                                                     unsigned long long *__restrict__ vtxt) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= nruns) return;
@@ -214,8 +262,7 @@ __global__ void __launch_bounds__(256) tz_line_len(TextJob job, long long nruns,
         const long long s = job.chunk_start[r.chunk];
         n = (job.name_off[cid + 1] - job.name_off[cid]) + natac_text::digits_i64(s + r.a_rel) + natac_text::digits_i64(s + r.b_rel) + nv + 4;
     }
-    len8[k] = (unsigned char)n;
-    is_line[k] = n ? 1 : 0;
+    len8[k] = (unsigned char)n;          // 0 = no line (NaN runs, zero runs without write_zero, the run lost before a NaN)
     if (hard) atomicAdd(hard_total, hard);
 }
 
@@ -525,9 +572,23 @@ struct DevStageSink {
 };
 // number of line segments of every member (for the offsets of the records above)
 __global__ void __launch_bounds__(256) tz_member_nseg(const long long *__restrict__ line_off, long long nlines, long long n_text,
-                                                       long long nblk, unsigned int *__restrict__ nseg) {
+                                                       long long nblk, unsigned int *__restrict__ nseg, long long *__restrict__ first_line) {
     const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (b < nblk) nseg[b] = (unsigned int)member_geom(line_off, nlines, n_text, b).nseg;
+    if (b < nblk) {
+        const MemberGeom g = member_geom(line_off, nlines, n_text, b);
+        nseg[b] = (unsigned int)g.nseg;
+        first_line[b] = g.k0;
+    }
+}
+// the geometry of member b from what tz_member_nseg left: the member kernels used to repeat its two binary searches over the line offsets
+// -- ~50 dependent loads in front of everything else, by every thread of the workgroup
+__device__ __forceinline__ MemberGeom member_geom_stored(const unsigned int *nseg, const long long *first_line, long long n_text, long long b) {
+    MemberGeom g;
+    g.bs = b * nd::BLK;
+    g.be = g.bs + nd::BLK < n_text ? g.bs + nd::BLK : n_text;
+    g.k0 = first_line[b];
+    g.nseg = nseg[b];
+    return g;
 }
 
 __device__ __forceinline__ void load_member_text(unsigned char *lds_text, const unsigned char *text, const MemberGeom &g) {
@@ -549,11 +610,12 @@ __device__ __forceinline__ void wave_range(const MemberGeom &g, int wave, long l
 // token histogram of the sampled members: workgroup j takes member j * stride (natac_deflate.hpp: sample_stride)
 __global__ void __launch_bounds__(TZ_THREADS) tz_count_tokens(const unsigned char *__restrict__ text, long long n_text,
                                                                const long long *__restrict__ line_off, long long nlines, int stride,
+                                                               const unsigned int *__restrict__ nseg, const long long *__restrict__ first_line,
                                                                unsigned int *__restrict__ hist /* [NLL + ND] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *lds_text = smem;
     unsigned int *h = (unsigned int *)(smem + 65536);
-    const MemberGeom g = member_geom(line_off, nlines, n_text, (long long)blockIdx.x * stride);
+    const MemberGeom g = member_geom_stored(nseg, first_line, n_text, (long long)blockIdx.x * stride);
     for (int i = threadIdx.x; i < nd::NLL + nd::ND; i += TZ_THREADS) h[i] = 0;
     load_member_text(lds_text, text, g);
     __syncthreads();
@@ -619,6 +681,7 @@ __device__ __forceinline__ unsigned long long wave_excl_scan(unsigned long long 
 // region (so that the deflate payload, 18 bytes later, starts on a 32-bit word).  sizes[b] = member size in bytes.
 __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) tz_emit_members(const unsigned char *__restrict__ text, long long n_text,
                                                                const long long *__restrict__ line_off, long long nlines,
+                                                               const unsigned int *__restrict__ nseg, const long long *__restrict__ first_line,
                                                                const unsigned long long *__restrict__ seg_base, unsigned int *__restrict__ stage, unsigned short *__restrict__ seg_bits,
                                                                const nd::Codes *__restrict__ codes_g, const nd::CrcTables *__restrict__ crc_g,
                                                                unsigned char *__restrict__ out_regions, unsigned int *__restrict__ sizes) {
@@ -629,7 +692,7 @@ __global__ void __launch_bounds__(TZ_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ unsigned int crc_w[TZ_WAVES];
     __shared__ unsigned int crc_tab[256];
     __shared__ unsigned int lit32[nd::NLL];
-    const MemberGeom g = member_geom(line_off, nlines, n_text, blockIdx.x);
+    const MemberGeom g = member_geom_stored(nseg, first_line, n_text, blockIdx.x);
     {
         const unsigned int *src = (const unsigned int *)codes_g;
         unsigned int *dst = (unsigned int *)codes;
