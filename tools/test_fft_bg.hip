@@ -65,7 +65,8 @@ float run_fft(const ChunkTable &ct, const VMatDev &v, int nc, int L, const doubl
 
 int main(int argc, char **argv) {
     int nc = argc > 1 ? atoi(argv[1]) : 20000, L = argc > 2 ? atoi(argv[2]) : 2120;
-    const int R = 146, W = 121, lo = getenv("NATAC_HARNESS_LO") ? atoi(getenv("NATAC_HARNESS_LO")) : 105, up = lo + R, bl = 246, br = 247;   // NATAC_HARNESS_LO=104: an even first insert size
+    const int R = getenv("NATAC_HARNESS_R") ? atoi(getenv("NATAC_HARNESS_R")) : 146, W = 121;      // NATAC_HARNESS_R=2: one row pair -- what a tile costs besides its pair loop
+    const int lo = getenv("NATAC_HARNESS_LO") ? atoi(getenv("NATAC_HARNESS_LO")) : 105, up = lo + R, bl = 246, br = 247;   // NATAC_HARNESS_LO=104: an even first insert size
     std::vector<int> len(nc, L); std::vector<long long> foff(nc + 1, 0), boff(nc + 1), ooff(nc + 1);
     for (int i = 0; i <= nc; ++i) { boff[i] = (long long)i * (L + bl + br); ooff[i] = (long long)i * L; }
     std::vector<double> bias((size_t)nc * (L + bl + br)); for (auto &x : bias) x = (rand() / (double)RAND_MAX - 0.5) * 3.0 - 4.0;
